@@ -1,0 +1,129 @@
+"""BN254 G1 affine arithmetic and the reference's linear-combination algorithm.
+(oracle: test infrastructure only)
+
+Group law: py_ecc 6.0.0 `bn128_curve.{add,double,multiply}` restated from its published
+algorithm — affine (x, y) over Fq, identity = None, one field inversion
+per add.  MSM: /root/reference/curve.py:38-111 (`ec_lincomb` -> `lincomb` -> `multisubset`),
+kept in its bit-sliced subset-sum shape so the CPU baseline has the reference's cost profile.
+"""
+import math
+
+from .field import Q_MOD, R_MOD, inv
+
+G1 = (1, 2)  # y^2 = x^3 + 3
+Z1 = None
+B_COEFF = 3
+
+
+def is_on_curve(pt):
+    if pt is None:
+        return True
+    x, y = pt
+    return (y * y - x * x * x - B_COEFF) % Q_MOD == 0
+
+
+def double(pt):
+    if pt is None:
+        return None
+    x, y = pt
+    if y == 0:
+        return None
+    m = 3 * x * x * inv(2 * y, Q_MOD) % Q_MOD
+    nx = (m * m - 2 * x) % Q_MOD
+    ny = (-m * nx + m * x - y) % Q_MOD
+    return (nx, ny)
+
+
+def add(p1, p2):
+    if p1 is None or p2 is None:
+        return p1 if p2 is None else p2
+    x1, y1 = p1
+    x2, y2 = p2
+    if x2 == x1 and y2 == y1:
+        return double(p1)
+    if x2 == x1:
+        return None
+    m = (y2 - y1) * inv(x2 - x1, Q_MOD) % Q_MOD
+    nx = (m * m - x1 - x2) % Q_MOD
+    ny = (-m * nx + m * x1 - y1) % Q_MOD
+    return (nx, ny)
+
+
+def neg(pt):
+    if pt is None:
+        return None
+    return (pt[0], (-pt[1]) % Q_MOD)
+
+
+def multiply(pt, n):
+    """py_ecc multiply: n == 0 -> identity; double-and-add (iterative form of its recursion)."""
+    if n == 0 or pt is None:
+        return None
+    result = None
+    addend = pt
+    while n:
+        if n & 1:
+            result = add(result, addend)
+        addend = double(addend)
+        n >>= 1
+    return result
+
+
+def ec_mul(pt, coeff):  # curve.py:30-33
+    return multiply(pt, int(coeff) % R_MOD)
+
+
+def multisubset(numbers, subsets, adder=lambda x, y: x + y, zero=0):
+    """curve.py:59-86 — partitioned power-set tables, one table lookup per partition."""
+    partition_size = 1 + int(math.log(len(subsets) + 1))
+    numbers = numbers[::]
+    while len(numbers) % partition_size != 0:
+        numbers.append(zero)
+    power_sets = []
+    for i in range(0, len(numbers), partition_size):
+        table = [zero]
+        for value in numbers[i : i + partition_size]:
+            table += [adder(n, value) for n in table]
+        power_sets.append(table)
+    subset_sums = []
+    for subset in subsets:
+        o = zero
+        for i in range(len(power_sets)):
+            idx = 0
+            for j in range(partition_size):
+                if i * partition_size + j in subset:
+                    idx += 2**j
+            o = adder(o, power_sets[i][idx])
+        subset_sums.append(o)
+    return subset_sums
+
+
+def lincomb(numbers, factors, adder=lambda x, y: x + y, zero=0):
+    """curve.py:91-111 — bit-slice the factors into subsets, then Horner over the bits."""
+    maxbitlen = max(len(bin(f)) - 2 for f in factors)
+    subsets = [
+        {i for i in range(len(numbers)) if factors[i] & (1 << j)} for j in range(maxbitlen + 1)
+    ]
+    subset_sums = multisubset(numbers, subsets, adder=adder, zero=zero)
+    o = zero
+    for i in range(len(subsets) - 1, -1, -1):
+        o = adder(adder(o, o), subset_sums[i])
+    return o
+
+
+def ec_lincomb(pairs):
+    """curve.py:38-44.  pairs: [(point, scalar)]; scalars reduced mod r first."""
+    return lincomb(
+        [pt for (pt, _) in pairs],
+        [int(n) % R_MOD for (_, n) in pairs],
+        add,
+        Z1,
+    )
+
+
+def ec_lincomb_naive(pairs):
+    """The `Equivalent to:` comment at curve.py:45-49; independent cross-check of lincomb."""
+    o = None
+    for pt, coeff in pairs:
+        o = add(o, ec_mul(pt, coeff))
+    return o
