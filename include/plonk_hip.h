@@ -1,0 +1,132 @@
+/* plonk_hip.h — C-ABI of libplonk_hip.so, the MI355X (gfx950) backend for plonkathon's prover hot path.
+ *
+ * The reference (0xPARC/plonkathon) is single-process pure Python and has no FFI layer; the drop-in
+ * boundary is therefore the set of Python methods on its hot path.  Each entry
+ * point below names the reference method it replaces (file:line under /root/reference); the
+ * ctypes stubs a maintainer would add to the reference are shown in INTEGRATION.md, and
+ * plonkathon_amd/ is a Python host layer with the reference's own class/method names on top.
+ *
+ * Conventions
+ *   - plain C, no C++ types, no exceptions cross the boundary; every call returns PLONK_OK (0) or
+ *     a negative PLONK_ERR_* and sets a thread-local message readable with plonk_last_error().
+ *   - host-side field elements are CANONICAL integers (< modulus), 32 bytes little-endian.
+ *     Device-side Fr vectors are 32 bytes/element in Montgomery form (R = 2^256) — the byte layout
+ *     of a coordinate in a snarkjs .ptau file — and are opaque to the caller.
+ *   - G1 points on the host are affine canonical x||y, 64 bytes little-endian each coordinate,
+ *     plus an out-of-band identity flag (py_ecc represents the identity as None).
+ *   - all work is enqueued on the context's HIP stream; calls that return host data synchronise.
+ *   - the library never retains caller host pointers past return.
+ */
+#ifndef PLONK_HIP_H
+#define PLONK_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PLONK_OK 0
+#define PLONK_ERR_ARG (-1)   /* bad argument (maps to AssertionError / ValueError in Python) */
+#define PLONK_ERR_HIP (-2)   /* a HIP runtime call failed */
+#define PLONK_ERR_NOMEM (-3) /* device allocation failed */
+#define PLONK_ERR_STATE (-4) /* object used in the wrong state */
+
+#define PLONK_ABI_VERSION 1
+
+typedef struct plonk_ctx plonk_ctx; /* one per (process, device): stream, twiddle caches, scratch */
+typedef struct plonk_srs plonk_srs; /* device-resident G1 bases + fixed-base window table */
+
+/* ---- library / context ---------------------------------------------------------------------- */
+const char* plonk_last_error(void);
+int plonk_abi_version(void);
+int plonk_device_count(int* out_count);
+int plonk_ctx_create(int device, plonk_ctx** out_ctx);
+int plonk_ctx_destroy(plonk_ctx* ctx);
+int plonk_ctx_sync(plonk_ctx* ctx);
+int plonk_ctx_device_name(plonk_ctx* ctx, char* buf, size_t buf_len);
+
+/* ---- raw device memory (Polynomial.values storage; poly.py:10-21) --------------------------- */
+int plonk_mem_alloc(plonk_ctx* ctx, size_t bytes, void** out_dptr);
+int plonk_mem_free(plonk_ctx* ctx, void* dptr);
+int plonk_mem_h2d(plonk_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);
+int plonk_mem_d2h(plonk_ctx* ctx, void* h_dst, const void* d_src, size_t bytes);
+int plonk_mem_d2d(plonk_ctx* ctx, void* d_dst, const void* d_src, size_t bytes);
+int plonk_mem_zero(plonk_ctx* ctx, void* d_dst, size_t bytes);
+
+/* ---- Fr vectors: host canonical LE  <->  device Montgomery ----------------------------------
+ * Replaces building `list[Scalar]` (curve.py:10-11; poly.py:14-18). Conversion runs on the GPU. */
+int plonk_fr_upload(plonk_ctx* ctx, void* d_dst, const uint8_t* h_src_le32, size_t count);
+int plonk_fr_download(plonk_ctx* ctx, uint8_t* h_dst_le32, const void* d_src, size_t count);
+
+/* ---- NTT family ------------------------------------------------------------------------------
+ * plonk_fr_ntt          Polynomial.fft / ifft            poly.py:113-148 (natural order in and out;
+ *                       inverse includes the 1/N scale; roots w = 5^((r-1)/N), curve.py:14-24)
+ * plonk_fr_coset_extend Polynomial.to_coset_extended_lagrange(offset)   poly.py:156-163
+ *                       in: N Lagrange values, out: 4N values P(offset * mu^k), mu = root_of_unity(4N)
+ * plonk_fr_coset_to_coeffs  Polynomial.coset_extended_lagrange_to_coeffs(offset)  poly.py:169-177
+ *                       in: M values on the coset, out: M coefficients (M = 1 << log_m)
+ * `batch` independent vectors are laid out back to back ([batch][N]). in may equal out.        */
+int plonk_fr_ntt(plonk_ctx* ctx, const void* d_in, void* d_out, unsigned log_n, int inverse, size_t batch);
+int plonk_fr_coset_extend(plonk_ctx* ctx, const void* d_in, void* d_out, unsigned log_n,
+                          const uint8_t offset_le32[32], size_t batch);
+int plonk_fr_coset_to_coeffs(plonk_ctx* ctx, const void* d_in, void* d_out, unsigned log_m,
+                             const uint8_t offset_le32[32], size_t batch);
+/* tuning / test knob (0 = default): LDS tile = 2^tile_log elements (<= 12), sizes <= 2^single_pass_log
+ * (<= 11) run as one pass, larger sizes split into passes of radix <= 2^radix_log (<= 10). */
+int plonk_ntt_configure(plonk_ctx* ctx, unsigned tile_log, unsigned single_pass_log, unsigned radix_log);
+/* Lower-level pieces used by the batched prover: coefficient form in, fixed offset table. */
+int plonk_fr_coset_ntt_from_coeffs(plonk_ctx* ctx, const void* d_coeffs, void* d_out, unsigned log_n,
+                                   unsigned log_expand, const uint8_t offset_le32[32], size_t batch);
+
+/* ---- pointwise arithmetic ---------------------------------------------------------------------
+ * plonk_fr_pointwise    Polynomial.__add__/__sub__/__mul__/__truediv__ with a Polynomial
+ *                       poly.py:23-36, 45-58, 68-77, 85-94   (x / 0 == 0, as py_ecc)
+ * plonk_fr_scalar_op    the same operators with a Scalar operand, poly.py:37-43, 59-65, 78-83, 95-100;
+ *                       constant_term_only=1 gives the MONOMIAL-basis +/- rule (poly.py:39-43, 61-65)
+ * plonk_fr_rotate       Polynomial.shift(k)                  poly.py:102-109
+ * plonk_fr_batch_inverse   the per-element inversions inside `/` and barycentric_eval
+ * plonk_fr_barycentric  Polynomial.barycentric_eval(x)       poly.py:181-195                      */
+#define PLONK_OP_ADD 0
+#define PLONK_OP_SUB 1
+#define PLONK_OP_MUL 2
+#define PLONK_OP_DIV 3
+int plonk_fr_pointwise(plonk_ctx* ctx, int op, const void* d_a, const void* d_b, void* d_out, size_t count);
+int plonk_fr_scalar_op(plonk_ctx* ctx, int op, const void* d_a, const uint8_t scalar_le32[32], void* d_out,
+                       size_t count, int constant_term_only);
+int plonk_fr_rotate(plonk_ctx* ctx, const void* d_in, void* d_out, size_t count, size_t shift);
+int plonk_fr_batch_inverse(plonk_ctx* ctx, const void* d_in, void* d_out, size_t count);
+int plonk_fr_barycentric(plonk_ctx* ctx, const void* d_vals, unsigned log_n, const uint8_t x_le32[32],
+                         uint8_t out_le32[32]);
+
+/* ---- G1 multi-scalar multiplication ------------------------------------------------------------
+ * plonk_srs_load_ptau   Setup.from_file's G1 section, setup.py:29-41: `n_points` affine points, each
+ *                       64 B = x||y little-endian in Montgomery form — bytes 80.. of a snarkjs .ptau
+ *                       are passed through unchanged (the Montgomery factor the reference divides
+ *                       out at setup.py:39-40 is exactly this library's internal representation).
+ * plonk_srs_load_affine arbitrary bases for ec_lincomb (curve.py:38-44): canonical x||y LE,
+ *                       (0,0) encodes the identity (py_ecc None).
+ * plonk_g1_msm          ec_lincomb / lincomb / multisubset, curve.py:38-111, i.e. the body of
+ *                       Setup.commit after its ifft (setup.py:66-72).  Pippenger over a fixed-base
+ *                       window table; `batch` scalar vectors share the bases.  Scalars are device Fr
+ *                       (Montgomery), vector b starts at d_scalars + b*scalar_stride elements and
+ *                       uses the first n bases.  Output: batch x 64 B canonical affine x||y LE and
+ *                       batch identity flags (1 = identity, coordinates then zero).               */
+int plonk_srs_load_ptau(plonk_ctx* ctx, const uint8_t* g1_mont_le, size_t n_points, plonk_srs** out_srs);
+int plonk_srs_load_affine(plonk_ctx* ctx, const uint8_t* xy_le, size_t n_points, plonk_srs** out_srs);
+int plonk_srs_free(plonk_ctx* ctx, plonk_srs* srs);
+int plonk_srs_size(const plonk_srs* srs, size_t* out_n);
+int plonk_g1_msm(plonk_ctx* ctx, plonk_srs* srs, const void* d_scalars, size_t n, size_t batch,
+                 size_t scalar_stride, uint8_t* h_out_xy_le, uint8_t* h_out_is_identity);
+/* tuning knobs (0 = library default): window bits c and window-groups per MSM */
+int plonk_msm_configure(plonk_ctx* ctx, unsigned window_bits, unsigned groups);
+
+/* ---- timing support for bench.py (HIP events on the context's stream) ------------------------ */
+int plonk_timer_start(plonk_ctx* ctx);
+int plonk_timer_stop_ms(plonk_ctx* ctx, float* out_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PLONK_HIP_H */

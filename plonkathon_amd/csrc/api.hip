@@ -1,0 +1,424 @@
+// api.hip — the extern "C" surface declared in include/plonk_hip.h: context, device memory,
+// conversions and the thin wrappers that turn one reference-level operation into kernel launches.
+#include <string.h>
+
+#include "plonk_internal.h"
+
+static thread_local char g_err[512] = "";
+
+void plonk_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+
+int ctx_scratch(plonk_ctx* ctx, int slot, size_t bytes, void** out) {
+    if (ctx->scratch_bytes[slot] < bytes) {
+        if (ctx->scratch[slot]) {
+            // the old buffer may still be in use by enqueued kernels
+            PLONK_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+            hipFree(ctx->scratch[slot]);
+            ctx->scratch[slot] = nullptr;
+            ctx->scratch_bytes[slot] = 0;
+        }
+        size_t want = bytes + bytes / 4;
+        void* p = nullptr;
+        if (hipMalloc(&p, want) != hipSuccess) {
+            plonk_set_error("hipMalloc of %zu scratch bytes failed", want);
+            return PLONK_ERR_NOMEM;
+        }
+        ctx->scratch[slot] = p;
+        ctx->scratch_bytes[slot] = want;
+    }
+    *out = ctx->scratch[slot];
+    return PLONK_OK;
+}
+
+static Fr fr_from_le32(const uint8_t* b) {
+    Fr a;
+    memcpy(a.v, b, 32);
+    return fp_to_mont(a);
+}
+
+static bool le32_below_modulus(const uint8_t* b, bool fq) {
+    uint32_t v[8];
+    memcpy(v, b, 32);
+    for (int i = 7; i >= 0; i--) {
+        uint32_t m = fq ? FqParams::mod(i) : FrParams::mod(i);
+        if (v[i] < m) return true;
+        if (v[i] > m) return false;
+    }
+    return false;
+}
+
+extern "C" {
+
+const char* plonk_last_error(void) { return g_err; }
+int plonk_abi_version(void) { return PLONK_ABI_VERSION; }
+
+int plonk_device_count(int* out_count) {
+    PLONK_REQUIRE(out_count, PLONK_ERR_ARG, "out_count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) n = 0;
+    *out_count = n;
+    return PLONK_OK;
+}
+
+int plonk_ctx_create(int device, plonk_ctx** out_ctx) {
+    PLONK_REQUIRE(out_ctx, PLONK_ERR_ARG, "out_ctx is NULL");
+    int n = 0;
+    PLONK_CHECK_HIP(hipGetDeviceCount(&n));
+    PLONK_REQUIRE(device >= 0 && device < n, PLONK_ERR_ARG, "device %d out of range (%d visible)", device, n);
+    PLONK_CHECK_HIP(hipSetDevice(device));
+    plonk_ctx* ctx = new plonk_ctx();
+    ctx->device = device;
+    PLONK_CHECK_HIP(hipStreamCreate(&ctx->stream));
+    PLONK_CHECK_HIP(hipEventCreate(&ctx->ev_a));
+    PLONK_CHECK_HIP(hipEventCreate(&ctx->ev_b));
+    *out_ctx = ctx;
+    return PLONK_OK;
+}
+
+int plonk_ctx_destroy(plonk_ctx* ctx) {
+    if (!ctx) return PLONK_OK;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    for (void* p : ctx->owned) hipFree(p);
+    for (auto& kv : ctx->power_tables) hipFree(kv.second);
+    for (int s = 0; s < PLONK_SCRATCH_SLOTS; s++)
+        if (ctx->scratch[s]) hipFree(ctx->scratch[s]);
+    hipEventDestroy(ctx->ev_a);
+    hipEventDestroy(ctx->ev_b);
+    hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return PLONK_OK;
+}
+
+int plonk_ctx_sync(plonk_ctx* ctx) {
+    PLONK_REQUIRE(ctx, PLONK_ERR_ARG, "ctx is NULL");
+    PLONK_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    return PLONK_OK;
+}
+
+int plonk_ctx_device_name(plonk_ctx* ctx, char* buf, size_t buf_len) {
+    PLONK_REQUIRE(ctx && buf && buf_len, PLONK_ERR_ARG, "bad argument");
+    hipDeviceProp_t prop;
+    PLONK_CHECK_HIP(hipGetDeviceProperties(&prop, ctx->device));
+    snprintf(buf, buf_len, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    return PLONK_OK;
+}
+
+// ---- memory ------------------------------------------------------------------------------------
+int plonk_mem_alloc(plonk_ctx* ctx, size_t bytes, void** out_dptr) {
+    PLONK_REQUIRE(ctx && out_dptr, PLONK_ERR_ARG, "bad argument");
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes ? bytes : 32) != hipSuccess) {
+        plonk_set_error("hipMalloc(%zu) failed", bytes);
+        return PLONK_ERR_NOMEM;
+    }
+    *out_dptr = p;
+    return PLONK_OK;
+}
+int plonk_mem_free(plonk_ctx* ctx, void* dptr) {
+    PLONK_REQUIRE(ctx, PLONK_ERR_ARG, "ctx is NULL");
+    if (dptr) PLONK_CHECK_HIP(hipFree(dptr));
+    return PLONK_OK;
+}
+int plonk_mem_h2d(plonk_ctx* ctx, void* d_dst, const void* h_src, size_t bytes) {
+    PLONK_REQUIRE(ctx && (bytes == 0 || (d_dst && h_src)), PLONK_ERR_ARG, "bad argument");
+    if (!bytes) return PLONK_OK;
+    PLONK_CHECK_HIP(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    PLONK_CHECK_HIP(hipStreamSynchronize(ctx->stream));  // the caller's buffer is not retained
+    return PLONK_OK;
+}
+int plonk_mem_d2h(plonk_ctx* ctx, void* h_dst, const void* d_src, size_t bytes) {
+    PLONK_REQUIRE(ctx && (bytes == 0 || (h_dst && d_src)), PLONK_ERR_ARG, "bad argument");
+    if (!bytes) return PLONK_OK;
+    PLONK_CHECK_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    PLONK_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    return PLONK_OK;
+}
+int plonk_mem_d2d(plonk_ctx* ctx, void* d_dst, const void* d_src, size_t bytes) {
+    PLONK_REQUIRE(ctx && (bytes == 0 || (d_dst && d_src)), PLONK_ERR_ARG, "bad argument");
+    if (!bytes) return PLONK_OK;
+    PLONK_CHECK_HIP(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return PLONK_OK;
+}
+int plonk_mem_zero(plonk_ctx* ctx, void* d_dst, size_t bytes) {
+    PLONK_REQUIRE(ctx && (bytes == 0 || d_dst), PLONK_ERR_ARG, "bad argument");
+    if (!bytes) return PLONK_OK;
+    PLONK_CHECK_HIP(hipMemsetAsync(d_dst, 0, bytes, ctx->stream));
+    return PLONK_OK;
+}
+
+// ---- Fr vectors --------------------------------------------------------------------------------
+int plonk_fr_upload(plonk_ctx* ctx, void* d_dst, const uint8_t* h_src_le32, size_t count) {
+    PLONK_REQUIRE(ctx && (count == 0 || (d_dst && h_src_le32)), PLONK_ERR_ARG, "bad argument");
+    if (!count) return PLONK_OK;
+    for (size_t i = 0; i < count; i++)
+        PLONK_REQUIRE(le32_below_modulus(h_src_le32 + 32 * i, false), PLONK_ERR_ARG,
+                      "element %zu is not a canonical Fr value (>= r)", i);
+    PLONK_CHECK_HIP(hipMemcpyAsync(d_dst, h_src_le32, count * 32, hipMemcpyHostToDevice, ctx->stream));
+    PLONK_TRY(k_fr_to_mont(ctx, (const Fr*)d_dst, (Fr*)d_dst, count));
+    PLONK_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    return PLONK_OK;
+}
+
+int plonk_fr_download(plonk_ctx* ctx, uint8_t* h_dst_le32, const void* d_src, size_t count) {
+    PLONK_REQUIRE(ctx && (count == 0 || (h_dst_le32 && d_src)), PLONK_ERR_ARG, "bad argument");
+    if (!count) return PLONK_OK;
+    void* tmp;
+    PLONK_TRY(ctx_scratch(ctx, 3, count * 32, &tmp));
+    PLONK_TRY(k_fr_from_mont(ctx, (const Fr*)d_src, (Fr*)tmp, count));
+    PLONK_CHECK_HIP(hipMemcpyAsync(h_dst_le32, tmp, count * 32, hipMemcpyDeviceToHost, ctx->stream));
+    PLONK_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    return PLONK_OK;
+}
+
+// ---- NTT family --------------------------------------------------------------------------------
+int plonk_ntt_configure(plonk_ctx* ctx, unsigned tile_log, unsigned single_pass_log, unsigned radix_log) {
+    PLONK_REQUIRE(ctx, PLONK_ERR_ARG, "ctx is NULL");
+    if (!tile_log) tile_log = 12;
+    if (!single_pass_log) single_pass_log = 11;
+    if (!radix_log) radix_log = 10;
+    PLONK_REQUIRE(tile_log >= 2 && tile_log <= 12, PLONK_ERR_ARG, "tile_log must be in [2, 12]");
+    PLONK_REQUIRE(single_pass_log <= 11 && single_pass_log <= tile_log, PLONK_ERR_ARG, "single_pass_log must be <= min(11, tile_log)");
+    PLONK_REQUIRE(radix_log >= 1 && radix_log <= 10 && radix_log <= tile_log, PLONK_ERR_ARG, "radix_log must be in [1, min(10, tile_log)]");
+    ctx->ntt_tile_log = tile_log;
+    ctx->ntt_single_log = single_pass_log;
+    ctx->ntt_radix_log = radix_log;
+    return PLONK_OK;
+}
+
+int plonk_fr_ntt(plonk_ctx* ctx, const void* d_in, void* d_out, unsigned log_n, int inverse, size_t batch) {
+    PLONK_REQUIRE(ctx && d_in && d_out, PLONK_ERR_ARG, "bad argument");
+    const size_t N = (size_t)1 << log_n;
+    return ntt_run(ctx, (const Fr*)d_in, (Fr*)d_out, log_n, inverse != 0, batch, N, N, N, nullptr, nullptr, inverse != 0);
+}
+
+// power table first * base^i, i < n, cached per (base, first, n)
+static int get_power_table(plonk_ctx* ctx, const Fr& base, const Fr& first, size_t n, const Fr** out) {
+    std::string key((const char*)base.v, 32);
+    key.append((const char*)first.v, 32);
+    key.append((const char*)&n, sizeof n);
+    auto it = ctx->power_tables.find(key);
+    if (it == ctx->power_tables.end()) {
+        if (ctx->power_tables.size() >= 64) {  // bound the cache: offsets are per-proof challenges in API mode
+            PLONK_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+            for (auto& kv : ctx->power_tables) hipFree(kv.second);
+            ctx->power_tables.clear();
+        }
+        void* p = nullptr;
+        if (hipMalloc(&p, n * sizeof(Fr)) != hipSuccess) {
+            plonk_set_error("hipMalloc of a %zu-entry power table failed", n);
+            return PLONK_ERR_NOMEM;
+        }
+        PLONK_TRY(k_fr_powers(ctx, base, first, (Fr*)p, n));
+        it = ctx->power_tables.emplace(key, (Fr*)p).first;
+    }
+    *out = it->second;
+    return PLONK_OK;
+}
+
+int plonk_fr_coset_ntt_from_coeffs(plonk_ctx* ctx, const void* d_coeffs, void* d_out, unsigned log_n,
+                                   unsigned log_expand, const uint8_t offset_le32[32], size_t batch) {
+    PLONK_REQUIRE(ctx && d_coeffs && d_out && offset_le32, PLONK_ERR_ARG, "bad argument");
+    PLONK_REQUIRE(le32_below_modulus(offset_le32, false), PLONK_ERR_ARG, "offset is not a canonical Fr value");
+    const size_t n = (size_t)1 << log_n, big = n << log_expand;
+    const Fr* pw;
+    PLONK_TRY(get_power_table(ctx, fr_from_le32(offset_le32), fp_one<FrParams>(), n, &pw));
+    // coefficients c_i * offset^i, zero-padded to 2^(log_n+log_expand), forward NTT     poly.py:160-163
+    return ntt_run(ctx, (const Fr*)d_coeffs, (Fr*)d_out, log_n + log_expand, false, batch, n, n, big, pw, nullptr, false);
+}
+
+int plonk_fr_coset_extend(plonk_ctx* ctx, const void* d_in, void* d_out, unsigned log_n,
+                          const uint8_t offset_le32[32], size_t batch) {
+    PLONK_REQUIRE(ctx && d_in && d_out && offset_le32, PLONK_ERR_ARG, "bad argument");
+    const size_t n = (size_t)1 << log_n;
+    void* coeffs;
+    PLONK_TRY(ctx_scratch(ctx, 2, batch * n * sizeof(Fr), &coeffs));
+    // poly.py:159 — ifft to coefficients first
+    PLONK_TRY(ntt_run(ctx, (const Fr*)d_in, (Fr*)coeffs, log_n, true, batch, n, n, n, nullptr, nullptr, true));
+    return plonk_fr_coset_ntt_from_coeffs(ctx, coeffs, d_out, log_n, 2, offset_le32, batch);
+}
+
+int plonk_fr_coset_to_coeffs(plonk_ctx* ctx, const void* d_in, void* d_out, unsigned log_m,
+                             const uint8_t offset_le32[32], size_t batch) {
+    PLONK_REQUIRE(ctx && d_in && d_out && offset_le32, PLONK_ERR_ARG, "bad argument");
+    PLONK_REQUIRE(le32_below_modulus(offset_le32, false), PLONK_ERR_ARG, "offset is not a canonical Fr value");
+    const size_t M = (size_t)1 << log_m;
+    // poly.py:172-176 — ifft, then v_i * (1/offset)^i; the 1/M of the ifft is folded into the table
+    Fr inv_off = fp_inv(fr_from_le32(offset_le32));
+    Fr m_mont = fp_zero<FrParams>();
+    m_mont.v[0] = (uint32_t)M;
+    m_mont.v[1] = (uint32_t)((uint64_t)M >> 32);
+    Fr m_inv = fp_inv(fp_to_mont(m_mont));
+    const Fr* pw;
+    PLONK_TRY(get_power_table(ctx, inv_off, m_inv, M, &pw));
+    return ntt_run(ctx, (const Fr*)d_in, (Fr*)d_out, log_m, true, batch, M, M, M, nullptr, pw, false);
+}
+
+// ---- pointwise ---------------------------------------------------------------------------------
+int plonk_fr_pointwise(plonk_ctx* ctx, int op, const void* d_a, const void* d_b, void* d_out, size_t count) {
+    PLONK_REQUIRE(ctx && (count == 0 || (d_a && d_b && d_out)), PLONK_ERR_ARG, "bad argument");
+    PLONK_REQUIRE(op >= PLONK_OP_ADD && op <= PLONK_OP_DIV, PLONK_ERR_ARG, "unknown pointwise op %d", op);
+    if (op == PLONK_OP_DIV) {
+        void* inv;
+        PLONK_TRY(ctx_scratch(ctx, 2, count * sizeof(Fr), &inv));
+        PLONK_TRY(k_fr_batch_inverse(ctx, (const Fr*)d_b, (Fr*)inv, count));
+        return k_fr_pointwise(ctx, PLONK_OP_MUL, (const Fr*)d_a, (const Fr*)inv, (Fr*)d_out, count);
+    }
+    return k_fr_pointwise(ctx, op, (const Fr*)d_a, (const Fr*)d_b, (Fr*)d_out, count);
+}
+
+int plonk_fr_scalar_op(plonk_ctx* ctx, int op, const void* d_a, const uint8_t scalar_le32[32], void* d_out,
+                       size_t count, int constant_term_only) {
+    PLONK_REQUIRE(ctx && scalar_le32 && (count == 0 || (d_a && d_out)), PLONK_ERR_ARG, "bad argument");
+    PLONK_REQUIRE(op >= PLONK_OP_ADD && op <= PLONK_OP_DIV, PLONK_ERR_ARG, "unknown scalar op %d", op);
+    PLONK_REQUIRE(le32_below_modulus(scalar_le32, false), PLONK_ERR_ARG, "scalar is not a canonical Fr value");
+    Fr s = fr_from_le32(scalar_le32);
+    if (op == PLONK_OP_DIV) {
+        s = fp_inv(s);  // x / 0 == 0
+        op = PLONK_OP_MUL;
+    }
+    return k_fr_pointwise_scalar(ctx, op, (const Fr*)d_a, s, (Fr*)d_out, count, constant_term_only ? 1 : count);
+}
+
+int plonk_fr_rotate(plonk_ctx* ctx, const void* d_in, void* d_out, size_t count, size_t shift) {
+    PLONK_REQUIRE(ctx && d_in && d_out && d_in != d_out, PLONK_ERR_ARG, "bad argument (rotate is out-of-place)");
+    PLONK_REQUIRE(shift < count, PLONK_ERR_ARG, "shift %zu must be < length %zu", shift, count);
+    return k_fr_rotate(ctx, (const Fr*)d_in, (Fr*)d_out, count, shift, 1);
+}
+
+int plonk_fr_batch_inverse(plonk_ctx* ctx, const void* d_in, void* d_out, size_t count) {
+    PLONK_REQUIRE(ctx && (count == 0 || (d_in && d_out)), PLONK_ERR_ARG, "bad argument");
+    return k_fr_batch_inverse(ctx, (const Fr*)d_in, (Fr*)d_out, count);
+}
+
+int plonk_fr_barycentric(plonk_ctx* ctx, const void* d_vals, unsigned log_n, const uint8_t x_le32[32],
+                         uint8_t out_le32[32]) {
+    PLONK_REQUIRE(ctx && d_vals && x_le32 && out_le32, PLONK_ERR_ARG, "bad argument");
+    PLONK_REQUIRE(log_n <= PLONK_FR_TWO_ADICITY, PLONK_ERR_ARG, "size 2^%u exceeds the 2-adicity of Fr", log_n);
+    PLONK_REQUIRE(le32_below_modulus(x_le32, false), PLONK_ERR_ARG, "x is not a canonical Fr value");
+    const Fr* roots;
+    PLONK_TRY(ntt_get_roots(ctx, log_n, false, &roots));
+    void* tmp;
+    PLONK_TRY(ctx_scratch(ctx, 2, 2 * sizeof(Fr), &tmp));
+    Fr* dx = (Fr*)tmp;
+    Fr x = fr_from_le32(x_le32);
+    PLONK_CHECK_HIP(hipMemcpyAsync(dx, &x, sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+    PLONK_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    Fr nn = fp_zero<FrParams>();
+    nn.v[0] = (uint32_t)((uint64_t)1 << log_n);
+    Fr n_inv = fp_inv(fp_to_mont(nn));
+    PLONK_TRY(k_fr_barycentric(ctx, (const Fr*)d_vals, roots, log_n, dx, 0, n_inv, dx + 1, 1));
+    PLONK_TRY(k_fr_from_mont(ctx, dx + 1, dx + 1, 1));
+    PLONK_CHECK_HIP(hipMemcpyAsync(out_le32, dx + 1, 32, hipMemcpyDeviceToHost, ctx->stream));
+    PLONK_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    return PLONK_OK;
+}
+
+// ---- G1 ----------------------------------------------------------------------------------------
+static int srs_alloc(plonk_ctx* ctx, size_t n_points, plonk_srs** out) {
+    plonk_srs* s = new plonk_srs();
+    s->n_points = n_points;
+    void* p = nullptr;
+    if (hipMalloc(&p, n_points * sizeof(G1Affine)) != hipSuccess) {
+        delete s;
+        plonk_set_error("hipMalloc of %zu G1 bases failed", n_points);
+        return PLONK_ERR_NOMEM;
+    }
+    s->bases = (G1Affine*)p;
+    *out = s;
+    (void)ctx;
+    return PLONK_OK;
+}
+
+int plonk_srs_load_ptau(plonk_ctx* ctx, const uint8_t* g1_mont_le, size_t n_points, plonk_srs** out_srs) {
+    PLONK_REQUIRE(ctx && g1_mont_le && out_srs && n_points, PLONK_ERR_ARG, "bad argument");
+    for (size_t i = 0; i < 2 * n_points; i++)  // setup.py:36 `assert max(values) < b.field_modulus`
+        PLONK_REQUIRE(le32_below_modulus(g1_mont_le + 32 * i, true), PLONK_ERR_ARG,
+                      "SRS coordinate %zu is >= the BN254 base-field modulus", i);
+    plonk_srs* s;
+    PLONK_TRY(srs_alloc(ctx, n_points, &s));
+    PLONK_CHECK_HIP(hipMemcpyAsync(s->bases, g1_mont_le, n_points * 64, hipMemcpyHostToDevice, ctx->stream));
+    PLONK_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    *out_srs = s;
+    return PLONK_OK;
+}
+
+int plonk_srs_load_affine(plonk_ctx* ctx, const uint8_t* xy_le, size_t n_points, plonk_srs** out_srs) {
+    PLONK_REQUIRE(ctx && xy_le && out_srs && n_points, PLONK_ERR_ARG, "bad argument");
+    std::vector<Fq> host(2 * n_points);
+    for (size_t i = 0; i < 2 * n_points; i++) {
+        PLONK_REQUIRE(le32_below_modulus(xy_le + 32 * i, true), PLONK_ERR_ARG,
+                      "coordinate %zu is >= the BN254 base-field modulus", i);
+        Fq a;
+        memcpy(a.v, xy_le + 32 * i, 32);
+        host[i] = fp_to_mont(a);  // host-side: API-mode lincombs are small
+    }
+    plonk_srs* s;
+    PLONK_TRY(srs_alloc(ctx, n_points, &s));
+    PLONK_CHECK_HIP(hipMemcpyAsync(s->bases, host.data(), n_points * 64, hipMemcpyHostToDevice, ctx->stream));
+    PLONK_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    *out_srs = s;
+    return PLONK_OK;
+}
+
+int plonk_srs_free(plonk_ctx* ctx, plonk_srs* srs) {
+    PLONK_REQUIRE(ctx, PLONK_ERR_ARG, "ctx is NULL");
+    if (!srs) return PLONK_OK;
+    PLONK_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    if (srs->bases) hipFree(srs->bases);
+    if (srs->table) hipFree(srs->table);
+    delete srs;
+    return PLONK_OK;
+}
+
+int plonk_srs_size(const plonk_srs* srs, size_t* out_n) {
+    PLONK_REQUIRE(srs && out_n, PLONK_ERR_ARG, "bad argument");
+    *out_n = srs->n_points;
+    return PLONK_OK;
+}
+
+int plonk_msm_configure(plonk_ctx* ctx, unsigned window_bits, unsigned groups) {
+    PLONK_REQUIRE(ctx, PLONK_ERR_ARG, "ctx is NULL");
+    PLONK_REQUIRE(window_bits == 0 || (window_bits >= 2 && window_bits <= 9), PLONK_ERR_ARG,
+                  "window_bits must be 0 (default) or in [2, 9]");
+    ctx->msm_window_bits = window_bits;
+    ctx->msm_groups = groups;
+    return PLONK_OK;
+}
+
+int plonk_g1_msm(plonk_ctx* ctx, plonk_srs* srs, const void* d_scalars, size_t n, size_t batch,
+                 size_t scalar_stride, uint8_t* h_out_xy_le, uint8_t* h_out_is_identity) {
+    PLONK_REQUIRE(ctx && srs && d_scalars && h_out_xy_le && h_out_is_identity, PLONK_ERR_ARG, "bad argument");
+    if (!batch) return PLONK_OK;
+    void* res;
+    PLONK_TRY(ctx_scratch(ctx, 2, batch * 64 + batch + 64, &res));
+    Fq* d_xy = (Fq*)res;
+    uint8_t* d_flags = (uint8_t*)res + batch * 64;
+    PLONK_TRY(msm_run_device(ctx, srs, (const Fr*)d_scalars, n, batch, scalar_stride, d_xy, d_flags));
+    PLONK_CHECK_HIP(hipMemcpyAsync(h_out_xy_le, d_xy, batch * 64, hipMemcpyDeviceToHost, ctx->stream));
+    PLONK_CHECK_HIP(hipMemcpyAsync(h_out_is_identity, d_flags, batch, hipMemcpyDeviceToHost, ctx->stream));
+    PLONK_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    return PLONK_OK;
+}
+
+// ---- timing ------------------------------------------------------------------------------------
+int plonk_timer_start(plonk_ctx* ctx) {
+    PLONK_REQUIRE(ctx, PLONK_ERR_ARG, "ctx is NULL");
+    PLONK_CHECK_HIP(hipEventRecord(ctx->ev_a, ctx->stream));
+    return PLONK_OK;
+}
+int plonk_timer_stop_ms(plonk_ctx* ctx, float* out_ms) {
+    PLONK_REQUIRE(ctx && out_ms, PLONK_ERR_ARG, "bad argument");
+    PLONK_CHECK_HIP(hipEventRecord(ctx->ev_b, ctx->stream));
+    PLONK_CHECK_HIP(hipEventSynchronize(ctx->ev_b));
+    PLONK_CHECK_HIP(hipEventElapsedTime(out_ms, ctx->ev_a, ctx->ev_b));
+    return PLONK_OK;
+}
+
+}  // extern "C"

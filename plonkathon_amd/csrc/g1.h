@@ -1,0 +1,139 @@
+// g1.h — BN254 G1 (y^2 = x^3 + 3 over Fq) group law for the MSM kernels.
+//
+// Replaces py_ecc.bn128 `add` / `double` / `multiply` as called from the reference's
+// `ec_lincomb` (/root/reference/curve.py:38-44).  py_ecc works on affine points with one field
+// inversion per addition; the group law is canonical, so any coordinate system gives the same
+// group element, and parity is defined on the unique affine representative produced at the very
+// end (g1_to_affine) — SURVEY.md Appendix B.
+//
+// Coordinates: bases are affine (x, y), 64 B, the .ptau layout (setup.py:29-41); the identity is
+// encoded as (0, 0), which is not on the curve (b = 3).  Accumulators are extended Jacobian
+// "XYZZ" (X, Y, ZZ, ZZZ) with x = X/ZZ, y = Y/ZZZ, ZZ^3 = ZZZ^2; identity <=> ZZ == 0.
+// Formulas: EFD short-Weierstrass xyzz add-2008-s (12M+2S), madd-2008-s (8M+2S), dbl-2008-s-1
+// (6M+4S for a = 0 ... counted as implemented below).  All exceptional cases (identity operands,
+// P == Q, P == -Q) are handled explicitly so `ec_lincomb` is correct for duplicate and cancelling
+// inputs as well as for the SRS.
+#pragma once
+#include "fp.h"
+
+struct alignas(16) G1Affine { Fq x, y; };
+struct alignas(16) G1Xyzz { Fq x, y, zz, zzz; };
+
+PLONK_HD bool g1_affine_is_identity(const G1Affine& p) { return fp_is_zero(p.x) && fp_is_zero(p.y); }
+PLONK_HD bool g1_is_identity(const G1Xyzz& p) { return fp_is_zero(p.zz); }
+
+PLONK_HD G1Xyzz g1_xyzz_identity() {
+    G1Xyzz r;
+    r.x = fp_zero<FqParams>(); r.y = fp_zero<FqParams>(); r.zz = fp_zero<FqParams>(); r.zzz = fp_zero<FqParams>();
+    return r;
+}
+PLONK_HD G1Affine g1_affine_identity() {
+    G1Affine r;
+    r.x = fp_zero<FqParams>(); r.y = fp_zero<FqParams>();
+    return r;
+}
+PLONK_HD G1Xyzz g1_xyzz_from_affine(const G1Affine& p) {
+    if (g1_affine_is_identity(p)) return g1_xyzz_identity();
+    G1Xyzz r;
+    r.x = p.x; r.y = p.y; r.zz = fp_one<FqParams>(); r.zzz = fp_one<FqParams>();
+    return r;
+}
+PLONK_HD G1Affine g1_affine_neg(const G1Affine& p) {
+    G1Affine r;
+    r.x = p.x; r.y = fp_neg(p.y);
+    return r;
+}
+
+// acc = 2*acc   (dbl-2008-s-1, a = 0)
+PLONK_HD void g1_dbl(G1Xyzz& p) {
+    if (g1_is_identity(p)) return;
+    Fq u = fp_dbl(p.y);
+    Fq v = fp_sqr(u);
+    Fq w = fp_mul(u, v);
+    Fq s = fp_mul(p.x, v);
+    Fq m = fp_mul3(fp_sqr(p.x));
+    Fq x3 = fp_sub(fp_sqr(m), fp_dbl(s));
+    Fq y3 = fp_sub(fp_mul(m, fp_sub(s, x3)), fp_mul(w, p.y));
+    p.zz = fp_mul(v, p.zz);
+    p.zzz = fp_mul(w, p.zzz);
+    p.x = x3;
+    p.y = y3;
+}
+
+// acc = 2*(affine q)   (mdbl-2008-s-1)
+PLONK_HD G1Xyzz g1_dbl_affine(const G1Affine& q) {
+    G1Xyzz r;
+    Fq u = fp_dbl(q.y);
+    r.zz = fp_sqr(u);
+    r.zzz = fp_mul(u, r.zz);
+    Fq s = fp_mul(q.x, r.zz);
+    Fq m = fp_mul3(fp_sqr(q.x));
+    r.x = fp_sub(fp_sqr(m), fp_dbl(s));
+    r.y = fp_sub(fp_mul(m, fp_sub(s, r.x)), fp_mul(r.zzz, q.y));
+    return r;
+}
+
+// acc += affine q   (madd-2008-s)
+PLONK_HD void g1_madd(G1Xyzz& p, const G1Affine& q) {
+    if (g1_affine_is_identity(q)) return;
+    if (g1_is_identity(p)) {
+        p.x = q.x; p.y = q.y; p.zz = fp_one<FqParams>(); p.zzz = fp_one<FqParams>();
+        return;
+    }
+    Fq u2 = fp_mul(q.x, p.zz);
+    Fq s2 = fp_mul(q.y, p.zzz);
+    Fq pp_ = fp_sub(u2, p.x);
+    Fq r = fp_sub(s2, p.y);
+    if (fp_is_zero(pp_)) {
+        if (fp_is_zero(r)) p = g1_dbl_affine(q);   // same point
+        else p = g1_xyzz_identity();               // opposite points
+        return;
+    }
+    Fq pp = fp_sqr(pp_);
+    Fq ppp = fp_mul(pp_, pp);
+    Fq qq = fp_mul(p.x, pp);
+    Fq x3 = fp_sub(fp_sub(fp_sqr(r), ppp), fp_dbl(qq));
+    Fq y3 = fp_sub(fp_mul(r, fp_sub(qq, x3)), fp_mul(p.y, ppp));
+    p.zz = fp_mul(p.zz, pp);
+    p.zzz = fp_mul(p.zzz, ppp);
+    p.x = x3;
+    p.y = y3;
+}
+
+// acc += xyzz q   (add-2008-s)
+PLONK_HD void g1_add(G1Xyzz& p, const G1Xyzz& q) {
+    if (g1_is_identity(q)) return;
+    if (g1_is_identity(p)) { p = q; return; }
+    Fq u1 = fp_mul(p.x, q.zz);
+    Fq u2 = fp_mul(q.x, p.zz);
+    Fq s1 = fp_mul(p.y, q.zzz);
+    Fq s2 = fp_mul(q.y, p.zzz);
+    Fq pp_ = fp_sub(u2, u1);
+    Fq r = fp_sub(s2, s1);
+    if (fp_is_zero(pp_)) {
+        if (fp_is_zero(r)) g1_dbl(p);
+        else p = g1_xyzz_identity();
+        return;
+    }
+    Fq pp = fp_sqr(pp_);
+    Fq ppp = fp_mul(pp_, pp);
+    Fq qq = fp_mul(u1, pp);
+    Fq x3 = fp_sub(fp_sub(fp_sqr(r), ppp), fp_dbl(qq));
+    Fq y3 = fp_sub(fp_mul(r, fp_sub(qq, x3)), fp_mul(s1, ppp));
+    p.zz = fp_mul(fp_mul(p.zz, q.zz), pp);
+    p.zzz = fp_mul(fp_mul(p.zzz, q.zzz), ppp);
+    p.x = x3;
+    p.y = y3;
+}
+
+// unique affine representative (Montgomery-form coordinates); identity -> (0, 0)
+PLONK_HD G1Affine g1_to_affine(const G1Xyzz& p) {
+    if (g1_is_identity(p)) return g1_affine_identity();
+    Fq t = fp_inv(fp_mul(p.zz, p.zzz));
+    Fq izz = fp_mul(t, p.zzz);
+    Fq izzz = fp_mul(t, p.zz);
+    G1Affine r;
+    r.x = fp_mul(p.x, izz);
+    r.y = fp_mul(p.y, izzz);
+    return r;
+}

@@ -1,0 +1,346 @@
+// ntt.hip — BN254-Fr number-theoretic transform engine (forward / inverse / coset), natural order
+// in and out, batched, any size 2^0 .. 2^28.
+//
+// Reference behaviour replaced: Polynomial.fft / ifft (/root/reference/poly.py:113-148, the
+// recursive `_fft` at 117-127), to_coset_extended_lagrange (poly.py:156-163) and
+// coset_extended_lagrange_to_coeffs (poly.py:169-177).  The transform is the plain DFT
+// X[k] = sum_j x[j] w^(jk), w = 5^((r-1)/N) (curve.py:14-16); the inverse uses w^-1 and 1/N.
+//
+// Algorithm: N = R1*R2*..*RP (P <= 3 passes, Ri <= 2^10 when P > 1, <= 2^11 for
+// a single pass).  Pass p runs Rp-point sub-transforms for a tile of C adjacent columns entirely in
+// LDS (tile of up to 4096 elements, stored as two 16-byte planes so unit-stride lanes are
+// bank-conflict-free), radix-2 Gentleman-Sande butterflies with the Rp/2 twiddles w_Rp^k staged in
+// LDS, then multiplies by the inter-pass twiddle w_N^(H*j*k) (two-level table: one extra
+// multiplication) on the way out.  Global accesses are chunks of C*32 B >= 128 B; the last pass
+// reads whole rows and performs the digit-reversing write that restores natural order, so no
+// separate transpose or bit-reversal kernel exists.  Coset scaling, zero padding, the 1/N factor
+// and the inverse-coset scaling are fused into the first-pass load / last-pass store.
+#include <string.h>
+
+#include "plonk_internal.h"
+
+// defaults live in plonk_ctx (ntt_tile_log = 12: 4096 elements = 128 KiB of LDS; ntt_single_log = 11;
+// ntt_radix_log = 10) and can be changed with plonk_ntt_configure for tuning / small-size tests.
+#define NTT_TW_LO_LOG 10
+
+struct NttPass {
+    const Fr* in;
+    Fr* out;
+    size_t in_bstride, out_bstride;
+    unsigned log_n, log_r, log_c;
+    unsigned log_h;  // product of the earlier passes' radices
+    unsigned log_s;  // element stride of this pass's digit
+    unsigned first, last;
+    unsigned in_len;
+    const Fr* small_tw;
+    const Fr* tw_lo;
+    const Fr* tw_hi;
+    const Fr* in_scale;
+    const Fr* out_scale;
+    Fr out_scalar;
+    unsigned has_out_scalar;
+    unsigned nprev;
+    unsigned prev_log_r[3];
+};
+
+PLONK_DEV unsigned bitrev(unsigned x, unsigned bits) { return bits ? (__brev(x) >> (32 - bits)) : 0; }
+
+PLONK_DEV Fr lds_ld(const u32x4* lo, const u32x4* hi, unsigned i) {
+    u32x4 a = lo[i], b = hi[i];
+    Fr r;
+    r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w;
+    r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
+    return r;
+}
+PLONK_DEV void lds_st(u32x4* lo, u32x4* hi, unsigned i, const Fr& a) {
+    lo[i] = u32x4{a.v[0], a.v[1], a.v[2], a.v[3]};
+    hi[i] = u32x4{a.v[4], a.v[5], a.v[6], a.v[7]};
+}
+
+__global__ void __launch_bounds__(1024) ntt_pass_kernel(NttPass p) {
+    PLONK_DYN_SMEM(smem);
+    const unsigned R = 1u << p.log_r, C = 1u << p.log_c;
+    const unsigned T = R * C;
+    // LDS index of tile element (r, c): column-interleaved for strided passes, padded rows for the
+    // row (last) pass so both the r-fastest load and the c-fastest store are conflict-free.
+    const unsigned row_pitch = p.last ? (R + (C > 1 ? 1 : 0)) : 0;
+    const unsigned t_pad = p.last ? row_pitch * C : T;
+    u32x4* d_lo = reinterpret_cast<u32x4*>(smem);
+    u32x4* d_hi = d_lo + t_pad;
+    u32x4* w_lo = d_hi + t_pad;
+    u32x4* w_hi = w_lo + (R / 2 ? R / 2 : 1);
+#define LIDX(r, c) (p.last ? ((c) * row_pitch + (r)) : (((r) << p.log_c) + (c)))
+
+    const unsigned tid = threadIdx.x, nthr = blockDim.x;
+    const Fr* in = p.in + (size_t)blockIdx.y * p.in_bstride;
+    Fr* out = p.out + (size_t)blockIdx.y * p.out_bstride;
+    const unsigned tile = blockIdx.x;
+
+    // tile coordinates
+    unsigned hi_idx = 0, cb = 0, kb = 0, rest = 0, log_r1 = 0;
+    size_t base = 0;
+    if (!p.last) {
+        const unsigned log_tiles_per_hi = p.log_s - p.log_c;
+        hi_idx = tile >> log_tiles_per_hi;
+        cb = tile & ((1u << log_tiles_per_hi) - 1);
+        base = ((size_t)hi_idx << (p.log_n - p.log_h)) + ((size_t)cb << p.log_c);
+    } else if (p.nprev) {
+        log_r1 = p.prev_log_r[0];
+        const unsigned log_kb = log_r1 - p.log_c;
+        kb = tile & ((1u << log_kb) - 1);
+        rest = tile >> log_kb;
+    }
+
+    // stage the pass's small twiddles
+    for (unsigned i = tid; i < R / 2; i += nthr) lds_st(w_lo, w_hi, i, fp_load(p.small_tw + i));
+
+    // load the tile
+    for (unsigned e = tid; e < T; e += nthr) {
+        unsigned r, c;
+        size_t g;
+        if (!p.last) {
+            c = e & (C - 1);
+            r = e >> p.log_c;
+            g = base + ((size_t)r << p.log_s) + c;
+        } else {
+            r = e & (R - 1);
+            c = e >> p.log_r;
+            size_t row = p.nprev ? ((((size_t)(kb << p.log_c) + c) << (p.log_h - log_r1)) + rest) : 0;
+            g = (row << p.log_r) + r;
+        }
+        Fr v;
+        if (p.first && g >= p.in_len) {
+            v = fp_zero<FrParams>();
+        } else {
+            v = fp_load(in + g);
+            if (p.first && p.in_scale) v = fp_mul(v, fp_load(p.in_scale + g));
+        }
+        lds_st(d_lo, d_hi, LIDX(r, c), v);
+    }
+    __syncthreads();
+
+    // radix-2 decimation-in-frequency stages: (a, b) -> (a + b, (a - b) * w)
+    const unsigned nbf = T / 2;
+    for (int lh = (int)p.log_r - 1; lh >= 0; lh--) {
+        const unsigned h = 1u << lh;
+        for (unsigned b = tid; b < nbf; b += nthr) {
+            unsigned c, bf;
+            if (!p.last) {
+                c = b & (C - 1);
+                bf = b >> p.log_c;
+            } else {
+                bf = b & (R / 2 - 1);
+                c = b >> (p.log_r - 1);
+            }
+            const unsigned off = bf & (h - 1);
+            const unsigned r0 = ((bf >> lh) << (lh + 1)) + off;
+            const unsigned i0 = LIDX(r0, c), i1 = LIDX(r0 + h, c);
+            Fr x = lds_ld(d_lo, d_hi, i0), y = lds_ld(d_lo, d_hi, i1);
+            Fr s = fp_add(x, y), d = fp_sub(x, y);
+            if (lh != 0) d = fp_mul(d, lds_ld(w_lo, w_hi, off << (p.log_r - 1 - lh)));
+            lds_st(d_lo, d_hi, i0, s);
+            lds_st(d_lo, d_hi, i1, d);
+        }
+        __syncthreads();
+    }
+
+    // store: frequency k of column c sits at row bitrev(k)
+    unsigned rev_rest = 0;
+    if (p.last && p.nprev > 1) {
+        unsigned rr = rest, weight = p.prev_log_r[0];
+        // rest = (k2, .., k_{P-1}) with k_{P-1} least significant; output weight of k_q is R1*..*R_{q-1}
+        unsigned w_of[3] = {0, 0, 0};
+        for (unsigned q = 1; q < p.nprev; q++) { w_of[q] = weight; weight += p.prev_log_r[q]; }
+        for (int q = (int)p.nprev - 1; q >= 1; q--) {
+            unsigned kq = rr & ((1u << p.prev_log_r[q]) - 1);
+            rr >>= p.prev_log_r[q];
+            rev_rest += kq << w_of[q];
+        }
+    }
+    for (unsigned e = tid; e < T; e += nthr) {
+        const unsigned c = e & (C - 1);
+        const unsigned k = e >> p.log_c;
+        Fr v = lds_ld(d_lo, d_hi, LIDX(bitrev(k, p.log_r), c));
+        if (!p.last) {
+            const size_t jrest = ((size_t)cb << p.log_c) + c;
+            const size_t ex = (jrest * k) << p.log_h;  // < N
+            if (ex) {
+                Fr tw = fp_load(p.tw_lo + (ex & ((1u << NTT_TW_LO_LOG) - 1)));
+                if (p.log_n > NTT_TW_LO_LOG) tw = fp_mul(tw, fp_load(p.tw_hi + (ex >> NTT_TW_LO_LOG)));
+                v = fp_mul(v, tw);
+            }
+            fp_store(out + base + ((size_t)k << p.log_s) + c, v);
+        } else {
+            size_t o = p.nprev ? (((size_t)(kb << p.log_c) + c) + rev_rest + ((size_t)k << p.log_h)) : k;
+            if (p.out_scale) v = fp_mul(v, fp_load(p.out_scale + o));
+            if (p.has_out_scalar) v = fp_mul(v, p.out_scalar);
+            fp_store(out + o, v);
+        }
+    }
+#undef LIDX
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side: roots of unity, cached tables, pass planning
+
+static Fr host_fr_from_u64(uint64_t x) {
+    Fr a = fp_zero<FrParams>();
+    a.v[0] = (uint32_t)x;
+    a.v[1] = (uint32_t)(x >> 32);
+    return fp_to_mont(a);
+}
+
+Fr host_root_of_unity(unsigned log_n, bool inverse) {
+    Fr w;
+    for (int i = 0; i < 8; i++) w.v[i] = inverse ? FrRoots::w28_inv(i) : FrRoots::w28(i);
+    for (unsigned i = log_n; i < PLONK_FR_TWO_ADICITY; i++) w = fp_sqr(w);
+    return w;
+}
+
+static int alloc_table(plonk_ctx* ctx, size_t n, Fr** out) {
+    void* p = nullptr;
+    if (hipMalloc(&p, (n ? n : 1) * sizeof(Fr)) != hipSuccess) {
+        plonk_set_error("hipMalloc of %zu-entry twiddle table failed", n);
+        return PLONK_ERR_NOMEM;
+    }
+    ctx->owned.push_back(p);
+    *out = (Fr*)p;
+    return PLONK_OK;
+}
+
+static int get_small_tw(plonk_ctx* ctx, unsigned log_r, bool inverse, const Fr** out) {
+    unsigned key = log_r | (inverse ? 256u : 0u);
+    auto it = ctx->tw.small.find(key);
+    if (it == ctx->tw.small.end()) {
+        Fr* t;
+        size_t n = log_r ? ((size_t)1 << (log_r - 1)) : 1;
+        PLONK_TRY(alloc_table(ctx, n, &t));
+        PLONK_TRY(k_fr_powers(ctx, host_root_of_unity(log_r, inverse), fp_one<FrParams>(), t, n));
+        it = ctx->tw.small.emplace(key, t).first;
+    }
+    *out = it->second;
+    return PLONK_OK;
+}
+
+static int get_lo_hi(plonk_ctx* ctx, unsigned log_n, bool inverse, const Fr** lo, const Fr** hi) {
+    unsigned key = log_n | (inverse ? 256u : 0u);
+    auto it = ctx->tw.lo.find(key);
+    if (it == ctx->tw.lo.end()) {
+        Fr w = host_root_of_unity(log_n, inverse);
+        unsigned log_lo = log_n < NTT_TW_LO_LOG ? log_n : NTT_TW_LO_LOG;
+        Fr *tl, *th;
+        PLONK_TRY(alloc_table(ctx, (size_t)1 << log_lo, &tl));
+        PLONK_TRY(k_fr_powers(ctx, w, fp_one<FrParams>(), tl, (size_t)1 << log_lo));
+        size_t nhi = log_n > NTT_TW_LO_LOG ? ((size_t)1 << (log_n - NTT_TW_LO_LOG)) : 1;
+        Fr whi = w;
+        for (unsigned i = 0; i < NTT_TW_LO_LOG; i++) whi = fp_sqr(whi);
+        PLONK_TRY(alloc_table(ctx, nhi, &th));
+        PLONK_TRY(k_fr_powers(ctx, whi, fp_one<FrParams>(), th, nhi));
+        ctx->tw.lo.emplace(key, tl);
+        ctx->tw.hi.emplace(key, th);
+        it = ctx->tw.lo.find(key);
+    }
+    *lo = it->second;
+    *hi = ctx->tw.hi[key];
+    return PLONK_OK;
+}
+
+// full table w^0 .. w^(N-1) (barycentric evaluation, permutation argument)
+int ntt_get_roots(plonk_ctx* ctx, unsigned log_n, bool inverse, const Fr** out) {
+    unsigned key = log_n | (inverse ? 256u : 0u);
+    auto it = ctx->tw.full.find(key);
+    if (it == ctx->tw.full.end()) {
+        Fr* t;
+        PLONK_TRY(alloc_table(ctx, (size_t)1 << log_n, &t));
+        PLONK_TRY(k_fr_powers(ctx, host_root_of_unity(log_n, inverse), fp_one<FrParams>(), t, (size_t)1 << log_n));
+        it = ctx->tw.full.emplace(key, t).first;
+    }
+    *out = it->second;
+    return PLONK_OK;
+}
+
+// pass radices, most significant digit first
+static unsigned plan_passes(const plonk_ctx* ctx, unsigned log_n, unsigned radices[4]) {
+    if (log_n <= ctx->ntt_single_log) {
+        radices[0] = log_n;
+        return 1;
+    }
+    unsigned P = (log_n + ctx->ntt_radix_log - 1) / ctx->ntt_radix_log;
+    if (P < 2) P = 2;
+    unsigned base = log_n / P, extra = log_n % P;
+    for (unsigned i = 0; i < P; i++) radices[i] = base + (i < extra ? 1 : 0);
+    return P;
+}
+
+int ntt_run(plonk_ctx* ctx, const Fr* in, Fr* out, unsigned log_n, bool inverse, size_t batch, size_t in_len,
+            size_t in_bstride, size_t out_bstride, const Fr* in_scale, const Fr* out_scale, bool scale_by_n_inv) {
+    PLONK_REQUIRE(log_n <= PLONK_FR_TWO_ADICITY, PLONK_ERR_ARG, "NTT size 2^%u exceeds the 2-adicity (28) of BN254 Fr", log_n);
+    if (!batch) return PLONK_OK;
+    PLONK_REQUIRE(batch <= 65535, PLONK_ERR_ARG, "NTT batch %zu exceeds 65535", batch);
+    const size_t N = (size_t)1 << log_n;
+    unsigned radices[4];
+    const unsigned P = plan_passes(ctx, log_n, radices);
+    PLONK_REQUIRE(P <= 4, PLONK_ERR_ARG, "NTT of size 2^%u needs %u passes at radix 2^%u (max 4)", log_n, P, ctx->ntt_radix_log);
+
+    Fr* tmp = nullptr;
+    if (P > 1) {
+        void* s;
+        PLONK_TRY(ctx_scratch(ctx, 0, batch * N * sizeof(Fr), &s));
+        tmp = (Fr*)s;
+    }
+    const Fr *lo = nullptr, *hi = nullptr;
+    if (P > 1) PLONK_TRY(get_lo_hi(ctx, log_n, inverse, &lo, &hi));
+
+    unsigned log_h = 0;
+    for (unsigned pi = 0; pi < P; pi++) {
+        NttPass p;
+        memset(&p, 0, sizeof p);
+        const bool first = pi == 0, last = pi == P - 1;
+        p.in = first ? in : tmp;
+        p.out = last ? out : tmp;
+        p.in_bstride = first ? in_bstride : N;
+        p.out_bstride = last ? out_bstride : N;
+        p.log_n = log_n;
+        p.log_r = radices[pi];
+        p.log_h = log_h;
+        p.log_s = log_n - log_h - p.log_r;
+        p.first = first;
+        p.last = last;
+        p.in_len = (unsigned)(in_len < N ? in_len : N);
+        unsigned log_c = ctx->ntt_tile_log > p.log_r ? ctx->ntt_tile_log - p.log_r : 0;
+        unsigned avail = last ? (P > 1 ? radices[0] : 0) : p.log_s;
+        if (log_c > avail) log_c = avail;
+        p.log_c = log_c;
+        PLONK_TRY(get_small_tw(ctx, p.log_r, inverse, &p.small_tw));
+        p.tw_lo = lo;
+        p.tw_hi = hi;
+        p.in_scale = first ? in_scale : nullptr;
+        p.out_scale = last ? out_scale : nullptr;
+        if (last && scale_by_n_inv) {
+            Fr nn = host_fr_from_u64((uint64_t)N);
+            p.out_scalar = fp_inv(nn);
+            p.has_out_scalar = 1;
+        }
+        p.nprev = last ? pi : 0;
+        for (unsigned q = 0; q < pi && q < 3; q++) p.prev_log_r[q] = radices[q];
+
+        const unsigned R = 1u << p.log_r, C = 1u << p.log_c, T = R * C;
+        unsigned nthr = T / 4;
+        if (nthr < 64) nthr = 64;
+        if (nthr > 1024) nthr = 1024;
+        const unsigned row_pitch = last ? (R + (C > 1 ? 1 : 0)) : 0;
+        const size_t t_pad = last ? (size_t)row_pitch * C : T;
+        const size_t shmem = 32 * t_pad + 32 * (size_t)(R / 2 ? R / 2 : 1);
+        const size_t tiles = N / T;
+        static size_t configured = 0;
+        if (shmem > configured) {
+            PLONK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ntt_pass_kernel),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
+            configured = 160 * 1024;
+        }
+        PLONK_LAUNCH(ntt_pass_kernel, dim3((unsigned)tiles, (unsigned)batch), dim3(nthr), shmem, ctx->stream, p);
+        PLONK_CHECK_HIP(hipGetLastError());
+        log_h += p.log_r;
+    }
+    return PLONK_OK;
+}

@@ -1,0 +1,90 @@
+// plonk_internal.h — context object and helpers shared by the C-ABI implementation files.
+#pragma once
+#include <stdarg.h>
+#include <stdio.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/plonk_hip.h"
+#include "fp.h"
+#include "g1.h"
+
+void plonk_set_error(const char* fmt, ...);
+
+#define PLONK_CHECK_HIP(expr)                                                                     \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess) {                                                                   \
+            plonk_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return PLONK_ERR_HIP;                                                                 \
+        }                                                                                         \
+    } while (0)
+
+#define PLONK_REQUIRE(cond, code, ...)    \
+    do {                                  \
+        if (!(cond)) {                    \
+            plonk_set_error(__VA_ARGS__); \
+            return (code);                \
+        }                                 \
+    } while (0)
+
+#define PLONK_TRY(expr)          \
+    do {                         \
+        int rc_ = (expr);        \
+        if (rc_ != PLONK_OK) return rc_; \
+    } while (0)
+
+struct NttTables {
+    // keys are log2(size) | inverse << 8
+    std::map<unsigned, Fr*> small;   // w_R^k, k < R/2              (per-pass LDS twiddles)
+    std::map<unsigned, Fr*> lo, hi;  // w_N^e = lo[e & 1023] * hi[e >> 10]   (inter-pass twiddles)
+    std::map<unsigned, Fr*> full;    // w_N^k, k < N                 (barycentric / permutation argument)
+};
+
+struct plonk_srs {
+    size_t n_points = 0;
+    G1Affine* bases = nullptr;  // device, Montgomery coordinates (.ptau layout)
+    unsigned window_bits = 0;   // c of the current window table (0 = not built)
+    unsigned n_windows = 0;
+    G1Affine* table = nullptr;  // device: table[w * n_points + i] = 2^(c*w) * bases[i]
+};
+
+#define PLONK_SCRATCH_SLOTS 4
+struct plonk_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    NttTables tw;
+    std::map<std::string, Fr*> power_tables;  // cached coset-offset power tables, keyed by (offset, n, kind)
+    std::vector<void*> owned;                 // device allocations released with the context
+    void* scratch[PLONK_SCRATCH_SLOTS] = {nullptr, nullptr, nullptr, nullptr};
+    size_t scratch_bytes[PLONK_SCRATCH_SLOTS] = {0, 0, 0, 0};
+    hipEvent_t ev_a = nullptr, ev_b = nullptr;
+    unsigned msm_window_bits = 0, msm_groups = 0;
+    unsigned ntt_tile_log = 12, ntt_single_log = 11, ntt_radix_log = 10;
+};
+
+// scratch slot use: 0 = NTT inter-pass buffer, 1 = MSM digits/partials, 2-3 = API-level temporaries
+int ctx_scratch(plonk_ctx* ctx, int slot, size_t bytes, void** out);
+
+// ---- enqueue helpers shared between translation units (all on ctx->stream) ---------------------
+// fr_ops.hip
+int k_fr_to_mont(plonk_ctx*, const Fr* in, Fr* out, size_t n);
+int k_fr_from_mont(plonk_ctx*, const Fr* in, Fr* out, size_t n);
+int k_fr_pointwise(plonk_ctx*, int op, const Fr* a, const Fr* b, Fr* out, size_t n);
+int k_fr_pointwise_scalar(plonk_ctx*, int op, const Fr* a, const Fr& s_mont, Fr* out, size_t n, size_t limit);
+int k_fr_batch_inverse(plonk_ctx*, const Fr* in, Fr* out, size_t n);
+int k_fr_powers(plonk_ctx*, const Fr& base_mont, const Fr& first_mont, Fr* out, size_t n);
+int k_fr_rotate(plonk_ctx*, const Fr* in, Fr* out, size_t n, size_t shift, size_t batch);
+int k_fr_barycentric(plonk_ctx*, const Fr* vals, const Fr* roots, unsigned log_n, const Fr* xs_dev, size_t x_stride,
+                     const Fr& n_inv_mont, Fr* out_dev, size_t n_polys);
+// ntt.hip
+Fr host_root_of_unity(unsigned log_n, bool inverse);
+int ntt_run(plonk_ctx*, const Fr* in, Fr* out, unsigned log_n, bool inverse, size_t batch, size_t in_len,
+            size_t in_bstride, size_t out_bstride, const Fr* in_scale, const Fr* out_scale, bool scale_by_n_inv);
+int ntt_get_roots(plonk_ctx*, unsigned log_n, bool inverse, const Fr** table_full);
+// msm.hip
+int msm_build_table(plonk_ctx*, plonk_srs*, unsigned c);
+int msm_run_device(plonk_ctx*, plonk_srs*, const Fr* d_scalars, size_t n, size_t M, size_t stride, Fq* d_out_xy,
+                   uint8_t* d_flags);

@@ -1,0 +1,63 @@
+// Host-side probe of the device field/curve primitives (fp.h / g1.h compiled with g++ via PLONK_EMU).
+// TEST INFRASTRUCTURE ONLY: lets tests/test_emu_primitives.py compare the primitives with Python ints.
+#include "fp.h"
+#include "g1.h"
+
+template <class P> static void binop(int op, const uint32_t* a, const uint32_t* b, uint32_t* out) {
+    Fp<P> x, y, r;
+    memcpy(x.v, a, 32);
+    memcpy(y.v, b, 32);
+    switch (op) {
+        case 0: r = fp_add(x, y); break;
+        case 1: r = fp_sub(x, y); break;
+        case 2: r = fp_mul(x, y); break;
+        case 3: r = fp_inv(x); break;
+        case 4: r = fp_to_mont(x); break;
+        case 5: r = fp_from_mont(x); break;
+        case 6: r = fp_neg(x); break;
+        case 7: r = fp_sqr(x); break;
+        default: r = fp_zero<P>();
+    }
+    memcpy(out, r.v, 32);
+}
+extern "C" void probe_fr(int op, const uint32_t* a, const uint32_t* b, uint32_t* out) { binop<FrParams>(op, a, b, out); }
+extern "C" void probe_fq(int op, const uint32_t* a, const uint32_t* b, uint32_t* out) { binop<FqParams>(op, a, b, out); }
+
+// points: affine in = 16 words (x,y Montgomery; (0,0) = identity); xyzz = 32 words
+extern "C" void probe_g1(int op, const uint32_t* p, const uint32_t* q, uint32_t* out) {
+    G1Xyzz acc;
+    G1Affine a, b2;
+    memcpy(&a, p, 64);
+    memcpy(&b2, q, 64);
+    switch (op) {
+        case 0:  // affine + affine through xyzz mixed add
+            acc = g1_xyzz_from_affine(a);
+            g1_madd(acc, b2);
+            break;
+        case 1:  // xyzz(a) + xyzz(b) full add
+            acc = g1_xyzz_from_affine(a);
+            g1_add(acc, g1_xyzz_from_affine(b2));
+            break;
+        case 2:  // double
+            acc = g1_xyzz_from_affine(a);
+            g1_dbl(acc);
+            break;
+        case 3: {  // (a+a) + b with non-trivial ZZ on the accumulator
+            acc = g1_xyzz_from_affine(a);
+            g1_dbl(acc);
+            g1_madd(acc, b2);
+            break;
+        }
+        case 4: {  // (2a) + (2b) full add with both ZZ non-trivial
+            acc = g1_xyzz_from_affine(a);
+            g1_dbl(acc);
+            G1Xyzz o = g1_xyzz_from_affine(b2);
+            g1_dbl(o);
+            g1_add(acc, o);
+            break;
+        }
+        default: acc = g1_xyzz_identity();
+    }
+    G1Affine r = g1_to_affine(acc);
+    memcpy(out, &r, 64);
+}
