@@ -122,8 +122,33 @@ int plonk_g1_msm(plonk_ctx* ctx, plonk_srs* srs, const void* d_scalars, size_t n
 /* tuning knobs (0 = library default): window bits c and window-groups per MSM */
 int plonk_msm_configure(plonk_ctx* ctx, unsigned window_bits, unsigned groups);
 
+/* ---- Fiat-Shamir transcript (host) ----------------------------------------------------------------
+ * Replaces `merlin.MerlinTranscript` (third-party) as subclassed by transcript.py:58-60:
+ *   plonk_transcript_new              MerlinTranscript(label)             (prover.py:53 uses b"plonk")
+ *   plonk_transcript_append_message   Transcript.append / append_message  transcript.py:59-67
+ *   plonk_transcript_challenge_bytes  MerlinTranscript.challenge_bytes    transcript.py:71
+ *   plonk_transcript_challenge_scalar Transcript.get_and_append_challenge transcript.py:69-75
+ *                                     (255 PRF bytes -> big-endian int mod r, retried while zero, then
+ *                                     the bytes are appended under the same label); canonical LE out. */
+typedef struct plonk_transcript plonk_transcript;
+int plonk_transcript_new(const uint8_t* label, size_t label_len, plonk_transcript** out);
+int plonk_transcript_clone(const plonk_transcript* t, plonk_transcript** out);
+int plonk_transcript_free(plonk_transcript* t);
+int plonk_transcript_append_message(plonk_transcript* t, const uint8_t* label, size_t label_len,
+                                    const uint8_t* msg, size_t msg_len);
+int plonk_transcript_challenge_bytes(plonk_transcript* t, const uint8_t* label, size_t label_len, uint8_t* out,
+                                     size_t n);
+int plonk_transcript_challenge_scalar(plonk_transcript* t, const uint8_t* label, size_t label_len,
+                                      uint8_t out_le32[32]);
+
 /* ---- timing support for bench.py (HIP events on the context's stream) ------------------------ */
 int plonk_timer_start(plonk_ctx* ctx);
+/* Per-kernel profiling: while enabled, each launch of an instrumented kernel ("msm_accumulate",
+ * "ntt_pass", ...) is bracketed by HIP events on the context's stream.  plonk_profile_read sums the
+ * durations, launch count and algorithmic bytes (SURVEY.md 8(d) figures) recorded for one kernel. */
+int plonk_profile_enable(plonk_ctx* ctx, int on);
+int plonk_profile_read(plonk_ctx* ctx, const char* kernel, double* total_ms, uint64_t* launches, double* algo_bytes);
+int plonk_profile_reset(plonk_ctx* ctx);
 int plonk_timer_stop_ms(plonk_ctx* ctx, float* out_ms);
 
 #ifdef __cplusplus

@@ -46,6 +46,15 @@ SIGNATURES = {
     "plonk_srs_size": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_size_t)]),
     "plonk_g1_msm": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]),
     "plonk_msm_configure": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint, ctypes.c_uint]),
+    "plonk_transcript_new": (ctypes.c_int, [_u8p, ctypes.c_size_t, c_void_pp]),
+    "plonk_transcript_clone": (ctypes.c_int, [ctypes.c_void_p, c_void_pp]),
+    "plonk_transcript_free": (ctypes.c_int, [ctypes.c_void_p]),
+    "plonk_transcript_append_message": (ctypes.c_int, [ctypes.c_void_p, _u8p, ctypes.c_size_t, _u8p, ctypes.c_size_t]),
+    "plonk_transcript_challenge_bytes": (ctypes.c_int, [ctypes.c_void_p, _u8p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t]),
+    "plonk_transcript_challenge_scalar": (ctypes.c_int, [ctypes.c_void_p, _u8p, ctypes.c_size_t, ctypes.c_void_p]),
+    "plonk_profile_enable": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    "plonk_profile_read": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_double)]),
+    "plonk_profile_reset": (ctypes.c_int, [ctypes.c_void_p]),
     "plonk_timer_start": (ctypes.c_int, [ctypes.c_void_p]),
     "plonk_timer_stop_ms": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]),
 }

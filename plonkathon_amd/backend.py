@@ -1,0 +1,113 @@
+"""Device context and buffer ownership for the Python host layer.
+
+One `Context` per (process, device) wraps a `plonk_ctx*`; `DeviceBuffer` owns one `plonk_mem_alloc`
+allocation and frees it when garbage collected (SURVEY.md §8(b) "Ownership").
+"""
+import ctypes
+import os
+
+from . import _lib
+from ._lib import check
+
+
+class Context:
+    def __init__(self, device=None):
+        L = _lib.lib()
+        if device is None:
+            device = int(os.environ.get("PLONK_HIP_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+        n = ctypes.c_int(0)
+        check(L.plonk_device_count(ctypes.byref(n)))
+        if n.value == 0:
+            raise _lib.BackendError("no HIP device visible: plonkathon_amd needs an MI355X (there is no CPU fallback)")
+        self.device = device % n.value
+        self.handle = ctypes.c_void_p()
+        check(L.plonk_ctx_create(self.device, ctypes.byref(self.handle)))
+        self.L = L
+
+    def name(self):
+        buf = ctypes.create_string_buffer(256)
+        check(self.L.plonk_ctx_device_name(self.handle, buf, 256))
+        return buf.value.decode()
+
+    def sync(self):
+        check(self.L.plonk_ctx_sync(self.handle))
+
+    def alloc(self, n_elems):
+        return DeviceBuffer(self, n_elems)
+
+    def upload_ints(self, ints):
+        buf = DeviceBuffer(self, len(ints))
+        if ints:
+            check(self.L.plonk_fr_upload(self.handle, buf.ptr, b"".join(int(v).to_bytes(32, "little") for v in ints), len(ints)))
+        return buf
+
+    def download_ints(self, buf, n=None, offset=0):
+        n = buf.n if n is None else n
+        if n == 0:
+            return []
+        out = ctypes.create_string_buffer(32 * n)
+        check(self.L.plonk_fr_download(self.handle, out, ctypes.c_void_p(buf.ptr.value + 32 * offset), n))
+        raw = out.raw
+        return [int.from_bytes(raw[32 * i : 32 * i + 32], "little") for i in range(n)]
+
+    def timer_start(self):
+        check(self.L.plonk_timer_start(self.handle))
+
+    def timer_stop_ms(self):
+        ms = ctypes.c_float(0)
+        check(self.L.plonk_timer_stop_ms(self.handle, ctypes.byref(ms)))
+        return ms.value
+
+    def profile(self, on):
+        check(self.L.plonk_profile_enable(self.handle, 1 if on else 0))
+
+    def profile_reset(self):
+        check(self.L.plonk_profile_reset(self.handle))
+
+    def profile_read(self, kernel):
+        """-> (total_ms, launches, algorithmic_bytes) recorded for `kernel` since the last reset."""
+        ms, n, by = ctypes.c_double(0), ctypes.c_uint64(0), ctypes.c_double(0)
+        check(self.L.plonk_profile_read(self.handle, kernel.encode(), ctypes.byref(ms), ctypes.byref(n), ctypes.byref(by)))
+        return ms.value, n.value, by.value
+
+    def close(self):
+        if self.handle:
+            self.L.plonk_ctx_destroy(self.handle)
+            self.handle = None
+
+
+class DeviceBuffer:
+    """`n` Fr elements (32 B each, Montgomery form) in HBM."""
+
+    def __init__(self, ctx, n_elems):
+        self.ctx = ctx
+        self.n = int(n_elems)
+        self.ptr = ctypes.c_void_p()
+        check(ctx.L.plonk_mem_alloc(ctx.handle, 32 * max(self.n, 1), ctypes.byref(self.ptr)))
+
+    def at(self, elem_offset):
+        return ctypes.c_void_p(self.ptr.value + 32 * elem_offset)
+
+    def __del__(self):
+        try:
+            if self.ptr and self.ctx.handle:
+                self.ctx.L.plonk_mem_free(self.ctx.handle, self.ptr)
+                self.ptr = None
+        except Exception:
+            pass
+
+
+_default = None
+
+
+def get_context():
+    """The process-wide default context (created on first use; raises without a GPU)."""
+    global _default
+    if _default is None:
+        _default = Context()
+    return _default
+
+
+def set_context(ctx):
+    global _default
+    _default = ctx

@@ -35,6 +35,34 @@ int ctx_scratch(plonk_ctx* ctx, int slot, size_t bytes, void** out) {
     return PLONK_OK;
 }
 
+static int prof_event(plonk_ctx* ctx, hipEvent_t* e) {
+    if (!ctx->event_pool.empty()) {
+        *e = ctx->event_pool.back();
+        ctx->event_pool.pop_back();
+        return PLONK_OK;
+    }
+    PLONK_CHECK_HIP(hipEventCreate(e));
+    return PLONK_OK;
+}
+
+int prof_begin(plonk_ctx* ctx, const char* name, double algo_bytes) {
+    if (!ctx->profiling) return PLONK_OK;
+    plonk_ctx::ProfRec r;
+    r.name = name;
+    r.algo_bytes = algo_bytes;
+    PLONK_TRY(prof_event(ctx, &r.a));
+    PLONK_TRY(prof_event(ctx, &r.b));
+    PLONK_CHECK_HIP(hipEventRecord(r.a, ctx->stream));
+    ctx->prof.push_back(r);
+    return PLONK_OK;
+}
+
+int prof_end(plonk_ctx* ctx) {
+    if (!ctx->profiling || ctx->prof.empty()) return PLONK_OK;
+    PLONK_CHECK_HIP(hipEventRecord(ctx->prof.back().b, ctx->stream));
+    return PLONK_OK;
+}
+
 static Fr fr_from_le32(const uint8_t* b) {
     Fr a;
     memcpy(a.v, b, 32);
@@ -89,6 +117,8 @@ int plonk_ctx_destroy(plonk_ctx* ctx) {
     for (auto& kv : ctx->power_tables) hipFree(kv.second);
     for (int s = 0; s < PLONK_SCRATCH_SLOTS; s++)
         if (ctx->scratch[s]) hipFree(ctx->scratch[s]);
+    for (auto& r : ctx->prof) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
+    for (auto e : ctx->event_pool) hipEventDestroy(e);
     hipEventDestroy(ctx->ev_a);
     hipEventDestroy(ctx->ev_b);
     hipStreamDestroy(ctx->stream);
@@ -404,6 +434,43 @@ int plonk_g1_msm(plonk_ctx* ctx, plonk_srs* srs, const void* d_scalars, size_t n
     PLONK_CHECK_HIP(hipMemcpyAsync(h_out_xy_le, d_xy, batch * 64, hipMemcpyDeviceToHost, ctx->stream));
     PLONK_CHECK_HIP(hipMemcpyAsync(h_out_is_identity, d_flags, batch, hipMemcpyDeviceToHost, ctx->stream));
     PLONK_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    return PLONK_OK;
+}
+
+// ---- per-kernel profiling ------------------------------------------------------------------------
+int plonk_profile_enable(plonk_ctx* ctx, int on) {
+    PLONK_REQUIRE(ctx, PLONK_ERR_ARG, "ctx is NULL");
+    ctx->profiling = on != 0;
+    return PLONK_OK;
+}
+
+int plonk_profile_read(plonk_ctx* ctx, const char* kernel, double* total_ms, uint64_t* launches, double* algo_bytes) {
+    PLONK_REQUIRE(ctx && kernel && total_ms && launches && algo_bytes, PLONK_ERR_ARG, "bad argument");
+    PLONK_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    double ms = 0, bytes = 0;
+    uint64_t n = 0;
+    for (auto& r : ctx->prof) {
+        if (strcmp(r.name, kernel) != 0) continue;
+        float t = 0;
+        PLONK_CHECK_HIP(hipEventElapsedTime(&t, r.a, r.b));
+        ms += t;
+        bytes += r.algo_bytes;
+        n++;
+    }
+    *total_ms = ms;
+    *launches = n;
+    *algo_bytes = bytes;
+    return PLONK_OK;
+}
+
+int plonk_profile_reset(plonk_ctx* ctx) {
+    PLONK_REQUIRE(ctx, PLONK_ERR_ARG, "ctx is NULL");
+    PLONK_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    for (auto& r : ctx->prof) {
+        ctx->event_pool.push_back(r.a);
+        ctx->event_pool.push_back(r.b);
+    }
+    ctx->prof.clear();
     return PLONK_OK;
 }
 

@@ -301,8 +301,11 @@ int msm_run_device(plonk_ctx* ctx, plonk_srs* srs, const Fr* d_scalars, size_t n
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
         configured = true;
     }
+    // algorithmic bytes of an MSM of size n: (64 + 32) * n + 64   
+    PLONK_TRY(prof_begin(ctx, "msm_accumulate", (double)M * (96.0 * (double)n + 64.0)));
     PLONK_LAUNCH(msm_accumulate_kernel, dim3((unsigned)(M * G)), dim3(MSM_BLOCK), shmem, ctx->stream,
                  (const G1Affine*)srs->table, srs->n_points, (const uint16_t*)digits, n, c, W, G, partial);
+    PLONK_TRY(prof_end(ctx));
     unsigned gf = (unsigned)((M + 63) / 64);
     PLONK_LAUNCH(msm_finalize_kernel, dim3(gf), dim3(64), 0, ctx->stream, (const G1Xyzz*)partial, M, G, d_out_xy, d_flags);
     PLONK_CHECK_HIP(hipGetLastError());

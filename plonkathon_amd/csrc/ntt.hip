@@ -338,7 +338,10 @@ int ntt_run(plonk_ctx* ctx, const Fr* in, Fr* out, unsigned log_n, bool inverse,
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
             configured = 160 * 1024;
         }
+        // algorithmic bytes of a size-N transform: 64 * N (read once, write once), split over its passes
+        PLONK_TRY(prof_begin(ctx, "ntt_pass", 64.0 * (double)N * (double)batch / (double)P));
         PLONK_LAUNCH(ntt_pass_kernel, dim3((unsigned)tiles, (unsigned)batch), dim3(nthr), shmem, ctx->stream, p);
+        PLONK_TRY(prof_end(ctx));
         PLONK_CHECK_HIP(hipGetLastError());
         log_h += p.log_r;
     }

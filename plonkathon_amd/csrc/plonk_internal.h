@@ -62,11 +62,19 @@ struct plonk_ctx {
     size_t scratch_bytes[PLONK_SCRATCH_SLOTS] = {0, 0, 0, 0};
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
     unsigned msm_window_bits = 0, msm_groups = 0;
+    // per-kernel HIP-event profiling (bench.py roofline): one record per instrumented launch
+    struct ProfRec { const char* name; hipEvent_t a, b; double algo_bytes; };
+    bool profiling = false;
+    std::vector<ProfRec> prof;
+    std::vector<hipEvent_t> event_pool;
     unsigned ntt_tile_log = 12, ntt_single_log = 11, ntt_radix_log = 10;
 };
 
 // scratch slot use: 0 = NTT inter-pass buffer, 1 = MSM digits/partials, 2-3 = API-level temporaries
 int ctx_scratch(plonk_ctx* ctx, int slot, size_t bytes, void** out);
+// bracket an instrumented launch: prof_begin before, prof_end after (no-ops unless profiling)
+int prof_begin(plonk_ctx* ctx, const char* name, double algo_bytes);
+int prof_end(plonk_ctx* ctx);
 
 // ---- enqueue helpers shared between translation units (all on ctx->stream) ---------------------
 // fr_ops.hip

@@ -1,0 +1,182 @@
+"""`Setup` (trusted-setup loader + KZG commit), `ec_lincomb`, `ec_mul` — the reference's
+/root/reference/setup.py:16-77 and /root/reference/curve.py:30-44 on the GPU.
+
+`Setup.from_file` keeps the reference's parsing contract (byte 60 = log2(#powers), G1 from byte 80,
+byte-wise scan for the G2 generator, setup.py:23-63) but hands the G1 section to the device
+unchanged: a .ptau stores coordinates little-endian in Montgomery form, which is exactly the
+library's internal layout.  `commit` = inverse NTT + fixed-base Pippenger MSM (setup.py:66-72).
+"""
+import ctypes
+from dataclasses import dataclass
+from typing import Optional
+
+from . import _lib
+from ._lib import check
+from .backend import get_context
+from .field import Fq, Q_MOD, R_MOD, Scalar, le32
+from .polynomial import Basis, Polynomial, _log2_exact
+
+SETUP_FILE_G1_STARTPOS = 80  # setup.py:11
+SETUP_FILE_POWERS_POS = 60  # setup.py:12
+
+G1 = (Fq(1), Fq(2))
+Z1 = None
+# x.c0 of py_ecc.bn128.G2 (published generator of the BN254 twist subgroup)
+_G2_X_C0 = 10857046999023057135944570762232829481370756359578518086990519993285655852781
+_MONT_R_Q = (1 << 256) % Q_MOD
+
+
+class Fq2:
+    """Minimal container for a G2 coordinate (only equality and `.coeffs` are needed here)."""
+
+    def __init__(self, coeffs):
+        self.coeffs = tuple(Fq(c) for c in coeffs)
+
+    def __eq__(self, other):
+        return isinstance(other, Fq2) and self.coeffs == other.coeffs
+
+    def __repr__(self):
+        return repr(self.coeffs)
+
+
+def _decode_points(xy: bytes, flags: bytes):
+    out = []
+    for i, f in enumerate(flags):
+        if f:
+            out.append(None)  # py_ecc identity (utils.py:13-14)
+        else:
+            out.append((Fq(int.from_bytes(xy[64 * i : 64 * i + 32], "little")),
+                        Fq(int.from_bytes(xy[64 * i + 32 : 64 * i + 64], "little"))))
+    return out
+
+
+class _DeviceBases:
+    """Owns a `plonk_srs*` (bases + window table in HBM)."""
+
+    def __init__(self, ctx, handle, n):
+        self.ctx, self.handle, self.n = ctx, handle, n
+
+    def __del__(self):
+        try:
+            if self.handle and self.ctx.handle:
+                self.ctx.L.plonk_srs_free(self.ctx.handle, self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+def _msm(bases: _DeviceBases, scalars_ptr, n, batch, stride):
+    ctx = bases.ctx
+    xy = ctypes.create_string_buffer(64 * batch)
+    flags = ctypes.create_string_buffer(batch)
+    check(ctx.L.plonk_g1_msm(ctx.handle, bases.handle, scalars_ptr, n, batch, stride, xy, flags))
+    return _decode_points(xy.raw, flags.raw[:batch])
+
+
+@dataclass
+class VerificationKey:
+    """verifier.py:9-34 (fields only; pairing-based verification is outside the prover hot path)."""
+
+    group_order: int
+    Qm: object
+    Ql: object
+    Qr: object
+    Qo: object
+    Qc: object
+    S1: object
+    S2: object
+    S3: object
+    X_2: object
+    w: Scalar
+
+
+class Setup:
+    def __init__(self, powers_of_x=None, X2=None, _g1_mont_bytes: Optional[bytes] = None):
+        self._powers = powers_of_x
+        self.X2 = X2
+        if _g1_mont_bytes is None:
+            # built from explicit affine points: re-encode in the .ptau layout
+            _g1_mont_bytes = b"".join(
+                le32(p[0].n * _MONT_R_Q % Q_MOD) + le32(p[1].n * _MONT_R_Q % Q_MOD) for p in powers_of_x
+            )
+        self._raw = _g1_mont_bytes
+        self._n = len(_g1_mont_bytes) // 64
+        self._dev = None
+
+    # setup.py:23-63
+    @classmethod
+    def from_file(cls, filename):
+        with open(filename, "rb") as f:
+            contents = f.read()
+        powers = 2 ** contents[SETUP_FILE_POWERS_POS]
+        g1_end = SETUP_FILE_G1_STARTPOS + 64 * powers
+        raw = contents[SETUP_FILE_G1_STARTPOS:g1_end]
+        assert len(raw) == 64 * powers
+        factor = int.from_bytes(raw[:32], "little")  # = R mod q, because G1[0] is the generator (1, 2)
+        assert factor * pow(G1[0].n, -1, Q_MOD) % Q_MOD == _MONT_R_Q, "unexpected .ptau encoding"
+        inv_factor = pow(factor, -1, Q_MOD)
+        target = (factor * _G2_X_C0 % Q_MOD).to_bytes(32, "little")
+        pos = contents.find(target, g1_end)  # setup.py:45-51
+        assert pos >= 0, "G2 generator not found in the setup file"
+        enc = contents[pos + 32 * 4 : pos + 32 * 8]
+        xv = [int.from_bytes(enc[i : i + 32], "little") * inv_factor % Q_MOD for i in range(0, 128, 32)]
+        X2 = (Fq2(xv[:2]), Fq2(xv[2:]))
+        return cls(None, X2, raw)
+
+    @property
+    def powers_of_x(self):
+        """list[(Fq, Fq)] — decoded lazily from the .ptau bytes (setup.py:39-41)."""
+        if self._powers is None:
+            inv_factor = pow(_MONT_R_Q, -1, Q_MOD)
+            vals = [int.from_bytes(self._raw[i : i + 32], "little") for i in range(0, len(self._raw), 32)]
+            assert max(vals) < Q_MOD  # setup.py:36
+            self._powers = [(Fq(vals[2 * i] * inv_factor), Fq(vals[2 * i + 1] * inv_factor)) for i in range(self._n)]
+        return self._powers
+
+    def device_bases(self) -> _DeviceBases:
+        if self._dev is None:
+            ctx = get_context()
+            h = ctypes.c_void_p()
+            check(ctx.L.plonk_srs_load_ptau(ctx.handle, self._raw, self._n, ctypes.byref(h)))
+            self._dev = _DeviceBases(ctx, h, self._n)
+        return self._dev
+
+    # setup.py:66-72
+    def commit(self, values: Polynomial):
+        assert values.basis == Basis.LAGRANGE
+        coeffs = values.ifft()
+        assert len(coeffs) <= self._n
+        return self.commit_coeffs(coeffs)
+
+    def commit_coeffs(self, coeffs: Polynomial):
+        """KZG commitment of a polynomial already in MONOMIAL basis (skips the ifft)."""
+        assert coeffs.basis == Basis.MONOMIAL
+        assert len(coeffs) <= self._n
+        return _msm(self.device_bases(), coeffs.device().ptr, len(coeffs), 1, len(coeffs))[0]
+
+    # setup.py:75-77
+    def verification_key(self, pk) -> VerificationKey:
+        polys = (pk.QM, pk.QL, pk.QR, pk.QO, pk.QC, pk.S1, pk.S2, pk.S3)
+        c = [self.commit(p) for p in polys]
+        return VerificationKey(pk.group_order, c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7], self.X2,
+                               Scalar.root_of_unity(pk.group_order))
+
+
+def ec_mul(pt, coeff):  # curve.py:30-33
+    return ec_lincomb([(pt, coeff)])
+
+
+def ec_lincomb(pairs):
+    """curve.py:38-44: sum_i coeff_i * pt_i for arbitrary affine points (None = identity)."""
+    pairs = list(pairs)
+    if not pairs:
+        raise ValueError("max() arg is an empty sequence")  # what curve.py:93 raises
+    ctx = get_context()
+    xy = b"".join(
+        (le32(0) + le32(0)) if p is None else (le32(int(p[0])) + le32(int(p[1]))) for p, _ in pairs
+    )
+    h = ctypes.c_void_p()
+    check(ctx.L.plonk_srs_load_affine(ctx.handle, xy, len(pairs), ctypes.byref(h)))
+    bases = _DeviceBases(ctx, h, len(pairs))
+    scalars = ctx.upload_ints([int(n) % R_MOD for _, n in pairs])  # curve.py:41
+    return _msm(bases, scalars.ptr, len(pairs), 1, len(pairs))[0]

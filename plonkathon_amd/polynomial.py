@@ -1,0 +1,175 @@
+"""`Polynomial` — the reference's Fr-vector type (/root/reference/poly.py:10-195) with the values
+resident in MI355X HBM and every operation executed by libplonk_hip.so.
+
+Same constructor, `basis` semantics, operators, asserts and method names as the reference, so code
+written against `poly.Polynomial` runs unchanged.  `values` is materialised lazily as a
+`list[Scalar]` only when host code reads it.
+"""
+import ctypes
+from enum import Enum
+
+from . import _lib
+from ._lib import OP_ADD, OP_DIV, OP_MUL, OP_SUB, check
+from .backend import DeviceBuffer, get_context
+from .field import Scalar, le32
+
+
+class Basis(Enum):  # poly.py:5-7
+    LAGRANGE = 1
+    MONOMIAL = 2
+
+
+def _log2_exact(n):
+    assert n >= 1 and n & (n - 1) == 0, "length must be a power of two"
+    return n.bit_length() - 1
+
+
+class Polynomial:
+    def __init__(self, values, basis):  # poly.py:14-18
+        assert all(isinstance(x, Scalar) for x in values)
+        assert isinstance(basis, Basis)
+        self._values = list(values)
+        self._dev = None
+        self._n = len(self._values)
+        self.basis = basis
+
+    # ---- construction from / access to device storage ---------------------------------------
+    @classmethod
+    def _from_device(cls, buf: DeviceBuffer, basis: Basis, n=None):
+        p = cls.__new__(cls)
+        p._values = None
+        p._dev = buf
+        p._n = buf.n if n is None else n
+        p.basis = basis
+        return p
+
+    @classmethod
+    def from_ints(cls, ints, basis):
+        """Convenience constructor from plain ints (reduced mod r)."""
+        return cls([Scalar(int(v)) for v in ints], basis)
+
+    @property
+    def values(self):
+        if self._values is None:
+            self._values = [Scalar(v) for v in get_context().download_ints(self._dev, self._n)]
+        return self._values
+
+    @values.setter
+    def values(self, v):
+        self._values = list(v)
+        self._n = len(self._values)
+        self._dev = None
+
+    def __len__(self):
+        return self._n
+
+    def device(self) -> DeviceBuffer:
+        if self._dev is None:
+            self._dev = get_context().upload_ints([x.n for x in self._values])
+        return self._dev
+
+    def __eq__(self, other):  # poly.py:20-21
+        return (self.basis == other.basis) and (self.values == other.values)
+
+    # ---- pointwise operators ------------------------------------------------------------------
+    def _binary(self, other, op):
+        ctx = get_context()
+        out = ctx.alloc(self._n)
+        check(ctx.L.plonk_fr_pointwise(ctx.handle, op, self.device().ptr, other.device().ptr, out.ptr, self._n))
+        return Polynomial._from_device(out, self.basis)
+
+    def _scalar(self, other, op, constant_term_only=False):
+        ctx = get_context()
+        out = ctx.alloc(self._n)
+        check(ctx.L.plonk_fr_scalar_op(ctx.handle, op, self.device().ptr, le32(other.n), out.ptr, self._n,
+                                       1 if constant_term_only else 0))
+        return Polynomial._from_device(out, self.basis)
+
+    def __add__(self, other):  # poly.py:23-43
+        if isinstance(other, Polynomial):
+            assert len(self) == len(other)
+            assert self.basis == other.basis
+            return self._binary(other, OP_ADD)
+        assert isinstance(other, Scalar)
+        return self._scalar(other, OP_ADD, self.basis != Basis.LAGRANGE)
+
+    def __sub__(self, other):  # poly.py:45-65
+        if isinstance(other, Polynomial):
+            assert len(self) == len(other)
+            assert self.basis == other.basis
+            return self._binary(other, OP_SUB)
+        assert isinstance(other, Scalar)
+        return self._scalar(other, OP_SUB, self.basis != Basis.LAGRANGE)
+
+    def __mul__(self, other):  # poly.py:68-83
+        if isinstance(other, Polynomial):
+            assert self.basis == Basis.LAGRANGE
+            assert self.basis == other.basis
+            assert len(self) == len(other)
+            return self._binary(other, OP_MUL)
+        assert isinstance(other, Scalar)
+        return self._scalar(other, OP_MUL)
+
+    def __truediv__(self, other):  # poly.py:85-100
+        if isinstance(other, Polynomial):
+            assert self.basis == Basis.LAGRANGE
+            assert self.basis == other.basis
+            assert len(self) == len(other)
+            return self._binary(other, OP_DIV)
+        assert isinstance(other, Scalar)
+        return self._scalar(other, OP_DIV)
+
+    def shift(self, shift: int):  # poly.py:102-109
+        assert self.basis == Basis.LAGRANGE
+        assert shift < len(self)
+        ctx = get_context()
+        out = ctx.alloc(self._n)
+        check(ctx.L.plonk_fr_rotate(ctx.handle, self.device().ptr, out.ptr, self._n, shift))
+        return Polynomial._from_device(out, self.basis)
+
+    # ---- NTT family ---------------------------------------------------------------------------
+    def fft(self, inv=False):  # poly.py:113-145
+        if inv:
+            assert self.basis == Basis.LAGRANGE
+        else:
+            assert self.basis == Basis.MONOMIAL
+        ctx = get_context()
+        out = ctx.alloc(self._n)
+        check(ctx.L.plonk_fr_ntt(ctx.handle, self.device().ptr, out.ptr, _log2_exact(self._n), 1 if inv else 0, 1))
+        return Polynomial._from_device(out, Basis.MONOMIAL if inv else Basis.LAGRANGE)
+
+    def ifft(self):  # poly.py:147-148
+        return self.fft(True)
+
+    def to_coset_extended_lagrange(self, offset):  # poly.py:156-163
+        assert self.basis == Basis.LAGRANGE
+        offset = Scalar(offset)
+        ctx = get_context()
+        out = ctx.alloc(4 * self._n)
+        check(ctx.L.plonk_fr_coset_extend(ctx.handle, self.device().ptr, out.ptr, _log2_exact(self._n), le32(offset.n), 1))
+        return Polynomial._from_device(out, Basis.LAGRANGE)
+
+    def coset_extended_lagrange_to_coeffs(self, offset):  # poly.py:169-177
+        assert self.basis == Basis.LAGRANGE
+        offset = Scalar(offset)
+        ctx = get_context()
+        out = ctx.alloc(self._n)
+        check(ctx.L.plonk_fr_coset_to_coeffs(ctx.handle, self.device().ptr, out.ptr, _log2_exact(self._n), le32(offset.n), 1))
+        return Polynomial._from_device(out, Basis.MONOMIAL)
+
+    def barycentric_eval(self, x):  # poly.py:181-195
+        assert self.basis == Basis.LAGRANGE
+        x = Scalar(x)
+        ctx = get_context()
+        out = ctypes.create_string_buffer(32)
+        check(ctx.L.plonk_fr_barycentric(ctx.handle, self.device().ptr, _log2_exact(self._n), le32(x.n), out))
+        return Scalar(int.from_bytes(out.raw, "little"))
+
+    # ---- helpers used by the prover -------------------------------------------------------------
+    def slice(self, start, stop, basis=None):
+        """Device-side copy of values[start:stop]."""
+        ctx = get_context()
+        n = stop - start
+        out = ctx.alloc(n)
+        check(ctx.L.plonk_mem_d2d(ctx.handle, out.ptr, self.device().at(start), 32 * n))
+        return Polynomial._from_device(out, basis or self.basis)

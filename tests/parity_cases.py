@@ -1,0 +1,272 @@
+"""Parity checks of the plonkathon_amd API against the oracle and the committed golden vectors.
+
+The same bodies run twice: under `-m gpu` against the real libplonk_hip.so on an MI355X (the parity
+tests proper), and in the CPU suite against the emulated build of the same kernel sources (logic
+check only).  They read like the reference's own test.py: build a Setup / Program / Prover, compare
+with known answers.
+"""
+import hashlib
+import os
+
+from helpers import GOLDEN, check_summary, digest, load, pt, rand_vec, R_MOD
+
+import plonkathon_amd as pa
+from plonkathon_amd import Basis, Polynomial, Program, Prover, Scalar, Setup, Transcript
+from oracle import field as ofield, g1 as og1
+from oracle.circuit import Program as OProgram
+from oracle.fr_poly import Basis as OBasis, Polynomial as OPoly, fft_ints
+from oracle.plonk_prover import Prover as OProver
+from oracle.poseidon import poseidon_hash, poseidon_program_lines
+from oracle.srs import Setup as OSetup
+
+PTAU = os.path.join(GOLDEN, "srs_2048.ptau")
+
+
+def P(ints, basis=Basis.LAGRANGE):
+    return Polynomial.from_ints(ints, basis)
+
+
+def ints(poly):
+    return [x.n for x in poly.values]
+
+
+def affine(p):
+    return None if p is None else (p[0].n, p[1].n)
+
+
+# ------------------------------------------------------------------------------------------ NTT
+def ntt_vs_oracle(log_ns, seed0=0):
+    for log_n in log_ns:
+        n = 1 << log_n
+        v = rand_vec(seed0 + log_n, n)
+        assert ints(P(v, Basis.MONOMIAL).fft()) == fft_ints(v), ("fft", log_n)
+        assert ints(P(v, Basis.LAGRANGE).ifft()) == fft_ints(v, True), ("ifft", log_n)
+
+
+def ntt_roundtrip_and_linearity(log_n, seed=5):
+    """Size-independent properties for sizes the oracle does not reach in seconds."""
+    n = 1 << log_n
+    a, b = rand_vec(seed, n), rand_vec(seed + 1, n)
+    pa_, pb = P(a, Basis.MONOMIAL), P(b, Basis.MONOMIAL)
+    fa, fb = pa_.fft(), pb.fft()
+    assert ints(fa.ifft()) == a  # ifft(fft(x)) == x
+    s = Scalar(rand_vec(seed + 2, 1)[0])
+    lhs = (pa_ * s + pb).fft()
+    rhs = fa * s + fb
+    assert ints(lhs) == ints(rhs)  # linearity
+    # X[0] = sum x_j ; X[n/2] = sum (-1)^j x_j   (w^(n/2) = -1)
+    out = ints(fa)
+    assert out[0] == sum(a) % R_MOD
+    assert out[n // 2] == (sum(a[0::2]) - sum(a[1::2])) % R_MOD
+    # a delta at index 1 transforms to the root-of-unity table
+    d = [0] * n
+    d[1] = 1
+    roots = ints(P(d, Basis.MONOMIAL).fft())
+    w = ofield.root_of_unity(n)
+    assert roots[:4] == [1, w, w * w % R_MOD, pow(w, 3, R_MOD)] and roots[n - 1] == pow(w, n - 1, R_MOD)
+
+
+def poly_golden(max_log_n):
+    """Every operator of poly.py on the reference-generated vectors (tests/golden/poly_vectors.json)."""
+    for case in load("poly_vectors.json")["cases"]:
+        log_n, seed = case["log_n"], case["seed"]
+        if log_n > max_log_n:
+            continue
+        n = 1 << log_n
+        vals = rand_vec(seed, n)
+        lag, mono = P(vals, Basis.LAGRANGE), P(vals, Basis.MONOMIAL)
+        check_summary(ints(mono.fft()), case["fft"])
+        check_summary(ints(lag.ifft()), case["ifft"])
+        if "offset" in case:
+            off = Scalar(int(case["offset"]))
+            if "coset_extend" in case:
+                check_summary(ints(lag.to_coset_extended_lagrange(off)), case["coset_extend"])
+            check_summary(ints(lag.coset_extended_lagrange_to_coeffs(off)), case["coset_to_coeffs"])
+        if "add" in case:
+            other = rand_vec(seed + 500, n)
+            if n >= 4:
+                other[1] = 0
+                other[3] = vals[3]
+            olag = P(other)
+            sc = Scalar(int(case["scalar"]))
+            check_summary(ints(lag + olag), case["add"])
+            check_summary(ints(lag - olag), case["sub"])
+            check_summary(ints(lag * olag), case["mul"])
+            check_summary(ints(lag / olag), case["div"])
+            check_summary(ints(lag + sc), case["add_scalar_lagrange"])
+            check_summary(ints(lag - sc), case["sub_scalar_lagrange"])
+            check_summary(ints(mono + sc), case["add_scalar_monomial"])
+            check_summary(ints(mono - sc), case["sub_scalar_monomial"])
+            check_summary(ints(lag * sc), case["mul_scalar"])
+            check_summary(ints(lag / sc), case["div_scalar"])
+            if "shift" in case:
+                check_summary(ints(lag.shift(case["shift_k"])), case["shift"])
+            assert lag.barycentric_eval(sc).n == int(case["barycentric_at_scalar"])
+
+
+def poly_asserts():
+    import pytest
+
+    a, m = P([1, 2, 3, 4]), P([1, 2, 3, 4], Basis.MONOMIAL)
+    with pytest.raises(AssertionError):
+        a.fft()  # poly.py:141
+    with pytest.raises(AssertionError):
+        m.ifft()  # poly.py:132
+    with pytest.raises(AssertionError):
+        m * m  # poly.py:70
+    with pytest.raises(AssertionError):
+        a + m  # poly.py:26
+    with pytest.raises(AssertionError):
+        a.shift(4)  # poly.py:104
+    with pytest.raises(AssertionError):
+        a + P([1, 2])  # poly.py:25
+    with pytest.raises(AssertionError):
+        Polynomial([1, 2], Basis.LAGRANGE)  # poly.py:15 — values must be Scalars
+    assert a == P([1, 2, 3, 4]) and not (a == m)
+    assert (a / Scalar(0)) == P([0, 0, 0, 0])  # x / 0 == 0
+    x = Scalar.roots_of_unity(4)[2]
+    assert a.barycentric_eval(x) == OPoly([1, 2, 3, 4], OBasis.LAGRANGE).barycentric_eval(x.n)
+
+
+# ------------------------------------------------------------------------------------------ MSM / commit
+def setup_k1():
+    sv = load("setup_vectors.json")
+    setup = Setup.from_file(PTAU)
+    dummy = Polynomial(list(map(Scalar, [1, 2, 3, 4, 5, 6, 7, 8])), Basis.LAGRANGE)
+    commitment = setup.commit(dummy)  # test.py:18-28
+    assert commitment == (
+        16120260411117808045030798560855586501988622612038310041007562782458075125622,
+        3125847109934958347271782137825877642397632921923926105820408033549219695465,
+    )
+    assert affine(setup.powers_of_x[1]) == pt(sv["powers_of_x_1"])
+    assert [[str(c.n) for c in setup.X2[0].coeffs], [str(c.n) for c in setup.X2[1].coeffs]] == sv["X2"]
+    vk = setup.verification_key(Program(["c <== a * b"], 8).common_preprocessed_input())
+    assert vk.w == 19540430494807482326159819597004422086093766032135589407132600596362845576832  # test.py:30-33
+    return setup
+
+
+def _vkey_point(p):
+    if p == ["0", "1", "0"]:
+        return None
+    return (int(p[0]), int(p[1]))
+
+
+def vkey_goldens(setup):
+    for fname, lines in (
+        ("main.plonk.vkey.json", ["c <== a * b"]),
+        ("main.plonk.vkey-58.json", ["ab === a - c", "-ab === a * b"]),
+        ("main.plonk.vkey-59.json", ["c public", "c === a * b"]),
+    ):
+        theirs = load(fname)
+        vk = setup.verification_key(Program(lines, 8).common_preprocessed_input())
+        for key in ("Qm", "Ql", "Qr", "Qo", "Qc", "S1", "S2", "S3"):
+            assert affine(getattr(vk, key)) == _vkey_point(theirs[key]), (fname, key)
+        assert vk.w == int(theirs["w"])
+
+
+def lincomb_golden(setup, full_size=True):
+    lv = load("lincomb_vectors.json")
+    Pts = setup.powers_of_x
+    for case in lv["cases"]:
+        if "seed" in case:
+            if not full_size:
+                continue
+            sc, idx = rand_vec(case["seed"], case["n"]), list(range(case["n"]))
+            coeffs = P(sc, Basis.MONOMIAL)
+            assert affine(setup.commit_coeffs(coeffs)) == pt(case["result"]), case["name"]
+            continue
+        sc, idx = [int(s) for s in case["scalars"]], case["points"]
+        got = pa.ec_lincomb([(Pts[i], s) for i, s in zip(idx, sc)])
+        assert affine(got) == pt(case["result"]), case["name"]
+    assert pa.ec_lincomb([(None, 5), (Pts[2], 1)]) == Pts[2]
+    assert pa.ec_mul(Pts[3], 0) is None
+    assert affine(pa.ec_mul(Pts[3], Scalar(7))) == og1.multiply(affine(Pts[3]), 7)
+
+
+def msm_vs_oracle(setup, n, seed, batch=1):
+    osetup = OSetup.from_file(PTAU)
+    for b in range(batch):
+        sc = rand_vec(seed + b, n)
+        want = og1.ec_lincomb([(osetup.powers_of_x[i], s) for i, s in enumerate(sc)])
+        assert affine(setup.commit_coeffs(P(sc, Basis.MONOMIAL))) == want
+
+
+# ------------------------------------------------------------------------------------------ transcript
+def transcript_golden():
+    tv = load("transcript_vectors.json")
+    t = Transcript(b"test protocol")
+    t.append_message(b"some label", b"some data")
+    assert t.challenge_bytes(b"challenge", 32).hex() == tv["merlin_simple_vector"]
+    g = load("k6_proof.json")["proof"]
+
+    def Pt(k):
+        return (pa.Fq(int(g[k][0])), pa.Fq(int(g[k][1])))
+
+    def S(k):
+        return Scalar(int(g[k]))
+
+    t = Transcript(b"plonk")
+    beta, gamma = t.round_1(pa.Message1(Pt("a_1"), Pt("b_1"), Pt("c_1")))
+    alpha, cof = t.round_2(pa.Message2(Pt("z_1")))
+    zeta = t.round_3(pa.Message3(Pt("t_lo_1"), Pt("t_mid_1"), Pt("t_hi_1")))
+    v = t.round_4(pa.Message4(S("a_eval"), S("b_eval"), S("c_eval"), S("s1_eval"), S("s2_eval"), S("z_shifted_eval")))
+    u = t.round_5(pa.Message5(Pt("W_z_1"), Pt("W_zw_1")))
+    got = dict(beta=beta, gamma=gamma, alpha=alpha, fft_cofactor=cof, zeta=zeta, v=v, u=u)
+    assert {k: str(x.n) for k, x in got.items()} == tv["k6_challenges"]
+    t2 = Transcript(b"plonk")
+    t2.append_scalar(b"x", Scalar(12345))
+    t2.append(b"raw", b"\x00\x01\x02")
+    assert str(t2.get_and_append_challenge(b"ch").n) == tv["misc_challenge"]
+
+
+# ------------------------------------------------------------------------------------------ prover
+def flat(proof):
+    out = {}
+    for k, v in proof.flatten().items():
+        out[k] = affine(v) if isinstance(v, tuple) or v is None else v.n
+    return out
+
+
+def prover_k6(setup):
+    """prover_test (test.py:136-146) against test/proof.pickle (K6)."""
+    k6 = load("k6_proof.json")
+    program = Program(k6["program"], k6["group_order"])
+    prover = Prover(setup, program)
+    proof = flat(prover.prove(dict(k6["witness"])))
+    for k, v in k6["proof"].items():
+        want = pt(v) if isinstance(v, list) else int(v)
+        assert proof[k] == want, k
+
+
+def prover_vs_oracle(setup, lines, group_order, start, name=""):
+    oprog = OProgram(lines, group_order)
+    wit = oprog.fill_variable_assignments(start)
+    want = OProver(OSetup.from_file(PTAU), oprog).prove(dict(wit)).flatten()
+    program = Program(lines, group_order)
+    assert program.fill_variable_assignments(start) == wit
+    got = flat(Prover(setup, program).prove(dict(wit)))
+    assert got == want, name
+
+
+FACTORIZATION = """n public
+pb0 === pb0 * pb0
+pb1 === pb1 * pb1
+pb2 === pb2 * pb2
+pb3 === pb3 * pb3
+qb0 === qb0 * qb0
+qb1 === qb1 * qb1
+qb2 === qb2 * qb2
+qb3 === qb3 * qb3
+pb01 <== pb0 + 2 * pb1
+pb012 <== pb01 + 4 * pb2
+p <== pb012 + 8 * pb3
+qb01 <== qb0 + 2 * qb1
+qb012 <== qb01 + 4 * qb2
+q <== qb012 + 8 * qb3
+n <== p * q""".split("\n")
+FACTORIZATION_START = {"pb3": 1, "pb2": 1, "pb1": 0, "pb0": 1, "qb3": 0, "qb2": 1, "qb1": 1, "qb0": 1}
+
+
+def prover_factorization(setup):
+    """factorization_test, test.py:171-213."""
+    prover_vs_oracle(setup, FACTORIZATION, 16, FACTORIZATION_START, "factorization")

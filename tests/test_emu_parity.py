@@ -1,0 +1,78 @@
+"""CPU suite: the product's Python layer + C-ABI over the EMULATED build of the kernel sources
+(tests/emu/).  Checks kernel index/barrier logic and the host layer without a GPU; small sizes only.
+The parity tests proper are tests/test_gpu_parity.py (-m gpu)."""
+import pytest
+
+import parity_cases as pc
+
+
+def test_ntt_vs_oracle_small(emu):
+    pc.ntt_vs_oracle([0, 1, 2, 3, 5, 8, 11, 12, 13])
+
+
+def test_ntt_multipass_paths(emu):
+    """Forces 2-, 3- and 4-pass plans at small sizes (digit-reversing store, inter-pass twiddles)."""
+    import ctypes
+    from plonkathon_amd import get_context
+    from plonkathon_amd._lib import check
+
+    ctx = get_context()
+    try:
+        for tile, single, radix, log_ns in ((4, 2, 2, (3, 4, 5, 6, 7, 8)), (5, 3, 3, (7, 9)), (6, 4, 4, (9, 11, 12))):
+            check(ctx.L.plonk_ntt_configure(ctx.handle, tile, single, radix))
+            pc.ntt_vs_oracle(log_ns, seed0=100 * tile)
+    finally:
+        check(ctx.L.plonk_ntt_configure(ctx.handle, 0, 0, 0))
+
+
+def test_ntt_properties(emu):
+    pc.ntt_roundtrip_and_linearity(12)
+
+
+def test_poly_golden(emu):
+    pc.poly_golden(max_log_n=11)
+
+
+def test_poly_asserts(emu):
+    pc.poly_asserts()
+
+
+def test_transcript(emu):
+    pc.transcript_golden()
+
+
+@pytest.fixture(scope="module")
+def setup_obj(emu_cdll):
+    return {}
+
+
+def test_setup_commit_vkeys_lincomb(emu):
+    setup = pc.setup_k1()
+    pc.vkey_goldens(setup)
+    pc.lincomb_golden(setup, full_size=False)
+    pc.msm_vs_oracle(setup, 200, seed=11)
+
+
+def test_msm_window_configs(emu):
+    from plonkathon_amd import Setup, get_context
+    from plonkathon_amd._lib import check
+
+    ctx = get_context()
+    try:
+        for c, groups in ((4, 1), (5, 3), (9, 2), (7, 0)):
+            check(ctx.L.plonk_msm_configure(ctx.handle, c, groups))
+            pc.msm_vs_oracle(Setup.from_file(pc.PTAU), 64, seed=20 + c)
+    finally:
+        check(ctx.L.plonk_msm_configure(ctx.handle, 0, 0))
+
+
+def test_prover_k6_golden_proof(emu):
+    from plonkathon_amd import Setup
+
+    pc.prover_k6(Setup.from_file(pc.PTAU))
+
+
+def test_prover_factorization(emu):
+    from plonkathon_amd import Setup
+
+    pc.prover_factorization(Setup.from_file(pc.PTAU))
