@@ -122,6 +122,34 @@ int plonk_g1_msm(plonk_ctx* ctx, plonk_srs* srs, const void* d_scalars, size_t n
 /* tuning knobs (0 = library default): window bits c and window-groups per MSM */
 int plonk_msm_configure(plonk_ctx* ctx, unsigned window_bits, unsigned groups);
 
+/* ---- batched GPU-resident prover ---------------------------------------------------------------------
+ * Replaces Prover.__init__ / Prover.prove / round_1..round_5 (prover.py:45-306) for `batch`
+ * independent proofs of ONE circuit proved in lock-step, Fiat-Shamir transcript included
+ * (transcript.py:77-123 runs on the device, one lane per proof).
+ *   plonk_prover_create   Prover(setup, program): `selectors_le32` = the eight CommonPreprocessedInput
+ *                         vectors QM, QL, QR, QO, QC, S1, S2, S3 (compiler/program.py:10-30), each
+ *                         2^log_n canonical Fr values; n_public = len(program.get_public_assignments()).
+ *                         Extends the circuit polynomials to the quotient coset once.
+ *   plonk_prover_upload_witness   the wire columns A, B, C of round 1 (prover.py:94-103) laid out
+ *                         [3][batch][n] and the public inputs [batch][n_public] (PI = -public,
+ *                         prover.py:57-62), canonical LE; they stay resident in HBM.
+ *   plonk_prover_run      enqueue all five rounds for the resident witnesses (asynchronous).
+ *   plonk_prover_download wait, then per proof 768 bytes: a_1, b_1, c_1, z_1, t_lo_1, t_mid_1, t_hi_1,
+ *                         W_z_1, W_zw_1 as canonical x||y LE (Proof.flatten order, prover.py:18-35) then
+ *                         a_eval, b_eval, c_eval, s1_eval, s2_eval, z_shifted_eval canonical LE;
+ *                         status[b]: bit 0 = some commitment is the identity (the reference's
+ *                         append_point(None) raises), bit 1 = Z does not close to 1 (prover.py:132),
+ *                         bit 2 = quotient degree >= 3n, i.e. a gate constraint fails (prover.py:108-116, 205-208).
+ *   plonk_prover_challenges  beta, gamma, alpha, fft_cofactor, zeta, v of proof b (tests).          */
+typedef struct plonk_prover plonk_prover;
+int plonk_prover_create(plonk_ctx* ctx, plonk_srs* srs, unsigned log_n, const uint8_t* selectors_le32,
+                        size_t n_public, plonk_prover** out);
+int plonk_prover_destroy(plonk_prover* p);
+int plonk_prover_upload_witness(plonk_prover* p, const uint8_t* abc_le32, const uint8_t* public_le32, size_t batch);
+int plonk_prover_run(plonk_prover* p, size_t batch);
+int plonk_prover_download(plonk_prover* p, size_t batch, uint8_t* out_proofs, uint8_t* out_status);
+int plonk_prover_challenges(plonk_prover* p, size_t b, uint8_t out_le32[6 * 32]);
+
 /* ---- Fiat-Shamir transcript (host) ----------------------------------------------------------------
  * Replaces `merlin.MerlinTranscript` (third-party) as subclassed by transcript.py:58-60:
  *   plonk_transcript_new              MerlinTranscript(label)             (prover.py:53 uses b"plonk")

@@ -11,10 +11,11 @@ from .kzg import G1, Z1, Setup, VerificationKey, ec_lincomb, ec_mul  # noqa: F40
 from .circuit import AssemblyEqn, CommonPreprocessedInput, GateWires, Program  # noqa: F401
 from .fiat_shamir import Message1, Message2, Message3, Message4, Message5, Transcript  # noqa: F401
 from .plonk import Proof, Prover  # noqa: F401
+from .batch import BatchProver, ProofError  # noqa: F401
 from .backend import Context, get_context, set_context  # noqa: F401
 
 __all__ = [
     "Scalar", "Fq", "Basis", "Polynomial", "Setup", "VerificationKey", "ec_lincomb", "ec_mul", "G1", "Z1",
     "Program", "CommonPreprocessedInput", "AssemblyEqn", "GateWires", "Transcript", "Message1", "Message2",
-    "Message3", "Message4", "Message5", "Prover", "Proof", "Context", "get_context", "set_context",
+    "Message3", "Message4", "Message5", "Prover", "BatchProver", "ProofError", "Proof", "Context", "get_context", "set_context",
 ]

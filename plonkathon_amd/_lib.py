@@ -46,6 +46,12 @@ SIGNATURES = {
     "plonk_srs_size": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_size_t)]),
     "plonk_g1_msm": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]),
     "plonk_msm_configure": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint, ctypes.c_uint]),
+    "plonk_prover_create": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint, _u8p, ctypes.c_size_t, c_void_pp]),
+    "plonk_prover_destroy": (ctypes.c_int, [ctypes.c_void_p]),
+    "plonk_prover_upload_witness": (ctypes.c_int, [ctypes.c_void_p, _u8p, _u8p, ctypes.c_size_t]),
+    "plonk_prover_run": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t]),
+    "plonk_prover_download": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]),
+    "plonk_prover_challenges": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "plonk_transcript_new": (ctypes.c_int, [_u8p, ctypes.c_size_t, c_void_pp]),
     "plonk_transcript_clone": (ctypes.c_int, [ctypes.c_void_p, c_void_pp]),
     "plonk_transcript_free": (ctypes.c_int, [ctypes.c_void_p]),

@@ -1,0 +1,142 @@
+"""`BatchProver` — many proofs of one circuit in lock-step, entirely GPU-resident.
+
+The throughput form of /root/reference/prover.py's `Prover`: same constructor arguments
+(`setup`, `program`), `prove(witness)` for one proof and `prove_batch(witnesses)` for many; returns
+the same `Proof` objects.  All five rounds and the Fiat-Shamir transcript run on the device
+(plonk_prover_* in include/plonk_hip.h), with one host synchronisation per batch.
+"""
+import ctypes
+
+from . import _lib
+from ._lib import check
+from .backend import get_context
+from .circuit import Program
+from .field import Fq, R_MOD, Scalar
+from .fiat_shamir import Message1, Message2, Message3, Message4, Message5
+from .kzg import Setup
+from .plonk import Proof
+from .polynomial import _log2_exact
+
+
+class ProofError(AssertionError):
+    """The witness does not satisfy the circuit (the reference's in-prover asserts fail)."""
+
+
+def _le(vals):
+    return b"".join(int(v).to_bytes(32, "little") for v in vals)
+
+
+class BatchProver:
+    def __init__(self, setup: Setup, program: Program):
+        self.group_order = program.group_order
+        self.setup = setup
+        self.program = program
+        self.ctx = get_context()
+        self._public_vars = program.get_public_assignments()
+        self._wires = [w.as_list() for w in program.wires()]
+        n = self.group_order
+        L, R, M, O, C = program.gate_columns()
+        sigma = program.permutation_columns()
+        sel = _le(M) + _le(L) + _le(R) + _le(O) + _le(C) + _le(sigma[1]) + _le(sigma[2]) + _le(sigma[3])
+        self._bases = setup.device_bases()
+        self._h = ctypes.c_void_p()
+        check(self.ctx.L.plonk_prover_create(self.ctx.handle, self._bases.handle, _log2_exact(n), sel,
+                                             len(self._public_vars), ctypes.byref(self._h)))
+        self._resident = 0
+
+    def __del__(self):
+        try:
+            if self._h and self.ctx.handle:
+                self.ctx.L.plonk_prover_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    # ---- inputs ---------------------------------------------------------------------------------
+    def wire_columns(self, witness):
+        """A, B, C value columns of round 1 (prover.py:94-103): witness[None] = 0, zero padded."""
+        n = self.group_order
+        cols = [[0] * n, [0] * n, [0] * n]
+        get = witness.get
+        for i, (wl, wr, wo) in enumerate(self._wires):
+            cols[0][i] = (get(wl, 0) if wl is not None else 0) % R_MOD
+            cols[1][i] = (get(wr, 0) if wr is not None else 0) % R_MOD
+            cols[2][i] = (get(wo, 0) if wo is not None else 0) % R_MOD
+            if (wl is not None and wl not in witness) or (wr is not None and wr not in witness) or (
+                wo is not None and wo not in witness
+            ):
+                raise KeyError([w for w in (wl, wr, wo) if w is not None and w not in witness][0])
+        return cols
+
+    def upload(self, witnesses):
+        """Stage a batch of witnesses in HBM ([3][B][n] wire columns + public inputs)."""
+        B = len(witnesses)
+        cols = [self.wire_columns(w) for w in witnesses]
+        abc = b"".join(_le(cols[b][j]) for j in range(3) for b in range(B))
+        pub = b"".join(_le([w[v] % R_MOD for v in self._public_vars]) for w in witnesses)
+        check(self.ctx.L.plonk_prover_upload_witness(self._h, abc, pub if self._public_vars else None, B))
+        self._resident = B
+
+    def upload_raw(self, abc_bytes, pub_bytes, B):
+        check(self.ctx.L.plonk_prover_upload_witness(self._h, abc_bytes, pub_bytes, B))
+        self._resident = B
+
+    # ---- proving --------------------------------------------------------------------------------
+    def run(self, B=None):
+        """Enqueue the five rounds for the resident witnesses (asynchronous)."""
+        B = self._resident if B is None else B
+        check(self.ctx.L.plonk_prover_run(self._h, B))
+
+    def download_raw(self, B=None):
+        B = self._resident if B is None else B
+        out = ctypes.create_string_buffer(768 * B)
+        status = ctypes.create_string_buffer(B)
+        check(self.ctx.L.plonk_prover_download(self._h, B, out, status))
+        return out.raw, status.raw[:B]
+
+    def download(self, B=None):
+        raw, status = self.download_raw(B)
+        proofs = []
+        for b, st in enumerate(status):
+            if st & 4:
+                raise ProofError("proof %d: witness does not satisfy the gate constraints "
+                                 "(prover.py:108-116; quotient degree check prover.py:205-208)" % b)
+            if st & 2:
+                raise ProofError("proof %d: permutation accumulator does not close to 1 (prover.py:132)" % b)
+            if st & 1:
+                raise ProofError("proof %d: a commitment is the identity; the reference's transcript "
+                                 "cannot absorb it (transcript.py:65-67)" % b)
+            proofs.append(self.decode(raw[768 * b : 768 * (b + 1)]))
+        return proofs
+
+    @staticmethod
+    def decode(blob):
+        def pt(i):
+            o = 64 * i
+            return (Fq(int.from_bytes(blob[o : o + 32], "little")), Fq(int.from_bytes(blob[o + 32 : o + 64], "little")))
+
+        def sc(i):
+            o = 576 + 32 * i
+            return Scalar(int.from_bytes(blob[o : o + 32], "little"))
+
+        return Proof(
+            Message1(pt(0), pt(1), pt(2)),
+            Message2(pt(3)),
+            Message3(pt(4), pt(5), pt(6)),
+            Message4(sc(0), sc(1), sc(2), sc(3), sc(4), sc(5)),
+            Message5(pt(7), pt(8)),
+        )
+
+    def prove_batch(self, witnesses):
+        self.upload(witnesses)
+        self.run()
+        return self.download()
+
+    def prove(self, witness) -> Proof:  # prover.py:51-84
+        return self.prove_batch([witness])[0]
+
+    def challenges(self, b=0):
+        out = ctypes.create_string_buffer(192)
+        check(self.ctx.L.plonk_prover_challenges(self._h, b, out))
+        names = ("beta", "gamma", "alpha", "fft_cofactor", "zeta", "v")
+        return {k: Scalar(int.from_bytes(out.raw[32 * i : 32 * i + 32], "little")) for i, k in enumerate(names)}

@@ -270,3 +270,66 @@ FACTORIZATION_START = {"pb3": 1, "pb2": 1, "pb1": 0, "pb0": 1, "qb3": 0, "qb2": 
 def prover_factorization(setup):
     """factorization_test, test.py:171-213."""
     prover_vs_oracle(setup, FACTORIZATION, 16, FACTORIZATION_START, "factorization")
+
+
+# ------------------------------------------------------------------------------------------ batched prover
+def chain_lines(n):
+    return ["x0 public"] + ["x%d <== x%d * x%d" % (i + 1, i, i) for i in range(n - 1)]
+
+
+def batch_prover_k6(setup):
+    """The GPU-resident lock-step prover reproduces test/proof.pickle (and the challenges)."""
+    k6 = load("k6_proof.json")
+    bp = pa.BatchProver(setup, Program(k6["program"], k6["group_order"]))
+    proofs = bp.prove_batch([dict(k6["witness"]), dict(k6["witness"])])
+    for proof in proofs:
+        got = flat(proof)
+        for k, v in k6["proof"].items():
+            want = pt(v) if isinstance(v, list) else int(v)
+            assert got[k] == want, k
+    tv = load("transcript_vectors.json")["k6_challenges"]
+    for b in (0, 1):
+        for k, v in bp.challenges(b).items():
+            assert str(v.n) == tv[k], k
+
+
+def batch_prover_vs_oracle(setup, lines, group_order, starts):
+    oprog = OProgram(lines, group_order)
+    osetup = OSetup.from_file(PTAU)
+    program = Program(lines, group_order)
+    wits = [oprog.fill_variable_assignments(s) for s in starts]
+    got = [flat(p) for p in pa.BatchProver(setup, program).prove_batch([dict(w) for w in wits])]
+    for w, g in zip(wits, got):
+        want = OProver(osetup, oprog).prove(dict(w)).flatten()
+        assert g == want
+
+
+def batch_prover_rejects_bad_witness(setup):
+    import pytest
+
+    program = Program(["e public", "c <== a * b", "e <== c * d"], 8)
+    bp = pa.BatchProver(setup, program)
+    with pytest.raises(pa.ProofError):
+        bp.prove({"a": 3, "b": 4, "c": 13, "d": 5, "e": 65})  # c != a*b: gate constraint fails
+    with pytest.raises(KeyError):
+        bp.prove({"a": 3, "b": 4})
+
+
+def batch_prover_fixture_cases(setup, names, batch_copies=1):
+    """group_order 2^10 / 2^11 proofs against tests/golden/oracle_proofs.json."""
+    fx = {c["name"]: c for c in load("oracle_proofs.json")["cases"]}
+    for name in names:
+        case = fx[name]
+        n = case["group_order"]
+        lines = chain_lines(n) if case["program"] == "chain" else poseidon_program_lines()
+        program = Program(lines, n)
+        wit = program.fill_variable_assignments({k: int(v) for k, v in case["start"].items()})
+        bp = pa.BatchProver(setup, program)
+        proofs = bp.prove_batch([dict(wit) for _ in range(batch_copies)])
+        for b, proof in enumerate(proofs):
+            got = flat(proof)
+            for k, v in case["proof"].items():
+                want = pt(v) if isinstance(v, list) else int(v)
+                assert got[k] == want, (name, b, k)
+            for k, v in bp.challenges(b).items():
+                assert str(v.n) == case["challenges"][k], (name, b, k)

@@ -76,3 +76,18 @@ def test_prover_factorization(emu):
     from plonkathon_amd import Setup
 
     pc.prover_factorization(Setup.from_file(pc.PTAU))
+
+
+def test_batch_prover_k6(emu):
+    from plonkathon_amd import Setup
+
+    pc.batch_prover_k6(Setup.from_file(pc.PTAU))
+
+
+def test_batch_prover_vs_oracle(emu):
+    from plonkathon_amd import Setup
+
+    setup = Setup.from_file(pc.PTAU)
+    pc.batch_prover_vs_oracle(setup, pc.FACTORIZATION, 16, [pc.FACTORIZATION_START])
+    pc.batch_prover_vs_oracle(setup, pc.chain_lines(32), 32, [{"x0": 3}, {"x0": 4}, {"x0": 12345678901234567890}])
+    pc.batch_prover_rejects_bad_witness(setup)

@@ -103,3 +103,36 @@ def test_deterministic_rerun(setup):
     a = setup.commit_coeffs(pc.P(sc, Basis.MONOMIAL))
     b = setup.commit_coeffs(pc.P(sc, Basis.MONOMIAL))
     assert a == b
+
+
+def test_batch_prover_k6(setup):
+    pc.batch_prover_k6(setup)
+
+
+def test_batch_prover_vs_oracle_small(setup):
+    pc.batch_prover_vs_oracle(setup, pc.FACTORIZATION, 16, [pc.FACTORIZATION_START])
+    pc.batch_prover_vs_oracle(setup, pc.chain_lines(32), 32, [{"x0": 3}, {"x0": 4}, {"x0": 12345678901234567890}])
+    pc.batch_prover_vs_oracle(setup, pc.chain_lines(256), 256, [{"x0": 7}])
+    pc.batch_prover_rejects_bad_witness(setup)
+
+
+def test_batch_prover_group_order_2_11(setup):
+    """BASELINE configs[1]: group_order = 2^11 on the powers-of-tau SRS; bit-identical proof + challenges."""
+    pc.batch_prover_fixture_cases(setup, ["chain_2048_x0_3", "chain_2048_x0_4"], batch_copies=3)
+
+
+def test_batch_prover_poseidon(setup):
+    """BASELINE configs[2]: the mini-Poseidon circuit of test.py:216-259 at 2^10 (reference) and 2^11."""
+    pc.batch_prover_fixture_cases(setup, ["poseidon_1024", "poseidon_2048"])
+
+
+def test_api_prover_matches_batch_prover_2_11(setup):
+    """The reference-shaped Prover (per-proof challenge as coset offset) and the lock-step prover
+    (fixed offset) produce the same proof: the schedule does not change the committed polynomials."""
+    from plonkathon_amd import BatchProver, Program, Prover
+
+    program = Program(pc.chain_lines(2048), 2048)
+    wit = program.fill_variable_assignments({"x0": 3})
+    p1 = Prover(setup, program)
+    p1.check = False
+    assert pc.flat(p1.prove(dict(wit))) == pc.flat(BatchProver(setup, program).prove(dict(wit)))

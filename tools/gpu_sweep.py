@@ -1,0 +1,100 @@
+#!/usr/bin/env python3
+"""GPU tuning sweep (writes JSON lines to stdout): batched MSM time vs window bits / groups, batched NTT
+times at the prover's sizes, standalone NTT sizes 2^16..2^24, BatchProver time vs batch size."""
+import ctypes
+import json
+import os
+import random
+import sys
+import time
+
+REPO = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, REPO)
+from plonkathon_amd import BatchProver, Context, Program, Setup, set_context  # noqa: E402
+from plonkathon_amd._lib import check  # noqa: E402
+
+ctx = Context(0)
+set_context(ctx)
+L, H = ctx.L, ctx.handle
+PTAU = os.path.join(REPO, "tests", "golden", "srs_2048.ptau")
+setup = Setup.from_file(PTAU)
+bases = setup.device_bases()
+rng = random.Random(1)
+
+
+def fill(n_elems):
+    per = min(n_elems, 4096)
+    src = ctx.upload_ints([rng.randrange(1 << 253) for _ in range(per)])
+    buf = ctx.alloc(n_elems)
+    for off in range(0, n_elems, per):
+        check(L.plonk_mem_d2d(H, buf.at(off), src.ptr, 32 * min(per, n_elems - off)))
+    return buf
+
+
+def timed(fn, reps=3):
+    fn()
+    ctx.sync()
+    best = 1e30
+    for _ in range(reps):
+        ctx.timer_start()
+        fn()
+        best = min(best, ctx.timer_stop_ms())
+    return best
+
+
+which = sys.argv[1:] or ["msm", "ntt", "prover"]
+if "msm" in which:
+    n = 2048
+    for M in (1, 64, 768):
+        sc = fill(n * M)
+        xy = ctypes.create_string_buffer(64 * M)
+        fl = ctypes.create_string_buffer(M)
+        for c in (6, 7, 8, 9):
+            for G in ((0,) if M > 1 else (1, 4, 8, 32)):
+                check(L.plonk_msm_configure(H, c, G))
+                t0 = time.perf_counter()
+                check(L.plonk_g1_msm(H, bases.handle, sc.ptr, n, M, n, xy, fl))  # includes table (re)build
+                first = time.perf_counter() - t0
+                ctx.profile_reset(); ctx.profile(True)
+                ms = timed(lambda: check(L.plonk_g1_msm(H, bases.handle, sc.ptr, n, M, n, xy, fl)))
+                acc_ms, launches, _ = ctx.profile_read("msm_accumulate")
+                ctx.profile(False)
+                print(json.dumps({"what": "msm", "n": n, "M": M, "c": c, "G": G, "ms": ms, "ms_per_msm": ms / M,
+                                  "accumulate_ms": acc_ms / max(launches, 1), "first_call_s": first}), flush=True)
+    check(L.plonk_msm_configure(H, 0, 0))
+if "ntt" in which:
+    for log_n, batch in ((11, 1), (11, 1024), (13, 1), (13, 1280), (16, 1), (16, 64), (18, 1), (20, 1), (22, 1), (24, 1)):
+        n = 1 << log_n
+        buf, out = fill(n * batch), ctx.alloc(n * batch)
+        for inv in (0, 1):
+            ms = timed(lambda: check(L.plonk_fr_ntt(H, buf.ptr, out.ptr, log_n, inv, batch)), reps=5)
+            print(json.dumps({"what": "ntt", "log_n": log_n, "batch": batch, "inverse": inv, "ms": ms,
+                              "gf_elems_per_s": n * batch / (ms * 1e-3), "algo_GBps": 64.0 * n * batch / (ms * 1e-3) / 1e9}), flush=True)
+        del buf, out
+    # tile / radix variants at 2^20
+    n = 1 << 20
+    buf, out = fill(n), ctx.alloc(n)
+    for tile, single, radix in ((12, 11, 10), (11, 11, 10), (12, 11, 7), (11, 10, 7), (10, 10, 7), (12, 11, 8), (9, 9, 7)):
+        check(L.plonk_ntt_configure(H, tile, single, radix))
+        ms = timed(lambda: check(L.plonk_fr_ntt(H, buf.ptr, out.ptr, 20, 0, 1)), reps=5)
+        print(json.dumps({"what": "ntt_cfg", "log_n": 20, "tile": tile, "single": single, "radix": radix, "ms": ms}), flush=True)
+    check(L.plonk_ntt_configure(H, 0, 0, 0))
+if "prover" in which:
+    sys.path.insert(0, os.path.join(REPO))
+    from bench import chain_program_lines, witness_for
+
+    program = Program(chain_program_lines(2048), 2048)
+    bp = BatchProver(setup, program)
+    wits = [witness_for(program, i) for i in range(4)]
+    for B in (1, 8, 64, 256, 512):
+        t0 = time.perf_counter()
+        bp.upload([wits[i % 4] for i in range(B)])
+        up = time.perf_counter() - t0
+        bp.run(); bp.download_raw()
+        t0 = time.perf_counter()
+        for _ in range(2):
+            bp.run()
+            raw, st = bp.download_raw()
+        dt = (time.perf_counter() - t0) / 2
+        print(json.dumps({"what": "prover", "B": B, "s_per_batch": dt, "proofs_per_s": B / dt, "ms_per_proof": 1e3 * dt / B,
+                          "upload_s": up, "status_ok": not any(st)}), flush=True)

@@ -76,7 +76,7 @@ template <class F> static double time_ms(F launch, int reps = 5) {
 int main() {
     hipDeviceProp_t prop; hipGetDeviceProperties(&prop, 0);
     const int blocks = prop.multiProcessorCount * 8, threads = 256;
-    uint32_t* out; hipMalloc(&out, (size_t)blocks * threads * 4);
+    uint32_t* out; hipMalloc(&out, (size_t)prop.multiProcessorCount * 32 * threads * 4);
     const double lanes = (double)blocks * threads;
     printf("{\"device\": \"%s\", \"cus\": %d, \"clock_mhz\": %d", prop.name, prop.multiProcessorCount, prop.clockRate / 1000);
     const char* names[7] = {"mad_u64_u32", "mul_lo_u32", "mul_hi_u32", "add_u64", "mul_u32_u24", "fma_f64", "add_u32_carry"};
@@ -97,7 +97,7 @@ int main() {
     printf(", \"fr_mul_Gops\": %.2f, \"fq_mul_Gops\": %.2f, \"fr_addsub_Gops\": %.2f", lanes * it * 2 / (m1 * 1e-3) / 1e9,
            lanes * it * 2 / (m2 * 1e-3) / 1e9, lanes * it * 8 * 2 / (m3 * 1e-3) / 1e9);
     // occupancy sweep for fr_mul: 1,2,4 blocks per CU
-    for (int bpc : {1, 2, 4, 16}) {
+    for (int bpc : {1, 2, 4, 8, 16, 32}) {
         int bl = prop.multiProcessorCount * bpc;
         double m = time_ms([&] { hipLaunchKernelGGL(k_fpmul<FrParams>, dim3(bl), dim3(threads), 0, 0, out, 1u, it); });
         printf(", \"fr_mul_Gops_%dbpc\": %.2f", bpc, (double)bl * threads * it * 2 / (m * 1e-3) / 1e9);
