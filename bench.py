@@ -104,29 +104,27 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from plonkathon_amd import BatchProver, Context, Program, Setup, set_context
+    from plonkathon_amd import distributed as D
 
+    dist = D.init_from_env("nccl") if world > 1 else None
     ctx = Context(local_rank)
     set_context(ctx)
     setup = Setup.from_file(PTAU)
     program = Program(chain_program_lines(GROUP_ORDER), GROUP_ORDER)
     prover = BatchProver(setup, program)
     B = args.batch
-    # synthetic witnesses, seeded per global proof index; staged in HBM before the timed region
-    distinct = min(B, 8)
-    base = [witness_for(program, rank * B + i) for i in range(distinct)]
-    prover.upload([base[i % distinct] for i in range(B)])
+    total = B * world  # weak scaling: every GPU proves B proofs per step
+    mine = D.shard_indices(total, rank, world)
+    # synthetic witnesses, seeded by GLOBAL proof index; staged in HBM before the timed region
+    distinct = {}
+    for idx in mine:
+        distinct.setdefault(idx % 8, witness_for(program, idx % 8))
+    prover.upload([distinct[idx % 8] for idx in mine])
 
     def step():
-        prover.run()      # all five rounds + transcript for B proofs: one stream of kernel launches
+        prover.run()                   # five rounds + transcript for B proofs: one stream of kernel launches
         return prover.download_raw()   # sync + 768 B per proof back to the host
 
     def barrier():
@@ -146,23 +144,12 @@ def main():
     for _ in range(args.steps):
         proofs = step()
     barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed = D.max_over_ranks(time.perf_counter() - t0, dist)
     ctx.profile(False)
-
-    if dist is not None:
-        import torch
-
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        # the only collective on the path: gather the 768-byte results of every proof
-        mine = torch.frombuffer(bytearray(proofs[0]), dtype=torch.uint8).cuda()
-        gathered = [torch.empty_like(mine) for _ in range(world)]
-        dist.all_gather(gathered, mine)
-        n_results = sum(int(g.numel()) for g in gathered) // 768
-    else:
-        n_results = len(proofs[0]) // 768
     assert not any(proofs[1]), "a proof in the batch reported a failure status"
+    # the only collective on the path: all_gather of the finished proofs (768 B each) over RCCL/xGMI
+    gathered = D.gather_proofs(proofs[0], total, dist)
+    n_results = len(gathered)
 
     msm_ms, msm_launches, msm_bytes = ctx.profile_read("msm_accumulate")
     total_proofs = args.steps * B * world
@@ -225,7 +212,7 @@ def main():
             "sample": "1 full proof of the same group_order=2^11 circuit by oracle/plonk_prover.py (pure Python), %.1f s" % dt,
         }
         # the GPU proof of the same witness must be bit-identical to the oracle's
-        got = BatchProver.decode(proofs[0][:768]).flatten()
+        got = BatchProver.decode(gathered[0]).flatten()
         want = oproof.flatten()
         same = all(
             ((got[k][0].n, got[k][1].n) if isinstance(got[k], tuple) else got[k].n) == want[k] for k in want

@@ -415,8 +415,8 @@ int plonk_srs_size(const plonk_srs* srs, size_t* out_n) {
 
 int plonk_msm_configure(plonk_ctx* ctx, unsigned window_bits, unsigned groups) {
     PLONK_REQUIRE(ctx, PLONK_ERR_ARG, "ctx is NULL");
-    PLONK_REQUIRE(window_bits == 0 || (window_bits >= 2 && window_bits <= 9), PLONK_ERR_ARG,
-                  "window_bits must be 0 (default) or in [2, 9]");
+    PLONK_REQUIRE(window_bits == 0 || (window_bits >= 2 && window_bits <= 13), PLONK_ERR_ARG,
+                  "window_bits must be 0 (default) or in [2, 13]");
     ctx->msm_window_bits = window_bits;
     ctx->msm_groups = groups;
     return PLONK_OK;

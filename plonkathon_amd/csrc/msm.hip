@@ -9,22 +9,27 @@
 // Schedule.  The bases are fixed (the SRS), so a window table
 // T[w][i] = 2^(c*w) * P_i is built once per SRS; every window of every scalar then lands in ONE
 // shared bucket set and no doublings remain in the per-MSM work:
-//   1. msm_digits_kernel     scalar -> canonical -> + sum_w 2^(cw+c-1)  -> W raw digits u_w;
-//                            signed digit d_w = u_w - 2^(c-1) in [-2^(c-1), 2^(c-1)).
-//   2. msm_accumulate_kernel one workgroup per (MSM, window group).  Per window: LDS counting sort
-//                            of the N digits by |d| (LDS atomics), then lane (bucket k, slice l)
-//                            walks its share of bucket k's list doing XYZZ += affine mixed adds
-//                            (sign folded into y).  Buckets live in registers / LDS, never in HBM.
-//                            Afterwards the slices are merged, lane k forms k * B_k by
-//                            double-and-add and the workgroup tree-reduces sum_k k*B_k through LDS.
-//   3. msm_finalize_kernel   adds the window-group partials, converts to the unique affine
-//                            representative (one Fermat inversion) and leaves canonical x||y.
-// All table reads hit L2 / Infinity Cache (4 MiB table); the kernel is integer-ALU bound.
+//   1. msm_sort_kernel        (one workgroup per MSM) scalar -> canonical -> + sum_w 2^(cw+c-1), signed
+//                             digits d_w in [-2^(c-1), 2^(c-1)); LDS counting sort (LDS atomics) of all
+//                             W*N (point, window) entries by bucket |d|; the sorted entry list and the
+//                             bucket boundaries go to HBM (256 KiB per MSM, L2-resident).
+//   2. msm_accumulate_kernel  (one workgroup per MSM segment) the sorted list is cut into EQUAL flat
+//                             ranges, one per lane, so every lane performs the same number of mixed
+//                             additions whatever the bucket sizes.  A lane walks its range from the
+//                             highest bucket down with two accumulators, run += entry and, at every
+//                             bucket boundary it crosses, tot += run; tot + k_low * run is then its
+//                             share of sum_k k * B_k.  The workgroup tree-reduces the 256 shares through
+//                             LDS ("wave-reduced bucket sum"); buckets never exist in memory.
+//   3. msm_finalize_kernel    adds the segment partials, converts to the unique affine representative
+//                             (one Fermat inversion) and leaves canonical x||y.
+// All table reads hit L2 / Infinity Cache (3 MiB table at c = 12); the kernels are integer-ALU bound.
 #include <string.h>
 
 #include "plonk_internal.h"
 
 #define MSM_BLOCK 256
+#define MSM_DEFAULT_WINDOW_BITS 12
+#define MSM_MAX_WINDOW_BITS 13
 
 // ------------------------------------------------------------------------------------------------
 // Window table: table[w*n + i] = 2^(c*w) * bases[i], affine.
@@ -78,127 +83,162 @@ __global__ void g1_batch_to_affine_kernel(const G1Xyzz* in, G1Affine* out, size_
 }
 
 // ------------------------------------------------------------------------------------------------
-// digits[(m*W + w)*n + i] = raw c-bit digit u_w of (scalar_i + K), K = sum_w 2^(c*w + c - 1)
+// Sorting.  Entry encoding: bits 0..14 base index, bit 15 sign, bits 16.. window.
 struct MsmRecode { uint32_t k[9]; };
 
-__global__ void msm_digits_kernel(const Fr* scalars, size_t n, size_t M, size_t stride, unsigned c, unsigned W,
-                                  MsmRecode rc, uint16_t* digits) {
-    const size_t total = n * M;
-    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
-        const size_t m = g / n, i = g - m * n;
-        Fr s = fp_from_mont(fp_load(scalars + m * stride + i));
-        uint32_t limb[10];
-        uint64_t carry = 0;
+PLONK_DEV void msm_recode(const Fr* scalars, size_t idx, const MsmRecode& rc, uint32_t limb[10]) {
+    Fr s = fp_from_mont(fp_load(scalars + idx));
+    uint64_t carry = 0;
 #pragma unroll
-        for (int j = 0; j < 9; j++) {
-            carry += (uint64_t)(j < 8 ? s.v[j] : 0) + rc.k[j];
-            limb[j] = (uint32_t)carry;
-            carry >>= 32;
-        }
-        limb[9] = 0;
+    for (int j = 0; j < 9; j++) {
+        carry += (uint64_t)(j < 8 ? s.v[j] : 0) + rc.k[j];
+        limb[j] = (uint32_t)carry;
+        carry >>= 32;
+    }
+    limb[9] = 0;
+}
+
+PLONK_DEV int msm_digit(const uint32_t limb[10], unsigned c, unsigned w) {
+    const unsigned bit = c * w, j = bit >> 5, sh = bit & 31;
+    const uint64_t two = (uint64_t)limb[j] | ((uint64_t)limb[j + 1] << 32);
+    return (int)((two >> sh) & ((1u << c) - 1)) - (int)(1u << (c - 1));
+}
+
+// starts[m][k] (k = 0..K+1): starts[k] = number of entries in buckets 1..k-1, starts[K+1] = total.
+__global__ void __launch_bounds__(MSM_BLOCK) msm_sort_kernel(const Fr* scalars, size_t n, size_t stride, unsigned c,
+                                                             unsigned W, MsmRecode rc, uint32_t* entries,
+                                                             size_t entry_stride, uint32_t* starts) {
+    PLONK_DYN_SMEM(smem);
+    __shared__ uint32_t chunk_tot[MSM_BLOCK];
+    const unsigned K = 1u << (c - 1);
+    uint32_t* cnt = reinterpret_cast<uint32_t*>(smem);  // K + 2 counters; cnt[0] collects the zero digits
+    const unsigned tid = threadIdx.x;
+    const size_t m = blockIdx.x;
+    const Fr* sc = scalars + m * stride;
+    uint32_t* out = entries + m * entry_stride;
+    uint32_t* st = starts + m * (size_t)(K + 2);
+
+    for (unsigned k = tid; k < K + 2; k += MSM_BLOCK) cnt[k] = 0;
+    __syncthreads();
+    for (size_t i = tid; i < n; i += MSM_BLOCK) {
+        uint32_t limb[10];
+        msm_recode(sc, i, rc, limb);
         for (unsigned w = 0; w < W; w++) {
-            unsigned bit = c * w, j = bit >> 5, sh = bit & 31;
-            uint64_t two = (uint64_t)limb[j] | ((uint64_t)limb[j + 1] << 32);
-            digits[(m * W + w) * n + i] = (uint16_t)((two >> sh) & ((1u << c) - 1));
+            int d = msm_digit(limb, c, w);
+            atomicAdd(&cnt[d < 0 ? -d : d], 1u);
+        }
+    }
+    __syncthreads();
+    // exclusive scan of cnt[1..K] -> bucket starts (bucket 0 = zero digits, dropped)
+    const unsigned per = (K + MSM_BLOCK - 1) / MSM_BLOCK;
+    const unsigned lo = 1 + tid * per, hi = (lo + per < K + 1) ? lo + per : K + 1;
+    uint32_t sum = 0;
+    for (unsigned k = lo; k < hi; k++) sum += cnt[k];
+    chunk_tot[tid] = sum;
+    __syncthreads();
+    for (unsigned off = 1; off < MSM_BLOCK; off <<= 1) {
+        uint32_t v = chunk_tot[tid];
+        if (tid >= off) v += chunk_tot[tid - off];
+        __syncthreads();
+        chunk_tot[tid] = v;
+        __syncthreads();
+    }
+    uint32_t run = tid ? chunk_tot[tid - 1] : 0;
+    for (unsigned k = lo; k < hi; k++) {
+        uint32_t v = cnt[k];
+        cnt[k] = run;  // becomes the scatter cursor
+        st[k] = run;
+        run += v;
+    }
+    if (tid == MSM_BLOCK - 1) {
+        st[K + 1] = chunk_tot[MSM_BLOCK - 1];
+        st[0] = 0;
+    }
+    __syncthreads();
+    for (size_t i = tid; i < n; i += MSM_BLOCK) {
+        uint32_t limb[10];
+        msm_recode(sc, i, rc, limb);
+        for (unsigned w = 0; w < W; w++) {
+            int d = msm_digit(limb, c, w);
+            if (d) {
+                uint32_t pos = atomicAdd(&cnt[d < 0 ? -d : d], 1u);
+                out[pos] = (uint32_t)i | (d < 0 ? 0x8000u : 0u) | (w << 16);
+            }
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-// LDS helpers for XYZZ points (plain layout; used once per window-group, not in the hot loop)
-PLONK_DEV void lds_put(G1Xyzz* s, unsigned i, const G1Xyzz& p) { s[i] = p; }
-
 __global__ void __launch_bounds__(MSM_BLOCK) msm_accumulate_kernel(const G1Affine* table, size_t table_n,
-                                                                   const uint16_t* digits, size_t n, unsigned c,
-                                                                   unsigned W, unsigned G, G1Xyzz* partial) {
+                                                                   const uint32_t* entries, size_t entry_stride,
+                                                                   const uint32_t* starts, unsigned c, unsigned G,
+                                                                   G1Xyzz* partial) {
     PLONK_DYN_SMEM(smem);
-    const unsigned K = 1u << (c - 1);            // buckets 1..K
-    const unsigned L = MSM_BLOCK / K ? MSM_BLOCK / K : 1;  // lanes per bucket (K <= MSM_BLOCK)
+    const unsigned K = 1u << (c - 1);
     const unsigned m = blockIdx.x / G, g = blockIdx.x % G;
-    const unsigned w_begin = (unsigned)(((size_t)W * g) / G), w_end = (unsigned)(((size_t)W * (g + 1)) / G);
     const unsigned tid = threadIdx.x;
-
-    // LDS carve-up: hist[K+1] | cursor[K+1] | sorted[n] (u16) | reduction scratch (XYZZ per thread)
-    unsigned* hist = reinterpret_cast<unsigned*>(smem);
-    unsigned* start = hist + (K + 1);
-    unsigned* cursor = start + (K + 1);
-    uint16_t* sorted = reinterpret_cast<uint16_t*>(cursor + (K + 1));
-    size_t off = (size_t)(3 * (K + 1)) * 4 + n * 2;
-    off = (off + 15) & ~(size_t)15;
-    G1Xyzz* red = reinterpret_cast<G1Xyzz*>(smem + off);
-
-    const unsigned my_bucket = tid / L + 1;  // 1..K (threads beyond K*L idle in the walk)
-    const unsigned my_slice = tid % L;
-    const bool walker = tid < K * L;
-    G1Xyzz acc = g1_xyzz_identity();
-
-    for (unsigned w = w_begin; w < w_end; w++) {
-        const uint16_t* dg = digits + ((size_t)m * W + w) * n;
-        for (unsigned k = tid; k <= K; k += MSM_BLOCK) hist[k] = 0;
-        __syncthreads();
-        for (size_t i = tid; i < n; i += MSM_BLOCK) {
-            int d = (int)dg[i] - (int)K;
-            unsigned a = d < 0 ? (unsigned)(-d) : (unsigned)d;
-            atomicAdd(&hist[a], 1u);
-        }
-        __syncthreads();
-        if (tid == 0) {
-            unsigned run = 0;
-            for (unsigned k = 0; k <= K; k++) {
-                start[k] = run;
-                cursor[k] = run;
-                run += hist[k];
-            }
-        }
-        __syncthreads();
-        for (size_t i = tid; i < n; i += MSM_BLOCK) {
-            int d = (int)dg[i] - (int)K;
-            unsigned a = d < 0 ? (unsigned)(-d) : (unsigned)d;
-            if (a) {
-                unsigned pos = atomicAdd(&cursor[a], 1u);
-                sorted[pos] = (uint16_t)(i | (d < 0 ? 0x8000u : 0u));
-            }
-        }
-        __syncthreads();
-        if (walker) {
-            const unsigned b = start[my_bucket], e = b + hist[my_bucket];
-            const G1Affine* tw = table + (size_t)w * table_n;
-            for (unsigned q = b + my_slice; q < e; q += L) {
-                const unsigned ent = sorted[q];
-                const G1Affine* src = tw + (ent & 0x7fffu);
-                G1Affine pt;
-                pt.x = fp_load(&src->x);
-                pt.y = fp_load(&src->y);
-                if (ent & 0x8000u) pt.y = fp_neg(pt.y);
-                g1_madd(acc, pt);
-            }
-        }
-        __syncthreads();
-    }
-
-    // merge the L slices of each bucket, weight by the bucket index, tree-reduce the workgroup
-    red[tid] = acc;
+    uint32_t* st = reinterpret_cast<uint32_t*>(smem);  // K + 2 bucket starts
+    G1Xyzz* red = reinterpret_cast<G1Xyzz*>(smem + (((size_t)(K + 2) * 4 + 15) & ~(size_t)15));
+    const uint32_t* gst = starts + (size_t)m * (K + 2);
+    for (unsigned k = tid; k < K + 2; k += MSM_BLOCK) st[k] = gst[k];
     __syncthreads();
-    if (walker && my_slice == 0) {
-        for (unsigned l = 1; l < L; l++) g1_add(acc, red[tid + l]);
-        // k * B_k, left-to-right double-and-add on the bucket index
-        G1Xyzz r = g1_xyzz_identity();
+    const uint32_t E = st[K + 1];
+    const uint32_t* ent = entries + (size_t)m * entry_stride;
+
+    // equal flat ranges: segment g of G, lane tid of 256; range lengths are multiples of 4 entries
+    uint32_t per = (E + G * MSM_BLOCK - 1) / (G * MSM_BLOCK);
+    per = (per + 3) & ~3u;
+    const uint64_t lo64 = ((uint64_t)g * MSM_BLOCK + tid) * per;
+    const uint32_t lo = lo64 < E ? (uint32_t)lo64 : E;
+    const uint32_t hi = (lo64 + per < E) ? (uint32_t)(lo64 + per) : E;
+
+    G1Xyzz run = g1_xyzz_identity(), tot = g1_xyzz_identity();
+    if (lo < hi) {
+        // bucket of the last entry: largest k in [1, K] with st[k] <= hi - 1
+        unsigned a = 1, b = K;
+        while (a < b) {
+            unsigned mid = (a + b + 1) >> 1;
+            if (st[mid] <= hi - 1) a = mid;
+            else b = mid - 1;
+        }
+        unsigned k = a;
+        for (uint32_t base = (hi - 1) & ~3u;; base -= 4) {
+            const u32x4 q = *reinterpret_cast<const u32x4*>(ent + base);
+            const uint32_t four[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int j = 3; j >= 0; j--) {
+                const uint32_t e = base + j;
+                if (e < hi && e >= lo) {
+                    while (e < st[k]) {  // crossed into a lower bucket: every finished point gains one more unit
+                        k--;
+                        g1_add(tot, run);
+                    }
+                    const uint32_t en = four[j];
+                    const G1Affine* src = table + (size_t)(en >> 16) * table_n + (en & 0x7fffu);
+                    G1Affine pt;
+                    pt.x = fp_load(&src->x);
+                    pt.y = fp_load(&src->y);
+                    if (en & 0x8000u) pt.y = fp_neg(pt.y);
+                    g1_madd(run, pt);
+                }
+            }
+            if (base <= lo) break;
+        }
+        // share = tot + k * run   (k = bucket of the lane's lowest entry)
+        G1Xyzz kr = g1_xyzz_identity();
         for (int bit = (int)c - 1; bit >= 0; bit--) {
-            g1_dbl(r);
-            if ((my_bucket >> bit) & 1) g1_add(r, acc);
+            g1_dbl(kr);
+            if ((k >> bit) & 1) g1_add(kr, run);
         }
-        acc = r;
-    } else {
-        acc = g1_xyzz_identity();
+        g1_add(tot, kr);
     }
-    __syncthreads();
-    red[tid] = acc;
+    red[tid] = tot;
     __syncthreads();
     for (unsigned s = MSM_BLOCK / 2; s > 0; s >>= 1) {
         if (tid < s) {
-            G1Xyzz a = red[tid];
-            g1_add(a, red[tid + s]);
-            red[tid] = a;
+            G1Xyzz x = red[tid];
+            g1_add(x, red[tid + s]);
+            red[tid] = x;
         }
         __syncthreads();
     }
@@ -218,7 +258,6 @@ __global__ void msm_finalize_kernel(const G1Xyzz* partial, size_t M, unsigned G,
     }
 }
 
-// ------------------------------------------------------------------------------------------------
 static unsigned windows_for(unsigned c) {
     // smallest W with 2^254 + K < 2^(c*W), K < 2^(c*W) * (1/2 + 2^-c): c*W >= 256 suffices
     return (256 + c - 1) / c;
@@ -258,53 +297,54 @@ int msm_build_table(plonk_ctx* ctx, plonk_srs* srs, unsigned c) {
 int msm_run_device(plonk_ctx* ctx, plonk_srs* srs, const Fr* d_scalars, size_t n, size_t M, size_t stride,
                    Fq* d_out_xy, uint8_t* d_flags) {
     PLONK_REQUIRE(n >= 1 && n <= srs->n_points, PLONK_ERR_ARG, "MSM size %zu exceeds the %zu loaded bases", n, srs->n_points);
-    PLONK_REQUIRE(n <= 32768, PLONK_ERR_ARG, "MSM size %zu > 32768 is not supported by the LDS sort", n);
+    PLONK_REQUIRE(n <= 32768, PLONK_ERR_ARG, "MSM size %zu > 32768 is not supported by the entry encoding", n);
     if (!M) return PLONK_OK;
-    unsigned c = ctx->msm_window_bits ? ctx->msm_window_bits : 8;
-    if (c < 2) c = 2;
-    if (c > 9) c = 9;  // K = 2^(c-1) buckets must fit one 256-lane workgroup
+    unsigned c = ctx->msm_window_bits ? ctx->msm_window_bits : MSM_DEFAULT_WINDOW_BITS;
     PLONK_TRY(msm_build_table(ctx, srs, c));
-    const unsigned W = srs->n_windows;
+    const unsigned W = srs->n_windows, K = 1u << (c - 1);
     unsigned G = ctx->msm_groups;
     if (!G) {
         // enough workgroups to fill 256 CUs a few times over, but no more splitting than needed
         G = 1;
-        while (G < W && M * G < 1024) G *= 2;
+        while (G < 64 && M * G < 1024) G *= 2;
     }
-    if (G > W) G = W;
-
-    const size_t dig_bytes = M * W * n * sizeof(uint16_t);
+    const size_t max_entries = (size_t)W * n;
+    while (G > 1 && (size_t)G * MSM_BLOCK * 4 > max_entries) G /= 2;  // tiny MSMs: one segment is plenty
+    const size_t entry_stride = ((max_entries + 3) & ~(size_t)3) + 4;
+    const size_t ent_bytes = (M * entry_stride * 4 + 255) & ~(size_t)255;
+    const size_t st_bytes = (M * (size_t)(K + 2) * 4 + 255) & ~(size_t)255;
     const size_t part_bytes = M * G * sizeof(G1Xyzz);
     void* s;
-    PLONK_TRY(ctx_scratch(ctx, 1, dig_bytes + 256 + part_bytes, &s));
-    uint16_t* digits = (uint16_t*)s;
-    G1Xyzz* partial = (G1Xyzz*)((uint8_t*)s + ((dig_bytes + 255) & ~(size_t)255));
+    PLONK_TRY(ctx_scratch(ctx, 1, ent_bytes + st_bytes + part_bytes, &s));
+    uint32_t* entries = (uint32_t*)s;
+    uint32_t* starts = (uint32_t*)((uint8_t*)s + ent_bytes);
+    G1Xyzz* partial = (G1Xyzz*)((uint8_t*)s + ent_bytes + st_bytes);
 
-    size_t total = n * M;
-    unsigned gd = (unsigned)((total + 255) / 256);
-    if (gd > 4096) gd = 4096;
     MsmRecode rc;
     memset(&rc, 0, sizeof rc);
     for (unsigned w = 0; w < W; w++) {
         unsigned bit = c * w + c - 1;
         rc.k[bit >> 5] |= 1u << (bit & 31);
     }
-    PLONK_LAUNCH(msm_digits_kernel, dim3(gd), dim3(256), 0, ctx->stream, d_scalars, n, M, stride, c, W, rc, digits);
-
-    const unsigned K = 1u << (c - 1);
-    size_t shmem = (size_t)(3 * (K + 1)) * 4 + n * 2;
-    shmem = ((shmem + 15) & ~(size_t)15) + (size_t)MSM_BLOCK * sizeof(G1Xyzz);
-    PLONK_REQUIRE(shmem <= 160 * 1024, PLONK_ERR_ARG, "MSM LDS footprint %zu exceeds 160 KiB", shmem);
+    const size_t sort_lds = (size_t)(K + 2) * 4;
+    const size_t acc_lds = (((size_t)(K + 2) * 4 + 15) & ~(size_t)15) + (size_t)MSM_BLOCK * sizeof(G1Xyzz);
     static bool configured = false;
     if (!configured) {
         PLONK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(msm_accumulate_kernel),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
+        PLONK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(msm_sort_kernel),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)(128 * 1024)));
         configured = true;
     }
+    PLONK_TRY(prof_begin(ctx, "msm_sort", (double)M * 32.0 * (double)n));
+    PLONK_LAUNCH(msm_sort_kernel, dim3((unsigned)M), dim3(MSM_BLOCK), sort_lds, ctx->stream, d_scalars, n, stride, c, W, rc,
+                 entries, entry_stride, starts);
+    PLONK_TRY(prof_end(ctx));
     // algorithmic bytes of an MSM of size n: (64 + 32) * n + 64   
     PLONK_TRY(prof_begin(ctx, "msm_accumulate", (double)M * (96.0 * (double)n + 64.0)));
-    PLONK_LAUNCH(msm_accumulate_kernel, dim3((unsigned)(M * G)), dim3(MSM_BLOCK), shmem, ctx->stream,
-                 (const G1Affine*)srs->table, srs->n_points, (const uint16_t*)digits, n, c, W, G, partial);
+    PLONK_LAUNCH(msm_accumulate_kernel, dim3((unsigned)(M * G)), dim3(MSM_BLOCK), acc_lds, ctx->stream,
+                 (const G1Affine*)srs->table, srs->n_points, (const uint32_t*)entries, entry_stride,
+                 (const uint32_t*)starts, c, G, partial);
     PLONK_TRY(prof_end(ctx));
     unsigned gf = (unsigned)((M + 63) / 64);
     PLONK_LAUNCH(msm_finalize_kernel, dim3(gf), dim3(64), 0, ctx->stream, (const G1Xyzz*)partial, M, G, d_out_xy, d_flags);

@@ -59,7 +59,7 @@ def test_msm_window_configs(emu):
 
     ctx = get_context()
     try:
-        for c, groups in ((4, 1), (5, 3), (9, 2), (7, 0)):
+        for c, groups in ((4, 1), (5, 3), (9, 2), (7, 0), (12, 1), (13, 4)):
             check(ctx.L.plonk_msm_configure(ctx.handle, c, groups))
             pc.msm_vs_oracle(Setup.from_file(pc.PTAU), 64, seed=20 + c)
     finally:

@@ -80,7 +80,7 @@ def test_msm_window_configs(setup):
 
     ctx = get_context()
     try:
-        for c, groups in ((4, 1), (5, 3), (6, 0), (7, 2), (8, 1), (8, 32), (9, 4)):
+        for c, groups in ((4, 1), (5, 3), (6, 0), (7, 2), (8, 1), (8, 32), (9, 4), (11, 0), (12, 1), (12, 64), (13, 3)):
             check(ctx.L.plonk_msm_configure(ctx.handle, c, groups))
             pc.msm_vs_oracle(setup, 300, seed=20 + c)
     finally:
@@ -136,3 +136,38 @@ def test_api_prover_matches_batch_prover_2_11(setup):
     p1 = Prover(setup, program)
     p1.check = False
     assert pc.flat(p1.prove(dict(wit))) == pc.flat(BatchProver(setup, program).prove(dict(wit)))
+
+
+@pytest.mark.parametrize("log_n", [17, 20])
+def test_ntt_exact_vs_c_oracle(log_n):
+    """Bit-exact forward and inverse transforms at microbench sizes against the C half of the oracle."""
+    from oracle import c_oracle
+    from plonkathon_amd import Basis
+
+    v = pc.rand_vec(4000 + log_n, 1 << log_n)
+    assert pc.ints(pc.P(v, Basis.MONOMIAL).fft()) == c_oracle.fr_ntt(v)
+    assert pc.ints(pc.P(v, Basis.LAGRANGE).ifft()) == c_oracle.fr_ntt(v, True)
+
+
+def test_batched_msm_vs_c_oracle(setup):
+    """A batch of 12 full-size MSMs over the shared SRS (the shape rounds 1-5 launch) against the C oracle."""
+    import ctypes
+    from oracle import c_oracle
+    from oracle.srs import Setup as OSetup
+    from plonkathon_amd import get_context
+    from plonkathon_amd._lib import check
+
+    ctx = get_context()
+    n, M = 2048, 12
+    scal = [pc.rand_vec(9000 + m, n) for m in range(M)]
+    scal[3] = [0] * n
+    scal[4] = [1] + [0] * (n - 1)
+    scal[5] = [pc.R_MOD - 1] * n
+    buf = ctx.upload_ints([x for s in scal for x in s])
+    xy, fl = ctypes.create_string_buffer(64 * M), ctypes.create_string_buffer(M)
+    check(ctx.L.plonk_g1_msm(ctx.handle, setup.device_bases().handle, buf.ptr, n, M, n, xy, fl))
+    P = OSetup.from_file(pc.PTAU).powers_of_x
+    for m in range(M):
+        got = None if fl.raw[m] else (int.from_bytes(xy.raw[64 * m : 64 * m + 32], "little"),
+                                      int.from_bytes(xy.raw[64 * m + 32 : 64 * m + 64], "little"))
+        assert got == c_oracle.g1_lincomb(P, scal[m]), m

@@ -1,0 +1,10 @@
+#!/bin/bash
+set -x
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+( timeout 1200 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> gpurun_out/pytest_gpu.log )
+tail -8 gpurun_out/pytest_gpu.log
+( timeout 900 python tools/gpu_sweep.py msm prover > gpurun_out/sweep.jsonl 2> gpurun_out/sweep.err; echo "sweep rc=$?" )
+cat gpurun_out/sweep.jsonl; tail -5 gpurun_out/sweep.err
+( timeout 600 python bench.py > gpurun_out/bench.json 2> gpurun_out/bench.err; echo "bench rc=$?" )
+cat gpurun_out/bench.json; tail -5 gpurun_out/bench.err

@@ -49,8 +49,8 @@ if "msm" in which:
         sc = fill(n * M)
         xy = ctypes.create_string_buffer(64 * M)
         fl = ctypes.create_string_buffer(M)
-        for c in (6, 7, 8, 9):
-            for G in ((0,) if M > 1 else (1, 4, 8, 32)):
+        for c in (8, 10, 11, 12, 13):
+            for G in ((0,) if M > 1 else (1, 8, 64)):
                 check(L.plonk_msm_configure(H, c, G))
                 t0 = time.perf_counter()
                 check(L.plonk_g1_msm(H, bases.handle, sc.ptr, n, M, n, xy, fl))  # includes table (re)build
