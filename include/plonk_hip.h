@@ -10,8 +10,8 @@
  *   - plain C, no C++ types, no exceptions cross the boundary; every call returns PLONK_OK (0) or
  *     a negative PLONK_ERR_* and sets a thread-local message readable with plonk_last_error().
  *   - host-side field elements are CANONICAL integers (< modulus), 32 bytes little-endian.
- *     Device-side Fr vectors are 32 bytes/element in Montgomery form (R = 2^256) — the byte layout
- *     of a coordinate in a snarkjs .ptau file — and are opaque to the caller.
+ *     Device-side Fr vectors are 32 bytes/element Montgomery residues (R = 2^261, 8 x u32 LE
+ *     limbs, canonical) and are opaque to the caller.
  *   - G1 points on the host are affine canonical x||y, 64 bytes little-endian each coordinate,
  *     plus an out-of-band identity flag (py_ecc represents the identity as None).
  *   - all work is enqueued on the context's HIP stream; calls that return host data synchronise.
@@ -102,9 +102,9 @@ int plonk_fr_barycentric(plonk_ctx* ctx, const void* d_vals, unsigned log_n, con
 
 /* ---- G1 multi-scalar multiplication ------------------------------------------------------------
  * plonk_srs_load_ptau   Setup.from_file's G1 section, setup.py:29-41: `n_points` affine points, each
- *                       64 B = x||y little-endian in Montgomery form — bytes 80.. of a snarkjs .ptau
- *                       are passed through unchanged (the Montgomery factor the reference divides
- *                       out at setup.py:39-40 is exactly this library's internal representation).
+ *                       64 B = x||y little-endian in Montgomery form with R = 2^256 — bytes 80.. of a snarkjs
+ *                       .ptau are passed through as they are; the device rescales them (x 2^5) to the
+ *                       library's radix instead of dividing the factor out as setup.py:39-40 does.
  * plonk_srs_load_affine arbitrary bases for ec_lincomb (curve.py:38-44): canonical x||y LE,
  *                       (0,0) encodes the identity (py_ecc None).
  * plonk_g1_msm          ec_lincomb / lincomb / multisubset, curve.py:38-111, i.e. the body of

@@ -80,6 +80,15 @@ static bool le32_below_modulus(const uint8_t* b, bool fq) {
     return false;
 }
 
+// .ptau coordinates are Montgomery residues with R = 2^256 (setup.py:39-40); ours use R = 2^PLONK_MONT_BITS.
+__global__ void fq_rescale_kernel(Fq* data, size_t n, unsigned doublings) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        Fq x = fp_load(data + i);
+        for (unsigned k = 0; k < doublings; k++) x = fp_dbl(x);
+        fp_store(data + i, x);
+    }
+}
+
 extern "C" {
 
 const char* plonk_last_error(void) { return g_err; }
@@ -374,6 +383,13 @@ int plonk_srs_load_ptau(plonk_ctx* ctx, const uint8_t* g1_mont_le, size_t n_poin
     plonk_srs* s;
     PLONK_TRY(srs_alloc(ctx, n_points, &s));
     PLONK_CHECK_HIP(hipMemcpyAsync(s->bases, g1_mont_le, n_points * 64, hipMemcpyHostToDevice, ctx->stream));
+    {
+        size_t nc = 2 * n_points;
+        unsigned g = (unsigned)((nc + 255) / 256);
+        if (g > 2048) g = 2048;
+        PLONK_LAUNCH(fq_rescale_kernel, dim3(g), dim3(256), 0, ctx->stream, (Fq*)s->bases, nc, (unsigned)(PLONK_MONT_BITS - 256));
+        PLONK_CHECK_HIP(hipGetLastError());
+    }
     PLONK_CHECK_HIP(hipStreamSynchronize(ctx->stream));
     *out_srs = s;
     return PLONK_OK;

@@ -1,14 +1,18 @@
-// fp.h — 254-bit prime-field arithmetic in Montgomery form (R = 2^256), 8 x u32 limbs.
+// fp.h — 254-bit prime-field arithmetic in Montgomery form, R = 2^261.
 //
 // Replaces py_ecc's `FQ.__add__/__sub__/__mul__/__truediv__/__pow__` as used through `Scalar`
-// (/root/reference/curve.py:10-11) and `b.FQ` (the G1 coordinates in curve.py:38-44): every
-// device-resident field element lives in Montgomery form, canonical (< m), little-endian limbs,
-// 32 bytes — the same layout as one coordinate in a snarkjs .ptau file (setup.py:29-41), so SRS
-// bytes upload without conversion.
+// (/root/reference/curve.py:10-11) and `b.FQ` (the G1 coordinates in curve.py:38-44).  Every
+// device-resident field element is a Montgomery residue, canonical (< m), stored as 8 x u32
+// little-endian limbs (32 bytes).  A snarkjs .ptau stores coordinates the same way with R = 2^256
+// (setup.py:29-41), so SRS bytes need only a x2^5 on upload (five modular doublings).
 //
-// Both BN254 moduli are 254-bit, so 2m < 2^255: sums never carry out of the top limb and the CIOS
-// accumulator needs a single extra word.  Multiplication is operand-scanning CIOS on 32-bit limbs;
-// hipcc lowers each `(u64)a*b + c` to one v_mad_u64_u32.  Not a dense contraction: no MFMA.
+// Multiplication: product scanning on 9 x 29-bit limbs with lazy carries.  Measured on gfx950
+// (profiles/r01_ubench.json) v_mad_u64_u32 issues at ~5 cycles per wave64 and plain VALU ops at ~2, and
+// clang pads carry-flag chains with s_nop; a 32-bit-limb CIOS therefore spends more cycles on carry
+// adds and register-pair moves (430 ops) than on its 136 multiply-adds.  With 29-bit limbs every
+// partial product is < 2^58 and a column holds at most 18 of them plus a carry (< 2^63), so a column is
+// a pure chain of v_mad_u64_u32 into one 64-bit accumulator — no carry flags, no zero-extension moves:
+// 161 mad + 9 mul_lo + ~160 cheap ops instead of 566.  Not a dense contraction: no MFMA.
 #pragma once
 #include "hip_compat.h"
 #include "bn254_constants.h"
@@ -110,42 +114,109 @@ template <class P> PLONK_HD Fp<P> fp_neg(const Fp<P>& a) {
 
 template <class P> PLONK_HD Fp<P> fp_dbl(const Fp<P>& a) { return fp_add(a, a); }
 
-// Montgomery product a*b*R^-1 mod m.  Inputs < m, output < m.
-template <class P> PLONK_HD Fp<P> fp_mul(const Fp<P>& a, const Fp<P>& b) {
-    uint32_t t[9];
-#pragma unroll
-    for (int i = 0; i < 9; i++) t[i] = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        uint64_t c = 0;
-        const uint32_t bi = b.v[i];
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            c += (uint64_t)a.v[j] * bi + t[j];
-            t[j] = (uint32_t)c;
-            c >>= 32;
-        }
-        t[8] += (uint32_t)c;  // t < 2m + (2^32-1) m: one extra word suffices, no further carry
-        const uint32_t q = t[0] * P::NINV;
-        c = ((uint64_t)q * P::mod(0) + t[0]) >> 32;
-#pragma unroll
-        for (int j = 1; j < 8; j++) {
-            c += (uint64_t)q * P::mod(j) + t[j];
-            t[j - 1] = (uint32_t)c;
-            c >>= 32;
-        }
-        c += t[8];
-        t[7] = (uint32_t)c;
-        t[8] = (uint32_t)(c >> 32);
-    }
-    Fp<P> r;
-#pragma unroll
-    for (int i = 0; i < 8; i++) r.v[i] = t[i];
-    fp_reduce_once<P>(r.v);
-    return r;
+#define FP29_MASK 0x1fffffffu
+
+template <class P> PLONK_HD constexpr uint32_t fp29_mod_limb(int i) {
+    const int bit = 29 * i, w = bit >> 5, s = bit & 31;
+    const uint64_t lo = P::mod(w);
+    const uint64_t hi = (w + 1 < 8) ? P::mod(w + 1) : 0;
+    return (uint32_t)(((lo | (hi << 32)) >> s) & FP29_MASK);
 }
 
-template <class P> PLONK_HD Fp<P> fp_sqr(const Fp<P>& a) { return fp_mul(a, a); }
+// 8 x u32 -> 9 x 29-bit limbs
+PLONK_HD void fp29_unpack(const uint32_t v[8], uint32_t l[9]) {
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        const int bit = 29 * i, w = bit >> 5, s = bit & 31;
+        uint32_t x = v[w] >> s;
+        if (s > 3 && w + 1 < 8) x |= v[w + 1] << (32 - s);
+        l[i] = x & FP29_MASK;
+    }
+}
+
+// 9 normalised 29-bit limbs (value < 2^256) -> 8 x u32
+PLONK_HD void fp29_pack(const uint32_t l[9], uint32_t v[8]) {
+#pragma unroll
+    for (int w = 0; w < 8; w++) {
+        const int first = (32 * w) / 29, off = 32 * w - 29 * first;  // bit offset inside limb `first`
+        uint32_t x = l[first] >> off;
+        int have = 29 - off;
+        if (first + 1 < 9) x |= l[first + 1] << have;
+        have += 29;
+        if (have < 32 && first + 2 < 9) x |= l[first + 2] << have;
+        v[w] = x;
+    }
+}
+
+// Montgomery product a*b*2^-261 mod m.  Inputs < m, output < m.
+template <class P> PLONK_HD Fp<P> fp_mul(const Fp<P>& a, const Fp<P>& b) {
+    uint32_t x[9], y[9], r[9];
+    fp29_unpack(a.v, x);
+    fp29_unpack(b.v, y);
+    const uint32_t ninv = P::NINV & FP29_MASK;
+    uint32_t q[9];
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+#pragma unroll
+        for (int i = 0; i <= k; i++) acc += (uint64_t)x[i] * y[k - i];
+#pragma unroll
+        for (int i = 0; i < k; i++) acc += (uint64_t)q[i] * fp29_mod_limb<P>(k - i);
+        q[k] = ((uint32_t)acc * ninv) & FP29_MASK;
+        acc += (uint64_t)q[k] * fp29_mod_limb<P>(0);
+        acc >>= 29;
+    }
+#pragma unroll
+    for (int k = 9; k < 17; k++) {
+#pragma unroll
+        for (int i = k - 8; i < 9; i++) acc += (uint64_t)x[i] * y[k - i];
+#pragma unroll
+        for (int i = k - 8; i < 9; i++) acc += (uint64_t)q[i] * fp29_mod_limb<P>(k - i);
+        r[k - 9] = (uint32_t)acc & FP29_MASK;
+        acc >>= 29;
+    }
+    r[8] = (uint32_t)acc;
+    Fp<P> out;
+    fp29_pack(r, out.v);
+    fp_reduce_once<P>(out.v);
+    return out;
+}
+
+// Squaring: the 81 cross products collapse to 45 (off-diagonal terms doubled).
+template <class P> PLONK_HD Fp<P> fp_sqr(const Fp<P>& a) {
+    uint32_t x[9], x2[9], r[9];
+    fp29_unpack(a.v, x);
+#pragma unroll
+    for (int i = 0; i < 9; i++) x2[i] = x[i] << 1;  // < 2^30: doubled partial products stay < 2^59
+    const uint32_t ninv = P::NINV & FP29_MASK;
+    uint32_t q[9];
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < 17; k++) {
+#pragma unroll
+        for (int i = 0; i <= k; i++) {
+            const int j = k - i;
+            if (i > 8 || j > 8 || i > j) continue;
+            acc += (i == j) ? (uint64_t)x[i] * x[i] : (uint64_t)x2[i] * x[j];
+        }
+        if (k < 9) {
+#pragma unroll
+            for (int i = 0; i < k; i++) acc += (uint64_t)q[i] * fp29_mod_limb<P>(k - i);
+            q[k] = ((uint32_t)acc * ninv) & FP29_MASK;
+            acc += (uint64_t)q[k] * fp29_mod_limb<P>(0);
+        } else {
+#pragma unroll
+            for (int i = k - 8; i < 9; i++) acc += (uint64_t)q[i] * fp29_mod_limb<P>(k - i);
+            r[k - 9] = (uint32_t)acc & FP29_MASK;
+        }
+        acc >>= 29;
+    }
+    r[8] = (uint32_t)acc;
+    Fp<P> out;
+    fp29_pack(r, out.v);
+    fp_reduce_once<P>(out.v);
+    return out;
+}
 
 // canonical integer (< m, plain limbs) -> Montgomery form, and back
 template <class P> PLONK_HD Fp<P> fp_to_mont(const Fp<P>& a) {

@@ -28,7 +28,7 @@
 #include "plonk_internal.h"
 
 #define MSM_BLOCK 256
-#define MSM_DEFAULT_WINDOW_BITS 12
+#define MSM_DEFAULT_WINDOW_BITS 10
 #define MSM_MAX_WINDOW_BITS 13
 
 // ------------------------------------------------------------------------------------------------

@@ -514,7 +514,7 @@ int plonk_prover_create(plonk_ctx* ctx, plonk_srs* srs, unsigned log_n, const ui
         p->zh_inv[k] = fp_inv(fp_sub(cur, one));
         cur = fp_mul(cur, i4);
     }
-    PLONK_TRY(msm_build_table(ctx, srs, ctx->msm_window_bits ? ctx->msm_window_bits : 12));
+    PLONK_TRY(msm_build_table(ctx, srs, ctx->msm_window_bits ? ctx->msm_window_bits : 10));
     *out = p;
     return PLONK_OK;
 }
