@@ -32,6 +32,7 @@ SIGNATURES = {
     "plonk_fr_download": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]),
     "plonk_fr_ntt": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint, ctypes.c_int, ctypes.c_size_t]),
     "plonk_ntt_configure": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint, ctypes.c_uint, ctypes.c_uint]),
+    "plonk_ntt_select_kernel": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint]),
     "plonk_fr_coset_extend": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint, _u8p, ctypes.c_size_t]),
     "plonk_fr_coset_to_coeffs": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint, _u8p, ctypes.c_size_t]),
     "plonk_fr_coset_ntt_from_coeffs": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint, ctypes.c_uint, _u8p, ctypes.c_size_t]),

@@ -27,18 +27,20 @@ def _le(vals):
 
 
 class BatchProver:
-    def __init__(self, setup: Setup, program: Program):
+    def __init__(self, setup: Setup, program: Program, ctx=None):
+        """`ctx`: the Context (HIP stream) to run on; several BatchProvers on distinct contexts of one
+        GPU overlap each other's latency-bound kernels (transcript, inversions) with MSM work."""
         self.group_order = program.group_order
         self.setup = setup
         self.program = program
-        self.ctx = get_context()
+        self.ctx = ctx or get_context()
         self._public_vars = program.get_public_assignments()
         self._wires = [w.as_list() for w in program.wires()]
         n = self.group_order
         L, R, M, O, C = program.gate_columns()
         sigma = program.permutation_columns()
         sel = _le(M) + _le(L) + _le(R) + _le(O) + _le(C) + _le(sigma[1]) + _le(sigma[2]) + _le(sigma[3])
-        self._bases = setup.device_bases()
+        self._bases = setup.device_bases(self.ctx)
         self._h = ctypes.c_void_p()
         check(self.ctx.L.plonk_prover_create(self.ctx.handle, self._bases.handle, _log2_exact(n), sel,
                                              len(self._public_vars), ctypes.byref(self._h)))

@@ -231,6 +231,13 @@ int plonk_ntt_configure(plonk_ctx* ctx, unsigned tile_log, unsigned single_pass_
     return PLONK_OK;
 }
 
+int plonk_ntt_select_kernel(plonk_ctx* ctx, unsigned kind) {
+    PLONK_REQUIRE(ctx, PLONK_ERR_ARG, "ctx is NULL");
+    PLONK_REQUIRE(kind <= 2, PLONK_ERR_ARG, "kernel kind must be 0 (default), 1 (radix-2 stages) or 2 (Stockham radix-8)");
+    ctx->ntt_kind = kind ? kind : 1;
+    return PLONK_OK;
+}
+
 int plonk_fr_ntt(plonk_ctx* ctx, const void* d_in, void* d_out, unsigned log_n, int inverse, size_t batch) {
     PLONK_REQUIRE(ctx && d_in && d_out, PLONK_ERR_ARG, "bad argument");
     const size_t N = (size_t)1 << log_n;

@@ -149,7 +149,7 @@ PLONK_HD void fp29_pack(const uint32_t l[9], uint32_t v[8]) {
 }
 
 // Montgomery product a*b*2^-261 mod m.  Inputs < m, output < m.
-template <class P> PLONK_HD Fp<P> fp_mul(const Fp<P>& a, const Fp<P>& b) {
+template <class P> PLONK_FP_CALL Fp<P> fp_mul(const Fp<P> a, const Fp<P> b) {
     uint32_t x[9], y[9], r[9];
     fp29_unpack(a.v, x);
     fp29_unpack(b.v, y);
@@ -183,7 +183,7 @@ template <class P> PLONK_HD Fp<P> fp_mul(const Fp<P>& a, const Fp<P>& b) {
 }
 
 // Squaring: the 81 cross products collapse to 45 (off-diagonal terms doubled).
-template <class P> PLONK_HD Fp<P> fp_sqr(const Fp<P>& a) {
+template <class P> PLONK_FP_CALL Fp<P> fp_sqr(const Fp<P> a) {
     uint32_t x[9], x2[9], r[9];
     fp29_unpack(a.v, x);
 #pragma unroll

@@ -137,3 +137,98 @@ PLONK_HD G1Affine g1_to_affine(const G1Xyzz& p) {
     r.y = fp_mul(p.y, izzz);
     return r;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Lazy-limb accumulator for the MSM inner loop (fpl.h): same madd-2008-s formulas, no canonical
+// reductions.  Invariants between calls (all limbs normalised): x < 8m, y < 4m, zz < 2m, zzz < 2m.
+#include "fpl.h"
+
+typedef FpL<FqParams> FqL;
+struct G1XyzzL {
+    FqL x, y, zz, zzz;
+    bool inf;
+};
+
+PLONK_HD G1XyzzL g1l_identity() {
+    G1XyzzL r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.x.l[i] = r.y.l[i] = r.zz.l[i] = r.zzz.l[i] = 0;
+    r.inf = true;
+    return r;
+}
+
+PLONK_HD G1Xyzz g1l_to_xyzz(const G1XyzzL& p) {
+    if (p.inf) return g1_xyzz_identity();
+    G1Xyzz r;
+    r.x = fpl_to_fp(p.x);
+    r.y = fpl_to_fp(p.y);
+    r.zz = fpl_to_fp(p.zz);
+    r.zzz = fpl_to_fp(p.zzz);
+    return r;
+}
+
+PLONK_HD G1XyzzL g1l_from_xyzz(const G1Xyzz& p) {
+    G1XyzzL r;
+    r.inf = g1_is_identity(p);
+    r.x = fpl_from_fp(p.x);
+    r.y = fpl_from_fp(p.y);
+    r.zz = fpl_from_fp(p.zz);
+    r.zzz = fpl_from_fp(p.zzz);
+    return r;
+}
+
+// rare tail of g1l_madd (P == +-Q): kept out of line so the hot loop stays small
+PLONK_HD_NOINLINE void g1l_madd_same_x(G1XyzzL& p, const Fq& x2p, const Fq& y2p, bool same_point) {
+    if (same_point) {
+        G1Affine q;
+        q.x = x2p;
+        q.y = y2p;
+        p = g1l_from_xyzz(g1_dbl_affine(q));
+    } else {
+        p = g1l_identity();
+    }
+}
+
+// acc += (x2, y2) affine, canonical packed coordinates; (0, 0) is the identity
+PLONK_HD void g1l_madd(G1XyzzL& p, const Fq& x2p, const Fq& y2p) {
+    if (fp_is_zero(x2p) && fp_is_zero(y2p)) return;
+    const FqL x2 = fpl_from_fp(x2p), y2 = fpl_from_fp(y2p);
+    if (p.inf) {
+        p.x = x2;
+        p.y = y2;
+        p.zz = fpl_one<FqParams>();
+        p.zzz = p.zz;
+        p.inf = false;
+        return;
+    }
+    const FqL u2 = fpl_mul(x2, p.zz);                                  // < 2m
+    PLONK_SCHED_FENCE();
+    const FqL pp_ = fpl_norm(fpl_sub<FqParams, 8>(u2, p.x));           // U2 - X1 + 8m   in (0, 10m)
+    const FqL s2 = fpl_mul(y2, p.zzz);                                 // < 2m
+    PLONK_SCHED_FENCE();
+    const FqL rr = fpl_norm(fpl_sub<FqParams, 4>(s2, p.y));            // S2 - Y1 + 4m   in (0, 6m)
+    if (fpl_is_zero_mod(pp_)) {                                        // same x: P == +-Q (rare)
+        g1l_madd_same_x(p, x2p, y2p, fpl_is_zero_mod(rr));
+        return;
+    }
+    const FqL pp = fpl_sqr(pp_);                                       // < 2m
+    PLONK_SCHED_FENCE();
+    const FqL q = fpl_mul(p.x, pp);                                    // < 2m   (X1 dead after this)
+    PLONK_SCHED_FENCE();
+    p.zz = fpl_mul(p.zz, pp);
+    PLONK_SCHED_FENCE();
+    const FqL ppp = fpl_mul(pp_, pp);                                  // < 2m   (P, PP dead after this)
+    PLONK_SCHED_FENCE();
+    p.zzz = fpl_mul(p.zzz, ppp);
+    PLONK_SCHED_FENCE();
+    const FqL m2 = fpl_mul(p.y, ppp);                                  // < 2m   (Y1 dead after this)
+    PLONK_SCHED_FENCE();
+    const FqL r2 = fpl_sqr(rr);                                        // < 2m
+    PLONK_SCHED_FENCE();
+    // X3 = R^2 - PPP - 2Q  ->  R^2 + (2m - PPP) + (4m - 2Q)  in (0, 8m)
+    p.x = fpl_norm(fpl_sub<FqParams, 4>(fpl_sub<FqParams, 2>(r2, ppp), fpl_add(q, q)));
+    const FqL d = fpl_norm(fpl_sub<FqParams, 8>(q, p.x));              // Q - X3 + 8m    in (0, 10m)
+    const FqL m1 = fpl_mul(rr, d);                                     // < 2m
+    PLONK_SCHED_FENCE();
+    p.y = fpl_norm(fpl_sub<FqParams, 2>(m1, m2));                      // in (0, 4m)
+}

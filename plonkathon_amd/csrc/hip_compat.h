@@ -10,9 +10,25 @@
 #else
 #include <hip/hip_runtime.h>
 #define PLONK_HD __host__ __device__ __forceinline__
+// The 254-bit multiply is ~330 instructions; inlining every call makes the hot kernels 60-300 KB of
+// code against a 64 KB instruction cache.  PLONK_FP_CALL = out-of-line (one copy per kernel image).
+// out-of-line helper for large, rarely-hot bodies (Keccak-f: inlining it at every sponge call site made
+// transcript_kernel 694 KB)
+#define PLONK_HD_NOINLINE __host__ __device__ inline __attribute__((noinline))
+#ifdef PLONK_FP_OUTLINE
+#define PLONK_FP_CALL __host__ __device__ __attribute__((noinline))
+#else
+#define PLONK_FP_CALL __host__ __device__ __forceinline__
+#endif
 #define PLONK_DEV __device__ __forceinline__
 #define PLONK_KERNEL(...) HIP_KERNEL_NAME(__VA_ARGS__)
 #define PLONK_LAUNCH(kern, grid, block, shmem, stream, ...) \
     hipLaunchKernelGGL(kern, grid, block, shmem, stream, __VA_ARGS__)
+// stops the scheduler from interleaving independent big-integer ops (which multiplies live registers)
+#ifdef __HIP_DEVICE_COMPILE__
+#define PLONK_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define PLONK_SCHED_FENCE() ((void)0)
+#endif
 #define PLONK_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
 #endif

@@ -340,13 +340,19 @@ PLONK_DEV LinWeights linearisation_weights(const ProofState& s, unsigned log_n, 
     return L;
 }
 
+// one lane per proof: the 15 weights (one field inversion each) are computed once, not once per tile
+__global__ void linearisation_weights_kernel(const ProofState* st, unsigned log_n, Fr n_inv, size_t B, LinWeights* out) {
+    const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) out[b] = linearisation_weights(st[b], log_n, n_inv);
+}
+
 __global__ void __launch_bounds__(256) linearisation_kernel(const Fr* coef, const Fr* fixed_coef, const Fr* tcoef,
-                                                           const ProofState* st, unsigned log_n, Fr n_inv, size_t B,
+                                                           const LinWeights* weights, unsigned log_n, size_t B,
                                                            Fr* out) {
     __shared__ LinWeights W;
     const size_t n = (size_t)1 << log_n;
     const size_t b = blockIdx.y;
-    if (threadIdx.x == 0) W = linearisation_weights(st[b], log_n, n_inv);
+    if (threadIdx.x < 15) W.w[threadIdx.x] = fp_load(&weights[b].w[threadIdx.x]);
     __syncthreads();
     const Fr* vec[15] = {fixed_coef + FX_QM * n, fixed_coef + FX_QL * n, fixed_coef + FX_QR * n, fixed_coef + FX_QO * n,
                          fixed_coef + FX_QC * n, coef + (4 * B + b) * n, fixed_coef + FX_S3 * n, tcoef + b * 4 * n,
@@ -594,8 +600,10 @@ int plonk_prover_run(plonk_prover* p, size_t B) {
     // ---- round 5: opening polynomials in coefficient form, commit              prover.py:241-306
     Fr ninv = fp_inv(host_fr_u64((uint64_t)n));
     unsigned gx = (unsigned)((n + 255) / 256);
+    LinWeights* lw = reinterpret_cast<LinWeights*>(p->wz);  // W_z buffer is free until divide_linear writes it
+    PLONK_LAUNCH(linearisation_weights_kernel, dim3(tb), dim3(64), 0, s, (const ProofState*)p->state, log_n, ninv, B, lw);
     PLONK_LAUNCH(linearisation_kernel, dim3(gx, (unsigned)B), dim3(256), 0, s, (const Fr*)p->coef,
-                 (const Fr*)p->fixed_coef, (const Fr*)p->quot, (const ProofState*)p->state, log_n, ninv, B, p->num);
+                 (const Fr*)p->fixed_coef, (const Fr*)p->quot, (const LinWeights*)lw, log_n, B, p->num);
     PLONK_LAUNCH(divide_linear_kernel, dim3((unsigned)B), dim3(DV_THREADS), 0, s, (const Fr*)p->num, n, 0, w,
                  (const ProofState*)p->state, n, p->wz);
     PLONK_LAUNCH(divide_linear_kernel, dim3((unsigned)B), dim3(DV_THREADS), 0, s, (const Fr*)(p->coef + 4 * B * n), n, 1,

@@ -36,7 +36,7 @@ PLONK_HD uint64_t keccak_rc(int round) {
     return rc[round];
 }
 
-PLONK_HD void keccak_f1600(uint64_t a[25]) {
+PLONK_HD_NOINLINE void keccak_f1600(uint64_t a[25]) {
     constexpr unsigned rot[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};
     for (int round = 0; round < 24; round++) {
         uint64_t c[5], d[5], b[25];

@@ -101,7 +101,7 @@ class Setup:
             )
         self._raw = _g1_mont_bytes
         self._n = len(_g1_mont_bytes) // 64
-        self._dev = None
+        self._dev = {}  # per-context device copies (bases + window table)
 
     # setup.py:23-63
     @classmethod
@@ -133,13 +133,14 @@ class Setup:
             self._powers = [(Fq(vals[2 * i] * inv_factor), Fq(vals[2 * i + 1] * inv_factor)) for i in range(self._n)]
         return self._powers
 
-    def device_bases(self) -> _DeviceBases:
-        if self._dev is None:
-            ctx = get_context()
+    def device_bases(self, ctx=None) -> _DeviceBases:
+        ctx = ctx or get_context()
+        dev = self._dev.get(id(ctx))
+        if dev is None:
             h = ctypes.c_void_p()
             check(ctx.L.plonk_srs_load_ptau(ctx.handle, self._raw, self._n, ctypes.byref(h)))
-            self._dev = _DeviceBases(ctx, h, self._n)
-        return self._dev
+            dev = self._dev[id(ctx)] = _DeviceBases(ctx, h, self._n)
+        return dev
 
     # setup.py:66-72
     def commit(self, values: Polynomial):

@@ -61,3 +61,16 @@ extern "C" void probe_g1(int op, const uint32_t* p, const uint32_t* q, uint32_t*
     G1Affine r = g1_to_affine(acc);
     memcpy(out, &r, 64);
 }
+
+// acc = sum_i (+/-) pts[i] through the LAZY accumulator of g1.h / fpl.h; affine Montgomery coords out
+extern "C" void probe_g1l_chain(const uint32_t* pts, const int* neg, int n, uint32_t* out) {
+    G1XyzzL acc = g1l_identity();
+    for (int i = 0; i < n; i++) {
+        G1Affine a;
+        memcpy(&a, pts + 16 * i, 64);
+        if (neg[i]) a.y = fp_neg(a.y);
+        g1l_madd(acc, a.x, a.y);
+    }
+    G1Affine r = g1_to_affine(g1l_to_xyzz(acc));
+    memcpy(out, &r, 64);
+}

@@ -21,6 +21,9 @@
 #define __launch_bounds__(...)
 #define __restrict__
 #define PLONK_HD inline
+#define PLONK_FP_CALL inline
+#define PLONK_HD_NOINLINE inline
+#define PLONK_SCHED_FENCE() ((void)0)
 #define PLONK_DEV inline
 #define PLONK_KERNEL(...) __VA_ARGS__
 #define PLONK_DYN_SMEM(name) unsigned char* name = ::hipemu::g_dyn_smem

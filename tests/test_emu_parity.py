@@ -25,6 +25,22 @@ def test_ntt_multipass_paths(emu):
         check(ctx.L.plonk_ntt_configure(ctx.handle, 0, 0, 0))
 
 
+def test_ntt_stockham_variant(emu):
+    """The Stockham radix-8 schedule (kind 2) against the oracle, single- and multi-pass."""
+    from plonkathon_amd import get_context
+    from plonkathon_amd._lib import check
+
+    ctx = get_context()
+    try:
+        check(ctx.L.plonk_ntt_select_kernel(ctx.handle, 2))
+        pc.ntt_vs_oracle([0, 1, 2, 3, 4, 5, 6, 7, 9, 11, 12, 13])
+        check(ctx.L.plonk_ntt_configure(ctx.handle, 6, 4, 4))
+        pc.ntt_vs_oracle((9, 11, 12), seed0=600)
+    finally:
+        check(ctx.L.plonk_ntt_configure(ctx.handle, 0, 0, 0))
+        check(ctx.L.plonk_ntt_select_kernel(ctx.handle, 0))
+
+
 def test_ntt_properties(emu):
     pc.ntt_roundtrip_and_linearity(12)
 

@@ -42,6 +42,22 @@ def test_ntt_multipass_plans():
         check(ctx.L.plonk_ntt_configure(ctx.handle, 0, 0, 0))
 
 
+def test_ntt_stockham_variant():
+    from plonkathon_amd import get_context
+    from plonkathon_amd._lib import check
+
+    ctx = get_context()
+    try:
+        check(ctx.L.plonk_ntt_select_kernel(ctx.handle, 2))
+        pc.ntt_vs_oracle([0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 16])
+        pc.ntt_roundtrip_and_linearity(20)
+        check(ctx.L.plonk_ntt_configure(ctx.handle, 6, 4, 4))
+        pc.ntt_vs_oracle((9, 12, 14), seed0=600)
+    finally:
+        check(ctx.L.plonk_ntt_configure(ctx.handle, 0, 0, 0))
+        check(ctx.L.plonk_ntt_select_kernel(ctx.handle, 0))
+
+
 @pytest.mark.parametrize("log_n", [18, 20, 22, 24])
 def test_ntt_large_properties(log_n):
     """BASELINE microbench sizes: round trip, linearity, DC/Nyquist bins, delta -> root table."""

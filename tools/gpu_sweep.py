@@ -79,22 +79,41 @@ if "ntt" in which:
         ms = timed(lambda: check(L.plonk_fr_ntt(H, buf.ptr, out.ptr, 20, 0, 1)), reps=5)
         print(json.dumps({"what": "ntt_cfg", "log_n": 20, "tile": tile, "single": single, "radix": radix, "ms": ms}), flush=True)
     check(L.plonk_ntt_configure(H, 0, 0, 0))
+if "nttkind" in which:
+    for kind in (1, 2):
+        check(L.plonk_ntt_select_kernel(H, kind))
+        for log_n, batch in ((11, 1024), (13, 1280), (16, 64), (20, 1), (24, 1)):
+            n = 1 << log_n
+            buf, out = fill(n * batch), ctx.alloc(n * batch)
+            ms = timed(lambda: check(L.plonk_fr_ntt(H, buf.ptr, out.ptr, log_n, 0, batch)), reps=5)
+            print(json.dumps({"what": "nttkind", "kind": kind, "log_n": log_n, "batch": batch, "ms": ms,
+                              "gf_elems_per_s": n * batch / (ms * 1e-3)}), flush=True)
+            del buf, out
+    check(L.plonk_ntt_select_kernel(H, 0))
 if "prover" in which:
-    sys.path.insert(0, os.path.join(REPO))
     from bench import chain_program_lines, witness_for
 
     program = Program(chain_program_lines(2048), 2048)
-    bp = BatchProver(setup, program)
     wits = [witness_for(program, i) for i in range(4)]
-    for B in (1, 8, 64, 256, 512):
+    ctxs = [ctx] + [Context(0) for _ in range(3)]
+    provers = [BatchProver(setup, program, c) for c in ctxs]
+    for B, S in ((1, 1), (64, 1), (256, 1), (256, 2), (256, 4), (512, 1), (512, 2), (512, 4), (1024, 2), (1024, 4)):
+        prs = provers[:S]
+        for k, pr in enumerate(prs):
+            pr.upload([wits[i % 4] for i in range(B // S)])
+        for pr in prs:
+            pr.run()
+        for pr in prs:
+            pr.download_raw()
         t0 = time.perf_counter()
-        bp.upload([wits[i % 4] for i in range(B)])
-        up = time.perf_counter() - t0
-        bp.run(); bp.download_raw()
-        t0 = time.perf_counter()
-        for _ in range(2):
-            bp.run()
-            raw, st = bp.download_raw()
-        dt = (time.perf_counter() - t0) / 2
-        print(json.dumps({"what": "prover", "B": B, "s_per_batch": dt, "proofs_per_s": B / dt, "ms_per_proof": 1e3 * dt / B,
-                          "upload_s": up, "status_ok": not any(st)}), flush=True)
+        reps = 3
+        for _ in range(reps):
+            for pr in prs:
+                pr.run()
+            ok = True
+            for pr in prs:
+                raw, st = pr.download_raw()
+                ok = ok and not any(st)
+        dt = (time.perf_counter() - t0) / reps
+        print(json.dumps({"what": "prover", "B": B, "streams": S, "s_per_batch": dt, "proofs_per_s": B / dt,
+                          "ms_per_proof": 1e3 * dt / B, "status_ok": ok}), flush=True)
