@@ -190,6 +190,17 @@ def main():
             "parallelism": "proof-sharded x%d" % world,
         },
     }
+    def pmc_traffic(kernel, run):
+        """HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside this process)."""
+        path = os.path.join(REPO, "profiles", "r01_pmc_summary.json")
+        if not os.path.exists(path):
+            return None, None
+        ks = [k for k in json.load(open(path))["kernels"] if k["kernel"] == kernel and k["run"] == run]
+        n = sum(k["launches"] for k in ks)
+        if not n:
+            return None, None
+        return sum(k["traffic_bytes"] * k["launches"] for k in ks) / n, "profiles/r01_pmc_summary.json"
+
     if msm_launches:
         avg_s = msm_ms * 1e-3 / msm_launches
         achieved = (msm_bytes / msm_launches) / avg_s / 1e9
@@ -200,7 +211,9 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
-            "traffic": None,
+            "traffic": pmc_traffic("msm_accumulate_kernel", "bench")[0] if B // S == 256 else None,
+            "traffic_source": "profiles/r01_pmc_summary.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                              "`bench.py --batch 256 --streams 1` (same per-stream launch shapes), 2*FETCH+WRITE",
             "launches": msm_launches,
             "avg_launch_us": avg_s * 1e6,
             "note": "algorithmic bytes = 96*N+64 per MSM; integer-ALU bound (DESIGN.md). Durations are those seen in the "

@@ -233,8 +233,8 @@ int plonk_ntt_configure(plonk_ctx* ctx, unsigned tile_log, unsigned single_pass_
 
 int plonk_ntt_select_kernel(plonk_ctx* ctx, unsigned kind) {
     PLONK_REQUIRE(ctx, PLONK_ERR_ARG, "ctx is NULL");
-    PLONK_REQUIRE(kind <= 2, PLONK_ERR_ARG, "kernel kind must be 0 (default), 1 (radix-2 stages) or 2 (Stockham radix-8)");
-    ctx->ntt_kind = kind ? kind : 1;
+    PLONK_REQUIRE(kind <= 2, PLONK_ERR_ARG, "kernel kind must be 0 (auto), 1 (radix-2 stages) or 2 (Stockham radix-8)");
+    ctx->ntt_kind = kind;
     return PLONK_OK;
 }
 

@@ -49,66 +49,53 @@ template <class P> PLONK_HD bool fp_eq(const Fp<P>& a, const Fp<P>& b) {
     return o == 0;
 }
 
+// 32-bit add/sub with carry.  clang lowers the builtins to v_add_co / v_addc_co chains (one VALU op per
+// limb); the portable u64 form compiles to v_lshl_add_u64 plus register-pair moves, ~3x the instructions.
+#if defined(__clang__)
+PLONK_HD uint32_t fp_adc(uint32_t a, uint32_t b, uint32_t& c) { unsigned co; uint32_t r = __builtin_addc(a, b, c, &co); c = co; return r; }
+PLONK_HD uint32_t fp_sbb(uint32_t a, uint32_t b, uint32_t& br) { unsigned bo; uint32_t r = __builtin_subc(a, b, br, &bo); br = bo; return r; }
+#else
+PLONK_HD uint32_t fp_adc(uint32_t a, uint32_t b, uint32_t& c) { uint64_t x = (uint64_t)a + b + c; c = (uint32_t)(x >> 32); return (uint32_t)x; }
+PLONK_HD uint32_t fp_sbb(uint32_t a, uint32_t b, uint32_t& br) { uint64_t x = (uint64_t)a - b - br; br = (uint32_t)(x >> 32) & 1; return (uint32_t)x; }
+#endif
+
 // r = t - m if t >= m else t      (t < 2m)
 template <class P> PLONK_HD void fp_reduce_once(uint32_t t[8]) {
-    uint32_t d[8];
-    uint64_t br = 0;
+    uint32_t d[8], br = 0;
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        uint64_t x = (uint64_t)t[i] - P::mod(i) - br;
-        d[i] = (uint32_t)x;
-        br = (x >> 32) & 1;
-    }
-    if (!br) {
+    for (int i = 0; i < 8; i++) d[i] = fp_sbb(t[i], P::mod(i), br);
 #pragma unroll
-        for (int i = 0; i < 8; i++) t[i] = d[i];
-    }
+    for (int i = 0; i < 8; i++) t[i] = br ? t[i] : d[i];
 }
 
 template <class P> PLONK_HD Fp<P> fp_add(const Fp<P>& a, const Fp<P>& b) {
     Fp<P> r;
-    uint64_t c = 0;
+    uint32_t c = 0;
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        c += (uint64_t)a.v[i] + b.v[i];
-        r.v[i] = (uint32_t)c;
-        c >>= 32;
-    }
+    for (int i = 0; i < 8; i++) r.v[i] = fp_adc(a.v[i], b.v[i], c);
     fp_reduce_once<P>(r.v);
     return r;
 }
 
 template <class P> PLONK_HD Fp<P> fp_sub(const Fp<P>& a, const Fp<P>& b) {
     Fp<P> r;
-    uint64_t br = 0;
+    uint32_t d[8], br = 0, c = 0;
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        uint64_t x = (uint64_t)a.v[i] - b.v[i] - br;
-        r.v[i] = (uint32_t)x;
-        br = (x >> 32) & 1;
-    }
-    if (br) {
-        uint64_t c = 0;
+    for (int i = 0; i < 8; i++) d[i] = fp_sbb(a.v[i], b.v[i], br);
+    const uint32_t mask = 0u - br;  // add m back when the difference went negative
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            c += (uint64_t)r.v[i] + P::mod(i);
-            r.v[i] = (uint32_t)c;
-            c >>= 32;
-        }
-    }
+    for (int i = 0; i < 8; i++) r.v[i] = fp_adc(d[i], P::mod(i) & mask, c);
     return r;
 }
 
 template <class P> PLONK_HD Fp<P> fp_neg(const Fp<P>& a) {
-    if (fp_is_zero(a)) return a;
-    Fp<P> r;
-    uint64_t br = 0;
+    uint32_t nz = 0, br = 0;
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        uint64_t x = (uint64_t)P::mod(i) - a.v[i] - br;
-        r.v[i] = (uint32_t)x;
-        br = (x >> 32) & 1;
-    }
+    for (int i = 0; i < 8; i++) nz |= a.v[i];
+    const uint32_t mask = nz ? 0xffffffffu : 0u;  // -0 == 0
+    Fp<P> r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.v[i] = fp_sbb(P::mod(i) & mask, a.v[i], br);
     return r;
 }
 

@@ -177,6 +177,46 @@ PLONK_HD G1XyzzL g1l_from_xyzz(const G1Xyzz& p) {
     return r;
 }
 
+// Hot-loop form: performs acc += (x2, y2) and returns true, or returns false WITHOUT touching acc when the
+// step is exceptional (identity base, acc identity handled inline, P == +-Q) so that the caller can
+// finish on the general packed path.  No calls, no packed arithmetic: minimal live registers.
+PLONK_HD bool g1l_madd_fast(G1XyzzL& p, const Fq& x2p, const Fq& y2p) {
+    if (fp_is_zero(x2p) && fp_is_zero(y2p)) return false;
+    const FqL x2 = fpl_from_fp(x2p), y2 = fpl_from_fp(y2p);
+    if (p.inf) {
+        p.x = x2;
+        p.y = y2;
+        p.zz = fpl_one<FqParams>();
+        p.zzz = p.zz;
+        p.inf = false;
+        return true;
+    }
+    const FqL u2 = fpl_mul(x2, p.zz);                                  // < 2m
+    const FqL pp_ = fpl_norm(fpl_sub<FqParams, 8>(u2, p.x));           // U2 - X1 + 8m   in (0, 10m)
+    {   // cheap filter for P == 0 (mod m): limb 0 must match limb 0 of some j*m, j < 16
+        bool maybe = false;
+#pragma unroll
+        for (unsigned j = 0; j < 16; j++)
+            maybe |= pp_.l[0] == (uint32_t)(((uint64_t)j * fp29_mod_limb<FqParams>(0)) & FP29_MASK);
+        if (maybe) return false;  // (2^-25 false-positive rate: the general path copes)
+    }
+    const FqL s2 = fpl_mul(y2, p.zzz);                                 // < 2m
+    const FqL rr = fpl_norm(fpl_sub<FqParams, 4>(s2, p.y));            // S2 - Y1 + 4m   in (0, 6m)
+    const FqL pp = fpl_sqr(pp_);                                       // < 2m
+    const FqL q = fpl_mul(p.x, pp);                                    // < 2m   (X1 dead after this)
+    p.zz = fpl_mul(p.zz, pp);
+    const FqL ppp = fpl_mul(pp_, pp);                                  // < 2m   (P, PP dead after this)
+    p.zzz = fpl_mul(p.zzz, ppp);
+    const FqL m2 = fpl_mul(p.y, ppp);                                  // < 2m   (Y1 dead after this)
+    const FqL r2 = fpl_sqr(rr);                                        // < 2m
+    // X3 = R^2 - PPP - 2Q  ->  R^2 + (2m - PPP) + (4m - 2Q)  in (0, 8m)
+    p.x = fpl_norm(fpl_sub<FqParams, 4>(fpl_sub<FqParams, 2>(r2, ppp), fpl_add(q, q)));
+    const FqL d = fpl_norm(fpl_sub<FqParams, 8>(q, p.x));              // Q - X3 + 8m    in (0, 10m)
+    const FqL m1 = fpl_mul(rr, d);                                     // < 2m
+    p.y = fpl_norm(fpl_sub<FqParams, 2>(m1, m2));                      // in (0, 4m)
+    return true;
+}
+
 // rare tail of g1l_madd (P == +-Q): kept out of line so the hot loop stays small
 PLONK_HD_NOINLINE void g1l_madd_same_x(G1XyzzL& p, const Fq& x2p, const Fq& y2p, bool same_point) {
     if (same_point) {

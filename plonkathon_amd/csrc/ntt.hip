@@ -521,7 +521,7 @@ int ntt_run(plonk_ctx* ctx, const Fr* in, Fr* out, unsigned log_n, bool inverse,
         p.w8_1 = w8;
         p.w8_2 = fp_sqr(w8);
         p.w8_3 = fp_mul(p.w8_2, w8);
-        const bool stockham = ctx->ntt_kind == 2;
+        const bool stockham = ctx->ntt_kind == 2 || (ctx->ntt_kind == 0 && P == 1);
         unsigned nthr = stockham ? T / 8 : T / 4;
         if (nthr < 64) nthr = 64;
         if (nthr > (stockham ? 512u : 1024u)) nthr = stockham ? 512 : 1024;

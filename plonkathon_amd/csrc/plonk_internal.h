@@ -68,7 +68,7 @@ struct plonk_ctx {
     std::vector<ProfRec> prof;
     std::vector<hipEvent_t> event_pool;
     unsigned ntt_tile_log = 12, ntt_single_log = 11, ntt_radix_log = 10;
-    unsigned ntt_kind = 1;  // 1 = radix-2 stages (default), 2 = Stockham radix-8 register butterflies
+    unsigned ntt_kind = 0;  // 0 = auto (Stockham radix-8 for single-pass sizes, radix-2 stages otherwise), 1 / 2 = force
 };
 
 // scratch slot use: 0 = NTT inter-pass buffer, 1 = MSM digits/partials, 2-3 = API-level temporaries

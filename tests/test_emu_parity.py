@@ -25,17 +25,19 @@ def test_ntt_multipass_paths(emu):
         check(ctx.L.plonk_ntt_configure(ctx.handle, 0, 0, 0))
 
 
-def test_ntt_stockham_variant(emu):
-    """The Stockham radix-8 schedule (kind 2) against the oracle, single- and multi-pass."""
+def test_ntt_forced_variants(emu):
+    """Both in-LDS schedules forced at every size class (auto picks Stockham for single-pass sizes only)."""
     from plonkathon_amd import get_context
     from plonkathon_amd._lib import check
 
     ctx = get_context()
     try:
-        check(ctx.L.plonk_ntt_select_kernel(ctx.handle, 2))
-        pc.ntt_vs_oracle([0, 1, 2, 3, 4, 5, 6, 7, 9, 11, 12, 13])
-        check(ctx.L.plonk_ntt_configure(ctx.handle, 6, 4, 4))
-        pc.ntt_vs_oracle((9, 11, 12), seed0=600)
+        for kind in (1, 2):
+            check(ctx.L.plonk_ntt_select_kernel(ctx.handle, kind))
+            check(ctx.L.plonk_ntt_configure(ctx.handle, 0, 0, 0))
+            pc.ntt_vs_oracle([0, 1, 2, 3, 4, 5, 6, 7, 9, 11, 12, 13], seed0=10 * kind)
+            check(ctx.L.plonk_ntt_configure(ctx.handle, 6, 4, 4))
+            pc.ntt_vs_oracle((9, 11, 12), seed0=600 + kind)
     finally:
         check(ctx.L.plonk_ntt_configure(ctx.handle, 0, 0, 0))
         check(ctx.L.plonk_ntt_select_kernel(ctx.handle, 0))

@@ -42,17 +42,19 @@ def test_ntt_multipass_plans():
         check(ctx.L.plonk_ntt_configure(ctx.handle, 0, 0, 0))
 
 
-def test_ntt_stockham_variant():
+def test_ntt_forced_variants():
     from plonkathon_amd import get_context
     from plonkathon_amd._lib import check
 
     ctx = get_context()
     try:
-        check(ctx.L.plonk_ntt_select_kernel(ctx.handle, 2))
-        pc.ntt_vs_oracle([0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 16])
-        pc.ntt_roundtrip_and_linearity(20)
-        check(ctx.L.plonk_ntt_configure(ctx.handle, 6, 4, 4))
-        pc.ntt_vs_oracle((9, 12, 14), seed0=600)
+        for kind in (1, 2):
+            check(ctx.L.plonk_ntt_select_kernel(ctx.handle, kind))
+            check(ctx.L.plonk_ntt_configure(ctx.handle, 0, 0, 0))
+            pc.ntt_vs_oracle([0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 16], seed0=10 * kind)
+            pc.ntt_roundtrip_and_linearity(20)
+            check(ctx.L.plonk_ntt_configure(ctx.handle, 6, 4, 4))
+            pc.ntt_vs_oracle((9, 12, 14), seed0=600 + kind)
     finally:
         check(ctx.L.plonk_ntt_configure(ctx.handle, 0, 0, 0))
         check(ctx.L.plonk_ntt_select_kernel(ctx.handle, 0))

@@ -80,7 +80,7 @@ if "ntt" in which:
         print(json.dumps({"what": "ntt_cfg", "log_n": 20, "tile": tile, "single": single, "radix": radix, "ms": ms}), flush=True)
     check(L.plonk_ntt_configure(H, 0, 0, 0))
 if "nttkind" in which:
-    for kind in (1, 2):
+    for kind in (0, 1, 2):
         check(L.plonk_ntt_select_kernel(H, kind))
         for log_n, batch in ((11, 1024), (13, 1280), (16, 64), (20, 1), (24, 1)):
             n = 1 << log_n
