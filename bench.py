@@ -98,6 +98,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=512, help="proofs per GPU per step")
     ap.add_argument("--streams", type=int, default=2, help="HIP streams per GPU: the batch is split into this many lock-step sub-batches that overlap each other")
+    ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-microbench", action="store_true")
     args = ap.parse_args()
@@ -109,7 +110,7 @@ def main():
     from plonkathon_amd import BatchProver, Context, Program, Setup, set_context
     from plonkathon_amd import distributed as D
 
-    dist = D.init_from_env("nccl") if world > 1 else None
+    dist = D.init_from_env(args.dist_backend) if world > 1 else None
     ctx = Context(local_rank)
     set_context(ctx)
     setup = Setup.from_file(PTAU)
@@ -145,9 +146,10 @@ def main():
         for c in ctxs:
             c.sync()
         if dist is not None:
-            import torch
+            if dist.get_backend() == "nccl":
+                import torch
 
-            torch.cuda.synchronize()
+                torch.cuda.synchronize()
             dist.barrier()
 
     for _ in range(args.warmup):

@@ -36,19 +36,33 @@ PLONK_HD uint64_t keccak_rc(int round) {
     return rc[round];
 }
 
-PLONK_HD_NOINLINE void keccak_f1600(uint64_t a[25]) {
+// Out of line (one copy per kernel image) but fully unrolled inside: the 25 lanes stay in registers for
+// all 24 rounds (constant indices everywhere), instead of living in scratch memory.
+PLONK_HD_NOINLINE void keccak_f1600(uint64_t st[25]) {
     constexpr unsigned rot[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};
+    uint64_t a[25];
+#pragma unroll
+    for (int i = 0; i < 25; i++) a[i] = st[i];
     for (int round = 0; round < 24; round++) {
         uint64_t c[5], d[5], b[25];
+#pragma unroll
         for (int x = 0; x < 5; x++) c[x] = a[x] ^ a[x + 5] ^ a[x + 10] ^ a[x + 15] ^ a[x + 20];
+#pragma unroll
         for (int x = 0; x < 5; x++) d[x] = c[(x + 4) % 5] ^ keccak_rotl(c[(x + 1) % 5], 1);
+#pragma unroll
         for (int i = 0; i < 25; i++) a[i] ^= d[i % 5];
+#pragma unroll
         for (int x = 0; x < 5; x++)
+#pragma unroll
             for (int y = 0; y < 5; y++) b[y + 5 * ((2 * x + 3 * y) % 5)] = keccak_rotl(a[x + 5 * y], rot[x + 5 * y]);
+#pragma unroll
         for (int y = 0; y < 5; y++)
+#pragma unroll
             for (int x = 0; x < 5; x++) a[x + 5 * y] = b[x + 5 * y] ^ (~b[(x + 1) % 5 + 5 * y] & b[(x + 2) % 5 + 5 * y]);
         a[0] ^= keccak_rc(round);
     }
+#pragma unroll
+    for (int i = 0; i < 25; i++) st[i] = a[i];
 }
 
 PLONK_HD uint8_t strobe_get(const MerlinState& s, unsigned i) { return (uint8_t)(s.st[i >> 3] >> (8 * (i & 7))); }
@@ -130,22 +144,30 @@ PLONK_HD void merlin_init(MerlinState& s, const uint8_t* label, size_t label_len
     merlin_append_message(s, dom, 7, label, label_len);
 }
 
-// big-endian bytes -> Fr (Montgomery), reducing mod r.  Horner in base 2^32.
+// big-endian bytes -> Fr (Montgomery), reducing mod r.  Horner in base 2^256: each 32-byte chunk is an
+// integer < 2^256 < 6r, which one Montgomery multiplication by R^2 maps to its residue (fp_mul only needs
+// a*b < R*m), so a 255-byte challenge costs 16 multiplications.
 PLONK_HD Fr fr_from_be_bytes_mod(const uint8_t* b, size_t n) {
-    Fr two32 = fp_zero<FrParams>();
-    two32.v[1] = 1;  // 2^32, canonical
-    two32 = fp_to_mont(two32);
+    Fr two256 = fp_zero<FrParams>();
+    two256.v[0] = 1;
+    two256 = fp_to_mont(two256);                       // R mod r ... times 2^256 below
+    {   // 2^256 in Montgomery form = to_mont(2^256 mod r); build it as (2^128)^2
+        Fr t = fp_zero<FrParams>();
+        t.v[4] = 1;                                    // 2^128, canonical
+        t = fp_to_mont(t);
+        two256 = fp_mul(t, t);
+    }
     Fr acc = fp_zero<FrParams>();
-    size_t head = n % 4;
     size_t i = 0;
     while (i < n) {
-        size_t take = (i == 0 && head) ? head : 4;
-        uint32_t w = 0;
-        for (size_t k = 0; k < take; k++) w = (w << 8) | b[i + k];
+        const size_t take = (i == 0 && (n % 32)) ? (n % 32) : 32;
+        Fr chunk = fp_zero<FrParams>();                // little-endian limbs of the big-endian chunk
+        for (size_t k = 0; k < take; k++) {
+            const size_t pos = take - 1 - k;           // byte significance within the chunk
+            chunk.v[pos >> 2] |= (uint32_t)b[i + k] << (8 * (pos & 3));
+        }
         i += take;
-        Fr t = fp_zero<FrParams>();
-        t.v[0] = w;
-        acc = fp_add(fp_mul(acc, two32), fp_to_mont(t));
+        acc = fp_add(fp_mul(acc, two256), fp_to_mont(chunk));
     }
     return acc;
 }

@@ -333,3 +333,72 @@ def batch_prover_fixture_cases(setup, names, batch_copies=1):
                 assert got[k] == want, (name, b, k)
             for k, v in bp.challenges(b).items():
                 assert str(v.n) == case["challenges"][k], (name, b, k)
+
+
+# ------------------------------------------------------------------------------------------ edges / errors
+def edge_and_error_paths(setup):
+    """Empty / minimal / oversize inputs and the C-ABI's argument checks (mapped to the reference's asserts)."""
+    import ctypes
+    import pytest
+    from plonkathon_amd import get_context
+    from plonkathon_amd._lib import check
+
+    ctx = get_context()
+    # minimal sizes
+    one = P([7], Basis.MONOMIAL)
+    assert ints(one.fft()) == [7] and ints(P([7]).ifft()) == [7]
+    assert P([7]).barycentric_eval(Scalar(3)) == OPoly([7], OBasis.LAGRANGE).barycentric_eval(3)
+    assert ints(P([5, 6]).shift(1)) == [6, 5]
+    assert affine(setup.commit_coeffs(P([5], Basis.MONOMIAL))) == og1.multiply(affine(setup.powers_of_x[0]), 5)
+    assert setup.commit_coeffs(P([0, 0], Basis.MONOMIAL)) is None  # identity, py_ecc None
+    with pytest.raises(ValueError):
+        pa.ec_lincomb([])  # curve.py:93 max() of an empty sequence
+    # reference asserts
+    with pytest.raises(AssertionError):
+        P([1, 2, 3], Basis.MONOMIAL).fft()  # not a power of two
+    with pytest.raises(AssertionError):
+        setup.commit(P([1] * 4096))  # setup.py:70: more coefficients than powers in the SRS
+    # C-ABI argument checks surface as AssertionError with a message
+    with pytest.raises(AssertionError, match="canonical"):
+        ctx.upload_ints([R_MOD])
+    buf = ctx.alloc(4)
+    with pytest.raises(AssertionError, match="2-adicity"):
+        check(ctx.L.plonk_fr_ntt(ctx.handle, buf.ptr, buf.ptr, 29, 0, 1))
+    with pytest.raises(AssertionError, match="shift"):
+        check(ctx.L.plonk_fr_rotate(ctx.handle, buf.ptr, ctx.alloc(4).ptr, 4, 4))
+    with pytest.raises(AssertionError, match="exceeds"):
+        xy, fl = ctypes.create_string_buffer(64), ctypes.create_string_buffer(1)
+        check(ctx.L.plonk_g1_msm(ctx.handle, setup.device_bases().handle, ctx.alloc(4096).ptr, 4096, 1, 4096, xy, fl))
+    with pytest.raises(AssertionError, match="window_bits"):
+        check(ctx.L.plonk_msm_configure(ctx.handle, 20, 0))
+    # a batch larger than one workgroup row and ragged batch sizes through the lock-step prover
+    program = Program(["e public", "c <== a * b", "e <== c * d"], 8)
+    bp = pa.BatchProver(setup, program)
+    wits = [{"a": 3 + i, "b": 4, "c": (3 + i) * 4, "d": 5, "e": (3 + i) * 20} for i in range(67)]
+    proofs = bp.prove_batch(wits)
+    osetup = OSetup.from_file(PTAU)
+    for i in (0, 1, 63, 64, 66):
+        assert flat(proofs[i]) == OProver(osetup, OProgram(["e public", "c <== a * b", "e <== c * d"], 8)).prove(dict(wits[i])).flatten()
+    proofs2 = bp.prove_batch(wits[:5])  # smaller batch on the same prover: buffers are reused
+    assert [flat(p) for p in proofs2] == [flat(p) for p in proofs[:5]]
+
+
+# ------------------------------------------------------------------------------------------ proofs verify
+def proofs_verify(setup, lines, group_order, start, public):
+    """Independent acceptance: the GPU's proof passes the oracle's pairing-based verifier against a
+    verification key the GPU committed (Setup.verification_key)."""
+    from oracle import pairing
+    from oracle.verifier import VerificationKey
+
+    program = Program(lines, group_order)
+    wit = program.fill_variable_assignments(start)
+    proof = flat(pa.BatchProver(setup, program).prove(dict(wit)))
+    vk = setup.verification_key(program.common_preprocessed_input())
+    x2 = (pairing.FQ2([c.n for c in vk.X_2[0].coeffs]), pairing.FQ2([c.n for c in vk.X_2[1].coeffs]))
+    ovk = VerificationKey(group_order, *[affine(getattr(vk, k)) for k in ("Qm", "Ql", "Qr", "Qo", "Qc", "S1", "S2", "S3")],
+                          x2, vk.w.n)
+    pub = [wit[v] for v in public]
+    assert ovk.verify_proof(group_order, proof, pub)
+    bad = dict(proof)
+    bad["b_eval"] = (bad["b_eval"] + 1) % R_MOD
+    assert not ovk.verify_proof(group_order, bad, pub)

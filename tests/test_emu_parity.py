@@ -109,3 +109,17 @@ def test_batch_prover_vs_oracle(emu):
     pc.batch_prover_vs_oracle(setup, pc.FACTORIZATION, 16, [pc.FACTORIZATION_START])
     pc.batch_prover_vs_oracle(setup, pc.chain_lines(32), 32, [{"x0": 3}, {"x0": 4}, {"x0": 12345678901234567890}])
     pc.batch_prover_rejects_bad_witness(setup)
+
+
+def test_edge_and_error_paths(emu):
+    from plonkathon_amd import Setup
+
+    pc.edge_and_error_paths(Setup.from_file(pc.PTAU))
+
+
+def test_proofs_verify_under_the_pairing_check(emu):
+    from plonkathon_amd import Setup
+
+    setup = Setup.from_file(pc.PTAU)
+    pc.proofs_verify(setup, ["e public", "c <== a * b", "e <== c * d"], 8, {"a": 3, "b": 4, "d": 5}, ["e"])
+    pc.proofs_verify(setup, pc.FACTORIZATION, 16, pc.FACTORIZATION_START, ["n"])

@@ -189,3 +189,33 @@ def test_batched_msm_vs_c_oracle(setup):
         got = None if fl.raw[m] else (int.from_bytes(xy.raw[64 * m : 64 * m + 32], "little"),
                                       int.from_bytes(xy.raw[64 * m + 32 : 64 * m + 64], "little"))
         assert got == c_oracle.g1_lincomb(P, scal[m]), m
+
+
+def test_edge_and_error_paths(setup):
+    pc.edge_and_error_paths(setup)
+
+
+def test_two_streams_share_the_gpu(setup):
+    """Two lock-step provers on two contexts (HIP streams) of one GPU run concurrently and stay bit-exact."""
+    from plonkathon_amd import BatchProver, Context, Program
+
+    program = Program(pc.chain_lines(256), 256)
+    wits = [program.fill_variable_assignments({"x0": 3 + i}) for i in range(6)]
+    ctx2 = Context(0)
+    p1, p2 = BatchProver(setup, program), BatchProver(setup, program, ctx2)
+    p1.upload(wits[:3])
+    p2.upload(wits[3:])
+    for _ in range(2):
+        p1.run()
+        p2.run()
+    got = [pc.flat(p) for p in p1.download() + p2.download()]
+    ref = BatchProver(setup, program)
+    assert got == [pc.flat(p) for p in ref.prove_batch(wits)]
+
+
+def test_gpu_proofs_verify_under_the_pairing_check(setup):
+    """group_order 2^11 (chain) and the Poseidon circuit at 2^11: proofs verify (TESTING_verifier's equations)."""
+    from oracle.poseidon import poseidon_program_lines
+
+    pc.proofs_verify(setup, pc.chain_lines(2048), 2048, {"x0": 5}, ["x0"])
+    pc.proofs_verify(setup, poseidon_program_lines(), 2048, {"L0": 1, "M0": 2}, ["L0", "M0", "M64"])

@@ -246,3 +246,36 @@ def test_k6_golden_proof(setup):
     tv = load("transcript_vectors.json")["k6_challenges"]
     for k, v in prover.challenges.items():
         assert str(v) == tv[k]
+
+
+# ---------------------------------------------------------------- N4: pairing + verifier (oracle only)
+def test_pairing_bilinearity():
+    from oracle import pairing as pr
+
+    assert pr.is_on_curve(pr.G2, pr.B2)
+    assert pr.multiply(pr.G2, R) is None
+    e1 = pr.pairing(pr.G2, g1.G1)
+    assert e1 != pr.FQ12.one() and e1 ** R == pr.FQ12.one()
+    assert pr.pairing(pr.multiply(pr.G2, 7), g1.multiply(g1.G1, 5)) == e1 ** 35
+    x = pr.FQ12(list(range(1, 13)))
+    assert x * x.inv() == pr.FQ12.one()
+
+
+def test_golden_proof_verifies(setup):
+    """test.py:272-275 — the reference's golden proof must pass the (restated) complete verifier;
+    tampered proofs and wrong public inputs must not."""
+    from oracle.verifier import VerificationKey
+
+    k6 = load("k6_proof.json")
+    pk = Program(k6["program"], 8).common_preprocessed_input()
+    vk = VerificationKey.from_setup(setup, pk)
+    proof = {k: (pt(v) if isinstance(v, list) else int(v)) for k, v in k6["proof"].items()}
+    assert vk.verify_proof(8, proof, [60])
+    assert not vk.verify_proof(8, proof, [61])
+    for key in ("a_eval", "z_shifted_eval"):
+        bad = dict(proof)
+        bad[key] = (bad[key] + 1) % R
+        assert not vk.verify_proof(8, bad, [60])
+    bad = dict(proof)
+    bad["W_z_1"] = g1.double(bad["W_z_1"])
+    assert not vk.verify_proof(8, bad, [60])
