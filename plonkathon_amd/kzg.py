@@ -2,9 +2,11 @@
 /root/reference/setup.py:16-77 and /root/reference/curve.py:30-44 on the GPU.
 
 `Setup.from_file` keeps the reference's parsing contract (byte 60 = log2(#powers), G1 from byte 80,
-byte-wise scan for the G2 generator, setup.py:23-63) but hands the G1 section to the device
-unchanged: a .ptau stores coordinates little-endian in Montgomery form, which is exactly the
-library's internal layout.  `commit` = inverse NTT + fixed-base Pippenger MSM (setup.py:66-72).
+byte-wise scan for the G2 generator, setup.py:23-63) but hands the G1 section's bytes to the
+device as they are: a .ptau stores coordinates little-endian in Montgomery form with R = 2^256, and
+the library (R = 2^261) rescales them on the GPU by five modular doublings instead of dividing the
+factor out on the host as setup.py:39-40 does.  `commit` = inverse NTT + fixed-base Pippenger MSM
+(setup.py:66-72).
 """
 import ctypes
 from dataclasses import dataclass

@@ -90,6 +90,19 @@ if "nttkind" in which:
                               "gf_elems_per_s": n * batch / (ms * 1e-3)}), flush=True)
             del buf, out
     check(L.plonk_ntt_select_kernel(H, 0))
+if "nttcfg" in which:
+    for log_n in (20, 24):
+        n = 1 << log_n
+        buf, out = fill(n), ctx.alloc(n)
+        for kind in (1, 2):
+            check(L.plonk_ntt_select_kernel(H, kind))
+            for tile, single, radix in ((12, 11, 10), (11, 11, 10), (11, 11, 7), (10, 10, 7), (12, 11, 8), (11, 11, 8), (12, 11, 7)):
+                check(L.plonk_ntt_configure(H, tile, single, radix))
+                ms = timed(lambda: check(L.plonk_fr_ntt(H, buf.ptr, out.ptr, log_n, 0, 1)), reps=5)
+                print(json.dumps({"what": "nttcfg", "log_n": log_n, "kind": kind, "tile": tile, "radix": radix, "ms": ms,
+                                  "gf_elems_per_s": n / (ms * 1e-3)}), flush=True)
+        del buf, out
+    check(L.plonk_ntt_configure(H, 0, 0, 0)); check(L.plonk_ntt_select_kernel(H, 0))
 if "prover" in which:
     from bench import chain_program_lines, witness_for
 
