@@ -239,12 +239,153 @@ template <class P> PLONK_HD Fp<P> fp_pow_u64(const Fp<P>& a, uint64_t e) {
     return fp_pow_limbs(a, l);
 }
 
-// Fermat inverse a^(m-2).  0 -> 0, which is exactly py_ecc's `x / 0 == 0`.
-template <class P> PLONK_HD Fp<P> fp_inv(const Fp<P>& a) {
+// Fermat inverse a^(m-2) (~380 multiplications); kept as the cross-check for fp_inv in the tests.
+template <class P> PLONK_HD Fp<P> fp_inv_fermat(const Fp<P>& a) {
     uint32_t e[8];
 #pragma unroll
     for (int i = 0; i < 8; i++) e[i] = P::mod_minus_2(i);
     return fp_pow_limbs(a, e);
+}
+
+// ---- inversion by Bernstein-Yang division steps -------------------------------------------------------
+// Values are 9 signed limbs of 30 bits.  Thirty division steps are run on the low limbs of (f, g) only and
+// recorded as a 2x2 integer matrix t with [f'; g'] = t [f; g] / 2^30; the matrix is then applied once to
+// the full (f, g) and, modulo m, to the pair (d, e) that tracks d*x = f, e*x = g (mod m).  When g reaches
+// 0, f = +-1 and +-d is the inverse.  ~19 rounds of ~700 instructions against ~110 000 for Fermat: this is
+// what the latency-bound kernels (affine conversion of commitments, grand product, batch inversion) wait
+// on.  Variable time (public data only).  0 -> 0, which is exactly py_ecc's `x / 0 == 0`.
+#define FP30_MASK 0x3fffffff
+
+template <class P> PLONK_HD constexpr int32_t fp30_mod_limb(int i) {
+    const int bit = 30 * i, j = bit >> 5, sh = bit & 31;
+    const uint64_t two = (uint64_t)P::mod(j) | (j + 1 < 8 ? (uint64_t)P::mod(j + 1) << 32 : 0);
+    return (int32_t)((two >> sh) & FP30_MASK);
+}
+
+struct Fp30Matrix { int32_t u, v, q, r; };
+
+// 30 division steps on the low words; delta carries over between rounds
+PLONK_HD Fp30Matrix fp30_divsteps(int32_t& delta, uint32_t f, uint32_t g) {
+    uint32_t u = 1, v = 0, q = 0, r = 1;
+    int32_t d = delta;
+    for (int i = 0; i < 30; i++) {
+        const uint32_t odd = 0u - (g & 1u);
+        const uint32_t sw = (d > 0 ? ~0u : 0u) & odd;  // delta > 0 and g odd: (f, g) <- (g, -f)
+        const uint32_t tf = f, tu = u, tv = v;
+        f = sw ? g : f;
+        g = sw ? 0u - tf : g;
+        u = sw ? q : u;
+        v = sw ? r : v;
+        q = sw ? 0u - tu : q;
+        r = sw ? 0u - tv : r;
+        d = sw ? -d : d;
+        g += f & odd;  // now even
+        q += u & odd;
+        r += v & odd;
+        g >>= 1;
+        u <<= 1;  // the f row absorbs the halving so the matrix stays integral
+        v <<= 1;
+        d += 1;
+    }
+    delta = d;
+    return Fp30Matrix{(int32_t)u, (int32_t)v, (int32_t)q, (int32_t)r};
+}
+
+// (f, g) <- t (f, g) / 2^30, exact
+PLONK_HD void fp30_update_fg(int32_t f[9], int32_t g[9], const Fp30Matrix& t) {
+    int64_t cf = (int64_t)t.u * f[0] + (int64_t)t.v * g[0];
+    int64_t cg = (int64_t)t.q * f[0] + (int64_t)t.r * g[0];
+    cf >>= 30;
+    cg >>= 30;
+#pragma unroll
+    for (int i = 1; i < 9; i++) {
+        cf += (int64_t)t.u * f[i] + (int64_t)t.v * g[i];
+        cg += (int64_t)t.q * f[i] + (int64_t)t.r * g[i];
+        f[i - 1] = (int32_t)cf & FP30_MASK;
+        g[i - 1] = (int32_t)cg & FP30_MASK;
+        cf >>= 30;
+        cg >>= 30;
+    }
+    f[8] = (int32_t)cf;
+    g[8] = (int32_t)cg;
+}
+
+// (d, e) <- t (d, e) / 2^30 mod m, keeping both in (-2m, m)
+template <class P> PLONK_HD void fp30_update_de(int32_t d[9], int32_t e[9], const Fp30Matrix& t) {
+    const uint32_t minv = (0u - P::NINV) & FP30_MASK;  // m^-1 mod 2^30
+    const int32_t sd = d[8] >> 31, se = e[8] >> 31;
+    int32_t md = (t.u & sd) + (t.v & se);  // + m for a negative d / e
+    int32_t me = (t.q & sd) + (t.r & se);
+    int64_t cd = (int64_t)t.u * d[0] + (int64_t)t.v * e[0];
+    int64_t ce = (int64_t)t.q * d[0] + (int64_t)t.r * e[0];
+    md -= (int32_t)((minv * (uint32_t)cd + (uint32_t)md) & FP30_MASK);  // low 30 bits of cd + md*m become 0
+    me -= (int32_t)((minv * (uint32_t)ce + (uint32_t)me) & FP30_MASK);
+    cd += (int64_t)fp30_mod_limb<P>(0) * md;
+    ce += (int64_t)fp30_mod_limb<P>(0) * me;
+    cd >>= 30;
+    ce >>= 30;
+#pragma unroll
+    for (int i = 1; i < 9; i++) {
+        cd += (int64_t)t.u * d[i] + (int64_t)t.v * e[i] + (int64_t)fp30_mod_limb<P>(i) * md;
+        ce += (int64_t)t.q * d[i] + (int64_t)t.r * e[i] + (int64_t)fp30_mod_limb<P>(i) * me;
+        d[i - 1] = (int32_t)cd & FP30_MASK;
+        e[i - 1] = (int32_t)ce & FP30_MASK;
+        cd >>= 30;
+        ce >>= 30;
+    }
+    d[8] = (int32_t)cd;
+    e[8] = (int32_t)ce;
+}
+
+// a^-1 in Montgomery form (input a R, output a^-1 R)
+template <class P> PLONK_HD Fp<P> fp_inv(const Fp<P>& a) {
+    int32_t f[9], g[9], d[9], e[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        const int bit = 30 * i, j = bit >> 5, sh = bit & 31;
+        const uint64_t two = (uint64_t)a.v[j] | (j + 1 < 8 ? (uint64_t)a.v[j + 1] << 32 : 0);
+        g[i] = (int32_t)((two >> sh) & FP30_MASK);
+        f[i] = fp30_mod_limb<P>(i);
+        d[i] = 0;
+        e[i] = 0;
+    }
+    e[0] = 1;
+    int32_t delta = 1;
+    for (int round = 0; round < 26; round++) {  // <= 741 steps for 256-bit inputs (Bernstein-Yang, Thm 11.2)
+        uint32_t nz = 0;
+#pragma unroll
+        for (int i = 0; i < 9; i++) nz |= (uint32_t)g[i];
+        if (!nz) break;
+        const Fp30Matrix t = fp30_divsteps(delta, (uint32_t)f[0], (uint32_t)g[0]);
+        fp30_update_fg(f, g, t);
+        fp30_update_de<P>(d, e, t);
+    }
+    // (a R)^-1 = sign(f) d, in (-2m, 2m): add 2m, carry-propagate, reduce
+    const bool neg = f[8] < 0;
+    uint32_t l[9];
+    int64_t acc = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        acc += (int64_t)(neg ? -d[i] : d[i]) + 2 * (int64_t)fp30_mod_limb<P>(i);
+        l[i] = (uint32_t)acc & FP30_MASK;
+        acc >>= 30;
+    }
+    Fp<P> y;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {  // 9 x 30 bits -> 8 x 32 bits (value < 4m < 2^256)
+        const int bit = 32 * j, i = bit / 30, sh = bit % 30;
+        uint64_t w = (uint64_t)l[i] >> sh;
+        w |= (uint64_t)l[i + 1] << (30 - sh);
+        if (i + 2 < 9) w |= (uint64_t)l[i + 2] << (60 - sh);
+        y.v[j] = (uint32_t)w;
+    }
+    fp_reduce_once<P>(y.v);
+    fp_reduce_once<P>(y.v);
+    fp_reduce_once<P>(y.v);
+    Fp<P> r3;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r3.v[i] = P::r3(i);
+    return fp_mul(y, r3);  // (a R)^-1 R^3 / R = a^-1 R
 }
 
 // small-constant multiples used by the curve formulas

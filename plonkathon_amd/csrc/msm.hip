@@ -98,10 +98,24 @@ PLONK_DEV void msm_recode(const Fr* scalars, size_t idx, const MsmRecode& rc, ui
     limb[9] = 0;
 }
 
-PLONK_DEV int msm_digit(const uint32_t limb[10], unsigned c, unsigned w) {
-    const unsigned bit = c * w, j = bit >> 5, sh = bit & 31;
-    const uint64_t two = (uint64_t)limb[j] | ((uint64_t)limb[j + 1] << 32);
-    return (int)((two >> sh) & ((1u << c) - 1)) - (int)(1u << (c - 1));
+// Calls emit(w, d) for the W signed c-bit digits d of the recoded scalar, low window first.  The limbs are
+// consumed through a 64-bit bit buffer with compile-time limb indices (a dynamically indexed register
+// array would live in scratch memory).
+template <class F> PLONK_DEV void msm_for_each_digit(const uint32_t limb[10], unsigned c, unsigned W, F emit) {
+    const uint32_t mask = (1u << c) - 1, half = 1u << (c - 1);
+    uint64_t buf = 0;
+    unsigned nb = 0, w = 0;
+#pragma unroll
+    for (int j = 0; j < 10; j++) {
+        buf |= (uint64_t)limb[j] << nb;
+        nb += 32;
+        while (nb >= c && w < W) {
+            emit(w, (int)((uint32_t)buf & mask) - (int)half);
+            buf >>= c;
+            nb -= c;
+            w++;
+        }
+    }
 }
 
 // starts[m][k] (k = 0..K+1): starts[k] = number of entries in buckets 1..k-1, starts[K+1] = total.
@@ -123,10 +137,7 @@ __global__ void __launch_bounds__(MSM_BLOCK) msm_sort_kernel(const Fr* scalars, 
     for (size_t i = tid; i < n; i += MSM_BLOCK) {
         uint32_t limb[10];
         msm_recode(sc, i, rc, limb);
-        for (unsigned w = 0; w < W; w++) {
-            int d = msm_digit(limb, c, w);
-            atomicAdd(&cnt[d < 0 ? -d : d], 1u);
-        }
+        msm_for_each_digit(limb, c, W, [&](unsigned, int d) { atomicAdd(&cnt[d < 0 ? -d : d], 1u); });
     }
     __syncthreads();
     // exclusive scan of cnt[1..K] -> bucket starts (bucket 0 = zero digits, dropped)
@@ -158,83 +169,126 @@ __global__ void __launch_bounds__(MSM_BLOCK) msm_sort_kernel(const Fr* scalars, 
     for (size_t i = tid; i < n; i += MSM_BLOCK) {
         uint32_t limb[10];
         msm_recode(sc, i, rc, limb);
-        for (unsigned w = 0; w < W; w++) {
-            int d = msm_digit(limb, c, w);
+        msm_for_each_digit(limb, c, W, [&](unsigned w, int d) {
             if (d) {
                 uint32_t pos = atomicAdd(&cnt[d < 0 ? -d : d], 1u);
                 out[pos] = (uint32_t)i | (d < 0 ? 0x8000u : 0u) | (w << 16);
             }
-        }
+        });
     }
 }
 
 // ------------------------------------------------------------------------------------------------
+// Entries per accumulate lane when E sorted entries are cut into `lanes` equal flat ranges (multiple of 4:
+// the entry list is read with 16-byte loads).  Used identically by the two kernels below.
+PLONK_HD uint32_t msm_lane_span(uint32_t E, uint32_t lanes) {
+    uint32_t per = (E + lanes - 1) / lanes;
+    per = (per + 3) & ~3u;
+    return per ? per : 4;
+}
+
+// Lane t (0 .. 256*G-1 within its MSM) sums its flat range [t*per, (t+1)*per) of the sorted entry list,
+// walking from the top entry down.  Whenever the walk leaves a bucket the partial sum of that bucket is
+// stored ("piece") and the accumulator restarts: no weighting, no cross-lane reduction, and a bucket
+// boundary costs eight 16-byte stores instead of a group addition, so lanes of a wave that cross
+// boundaries at different steps do not serialise anything expensive.  Piece slot: t + k - 1 — lanes and
+// the buckets they touch are both monotone, so the slot is unique, and msm_bucket_reduce_kernel can
+// recompute which lanes touched bucket k from the bucket starts alone.
 __global__ void __launch_bounds__(MSM_BLOCK) msm_accumulate_kernel(const G1Affine* table, size_t table_n,
                                                                    const uint32_t* entries, size_t entry_stride,
                                                                    const uint32_t* starts, unsigned c, unsigned G,
-                                                                   G1Xyzz* partial) {
+                                                                   G1Xyzz* pieces, size_t piece_stride) {
     PLONK_DYN_SMEM(smem);
     const unsigned K = 1u << (c - 1);
     const unsigned m = blockIdx.x / G, g = blockIdx.x % G;
     const unsigned tid = threadIdx.x;
     uint32_t* st = reinterpret_cast<uint32_t*>(smem);  // K + 2 bucket starts
-    G1Xyzz* red = reinterpret_cast<G1Xyzz*>(smem + (((size_t)(K + 2) * 4 + 15) & ~(size_t)15));
     const uint32_t* gst = starts + (size_t)m * (K + 2);
     for (unsigned k = tid; k < K + 2; k += MSM_BLOCK) st[k] = gst[k];
     __syncthreads();
     const uint32_t E = st[K + 1];
     const uint32_t* ent = entries + (size_t)m * entry_stride;
-
-    // equal flat ranges: segment g of G, lane tid of 256; range lengths are multiples of 4 entries
-    uint32_t per = (E + G * MSM_BLOCK - 1) / (G * MSM_BLOCK);
-    per = (per + 3) & ~3u;
-    const uint64_t lo64 = ((uint64_t)g * MSM_BLOCK + tid) * per;
-    const uint32_t lo = lo64 < E ? (uint32_t)lo64 : E;
+    const uint32_t per = msm_lane_span(E, G * MSM_BLOCK);
+    const uint32_t t = g * MSM_BLOCK + tid;
+    const uint64_t lo64 = (uint64_t)t * per;
+    if (lo64 >= E) return;
+    const uint32_t lo = (uint32_t)lo64;
     const uint32_t hi = (lo64 + per < E) ? (uint32_t)(lo64 + per) : E;
 
+    // bucket of the top entry: largest k in [1, K] with st[k] <= hi - 1
+    unsigned a = 1, b = K;
+    while (a < b) {
+        unsigned mid = (a + b + 1) >> 1;
+        if (st[mid] <= hi - 1) a = mid;
+        else b = mid - 1;
+    }
+    unsigned k = a;
+    G1Xyzz* out = pieces + (size_t)m * piece_stride + t - 1;  // out[k] = slot t + k - 1
+    G1Xyzz run = g1_xyzz_identity();
+    auto step = [&](uint32_t e, uint32_t en) {
+        if (e >= hi || e < lo) return;
+        if (e < st[k]) {  // left bucket k: its partial sum is complete
+            out[k] = run;
+            run = g1_xyzz_identity();
+            do k--;
+            while (e < st[k]);
+        }
+        const G1Affine* src = table + (size_t)(en >> 16) * table_n + (en & 0x7fffu);
+        G1Affine pt;
+        pt.x = fp_load(&src->x);
+        pt.y = fp_load(&src->y);
+        if (en & 0x8000u) pt.y = fp_neg(pt.y);
+        g1_madd(run, pt);
+    };
+    for (uint32_t base = (hi - 1) & ~3u;; base -= 4) {
+        const u32x4 q = *reinterpret_cast<const u32x4*>(ent + base);
+        step(base + 3, q.w);
+        step(base + 2, q.z);
+        step(base + 1, q.y);
+        step(base, q.x);
+        if (base <= lo) break;
+    }
+    out[k] = run;
+}
+
+// sum_k k * B_k for one MSM from the pieces.  Lane l owns the buckets (l*pb, (l+1)*pb]: walking them from
+// the top, run += (pieces of bucket k), tot += run, gives tot = sum (k - l*pb) B_k and run = sum B_k, so
+// the lane's share is tot + (l*pb) * run; the shares are tree-reduced through LDS.  Every lane adds into
+// tot once per bucket, so the wave stays converged; only the (1-3 piece) inner loop varies.
+__global__ void __launch_bounds__(256) msm_bucket_reduce_kernel(const uint32_t* starts, unsigned c, unsigned acc_lanes, const G1Xyzz* pieces,
+                                         size_t piece_stride, G1Xyzz* partial) {
+    PLONK_DYN_SMEM(smem);
+    G1Xyzz* red = reinterpret_cast<G1Xyzz*>(smem);
+    const unsigned K = 1u << (c - 1);
+    const unsigned m = blockIdx.x, tid = threadIdx.x, nl = blockDim.x;
+    const uint32_t* gst = starts + (size_t)m * (K + 2);
+    const uint32_t per = msm_lane_span(gst[K + 1], acc_lanes);
+    const unsigned pb = (K + nl - 1) / nl;
+    const unsigned b_lo = tid * pb < K ? tid * pb : K;
+    const unsigned b_hi = b_lo + pb < K ? b_lo + pb : K;
+    const G1Xyzz* pc = pieces + (size_t)m * piece_stride - 1;  // pc[t + k] = piece of lane t for bucket k
     G1Xyzz run = g1_xyzz_identity(), tot = g1_xyzz_identity();
-    if (lo < hi) {
-        // bucket of the last entry: largest k in [1, K] with st[k] <= hi - 1
-        unsigned a = 1, b = K;
-        while (a < b) {
-            unsigned mid = (a + b + 1) >> 1;
-            if (st[mid] <= hi - 1) a = mid;
-            else b = mid - 1;
+    uint32_t s_hi = gst[b_hi + 1];
+    for (unsigned k = b_hi; k > b_lo; k--) {
+        const uint32_t s_lo = gst[k];
+        if (s_hi > s_lo) {
+            const uint32_t t_last = (s_hi - 1) / per;
+            for (uint32_t t = s_lo / per; t <= t_last; t++) g1_add(run, pc[(size_t)t + k]);
         }
-        unsigned k = a;
-        for (uint32_t base = (hi - 1) & ~3u;; base -= 4) {
-            const u32x4 q = *reinterpret_cast<const u32x4*>(ent + base);
-            const uint32_t four[4] = {q.x, q.y, q.z, q.w};
-#pragma unroll
-            for (int j = 3; j >= 0; j--) {
-                const uint32_t e = base + j;
-                if (e < hi && e >= lo) {
-                    while (e < st[k]) {  // crossed into a lower bucket: every finished point gains one more unit
-                        k--;
-                        g1_add(tot, run);
-                    }
-                    const uint32_t en = four[j];
-                    const G1Affine* src = table + (size_t)(en >> 16) * table_n + (en & 0x7fffu);
-                    G1Affine pt;
-                    pt.x = fp_load(&src->x);
-                    pt.y = fp_load(&src->y);
-                    if (en & 0x8000u) pt.y = fp_neg(pt.y);
-                    g1_madd(run, pt);
-                }
-            }
-            if (base <= lo) break;
-        }
-        // share = tot + k * run   (k = bucket of the lane's lowest entry)
+        g1_add(tot, run);
+        s_hi = s_lo;
+    }
+    if (b_lo) {
         G1Xyzz kr = g1_xyzz_identity();
         for (int bit = (int)c - 1; bit >= 0; bit--) {
             g1_dbl(kr);
-            if ((k >> bit) & 1) g1_add(kr, run);
+            if ((b_lo >> bit) & 1) g1_add(kr, run);
         }
         g1_add(tot, kr);
     }
     red[tid] = tot;
     __syncthreads();
-    for (unsigned s = MSM_BLOCK / 2; s > 0; s >>= 1) {
+    for (unsigned s = nl / 2; s > 0; s >>= 1) {
         if (tid < s) {
             G1Xyzz x = red[tid];
             g1_add(x, red[tid + s]);
@@ -242,12 +296,12 @@ __global__ void __launch_bounds__(MSM_BLOCK) msm_accumulate_kernel(const G1Affin
         }
         __syncthreads();
     }
-    if (tid == 0) partial[(size_t)m * G + g] = red[0];
+    if (tid == 0) partial[m] = red[0];
 }
 
 // ------------------------------------------------------------------------------------------------
 // out_xy[m] = canonical affine of sum_g partial[m][g]; flags[m] = 1 for the identity
-__global__ void msm_finalize_kernel(const G1Xyzz* partial, size_t M, unsigned G, Fq* out_xy, uint8_t* flags) {
+__global__ void __launch_bounds__(64) msm_finalize_kernel(const G1Xyzz* partial, size_t M, unsigned G, Fq* out_xy, uint8_t* flags) {
     for (size_t m = (size_t)blockIdx.x * blockDim.x + threadIdx.x; m < M; m += (size_t)gridDim.x * blockDim.x) {
         G1Xyzz acc = partial[m * G];
         for (unsigned g = 1; g < G; g++) g1_add(acc, partial[m * G + g]);
@@ -304,21 +358,25 @@ int msm_run_device(plonk_ctx* ctx, plonk_srs* srs, const Fr* d_scalars, size_t n
     const unsigned W = srs->n_windows, K = 1u << (c - 1);
     unsigned G = ctx->msm_groups;
     if (!G) {
-        // enough workgroups to fill 256 CUs a few times over, but no more splitting than needed
+        // enough workgroups to fill 256 CUs a few times over, but no more pieces than needed
         G = 1;
-        while (G < 64 && M * G < 1024) G *= 2;
+        while (G < 16 && M * G < 1024) G *= 2;
     }
     const size_t max_entries = (size_t)W * n;
     while (G > 1 && (size_t)G * MSM_BLOCK * 4 > max_entries) G /= 2;  // tiny MSMs: one segment is plenty
+    const unsigned red_lanes = G >= 8 ? 256 : 64;  // few big MSMs: spread the bucket reduction wider
     const size_t entry_stride = ((max_entries + 3) & ~(size_t)3) + 4;
+    const size_t piece_stride = (size_t)G * MSM_BLOCK + K;
     const size_t ent_bytes = (M * entry_stride * 4 + 255) & ~(size_t)255;
     const size_t st_bytes = (M * (size_t)(K + 2) * 4 + 255) & ~(size_t)255;
-    const size_t part_bytes = M * G * sizeof(G1Xyzz);
+    const size_t part_bytes = (M * sizeof(G1Xyzz) + 255) & ~(size_t)255;
+    const size_t piece_bytes = M * piece_stride * sizeof(G1Xyzz);
     void* s;
-    PLONK_TRY(ctx_scratch(ctx, 1, ent_bytes + st_bytes + part_bytes, &s));
+    PLONK_TRY(ctx_scratch(ctx, 1, ent_bytes + st_bytes + part_bytes + piece_bytes, &s));
     uint32_t* entries = (uint32_t*)s;
     uint32_t* starts = (uint32_t*)((uint8_t*)s + ent_bytes);
     G1Xyzz* partial = (G1Xyzz*)((uint8_t*)s + ent_bytes + st_bytes);
+    G1Xyzz* pieces = (G1Xyzz*)((uint8_t*)s + ent_bytes + st_bytes + part_bytes);
 
     MsmRecode rc;
     memset(&rc, 0, sizeof rc);
@@ -327,11 +385,8 @@ int msm_run_device(plonk_ctx* ctx, plonk_srs* srs, const Fr* d_scalars, size_t n
         rc.k[bit >> 5] |= 1u << (bit & 31);
     }
     const size_t sort_lds = (size_t)(K + 2) * 4;
-    const size_t acc_lds = (((size_t)(K + 2) * 4 + 15) & ~(size_t)15) + (size_t)MSM_BLOCK * sizeof(G1Xyzz);
     static bool configured = false;
     if (!configured) {
-        PLONK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(msm_accumulate_kernel),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
         PLONK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(msm_sort_kernel),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)(128 * 1024)));
         configured = true;
@@ -342,12 +397,16 @@ int msm_run_device(plonk_ctx* ctx, plonk_srs* srs, const Fr* d_scalars, size_t n
     PLONK_TRY(prof_end(ctx));
     // algorithmic bytes of an MSM of size n: (64 + 32) * n + 64   
     PLONK_TRY(prof_begin(ctx, "msm_accumulate", (double)M * (96.0 * (double)n + 64.0)));
-    PLONK_LAUNCH(msm_accumulate_kernel, dim3((unsigned)(M * G)), dim3(MSM_BLOCK), acc_lds, ctx->stream,
+    PLONK_LAUNCH(msm_accumulate_kernel, dim3((unsigned)(M * G)), dim3(MSM_BLOCK), sort_lds, ctx->stream,
                  (const G1Affine*)srs->table, srs->n_points, (const uint32_t*)entries, entry_stride,
-                 (const uint32_t*)starts, c, G, partial);
+                 (const uint32_t*)starts, c, G, pieces, piece_stride);
+    PLONK_TRY(prof_end(ctx));
+    PLONK_TRY(prof_begin(ctx, "msm_bucket_reduce", (double)M * (double)piece_stride * sizeof(G1Xyzz)));
+    PLONK_LAUNCH(msm_bucket_reduce_kernel, dim3((unsigned)M), dim3(red_lanes), (size_t)red_lanes * sizeof(G1Xyzz), ctx->stream,
+                 (const uint32_t*)starts, c, G * MSM_BLOCK, (const G1Xyzz*)pieces, piece_stride, partial);
     PLONK_TRY(prof_end(ctx));
     unsigned gf = (unsigned)((M + 63) / 64);
-    PLONK_LAUNCH(msm_finalize_kernel, dim3(gf), dim3(64), 0, ctx->stream, (const G1Xyzz*)partial, M, G, d_out_xy, d_flags);
+    PLONK_LAUNCH(msm_finalize_kernel, dim3(gf), dim3(64), 0, ctx->stream, (const G1Xyzz*)partial, M, 1u, d_out_xy, d_flags);
     PLONK_CHECK_HIP(hipGetLastError());
     return PLONK_OK;
 }

@@ -16,6 +16,7 @@ template <class P> static void binop(int op, const uint32_t* a, const uint32_t* 
         case 5: r = fp_from_mont(x); break;
         case 6: r = fp_neg(x); break;
         case 7: r = fp_sqr(x); break;
+        case 8: r = fp_inv_fermat(x); break;
         default: r = fp_zero<P>();
     }
     memcpy(out, r.v, 32);

@@ -52,8 +52,13 @@ def test_field_ops(probe, name, m):
         assert _call(fn, 4, a) == a * Rm % m
         assert _call(fn, 5, a) == a * Ri % m
         assert _call(fn, 6, a) == (-a) % m
+        want_inv = field.inv(a, m) * Rm % m  # inverse of 0 is 0
+        assert _call(fn, 3, a * Rm % m) == want_inv  # division-step inversion
         if it < 40:
-            assert _call(fn, 3, a * Rm % m) == field.inv(a, m) * Rm % m  # inverse of 0 is 0
+            assert _call(fn, 8, a * Rm % m) == want_inv  # Fermat cross-check
+    # inputs that make the division steps take unusually many / few rounds
+    for a in [1 << k for k in range(0, 254, 7)] + [m - (1 << k) for k in range(0, 254, 11)] + [3, m // 3, (m + 1) // 2]:
+        assert _call(fn, 3, a % m * Rm % m) == field.inv(a % m, m) * Rm % m
 
 
 def _pt_words(p, m, Rm):

@@ -49,8 +49,8 @@ if "msm" in which:
         sc = fill(n * M)
         xy = ctypes.create_string_buffer(64 * M)
         fl = ctypes.create_string_buffer(M)
-        for c in (8, 10, 11, 12, 13):
-            for G in ((0,) if M > 1 else (1, 8, 64)):
+        for c in (9, 10, 11, 12, 13):
+            for G in ((0, 1, 2, 4) if M == 768 else (0,) if M > 1 else (4, 8, 16)):
                 check(L.plonk_msm_configure(H, c, G))
                 t0 = time.perf_counter()
                 check(L.plonk_g1_msm(H, bases.handle, sc.ptr, n, M, n, xy, fl))  # includes table (re)build
@@ -58,9 +58,13 @@ if "msm" in which:
                 ctx.profile_reset(); ctx.profile(True)
                 ms = timed(lambda: check(L.plonk_g1_msm(H, bases.handle, sc.ptr, n, M, n, xy, fl)))
                 acc_ms, launches, _ = ctx.profile_read("msm_accumulate")
+                sort_ms, _, _ = ctx.profile_read("msm_sort")
+                red_ms, _, _ = ctx.profile_read("msm_bucket_reduce")
                 ctx.profile(False)
+                L_ = max(launches, 1)
                 print(json.dumps({"what": "msm", "n": n, "M": M, "c": c, "G": G, "ms": ms, "ms_per_msm": ms / M,
-                                  "accumulate_ms": acc_ms / max(launches, 1), "first_call_s": first}), flush=True)
+                                  "sort_ms": sort_ms / L_, "accumulate_ms": acc_ms / L_, "bucket_reduce_ms": red_ms / L_,
+                                  "first_call_s": first}), flush=True)
     check(L.plonk_msm_configure(H, 0, 0))
 if "ntt" in which:
     for log_n, batch in ((11, 1), (11, 1024), (13, 1), (13, 1280), (16, 1), (16, 64), (18, 1), (20, 1), (22, 1), (24, 1)):
