@@ -119,16 +119,18 @@ template <class F> PLONK_DEV void msm_for_each_digit(const uint32_t limb[10], un
 }
 
 // starts[m][k] (k = 0..K+1): starts[k] = number of entries in buckets 1..k-1, starts[K+1] = total.
-__global__ void __launch_bounds__(MSM_BLOCK) msm_sort_kernel(const Fr* scalars, size_t n, size_t stride, unsigned c,
-                                                             unsigned W, MsmRecode rc, uint32_t* entries,
-                                                             size_t entry_stride, uint32_t* starts) {
+// Scalar vector of MSM m: scalars + (m % inner) * stride + (m / inner) * outer_stride  (lets one call commit
+// several slices of each row of a [batch][4n] array, e.g. the three quotient parts).
+__global__ void __launch_bounds__(MSM_BLOCK) msm_sort_kernel(const Fr* scalars, size_t n, size_t stride, size_t inner,
+                                                             size_t outer_stride, unsigned c, unsigned W, MsmRecode rc,
+                                                             uint32_t* entries, size_t entry_stride, uint32_t* starts) {
     PLONK_DYN_SMEM(smem);
     __shared__ uint32_t chunk_tot[MSM_BLOCK];
     const unsigned K = 1u << (c - 1);
     uint32_t* cnt = reinterpret_cast<uint32_t*>(smem);  // K + 2 counters; cnt[0] collects the zero digits
     const unsigned tid = threadIdx.x;
     const size_t m = blockIdx.x;
-    const Fr* sc = scalars + m * stride;
+    const Fr* sc = scalars + (m % inner) * stride + (m / inner) * outer_stride;
     uint32_t* out = entries + m * entry_stride;
     uint32_t* st = starts + m * (size_t)(K + 2);
 
@@ -349,7 +351,8 @@ int msm_build_table(plonk_ctx* ctx, plonk_srs* srs, unsigned c) {
 
 // Enqueue a batch of M MSMs; results land in device buffers (d_out_xy: 2*M Fq canonical, d_flags: M bytes).
 int msm_run_device(plonk_ctx* ctx, plonk_srs* srs, const Fr* d_scalars, size_t n, size_t M, size_t stride,
-                   Fq* d_out_xy, uint8_t* d_flags) {
+                   Fq* d_out_xy, uint8_t* d_flags, size_t inner, size_t outer_stride) {
+    if (!inner) inner = M ? M : 1;
     PLONK_REQUIRE(n >= 1 && n <= srs->n_points, PLONK_ERR_ARG, "MSM size %zu exceeds the %zu loaded bases", n, srs->n_points);
     PLONK_REQUIRE(n <= 32768, PLONK_ERR_ARG, "MSM size %zu > 32768 is not supported by the entry encoding", n);
     if (!M) return PLONK_OK;
@@ -392,7 +395,7 @@ int msm_run_device(plonk_ctx* ctx, plonk_srs* srs, const Fr* d_scalars, size_t n
         configured = true;
     }
     PLONK_TRY(prof_begin(ctx, "msm_sort", (double)M * 32.0 * (double)n));
-    PLONK_LAUNCH(msm_sort_kernel, dim3((unsigned)M), dim3(MSM_BLOCK), sort_lds, ctx->stream, d_scalars, n, stride, c, W, rc,
+    PLONK_LAUNCH(msm_sort_kernel, dim3((unsigned)M), dim3(MSM_BLOCK), sort_lds, ctx->stream, d_scalars, n, stride, inner, outer_stride, c, W, rc,
                  entries, entry_stride, starts);
     PLONK_TRY(prof_end(ctx));
     // algorithmic bytes of an MSM of size n: (64 + 32) * n + 64   

@@ -95,5 +95,6 @@ int ntt_run(plonk_ctx*, const Fr* in, Fr* out, unsigned log_n, bool inverse, siz
 int ntt_get_roots(plonk_ctx*, unsigned log_n, bool inverse, const Fr** table_full);
 // msm.hip
 int msm_build_table(plonk_ctx*, plonk_srs*, unsigned c);
+// MSM m reads its scalars at d_scalars + (m % inner) * stride + (m / inner) * outer_stride (inner = 0: inner = M)
 int msm_run_device(plonk_ctx*, plonk_srs*, const Fr* d_scalars, size_t n, size_t M, size_t stride, Fq* d_out_xy,
-                   uint8_t* d_flags);
+                   uint8_t* d_flags, size_t inner = 0, size_t outer_stride = 0);

@@ -31,6 +31,8 @@ struct ProofState {
     uint32_t pad_[3];
 };
 
+struct ChallengeConsts { Fr c[8]; };  // c[j] = 2^(256 j) R^2 mod r (transcript_kernel)
+
 enum { FX_QM = 0, FX_QL, FX_QR, FX_QO, FX_QC, FX_S1, FX_S2, FX_S3, FX_COUNT };
 
 struct plonk_prover {
@@ -60,6 +62,7 @@ struct plonk_prover {
     Fq *commit_xy; // [9][B] x||y canonical
     uint8_t* commit_flags;  // [9][B]
     ProofState* state;      // [B]
+    ChallengeConsts chal;   // 2^(256 j) R^2 mod r, for the challenge reduction in transcript_kernel
 };
 
 static inline dim3 grid1(size_t n, unsigned block = 256, size_t cap = 4096) {
@@ -82,62 +85,242 @@ __global__ void pi_fill_kernel(const Fr* pub, size_t n_public, size_t n, size_t 
 }
 
 // ------------------------------------------------------------------------------------------------
-// Transcript rounds on the device: one lane per proof.
-PLONK_DEV bool absorb_point(MerlinState& t, const char* label, size_t llen, const Fq* xy, uint8_t flag) {
-    if (flag) return false;
-    uint8_t be[32];
-    Fq x = fp_load(xy), y = fp_load(xy + 1);
-    limbs_to_be32(x.v, be);
-    merlin_append_message(t, (const uint8_t*)label, llen, be, 32);
-    limbs_to_be32(y.v, be);
-    merlin_append_message(t, (const uint8_t*)label, llen, be, 32);
-    return true;
-}
+// Transcript rounds on the device (transcript.py:77-123 + merlin): 32 lanes per proof, two proofs per
+// 64-lane workgroup.  Lane i < 25 keeps Keccak lane st[i] in registers; a permutation round exchanges
+// lanes through LDS (two barriers per round) instead of one thread grinding through all 25 lanes, the
+// STROBE byte operations become "the lane that owns byte idx xors it", and the 255-byte challenge is
+// reduced mod r by eight lanes in parallel.  Same byte stream as csrc/transcript.h (the host C-ABI
+// transcript), which the tests pin against the merlin test vector and the golden proof.
+// Control flow depends only on message lengths, which are the same for every proof, so the barriers
+// are uniform; an identity commitment (flag set) is absorbed as zeros and reported through `error`.
+#define TC_LANES 32
+struct TcShared {
+    uint64_t buf[2][25];
+    uint8_t msg[256];
+    Fr part[8];
+};
+struct TcState {
+    uint64_t w;  // st[lane] for lane < 25
+    uint32_t pos, pos_begin;
+};
 
-PLONK_DEV Fr draw(MerlinState& t, const char* label, size_t llen) {
-    return plonk_get_and_append_challenge(t, (const uint8_t*)label, llen);
-}
-
-__global__ void transcript_kernel(int round, ProofState* st, size_t B, const Fq* commit_xy, const uint8_t* flags) {
-    const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-    ProofState& s = st[b];
-    MerlinState t = s.transcript;
-    auto P = [&](int slot) { return commit_xy + 2 * ((size_t)slot * B + b); };
-    auto F = [&](int slot) { return flags[(size_t)slot * B + b]; };
-    bool ok = true;
-    if (round == 0) {
-        const uint8_t lbl[5] = {'p', 'l', 'o', 'n', 'k'};
-        merlin_init(t, lbl, 5);  // Transcript(b"plonk"), prover.py:53
-        s.error = 0;
-    } else if (round == 1) {  // transcript.py:77-86
-        ok &= absorb_point(t, "a_1", 3, P(0), F(0));
-        ok &= absorb_point(t, "b_1", 3, P(1), F(1));
-        ok &= absorb_point(t, "c_1", 3, P(2), F(2));
-        s.beta = draw(t, "beta", 4);
-        s.gamma = draw(t, "gamma", 5);
-    } else if (round == 2) {  // transcript.py:88-97
-        ok &= absorb_point(t, "z_1", 3, P(3), F(3));
-        s.alpha = draw(t, "alpha", 5);
-        s.fft_cofactor = draw(t, "fft_cofactor", 12);
-    } else if (round == 3) {  // transcript.py:99-105
-        ok &= absorb_point(t, "t_lo_1", 6, P(4), F(4));
-        ok &= absorb_point(t, "t_mid_1", 7, P(5), F(5));
-        ok &= absorb_point(t, "t_hi_1", 6, P(6), F(6));
-        s.zeta = draw(t, "zeta", 4);
-    } else if (round == 4) {  // transcript.py:107-116
-        const char* names[6] = {"a_eval", "b_eval", "c_eval", "s1_eval", "s2_eval", "z_shifted_eval"};
-        const size_t lens[6] = {6, 6, 6, 7, 7, 14};
-        for (int i = 0; i < 6; i++) {
-            uint8_t be[32];
-            Fr e = fp_from_mont(s.evals[i]);
-            limbs_to_be32(e.v, be);
-            merlin_append_message(t, (const uint8_t*)names[i], lens[i], be, 32);
+PLONK_DEV void tc_keccak(TcState& t, TcShared& sh, unsigned lane) {
+    constexpr unsigned rot[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};
+    const bool act = lane < 25;
+    const unsigned i = act ? lane : 24, x = i % 5, y = i / 5;
+    const unsigned r = rot[i], dst = y + 5 * ((2 * x + 3 * y) % 5);
+    const unsigned ca = (x + 4) % 5, cb = (x + 1) % 5, n1 = (x + 1) % 5 + 5 * y, n2 = (x + 2) % 5 + 5 * y;
+    uint64_t a = t.w;
+    for (int round = 0; round < 24; round++) {
+        if (act) sh.buf[0][i] = a;
+        __syncthreads();
+        uint64_t c0 = 0, c1 = 0;
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            c0 ^= sh.buf[0][ca + 5 * k];
+            c1 ^= sh.buf[0][cb + 5 * k];
         }
-        s.v = draw(t, "v", 1);
+        a ^= c0 ^ keccak_rotl(c1, 1);
+        if (act) sh.buf[1][dst] = keccak_rotl(a, r);
+        __syncthreads();
+        a = sh.buf[1][i] ^ (~sh.buf[1][n1] & sh.buf[1][n2]);
+        if (i == 0) a ^= keccak_rc(round);
     }
-    if (!ok) s.error = 1;
-    s.transcript = t;
+    t.w = a;
+}
+
+PLONK_DEV void tc_xor_byte(TcState& t, unsigned lane, unsigned idx, uint8_t b) {
+    if (lane == (idx >> 3)) t.w ^= (uint64_t)b << (8 * (idx & 7));
+}
+PLONK_DEV void tc_run_f(TcState& t, TcShared& sh, unsigned lane) {
+    tc_xor_byte(t, lane, t.pos, (uint8_t)t.pos_begin);
+    tc_xor_byte(t, lane, t.pos + 1, 0x04);
+    tc_xor_byte(t, lane, STROBE_R + 1, 0x80);
+    tc_keccak(t, sh, lane);
+    t.pos = 0;
+    t.pos_begin = 0;
+}
+PLONK_DEV void tc_absorb_byte(TcState& t, TcShared& sh, unsigned lane, uint8_t b) {
+    tc_xor_byte(t, lane, t.pos, b);
+    if (++t.pos == STROBE_R) tc_run_f(t, sh, lane);
+}
+// data: constant / global / LDS bytes readable by every lane of the group
+PLONK_DEV void tc_absorb(TcState& t, TcShared& sh, unsigned lane, const uint8_t* data, unsigned n) {
+    while (n) {
+        const unsigned take = n < STROBE_R - t.pos ? n : STROBE_R - t.pos;
+#pragma unroll
+        for (unsigned j = 0; j < 8; j++) {
+            const unsigned idx = 8 * lane + j;
+            if (idx >= t.pos && idx < t.pos + take) t.w ^= (uint64_t)data[idx - t.pos] << (8 * j);
+        }
+        t.pos += take;
+        data += take;
+        n -= take;
+        if (t.pos == STROBE_R) tc_run_f(t, sh, lane);
+    }
+}
+PLONK_DEV void tc_squeeze(TcState& t, TcShared& sh, unsigned lane, uint8_t* out, unsigned n) {
+    while (n) {
+        const unsigned take = n < STROBE_R - t.pos ? n : STROBE_R - t.pos;
+#pragma unroll
+        for (unsigned j = 0; j < 8; j++) {
+            const unsigned idx = 8 * lane + j;
+            if (idx >= t.pos && idx < t.pos + take) {
+                out[idx - t.pos] = (uint8_t)(t.w >> (8 * j));
+                t.w &= ~((uint64_t)0xff << (8 * j));
+            }
+        }
+        t.pos += take;
+        out += take;
+        n -= take;
+        if (t.pos == STROBE_R) tc_run_f(t, sh, lane);
+    }
+}
+PLONK_DEV void tc_begin_op(TcState& t, TcShared& sh, unsigned lane, uint32_t flags) {
+    const uint8_t h0 = (uint8_t)t.pos_begin;
+    t.pos_begin = t.pos + 1;
+    tc_absorb_byte(t, sh, lane, h0);
+    tc_absorb_byte(t, sh, lane, (uint8_t)flags);
+    if ((flags & (STROBE_FLAG_C | STROBE_FLAG_K)) && t.pos != 0) tc_run_f(t, sh, lane);
+}
+// meta-AD of label || u32le(len): the framing merlin puts in front of every message and challenge
+PLONK_DEV void tc_frame(TcState& t, TcShared& sh, unsigned lane, const char* label, unsigned llen, unsigned len) {
+    tc_begin_op(t, sh, lane, STROBE_FLAG_M | STROBE_FLAG_A);
+    tc_absorb(t, sh, lane, (const uint8_t*)label, llen);
+    for (int k = 0; k < 4; k++) tc_absorb_byte(t, sh, lane, (uint8_t)(len >> (8 * k)));
+}
+PLONK_DEV void tc_append_message(TcState& t, TcShared& sh, unsigned lane, const char* label, unsigned llen,
+                                 const uint8_t* msg, unsigned mlen) {
+    tc_frame(t, sh, lane, label, llen, mlen);
+    tc_begin_op(t, sh, lane, STROBE_FLAG_A);
+    tc_absorb(t, sh, lane, msg, mlen);
+}
+
+// transcript.py:69-75: 255 PRF bytes -> big-endian integer mod r (retry on zero) -> re-appended.  Returns the
+// challenge (Montgomery form) in every lane of the group.
+PLONK_DEV Fr tc_draw(TcState& t, TcShared& sh, unsigned lane, const ChallengeConsts& cc, const char* label, unsigned llen) {
+    for (;;) {
+        tc_frame(t, sh, lane, label, llen, 255);
+        tc_begin_op(t, sh, lane, STROBE_FLAG_I | STROBE_FLAG_A | STROBE_FLAG_C);
+        __syncthreads();  // earlier readers of sh.msg are done
+        tc_squeeze(t, sh, lane, sh.msg, 255);
+        __syncthreads();
+        if (lane < 8) {  // chunk 0 = the leading 31 bytes, chunk c >= 1 = the next 32; weight 2^(256 (7 - c))
+            const unsigned take = lane ? 32 : 31, off = lane ? 31 + 32 * (lane - 1) : 0;
+            Fr chunk;  // little-endian limbs of the big-endian chunk
+#pragma unroll
+            for (unsigned l = 0; l < 8; l++) {
+                uint32_t wv = 0;
+#pragma unroll
+                for (unsigned k = 0; k < 4; k++) {
+                    const unsigned sig = 4 * l + k;  // byte significance within the chunk
+                    if (sig < take) wv |= (uint32_t)sh.msg[off + take - 1 - sig] << (8 * k);
+                }
+                chunk.v[l] = wv;
+            }
+            sh.part[lane] = fp_mul(chunk, cc.c[7 - lane]);
+        }
+        __syncthreads();
+        Fr f = sh.part[0];
+        for (int k = 1; k < 8; k++) f = fp_add(f, sh.part[k]);
+        if (!fp_is_zero(f)) {
+            tc_append_message(t, sh, lane, label, llen, sh.msg, 255);
+            return f;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(2 * TC_LANES) transcript_kernel(int round, ProofState* st, size_t B, const Fq* commit_xy,
+                                                                  const uint8_t* flags, ChallengeConsts cc) {
+    __shared__ TcShared shared[2];
+    const unsigned grp = threadIdx.x / TC_LANES, lane = threadIdx.x % TC_LANES;
+    TcShared& sh = shared[grp];
+    size_t b = (size_t)blockIdx.x * 2 + grp;
+    const bool live = b < B;
+    if (!live) b = B - 1;  // shadow the last proof so the barriers stay uniform; nothing is stored
+    ProofState& s = st[b];
+    TcState t;
+    t.w = lane < 25 ? s.transcript.st[lane] : 0;
+    t.pos = s.transcript.pos;
+    t.pos_begin = s.transcript.pos_begin;
+    uint32_t error = 0;
+    Fr c0 = fp_zero<FrParams>(), c1 = fp_zero<FrParams>();
+
+    // 32-byte big-endian encodings of up to six values go to sh.msg[32 k]
+    auto stage_points = [&](int first_slot, int count) {
+        if (lane < 2u * count) {
+            const size_t slot = (size_t)first_slot + lane / 2;
+            const uint8_t fl = flags[slot * B + b];
+            Fq v = fp_load(commit_xy + 2 * (slot * B + b) + (lane & 1));
+            if (fl) {
+                v = fp_zero<FqParams>();
+                error = 1;
+            }
+            limbs_to_be32(v.v, sh.msg + 32 * lane);
+        }
+        __syncthreads();
+    };
+    auto absorb_point = [&](int k, const char* label, unsigned llen) {  // transcript.py:62-67: x then y
+        tc_append_message(t, sh, lane, label, llen, sh.msg + 64 * k, 32);
+        tc_append_message(t, sh, lane, label, llen, sh.msg + 64 * k + 32, 32);
+    };
+
+    if (round == 0) {  // Transcript(b"plonk"), prover.py:53
+        const uint8_t init[18] = {1, STROBE_R + 2, 1, 0, 1, 96, 'S', 'T', 'R', 'O', 'B', 'E', 'v', '1', '.', '0', '.', '2'};
+        t.w = 0;
+        for (unsigned j = 0; j < 8; j++)
+            if (8 * lane + j < 18) t.w |= (uint64_t)init[8 * lane + j] << (8 * j);
+        tc_keccak(t, sh, lane);
+        t.pos = 0;
+        t.pos_begin = 0;
+        tc_begin_op(t, sh, lane, STROBE_FLAG_M | STROBE_FLAG_A);
+        tc_absorb(t, sh, lane, (const uint8_t*)"Merlin v1.0", 11);
+        tc_append_message(t, sh, lane, "dom-sep", 7, (const uint8_t*)"plonk", 5);
+    } else if (round == 1) {  // transcript.py:77-86
+        stage_points(0, 3);
+        absorb_point(0, "a_1", 3);
+        absorb_point(1, "b_1", 3);
+        absorb_point(2, "c_1", 3);
+        c0 = tc_draw(t, sh, lane, cc, "beta", 4);
+        c1 = tc_draw(t, sh, lane, cc, "gamma", 5);
+    } else if (round == 2) {  // transcript.py:88-97
+        stage_points(3, 1);
+        absorb_point(0, "z_1", 3);
+        c0 = tc_draw(t, sh, lane, cc, "alpha", 5);
+        c1 = tc_draw(t, sh, lane, cc, "fft_cofactor", 12);
+    } else if (round == 3) {  // transcript.py:99-105
+        stage_points(4, 3);
+        absorb_point(0, "t_lo_1", 6);
+        absorb_point(1, "t_mid_1", 7);
+        absorb_point(2, "t_hi_1", 6);
+        c0 = tc_draw(t, sh, lane, cc, "zeta", 4);
+    } else if (round == 4) {  // transcript.py:107-116
+        if (lane < 6) {
+            Fr e = fp_from_mont(s.evals[lane]);
+            limbs_to_be32(e.v, sh.msg + 32 * lane);
+        }
+        __syncthreads();
+        tc_append_message(t, sh, lane, "a_eval", 6, sh.msg, 32);
+        tc_append_message(t, sh, lane, "b_eval", 6, sh.msg + 32, 32);
+        tc_append_message(t, sh, lane, "c_eval", 6, sh.msg + 64, 32);
+        tc_append_message(t, sh, lane, "s1_eval", 7, sh.msg + 96, 32);
+        tc_append_message(t, sh, lane, "s2_eval", 7, sh.msg + 128, 32);
+        tc_append_message(t, sh, lane, "z_shifted_eval", 14, sh.msg + 160, 32);
+        c0 = tc_draw(t, sh, lane, cc, "v", 1);
+    }
+    if (!live) return;
+    if (lane < 25) s.transcript.st[lane] = t.w;
+    // `error` was raised by the lanes that staged a flagged coordinate
+    if (error) s.error = 1;
+    if (lane == 0) {
+        s.transcript.pos = t.pos;
+        s.transcript.pos_begin = t.pos_begin;
+        if (round == 0) s.error = 0;
+        if (round == 1) { s.beta = c0; s.gamma = c1; }
+        if (round == 2) { s.alpha = c0; s.fft_cofactor = c1; }
+        if (round == 3) s.zeta = c0;
+        if (round == 4) s.v = c0;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -485,6 +668,14 @@ int plonk_prover_create(plonk_ctx* ctx, plonk_srs* srs, unsigned log_n, const ui
     p->log_n = log_n;
     p->n = n;
     p->n_public = n_public;
+    {   // c[j] = 2^(256 j) R^2: one Montgomery multiplication maps a 256-bit chunk to chunk * 2^(256 j) in Montgomery form
+        Fr t = fp_zero<FrParams>();
+        t.v[4] = 1;  // 2^128
+        t = fp_to_mont(t);
+        const Fr two256 = fp_mul(t, t);
+        for (int i = 0; i < 8; i++) p->chal.c[0].v[i] = FrParams::r2(i);
+        for (int j = 1; j < 8; j++) p->chal.c[j] = fp_mul(p->chal.c[j - 1], two256);
+    }
     p->g = host_fr_u64(5);  // multiplicative generator (curve.py:5): g^(4n) != 1, so Z_H != 0 on the coset
     const size_t e = sizeof(Fr);
     PLONK_TRY(dev_alloc((void**)&p->fixed_lag, 8 * n * e));
@@ -563,23 +754,23 @@ int plonk_prover_run(plonk_prover* p, size_t B) {
     plonk_ctx* ctx = p->ctx;
     const size_t n = p->n, n4 = 4 * n;
     const unsigned log_n = p->log_n;
-    const unsigned tb = (unsigned)((B + 63) / 64);
+    const unsigned tb = (unsigned)((B + 63) / 64), tg = (unsigned)((B + 1) / 2);
     hipStream_t s = ctx->stream;
     Fq* cxy = p->commit_xy;
     uint8_t* cfl = p->commit_flags;
     uint32_t* closes = reinterpret_cast<uint32_t*>(p->den);
 
-    PLONK_LAUNCH(transcript_kernel, dim3(tb), dim3(64), 0, s, 0, p->state, B, (const Fq*)cxy, (const uint8_t*)cfl);
+    PLONK_LAUNCH(transcript_kernel, dim3(tg), dim3(2 * TC_LANES), 0, s, 0, p->state, B, (const Fq*)cxy, (const uint8_t*)cfl, p->chal);
     // ---- round 1: coefficient forms of A, B, C, PI; commit A, B, C            prover.py:86-119
     PLONK_TRY(ntt_run(ctx, p->wit_lag, p->coef, log_n, true, 4 * B, n, n, n, nullptr, nullptr, true));
     PLONK_TRY(msm_run_device(ctx, p->srs, p->coef, n, 3 * B, n, cxy, cfl));
-    PLONK_LAUNCH(transcript_kernel, dim3(tb), dim3(64), 0, s, 1, p->state, B, (const Fq*)cxy, (const uint8_t*)cfl);
+    PLONK_LAUNCH(transcript_kernel, dim3(tg), dim3(2 * TC_LANES), 0, s, 1, p->state, B, (const Fq*)cxy, (const uint8_t*)cfl, p->chal);
     // ---- round 2: grand product Z, commit                                      prover.py:121-152
     PLONK_LAUNCH(grand_product_kernel, dim3((unsigned)B), dim3(GP_THREADS), 0, s, (const Fr*)p->wit_lag,
                  (const Fr*)(p->fixed_lag + FX_S1 * n), p->roots, (const ProofState*)p->state, n, B, p->z_lag, closes);
     PLONK_TRY(ntt_run(ctx, p->z_lag, p->coef + 4 * B * n, log_n, true, B, n, n, n, nullptr, nullptr, true));
     PLONK_TRY(msm_run_device(ctx, p->srs, p->coef + 4 * B * n, n, B, n, cxy + 2 * 3 * B, cfl + 3 * B));
-    PLONK_LAUNCH(transcript_kernel, dim3(tb), dim3(64), 0, s, 2, p->state, B, (const Fq*)cxy, (const uint8_t*)cfl);
+    PLONK_LAUNCH(transcript_kernel, dim3(tg), dim3(2 * TC_LANES), 0, s, 2, p->state, B, (const Fq*)cxy, (const uint8_t*)cfl, p->chal);
     // ---- round 3: coset extensions, fused quotient, back to coefficients, commit T1..T3   prover.py:154-226
     PLONK_TRY(ntt_run(ctx, p->coef, p->big, log_n + 2, false, 5 * B, n, n, n4, p->g_pow, nullptr, false));
     ZhInv zh;
@@ -589,14 +780,14 @@ int plonk_prover_run(plonk_prover* p, size_t B) {
     PLONK_TRY(ntt_run(ctx, p->quot, p->quot, log_n + 2, true, B, n4, n4, n4, nullptr, p->ginv_pow, false));
     PLONK_CHECK_HIP(hipMemsetAsync(closes + B, 0, B * sizeof(uint32_t), s));
     PLONK_LAUNCH(quotient_degree_check_kernel, grid1(B * n), dim3(256), 0, s, (const Fr*)p->quot, n, B, closes + B);
-    for (int k = 0; k < 3; k++)
-        PLONK_TRY(msm_run_device(ctx, p->srs, p->quot + k * n, n, B, n4, cxy + 2 * (4 + k) * B, cfl + (4 + k) * B));
-    PLONK_LAUNCH(transcript_kernel, dim3(tb), dim3(64), 0, s, 3, p->state, B, (const Fq*)cxy, (const uint8_t*)cfl);
+    // T1..T3 = the three n-coefficient slices of each quotient row, one batched call (MSM k*B + b = slice k of proof b)
+    PLONK_TRY(msm_run_device(ctx, p->srs, p->quot, n, 3 * B, n4, cxy + 2 * 4 * B, cfl + 4 * B, B, n));
+    PLONK_LAUNCH(transcript_kernel, dim3(tg), dim3(2 * TC_LANES), 0, s, 3, p->state, B, (const Fq*)cxy, (const uint8_t*)cfl, p->chal);
     // ---- round 4: evaluations                                                  prover.py:228-239
     Fr w = host_root_of_unity(log_n, false);
     PLONK_LAUNCH(eval_kernel, dim3((unsigned)B), dim3(EV_THREADS), 0, s, (const Fr*)p->coef, (const Fr*)p->fixed_coef, w,
                  p->state, n, B);
-    PLONK_LAUNCH(transcript_kernel, dim3(tb), dim3(64), 0, s, 4, p->state, B, (const Fq*)cxy, (const uint8_t*)cfl);
+    PLONK_LAUNCH(transcript_kernel, dim3(tg), dim3(2 * TC_LANES), 0, s, 4, p->state, B, (const Fq*)cxy, (const uint8_t*)cfl, p->chal);
     // ---- round 5: opening polynomials in coefficient form, commit              prover.py:241-306
     Fr ninv = fp_inv(host_fr_u64((uint64_t)n));
     unsigned gx = (unsigned)((n + 255) / 256);
