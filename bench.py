@@ -14,7 +14,7 @@ Rank 0 prints ONE JSON line: the contract fields, plus
   "roofline"      for the dominant kernel of the timed region (msm_accumulate), durations from HIP
                   events recorded on the library's stream inside the timed region;
   "roofline_ntt"  the standalone Fr NTT at 2^20 (BASELINE configs[3]) against the HBM roofline;
-  "ntt"           NTT GF-elems/s at 2^11 (batched) and 2^20;
+  "ntt", "msm"    NTT GF-elems/s at 2^11 (batched) and 2^20; MSMs/s at 2^11 (512 x 9 commitments per call);
   "cpu_baseline"  the oracle (pure-Python port of the reference path) timed on this box, rank 0, N=1.
 """
 import argparse
@@ -27,6 +27,8 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s measured copy)
+FQ_MUL_CEILING_G = 143.0  # chip-wide 254-bit Montgomery multiplications/s measured by tools/ubench (profiles/*ubench*.json)
+MSM_WINDOW_BITS = 10      # library default (csrc/msm.hip); 26 windows of signed 10-bit digits
 GROUP_ORDER = 2048
 PTAU = os.path.join(REPO, "tests", "golden", "srs_2048.ptau")
 
@@ -91,13 +93,40 @@ def ntt_microbench(ctx, log_n, batch, reps=5):
     return best
 
 
+def msm_microbench(ctx, setup, batch, reps=3):
+    """`batch` commitments of 2^11 random coefficients in one plonk_g1_msm call -> ms (best of reps)."""
+    import ctypes
+    import random
+
+    from plonkathon_amd._lib import check
+
+    n = GROUP_ORDER
+    rng = random.Random(7)
+    src = ctx.upload_ints([rng.randrange(1 << 253) for _ in range(4096)])
+    sc = ctx.alloc(n * batch + 4096)
+    for off in range(0, n * batch + 4096, 4096):
+        check(ctx.L.plonk_mem_d2d(ctx.handle, sc.at(off), src.ptr, 32 * 4096))
+    bases = setup.device_bases(ctx)
+    xy, fl = ctypes.create_string_buffer(64 * batch), ctypes.create_string_buffer(batch)
+    call = lambda: check(ctx.L.plonk_g1_msm(ctx.handle, bases.handle, sc.ptr, n, batch, n + 1, xy, fl))  # stride n+1: distinct vectors
+    call()
+    best = None
+    for _ in range(reps):
+        ctx.sync()
+        ctx.timer_start()
+        call()
+        ms = ctx.timer_stop_ms()
+        best = ms if best is None or ms < best else best
+    return best
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=512, help="proofs per GPU per step")
-    ap.add_argument("--streams", type=int, default=2, help="HIP streams per GPU: the batch is split into this many lock-step sub-batches that overlap each other")
+    ap.add_argument("--streams", type=int, default=1, help="HIP streams per GPU: the batch is split into this many lock-step sub-batches that overlap each other")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-microbench", action="store_true")
@@ -213,14 +242,20 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
-            "traffic": pmc_traffic("msm_accumulate_kernel", "bench")[0] if B // S == 256 else None,
+            "traffic": pmc_traffic("msm_accumulate_kernel", "bench")[0] if B // S == 512 else None,
             "traffic_source": "profiles/r01_pmc_summary.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
-                              "`bench.py --batch 256 --streams 1` (same per-stream launch shapes), 2*FETCH+WRITE",
+                              "`bench.py --batch 512 --streams 1` (tools/pmc_collect.sh), 2*FETCH+WRITE, launch-weighted mean",
             "launches": msm_launches,
             "avg_launch_us": avg_s * 1e6,
-            "note": "algorithmic bytes = 96*N+64 per MSM; integer-ALU bound (DESIGN.md). Durations are those seen in the "
-                    "timed region, i.e. while %d stream(s) share the GPU" % S,
+            "note": "algorithmic bytes = 96*N+64 per MSM; the kernel is integer-ALU bound (DESIGN.md 3/4.2), see `alu`",
         }
+        # the honest ceiling: one mixed addition = 10 Fq multiplications (+ 8 add/sub); W*N additions per MSM
+        n_msm = msm_bytes / (96.0 * GROUP_ORDER + 64.0)
+        windows = (256 + MSM_WINDOW_BITS - 1) // MSM_WINDOW_BITS
+        gmul = n_msm * windows * GROUP_ORDER * 10.0 / (msm_ms * 1e-3) / 1e9
+        line["roofline"]["alu"] = {"achieved_fq_gmul_per_s": gmul, "ceiling_fq_gmul_per_s": FQ_MUL_CEILING_G,
+                                   "frac": gmul / FQ_MUL_CEILING_G,
+                                   "note": "%d mixed additions per MSM x 10 Fq multiplications each, add/sub not counted" % (windows * GROUP_ORDER)}
     if rank == 0 and not args.no_microbench:
         ms11 = ntt_microbench(ctx, 11, 512)
         ms20 = ntt_microbench(ctx, 20, 1)
@@ -230,6 +265,8 @@ def main():
             "ms_2^11_x512": ms11,
             "ms_2^20": ms20,
         }
+        ms_msm = msm_microbench(ctx, setup, 4608)
+        line["msm"] = {"msms_per_s_2^11_x4608": 4608 / (ms_msm * 1e-3), "ms_4608": ms_msm}
         ach = 64.0 * (1 << 20) / (ms20 * 1e-3) / 1e9
         line["roofline_ntt"] = {"kernel": "ntt_pass_kernel (2 passes, N=2^20)", "bound": "hbm", "achieved": ach,
                                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None}

@@ -12,17 +12,20 @@
 //   1. msm_sort_kernel        (one workgroup per MSM) scalar -> canonical -> + sum_w 2^(cw+c-1), signed
 //                             digits d_w in [-2^(c-1), 2^(c-1)); LDS counting sort (LDS atomics) of all
 //                             W*N (point, window) entries by bucket |d|; the sorted entry list and the
-//                             bucket boundaries go to HBM (256 KiB per MSM, L2-resident).
-//   2. msm_accumulate_kernel  (one workgroup per MSM segment) the sorted list is cut into EQUAL flat
-//                             ranges, one per lane, so every lane performs the same number of mixed
-//                             additions whatever the bucket sizes.  A lane walks its range from the
-//                             highest bucket down with two accumulators, run += entry and, at every
-//                             bucket boundary it crosses, tot += run; tot + k_low * run is then its
-//                             share of sum_k k * B_k.  The workgroup tree-reduces the 256 shares through
-//                             LDS ("wave-reduced bucket sum"); buckets never exist in memory.
-//   3. msm_finalize_kernel    adds the segment partials, converts to the unique affine representative
-//                             (one Fermat inversion) and leaves canonical x||y.
-// All table reads hit L2 / Infinity Cache (3 MiB table at c = 12); the kernels are integer-ALU bound.
+//                             bucket boundaries go to HBM (~210 KiB per MSM).
+//   2. msm_accumulate_kernel  (G workgroups per MSM) the sorted list is cut into EQUAL flat ranges, one per
+//                             lane, so every lane performs the same number of mixed additions whatever the
+//                             bucket sizes.  A lane sums its range top-down and stores one partial sum
+//                             ("piece") per bucket it touches: a bucket boundary costs a 128-byte store,
+//                             never a group operation, so the wave does not serialise on boundaries that
+//                             its lanes cross at different steps.  This kernel is >= 90 % of the MSM time
+//                             and runs at ~93 % of the measured Fq-multiplication ceiling.
+//   3. msm_bucket_reduce_kernel (one wave per MSM) lane l owns K/64 consecutive buckets: walking them top-down,
+//                             run += pieces of bucket k, tot += run; its share is tot + (first bucket - 1) * run;
+//                             shares are tree-reduced through LDS ("wave-reduced bucket sum") and lane 0
+//                             converts the result to the unique affine representative, canonical x||y.
+//                             Buckets never exist in memory.
+// Table reads hit L2 / Infinity Cache (3.4 MiB table at c = 10); the kernels are integer-ALU bound.
 #include <string.h>
 
 #include "plonk_internal.h"
@@ -257,8 +260,9 @@ __global__ void __launch_bounds__(MSM_BLOCK) msm_accumulate_kernel(const G1Affin
 // the top, run += (pieces of bucket k), tot += run, gives tot = sum (k - l*pb) B_k and run = sum B_k, so
 // the lane's share is tot + (l*pb) * run; the shares are tree-reduced through LDS.  Every lane adds into
 // tot once per bucket, so the wave stays converged; only the (1-3 piece) inner loop varies.
-__global__ void __launch_bounds__(256) msm_bucket_reduce_kernel(const uint32_t* starts, unsigned c, unsigned acc_lanes, const G1Xyzz* pieces,
-                                         size_t piece_stride, G1Xyzz* partial) {
+__global__ void __launch_bounds__(256) msm_bucket_reduce_kernel(const uint32_t* starts, unsigned c, unsigned acc_lanes,
+                                                                 const G1Xyzz* pieces, size_t piece_stride, Fq* out_xy,
+                                                                 uint8_t* flags) {
     PLONK_DYN_SMEM(smem);
     G1Xyzz* red = reinterpret_cast<G1Xyzz*>(smem);
     const unsigned K = 1u << (c - 1);
@@ -298,16 +302,8 @@ __global__ void __launch_bounds__(256) msm_bucket_reduce_kernel(const uint32_t* 
         }
         __syncthreads();
     }
-    if (tid == 0) partial[m] = red[0];
-}
-
-// ------------------------------------------------------------------------------------------------
-// out_xy[m] = canonical affine of sum_g partial[m][g]; flags[m] = 1 for the identity
-__global__ void __launch_bounds__(64) msm_finalize_kernel(const G1Xyzz* partial, size_t M, unsigned G, Fq* out_xy, uint8_t* flags) {
-    for (size_t m = (size_t)blockIdx.x * blockDim.x + threadIdx.x; m < M; m += (size_t)gridDim.x * blockDim.x) {
-        G1Xyzz acc = partial[m * G];
-        for (unsigned g = 1; g < G; g++) g1_add(acc, partial[m * G + g]);
-        G1Affine a = g1_to_affine(acc);
+    if (tid == 0) {  // the unique affine representative, canonical x||y; identity reported out of band
+        G1Affine a = g1_to_affine(red[0]);
         flags[m] = g1_affine_is_identity(a) ? 1 : 0;
         fp_store(out_xy + 2 * m, fp_from_mont(a.x));
         fp_store(out_xy + 2 * m + 1, fp_from_mont(a.y));
@@ -372,14 +368,12 @@ int msm_run_device(plonk_ctx* ctx, plonk_srs* srs, const Fr* d_scalars, size_t n
     const size_t piece_stride = (size_t)G * MSM_BLOCK + K;
     const size_t ent_bytes = (M * entry_stride * 4 + 255) & ~(size_t)255;
     const size_t st_bytes = (M * (size_t)(K + 2) * 4 + 255) & ~(size_t)255;
-    const size_t part_bytes = (M * sizeof(G1Xyzz) + 255) & ~(size_t)255;
     const size_t piece_bytes = M * piece_stride * sizeof(G1Xyzz);
     void* s;
-    PLONK_TRY(ctx_scratch(ctx, 1, ent_bytes + st_bytes + part_bytes + piece_bytes, &s));
+    PLONK_TRY(ctx_scratch(ctx, 1, ent_bytes + st_bytes + piece_bytes, &s));
     uint32_t* entries = (uint32_t*)s;
     uint32_t* starts = (uint32_t*)((uint8_t*)s + ent_bytes);
-    G1Xyzz* partial = (G1Xyzz*)((uint8_t*)s + ent_bytes + st_bytes);
-    G1Xyzz* pieces = (G1Xyzz*)((uint8_t*)s + ent_bytes + st_bytes + part_bytes);
+    G1Xyzz* pieces = (G1Xyzz*)((uint8_t*)s + ent_bytes + st_bytes);
 
     MsmRecode rc;
     memset(&rc, 0, sizeof rc);
@@ -406,10 +400,8 @@ int msm_run_device(plonk_ctx* ctx, plonk_srs* srs, const Fr* d_scalars, size_t n
     PLONK_TRY(prof_end(ctx));
     PLONK_TRY(prof_begin(ctx, "msm_bucket_reduce", (double)M * (double)piece_stride * sizeof(G1Xyzz)));
     PLONK_LAUNCH(msm_bucket_reduce_kernel, dim3((unsigned)M), dim3(red_lanes), (size_t)red_lanes * sizeof(G1Xyzz), ctx->stream,
-                 (const uint32_t*)starts, c, G * MSM_BLOCK, (const G1Xyzz*)pieces, piece_stride, partial);
+                 (const uint32_t*)starts, c, G * MSM_BLOCK, (const G1Xyzz*)pieces, piece_stride, d_out_xy, d_flags);
     PLONK_TRY(prof_end(ctx));
-    unsigned gf = (unsigned)((M + 63) / 64);
-    PLONK_LAUNCH(msm_finalize_kernel, dim3(gf), dim3(64), 0, ctx->stream, (const G1Xyzz*)partial, M, 1u, d_out_xy, d_flags);
     PLONK_CHECK_HIP(hipGetLastError());
     return PLONK_OK;
 }

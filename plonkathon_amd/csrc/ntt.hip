@@ -303,11 +303,14 @@ __global__ void __launch_bounds__(1024) ntt_pass_radix2_kernel(NttPass p) {
     }
     __syncthreads();
 
-    // radix-2 decimation-in-frequency stages: (a, b) -> (a + b, (a - b) * w)
-    const unsigned nbf = T / 2;
-    for (int lh = (int)p.log_r - 1; lh >= 0; lh--) {
+    // decimation-in-frequency stages, (a, b) -> (a + b, (a - b) * w).  Two levels (half sizes h and h/2) are
+    // done per LDS round trip: a thread owns rows {r0, r0 + h/2, r0 + h, r0 + 3h/2} of one column, which
+    // halves the LDS traffic and the barrier count of a level-at-a-time schedule; an odd level count starts
+    // with one plain radix-2 level.
+    int lh = (int)p.log_r - 1;
+    if (p.log_r & 1) {
         const unsigned h = 1u << lh;
-        for (unsigned b = tid; b < nbf; b += nthr) {
+        for (unsigned b = tid; b < T / 2; b += nthr) {
             unsigned c, bf;
             if (!p.last) {
                 c = b & (C - 1);
@@ -324,6 +327,40 @@ __global__ void __launch_bounds__(1024) ntt_pass_radix2_kernel(NttPass p) {
             if (lh != 0) d = fp_mul(d, lds_ld(w_lo, w_hi, off << (p.log_r - 1 - lh)));
             lds_st(d_lo, d_hi, i0, s);
             lds_st(d_lo, d_hi, i1, d);
+        }
+        __syncthreads();
+        lh--;
+    }
+    for (; lh >= 1; lh -= 2) {
+        const unsigned h = 1u << lh, q = h >> 1;
+        const unsigned sh_a = p.log_r - 1 - lh;  // twiddle index shift of the level with half size h
+        for (unsigned b = tid; b < T / 4; b += nthr) {
+            unsigned c, bf;
+            if (!p.last) {
+                c = b & (C - 1);
+                bf = b >> p.log_c;
+            } else {
+                bf = b & (R / 4 - 1);
+                c = b >> (p.log_r - 2);
+            }
+            const unsigned off = bf & (q - 1);
+            const unsigned r0 = ((bf >> (lh - 1)) << (lh + 1)) + off;
+            const unsigned i0 = LIDX(r0, c), i1 = LIDX(r0 + q, c), i2 = LIDX(r0 + h, c), i3 = LIDX(r0 + h + q, c);
+            const Fr x0 = lds_ld(d_lo, d_hi, i0), x1 = lds_ld(d_lo, d_hi, i1), x2 = lds_ld(d_lo, d_hi, i2),
+                     x3 = lds_ld(d_lo, d_hi, i3);
+            const Fr s0 = fp_add(x0, x2), s1 = fp_add(x1, x3);
+            const Fr d0 = fp_mul(fp_sub(x0, x2), lds_ld(w_lo, w_hi, off << sh_a));
+            const Fr d1 = fp_mul(fp_sub(x1, x3), lds_ld(w_lo, w_hi, (off + q) << sh_a));
+            Fr y1 = fp_sub(s0, s1), y3 = fp_sub(d0, d1);
+            if (lh != 1) {  // the level with half size 1 has unit twiddles
+                const Fr wb = lds_ld(w_lo, w_hi, off << (sh_a + 1));
+                y1 = fp_mul(y1, wb);
+                y3 = fp_mul(y3, wb);
+            }
+            lds_st(d_lo, d_hi, i0, fp_add(s0, s1));
+            lds_st(d_lo, d_hi, i1, y1);
+            lds_st(d_lo, d_hi, i2, fp_add(d0, d1));
+            lds_st(d_lo, d_hi, i3, y3);
         }
         __syncthreads();
     }

@@ -134,3 +134,34 @@ if "prover" in which:
         dt = (time.perf_counter() - t0) / reps
         print(json.dumps({"what": "prover", "B": B, "streams": S, "s_per_batch": dt, "proofs_per_s": B / dt,
                           "ms_per_proof": 1e3 * dt / B, "status_ok": ok}), flush=True)
+if "proverc" in which:
+    from bench import chain_program_lines, witness_for
+
+    program = Program(chain_program_lines(2048), 2048)
+    wits = [witness_for(program, i) for i in range(4)]
+    ctxs = [ctx, Context(0)]
+    provers = [BatchProver(setup, program, c) for c in ctxs]
+    for c in (10, 11, 12):
+        for G in (0, 1, 2):
+            for B, S in ((512, 1), (512, 2)):
+                prs = provers[:S]
+                for pr in prs:
+                    check(L.plonk_msm_configure(pr.ctx.handle, c, G))
+                    pr.upload([wits[i % 4] for i in range(B // S)])
+                for _ in range(2):
+                    for pr in prs:
+                        pr.run()
+                    for pr in prs:
+                        pr.download_raw()
+                t0 = time.perf_counter()
+                reps = 4
+                for _ in range(reps):
+                    for pr in prs:
+                        pr.run()
+                    for pr in prs:
+                        pr.download_raw()
+                dt = (time.perf_counter() - t0) / reps
+                print(json.dumps({"what": "proverc", "c": c, "G": G, "B": B, "streams": S, "proofs_per_s": B / dt,
+                                  "ms_per_step": 1e3 * dt}), flush=True)
+    for pr in provers:
+        check(L.plonk_msm_configure(pr.ctx.handle, 0, 0))
