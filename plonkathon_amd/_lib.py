@@ -8,7 +8,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libplonk_hip.so")
+# PLONK_HIP_LIB: path of an alternative build of the same library (tuning experiments)
+LIB_PATH = os.environ.get("PLONK_HIP_LIB") or os.path.join(_HERE, "libplonk_hip.so")
 
 c_void_pp = ctypes.POINTER(ctypes.c_void_p)
 _u8p = ctypes.c_char_p

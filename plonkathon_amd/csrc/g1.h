@@ -272,3 +272,54 @@ PLONK_HD void g1l_madd(G1XyzzL& p, const Fq& x2p, const Fq& y2p) {
     PLONK_SCHED_FENCE();
     p.y = fpl_norm(fpl_sub<FqParams, 2>(m1, m2));                      // in (0, 4m)
 }
+
+// Piece form of a lazy accumulator for msm_accumulate_kernel: four 256-bit words, x and y < 4m, zz and zzz
+// < 2m (not canonical; g1_piece_load canonicalises), identity = all zero.  Costs ~100 instructions, no
+// multiplication, so flushing at a bucket boundary stays cheap.
+PLONK_HD void fpl_pack_lt4m(const FqL& a, bool sub4m, uint32_t out[8]) {
+    uint32_t w[9];
+    fp29_pack(a.l, w);                      // limbs 0..8 -> words 0..7 (bits < 256) ...
+    w[8] = a.l[8] >> 24;                    // ... bit 256 and up (limb 8 starts at bit 232)
+    if (sub4m) {                            // value < 8m: subtract 4m when that does not go negative
+        uint32_t t[9], borrow = 0;
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+            // 4m as 9 words
+            const uint32_t mi = i < 8 ? ((FqParams::mod(i) << 2) | (i ? FqParams::mod(i - 1) >> 30 : 0)) : (FqParams::mod(7) >> 30);
+            t[i] = fp_sbb(w[i], mi, borrow);
+        }
+        if (!borrow) {
+#pragma unroll
+            for (int i = 0; i < 9; i++) w[i] = t[i];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) out[i] = w[i];
+}
+
+PLONK_HD G1Xyzz g1l_to_piece(const G1XyzzL& p) {
+    if (p.inf) return g1_xyzz_identity();
+    G1Xyzz r;
+    fpl_pack_lt4m(p.x, true, r.x.v);
+    fpl_pack_lt4m(p.y, false, r.y.v);
+    fpl_pack_lt4m(p.zz, false, r.zz.v);
+    fpl_pack_lt4m(p.zzz, false, r.zzz.v);
+    return r;
+}
+
+// canonical XYZZ from a stored piece (either form: canonical pieces pass through unchanged)
+PLONK_HD G1Xyzz g1_piece_load(const G1Xyzz* src) {
+    G1Xyzz r;
+    r.x = fp_load(&src->x);
+    r.y = fp_load(&src->y);
+    r.zz = fp_load(&src->zz);
+    r.zzz = fp_load(&src->zzz);
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        fp_reduce_once<FqParams>(r.x.v);
+        fp_reduce_once<FqParams>(r.y.v);
+    }
+    fp_reduce_once<FqParams>(r.zz.v);
+    fp_reduce_once<FqParams>(r.zzz.v);
+    return r;
+}

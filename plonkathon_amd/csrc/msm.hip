@@ -33,6 +33,9 @@
 #define MSM_BLOCK 256
 #define MSM_DEFAULT_WINDOW_BITS 10
 #define MSM_MAX_WINDOW_BITS 13
+#ifndef MSM_ACC_WAVES
+#define MSM_ACC_WAVES 4  // waves per SIMD the accumulate kernel is compiled for (register budget 512 / waves)
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // Window table: table[w*n + i] = 2^(c*w) * bases[i], affine.
@@ -88,6 +91,7 @@ __global__ void g1_batch_to_affine_kernel(const G1Xyzz* in, G1Affine* out, size_
 // ------------------------------------------------------------------------------------------------
 // Sorting.  Entry encoding: bits 0..14 base index, bit 15 sign, bits 16.. window.
 struct MsmRecode { uint32_t k[9]; };
+struct alignas(8) MsmDeferred { uint32_t bucket, entry; };  // an addition left to msm_bucket_reduce_kernel
 
 PLONK_DEV void msm_recode(const Fr* scalars, size_t idx, const MsmRecode& rc, uint32_t limb[10]) {
     Fr s = fp_from_mont(fp_load(scalars + idx));
@@ -126,7 +130,8 @@ template <class F> PLONK_DEV void msm_for_each_digit(const uint32_t limb[10], un
 // several slices of each row of a [batch][4n] array, e.g. the three quotient parts).
 __global__ void __launch_bounds__(MSM_BLOCK) msm_sort_kernel(const Fr* scalars, size_t n, size_t stride, size_t inner,
                                                              size_t outer_stride, unsigned c, unsigned W, MsmRecode rc,
-                                                             uint32_t* entries, size_t entry_stride, uint32_t* starts) {
+                                                             uint32_t* entries, size_t entry_stride, uint32_t* starts,
+                                                             uint32_t* n_deferred) {
     PLONK_DYN_SMEM(smem);
     __shared__ uint32_t chunk_tot[MSM_BLOCK];
     const unsigned K = 1u << (c - 1);
@@ -169,6 +174,7 @@ __global__ void __launch_bounds__(MSM_BLOCK) msm_sort_kernel(const Fr* scalars, 
     if (tid == MSM_BLOCK - 1) {
         st[K + 1] = chunk_tot[MSM_BLOCK - 1];
         st[0] = 0;
+        n_deferred[m] = 0;
     }
     __syncthreads();
     for (size_t i = tid; i < n; i += MSM_BLOCK) {
@@ -199,10 +205,11 @@ PLONK_HD uint32_t msm_lane_span(uint32_t E, uint32_t lanes) {
 // boundaries at different steps do not serialise anything expensive.  Piece slot: t + k - 1 — lanes and
 // the buckets they touch are both monotone, so the slot is unique, and msm_bucket_reduce_kernel can
 // recompute which lanes touched bucket k from the bucket starts alone.
-__global__ void __launch_bounds__(MSM_BLOCK) msm_accumulate_kernel(const G1Affine* table, size_t table_n,
+__global__ void __launch_bounds__(MSM_BLOCK, MSM_ACC_WAVES) msm_accumulate_kernel(const G1Affine* table, size_t table_n,
                                                                    const uint32_t* entries, size_t entry_stride,
                                                                    const uint32_t* starts, unsigned c, unsigned G,
-                                                                   G1Xyzz* pieces, size_t piece_stride) {
+                                                                   G1Xyzz* pieces, size_t piece_stride,
+                                                                   MsmDeferred* deferred, uint32_t* n_deferred) {
     PLONK_DYN_SMEM(smem);
     const unsigned K = 1u << (c - 1);
     const unsigned m = blockIdx.x / G, g = blockIdx.x % G;
@@ -229,21 +236,48 @@ __global__ void __launch_bounds__(MSM_BLOCK) msm_accumulate_kernel(const G1Affin
     }
     unsigned k = a;
     G1Xyzz* out = pieces + (size_t)m * piece_stride + t - 1;  // out[k] = slot t + k - 1
+#ifndef PLONK_MSM_PACKED
+    // Accumulator kept as 9 x 29-bit limbs with lazy reductions (fpl.h / g1l_madd_fast): the same 1548
+    // multiplier instructions per mixed addition as the packed canonical form but ~2x fewer of everything
+    // else.  The rare steps the fast formulas cannot take (the accumulator equals +-the table point, i.e.
+    // duplicate bases) are not resolved here — a call or an inlined general addition in this loop costs
+    // 25 % of its speed — they are appended to the MSM's deferred list with their bucket, and
+    // msm_bucket_reduce_kernel adds them to that bucket with the general formulas.
+    G1XyzzL run = g1l_identity();
+    auto flush = [&](unsigned kk) {
+        out[kk] = g1l_to_piece(run);
+        run.inf = true;
+    };
+    auto accumulate = [&](const Fq& x, const Fq& y, uint32_t en) {
+        if (!g1l_madd_fast(run, x, y) && !(fp_is_zero(x) && fp_is_zero(y))) {
+            const uint32_t slot = atomicAdd(n_deferred + m, 1u);
+            deferred[(size_t)m * entry_stride + slot] = MsmDeferred{k, en};
+        }
+    };
+#else
     G1Xyzz run = g1_xyzz_identity();
+    auto flush = [&](unsigned kk) {
+        out[kk] = run;
+        run = g1_xyzz_identity();
+    };
+    auto accumulate = [&](const Fq& x, const Fq& y, uint32_t) {
+        G1Affine pt;
+        pt.x = x;
+        pt.y = y;
+        g1_madd(run, pt);
+    };
+#endif
     auto step = [&](uint32_t e, uint32_t en) {
         if (e >= hi || e < lo) return;
         if (e < st[k]) {  // left bucket k: its partial sum is complete
-            out[k] = run;
-            run = g1_xyzz_identity();
+            flush(k);
             do k--;
             while (e < st[k]);
         }
         const G1Affine* src = table + (size_t)(en >> 16) * table_n + (en & 0x7fffu);
-        G1Affine pt;
-        pt.x = fp_load(&src->x);
-        pt.y = fp_load(&src->y);
-        if (en & 0x8000u) pt.y = fp_neg(pt.y);
-        g1_madd(run, pt);
+        Fq x = fp_load(&src->x), y = fp_load(&src->y);
+        if (en & 0x8000u) y = fp_neg(y);
+        accumulate(x, y, en);
     };
     for (uint32_t base = (hi - 1) & ~3u;; base -= 4) {
         const u32x4 q = *reinterpret_cast<const u32x4*>(ent + base);
@@ -253,7 +287,7 @@ __global__ void __launch_bounds__(MSM_BLOCK) msm_accumulate_kernel(const G1Affin
         step(base, q.x);
         if (base <= lo) break;
     }
-    out[k] = run;
+    flush(k);
 }
 
 // sum_k k * B_k for one MSM from the pieces.  Lane l owns the buckets (l*pb, (l+1)*pb]: walking them from
@@ -261,8 +295,10 @@ __global__ void __launch_bounds__(MSM_BLOCK) msm_accumulate_kernel(const G1Affin
 // the lane's share is tot + (l*pb) * run; the shares are tree-reduced through LDS.  Every lane adds into
 // tot once per bucket, so the wave stays converged; only the (1-3 piece) inner loop varies.
 __global__ void __launch_bounds__(256) msm_bucket_reduce_kernel(const uint32_t* starts, unsigned c, unsigned acc_lanes,
-                                                                 const G1Xyzz* pieces, size_t piece_stride, Fq* out_xy,
-                                                                 uint8_t* flags) {
+                                                                 const G1Xyzz* pieces, size_t piece_stride,
+                                                                 const G1Affine* table, size_t table_n, const MsmDeferred* deferred,
+                                                                 size_t deferred_stride, const uint32_t* n_deferred,
+                                                                 Fq* out_xy, uint8_t* flags) {
     PLONK_DYN_SMEM(smem);
     G1Xyzz* red = reinterpret_cast<G1Xyzz*>(smem);
     const unsigned K = 1u << (c - 1);
@@ -274,12 +310,24 @@ __global__ void __launch_bounds__(256) msm_bucket_reduce_kernel(const uint32_t* 
     const unsigned b_hi = b_lo + pb < K ? b_lo + pb : K;
     const G1Xyzz* pc = pieces + (size_t)m * piece_stride - 1;  // pc[t + k] = piece of lane t for bucket k
     G1Xyzz run = g1_xyzz_identity(), tot = g1_xyzz_identity();
+    const MsmDeferred* dfr = deferred + (size_t)m * deferred_stride;
+    const uint32_t n_dfr = n_deferred[m];  // additions msm_accumulate_kernel left to the general formulas (normally 0)
     uint32_t s_hi = gst[b_hi + 1];
     for (unsigned k = b_hi; k > b_lo; k--) {
         const uint32_t s_lo = gst[k];
         if (s_hi > s_lo) {
             const uint32_t t_last = (s_hi - 1) / per;
-            for (uint32_t t = s_lo / per; t <= t_last; t++) g1_add(run, pc[(size_t)t + k]);
+            for (uint32_t t = s_lo / per; t <= t_last; t++) g1_add(run, g1_piece_load(pc + (size_t)t + k));
+            for (uint32_t i = 0; i < n_dfr; i++) {
+                const MsmDeferred d = dfr[i];
+                if (d.bucket != k) continue;
+                const G1Affine* src = table + (size_t)(d.entry >> 16) * table_n + (d.entry & 0x7fffu);
+                G1Affine pt;
+                pt.x = fp_load(&src->x);
+                pt.y = fp_load(&src->y);
+                if (d.entry & 0x8000u) pt.y = fp_neg(pt.y);
+                g1_madd(run, pt);
+            }
         }
         g1_add(tot, run);
         s_hi = s_lo;
@@ -368,12 +416,16 @@ int msm_run_device(plonk_ctx* ctx, plonk_srs* srs, const Fr* d_scalars, size_t n
     const size_t piece_stride = (size_t)G * MSM_BLOCK + K;
     const size_t ent_bytes = (M * entry_stride * 4 + 255) & ~(size_t)255;
     const size_t st_bytes = (M * (size_t)(K + 2) * 4 + 255) & ~(size_t)255;
-    const size_t piece_bytes = M * piece_stride * sizeof(G1Xyzz);
+    const size_t piece_bytes = (M * piece_stride * sizeof(G1Xyzz) + 255) & ~(size_t)255;
+    const size_t cnt_bytes = (M * 4 + 255) & ~(size_t)255;
+    const size_t dfr_bytes = M * entry_stride * sizeof(MsmDeferred);  // worst case: every addition deferred (all bases equal)
     void* s;
-    PLONK_TRY(ctx_scratch(ctx, 1, ent_bytes + st_bytes + piece_bytes, &s));
+    PLONK_TRY(ctx_scratch(ctx, 1, ent_bytes + st_bytes + piece_bytes + cnt_bytes + dfr_bytes, &s));
     uint32_t* entries = (uint32_t*)s;
     uint32_t* starts = (uint32_t*)((uint8_t*)s + ent_bytes);
     G1Xyzz* pieces = (G1Xyzz*)((uint8_t*)s + ent_bytes + st_bytes);
+    uint32_t* n_deferred = (uint32_t*)((uint8_t*)s + ent_bytes + st_bytes + piece_bytes);
+    MsmDeferred* deferred = (MsmDeferred*)((uint8_t*)s + ent_bytes + st_bytes + piece_bytes + cnt_bytes);
 
     MsmRecode rc;
     memset(&rc, 0, sizeof rc);
@@ -390,17 +442,19 @@ int msm_run_device(plonk_ctx* ctx, plonk_srs* srs, const Fr* d_scalars, size_t n
     }
     PLONK_TRY(prof_begin(ctx, "msm_sort", (double)M * 32.0 * (double)n));
     PLONK_LAUNCH(msm_sort_kernel, dim3((unsigned)M), dim3(MSM_BLOCK), sort_lds, ctx->stream, d_scalars, n, stride, inner, outer_stride, c, W, rc,
-                 entries, entry_stride, starts);
+                 entries, entry_stride, starts, n_deferred);
     PLONK_TRY(prof_end(ctx));
     // algorithmic bytes of an MSM of size n: (64 + 32) * n + 64   
     PLONK_TRY(prof_begin(ctx, "msm_accumulate", (double)M * (96.0 * (double)n + 64.0)));
     PLONK_LAUNCH(msm_accumulate_kernel, dim3((unsigned)(M * G)), dim3(MSM_BLOCK), sort_lds, ctx->stream,
                  (const G1Affine*)srs->table, srs->n_points, (const uint32_t*)entries, entry_stride,
-                 (const uint32_t*)starts, c, G, pieces, piece_stride);
+                 (const uint32_t*)starts, c, G, pieces, piece_stride, deferred, n_deferred);
     PLONK_TRY(prof_end(ctx));
     PLONK_TRY(prof_begin(ctx, "msm_bucket_reduce", (double)M * (double)piece_stride * sizeof(G1Xyzz)));
     PLONK_LAUNCH(msm_bucket_reduce_kernel, dim3((unsigned)M), dim3(red_lanes), (size_t)red_lanes * sizeof(G1Xyzz), ctx->stream,
-                 (const uint32_t*)starts, c, G * MSM_BLOCK, (const G1Xyzz*)pieces, piece_stride, d_out_xy, d_flags);
+                 (const uint32_t*)starts, c, G * MSM_BLOCK, (const G1Xyzz*)pieces, piece_stride,
+                 (const G1Affine*)srs->table, srs->n_points, (const MsmDeferred*)deferred, entry_stride, (const uint32_t*)n_deferred,
+                 d_out_xy, d_flags);
     PLONK_TRY(prof_end(ctx));
     PLONK_CHECK_HIP(hipGetLastError());
     return PLONK_OK;

@@ -179,6 +179,13 @@ def lincomb_golden(setup, full_size=True):
         got = pa.ec_lincomb([(Pts[i], s) for i, s in zip(idx, sc)])
         assert affine(got) == pt(case["result"]), case["name"]
     assert pa.ec_lincomb([(None, 5), (Pts[2], 1)]) == Pts[2]
+    # duplicate bases: every addition inside a bucket hits P == +-Q, the case the MSM's fast formulas defer to
+    # the bucket reduction (csrc/msm.hip); 40 x the same point with the same scalar, then with cancelling signs
+    g2, s7 = affine(Pts[2]), 0x1234567890ABCDEF1234567890ABCDEF
+    assert affine(pa.ec_lincomb([(Pts[2], s7)] * 40)) == og1.multiply(g2, 40 * s7 % R_MOD)
+    assert pa.ec_lincomb([(Pts[2], s7), (Pts[2], -s7)] * 9) is None
+    mixed = [(Pts[2], 3), (Pts[5], 11), (Pts[2], 3), (None, 9), (Pts[5], 11), (Pts[2], 3)]
+    assert affine(pa.ec_lincomb(mixed)) == og1.ec_lincomb([(None if p is None else affine(p), k) for p, k in mixed])
     assert pa.ec_mul(Pts[3], 0) is None
     assert affine(pa.ec_mul(Pts[3], Scalar(7))) == og1.multiply(affine(Pts[3]), 7)
 
