@@ -177,9 +177,10 @@ PLONK_HD G1XyzzL g1l_from_xyzz(const G1Xyzz& p) {
     return r;
 }
 
-// Hot-loop form: performs acc += (x2, y2) and returns true, or returns false WITHOUT touching acc when the
-// step is exceptional (identity base, acc identity handled inline, P == +-Q) so that the caller can
-// finish on the general packed path.  No calls, no packed arithmetic: minimal live registers.
+// acc += (x2, y2), canonical Montgomery coordinates.  Returns false WITHOUT touching acc when the step is
+// exceptional — identity base (0, 0), or P == +-Q (detected by a cheap filter with a 2^-25 false-positive
+// rate) — and the caller resolves it with the general packed formulas (msm.hip defers it to the bucket
+// reduction).  No calls, no packed arithmetic: minimal live registers.
 PLONK_HD bool g1l_madd_fast(G1XyzzL& p, const Fq& x2p, const Fq& y2p) {
     if (fp_is_zero(x2p) && fp_is_zero(y2p)) return false;
     const FqL x2 = fpl_from_fp(x2p), y2 = fpl_from_fp(y2p);
@@ -207,70 +208,17 @@ PLONK_HD bool g1l_madd_fast(G1XyzzL& p, const Fq& x2p, const Fq& y2p) {
     p.zz = fpl_mul(p.zz, pp);
     const FqL ppp = fpl_mul(pp_, pp);                                  // < 2m   (P, PP dead after this)
     p.zzz = fpl_mul(p.zzz, ppp);
-    const FqL m2 = fpl_mul(p.y, ppp);                                  // < 2m   (Y1 dead after this)
     const FqL r2 = fpl_sqr(rr);                                        // < 2m
     // X3 = R^2 - PPP - 2Q  ->  R^2 + (2m - PPP) + (4m - 2Q)  in (0, 8m)
     p.x = fpl_norm(fpl_sub<FqParams, 4>(fpl_sub<FqParams, 2>(r2, ppp), fpl_add(q, q)));
     const FqL d = fpl_norm(fpl_sub<FqParams, 8>(q, p.x));              // Q - X3 + 8m    in (0, 10m)
-    const FqL m1 = fpl_mul(rr, d);                                     // < 2m
-    p.y = fpl_norm(fpl_sub<FqParams, 2>(m1, m2));                      // in (0, 4m)
+    FqL zero;
+#pragma unroll
+    for (int i = 0; i < 9; i++) zero.l[i] = 0;
+    const FqL ny1 = fpl_norm(fpl_sub<FqParams, 4>(zero, p.y));         // 4m - Y1        in (0, 4m]
+    // Y3 = R (Q - X3) - Y1 PPP as one sum of products with a single reduction: 6*10 + 4*2 <= 128
+    p.y = fpl_mul_add(rr, d, ny1, ppp);                                // < 2m
     return true;
-}
-
-// rare tail of g1l_madd (P == +-Q): kept out of line so the hot loop stays small
-PLONK_HD_NOINLINE void g1l_madd_same_x(G1XyzzL& p, const Fq& x2p, const Fq& y2p, bool same_point) {
-    if (same_point) {
-        G1Affine q;
-        q.x = x2p;
-        q.y = y2p;
-        p = g1l_from_xyzz(g1_dbl_affine(q));
-    } else {
-        p = g1l_identity();
-    }
-}
-
-// acc += (x2, y2) affine, canonical packed coordinates; (0, 0) is the identity
-PLONK_HD void g1l_madd(G1XyzzL& p, const Fq& x2p, const Fq& y2p) {
-    if (fp_is_zero(x2p) && fp_is_zero(y2p)) return;
-    const FqL x2 = fpl_from_fp(x2p), y2 = fpl_from_fp(y2p);
-    if (p.inf) {
-        p.x = x2;
-        p.y = y2;
-        p.zz = fpl_one<FqParams>();
-        p.zzz = p.zz;
-        p.inf = false;
-        return;
-    }
-    const FqL u2 = fpl_mul(x2, p.zz);                                  // < 2m
-    PLONK_SCHED_FENCE();
-    const FqL pp_ = fpl_norm(fpl_sub<FqParams, 8>(u2, p.x));           // U2 - X1 + 8m   in (0, 10m)
-    const FqL s2 = fpl_mul(y2, p.zzz);                                 // < 2m
-    PLONK_SCHED_FENCE();
-    const FqL rr = fpl_norm(fpl_sub<FqParams, 4>(s2, p.y));            // S2 - Y1 + 4m   in (0, 6m)
-    if (fpl_is_zero_mod(pp_)) {                                        // same x: P == +-Q (rare)
-        g1l_madd_same_x(p, x2p, y2p, fpl_is_zero_mod(rr));
-        return;
-    }
-    const FqL pp = fpl_sqr(pp_);                                       // < 2m
-    PLONK_SCHED_FENCE();
-    const FqL q = fpl_mul(p.x, pp);                                    // < 2m   (X1 dead after this)
-    PLONK_SCHED_FENCE();
-    p.zz = fpl_mul(p.zz, pp);
-    PLONK_SCHED_FENCE();
-    const FqL ppp = fpl_mul(pp_, pp);                                  // < 2m   (P, PP dead after this)
-    PLONK_SCHED_FENCE();
-    p.zzz = fpl_mul(p.zzz, ppp);
-    PLONK_SCHED_FENCE();
-    const FqL m2 = fpl_mul(p.y, ppp);                                  // < 2m   (Y1 dead after this)
-    PLONK_SCHED_FENCE();
-    const FqL r2 = fpl_sqr(rr);                                        // < 2m
-    PLONK_SCHED_FENCE();
-    // X3 = R^2 - PPP - 2Q  ->  R^2 + (2m - PPP) + (4m - 2Q)  in (0, 8m)
-    p.x = fpl_norm(fpl_sub<FqParams, 4>(fpl_sub<FqParams, 2>(r2, ppp), fpl_add(q, q)));
-    const FqL d = fpl_norm(fpl_sub<FqParams, 8>(q, p.x));              // Q - X3 + 8m    in (0, 10m)
-    const FqL m1 = fpl_mul(rr, d);                                     // < 2m
-    PLONK_SCHED_FENCE();
-    p.y = fpl_norm(fpl_sub<FqParams, 2>(m1, m2));                      // in (0, 4m)
 }
 
 // Piece form of a lazy accumulator for msm_accumulate_kernel: four 256-bit words, x and y < 4m, zz and zzz

@@ -70,8 +70,16 @@ extern "C" void probe_g1l_chain(const uint32_t* pts, const int* neg, int n, uint
         G1Affine a;
         memcpy(&a, pts + 16 * i, 64);
         if (neg[i]) a.y = fp_neg(a.y);
-        g1l_madd(acc, a.x, a.y);
+        if (!g1l_madd_fast(acc, a.x, a.y)) {  // exceptional step: the general packed formulas
+            G1Xyzz t = g1l_to_xyzz(acc);
+            g1_madd(t, a);
+            acc = g1l_from_xyzz(t);
+        }
     }
-    G1Affine r = g1_to_affine(g1l_to_xyzz(acc));
+    // through the stored "piece" form and back, as msm_accumulate_kernel / msm_bucket_reduce_kernel do
+    const G1Xyzz piece = g1l_to_piece(acc);
+    G1Affine r = g1_to_affine(g1_piece_load(&piece));
+    G1Affine direct = g1_to_affine(g1l_to_xyzz(acc));
+    if (memcmp(&r, &direct, 64) != 0) memset(&r, 0xff, 64);  // the two routes must agree
     memcpy(out, &r, 64);
 }
