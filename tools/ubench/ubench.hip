@@ -6,6 +6,7 @@
 #include <stdio.h>
 #include <stdint.h>
 #include "fp.h"
+#include "g1.h"
 
 #define ITERS 2048
 #define CHAINS 8
@@ -59,6 +60,35 @@ __global__ void __launch_bounds__(256) k_fpadd(uint32_t* out, uint32_t seed, int
     out[tid] = s;
 }
 
+// the MSM inner loop's own units: lazy 9x29-bit multiplication and the lazy mixed addition, register-resident operands
+__global__ void __launch_bounds__(256) k_fplmul(uint32_t* out, uint32_t seed, int iters) {
+    uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    FqL a, b;
+    for (int i = 0; i < 9; i++) { a.l[i] = (tid * 2654435761u + i * 40503u + seed) & FP29_MASK; b.l[i] = (tid * 40503u + i * 2654435761u + 7u) & FP29_MASK; }
+    a.l[8] &= 0xfffff; b.l[8] &= 0xfffff;
+    for (int i = 0; i < iters; i++) { a = fpl_mul(a, b); b = fpl_mul(b, a); }
+    uint32_t s = 0;
+    for (int i = 0; i < 9; i++) s ^= a.l[i] ^ b.l[i];
+    out[tid] = s;
+}
+__global__ void __launch_bounds__(256, 4) k_g1lmadd(uint32_t* out, uint32_t seed, int iters) {
+    uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    // not curve points: the formulas do not care, and the exceptional-case filter almost never fires on random data
+    Fq x, y;
+    for (int i = 0; i < 8; i++) { x.v[i] = tid * 2654435761u + i * 40503u + seed; y.v[i] = tid * 40503u + i * 2654435761u + 7u; }
+    x.v[7] &= 0x0fffffffu; y.v[7] &= 0x0fffffffu;
+    G1XyzzL acc = g1l_identity();
+    uint32_t skipped = 0;
+    for (int i = 0; i < iters; i++) {
+        skipped += !g1l_madd_fast(acc, x, y);
+        x.v[0] += 0x9e3779b9u;  // a different base every step
+        y.v[1] ^= x.v[0];
+    }
+    uint32_t s = skipped;
+    for (int i = 0; i < 9; i++) s ^= acc.x.l[i] ^ acc.y.l[i] ^ acc.zz.l[i] ^ acc.zzz.l[i];
+    out[tid] = s;
+}
+
 template <class F> static double time_ms(F launch, int reps = 5) {
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
@@ -96,6 +126,9 @@ int main() {
     double m3 = time_ms([&] { hipLaunchKernelGGL(k_fpadd<FrParams>, dim3(blocks), dim3(threads), 0, 0, out, 1u, it * 8); });
     printf(", \"fr_mul_Gops\": %.2f, \"fq_mul_Gops\": %.2f, \"fr_addsub_Gops\": %.2f", lanes * it * 2 / (m1 * 1e-3) / 1e9,
            lanes * it * 2 / (m2 * 1e-3) / 1e9, lanes * it * 8 * 2 / (m3 * 1e-3) / 1e9);
+    double m4 = time_ms([&] { hipLaunchKernelGGL(k_fplmul, dim3(blocks), dim3(threads), 0, 0, out, 1u, it); });
+    double m5 = time_ms([&] { hipLaunchKernelGGL(k_g1lmadd, dim3(blocks), dim3(threads), 0, 0, out, 1u, it); });
+    printf(", \"fq_lazy_mul_Gops\": %.2f, \"g1_lazy_madd_Gops\": %.3f", lanes * it * 2 / (m4 * 1e-3) / 1e9, lanes * it / (m5 * 1e-3) / 1e9);
     // occupancy sweep for fr_mul: 1,2,4 blocks per CU
     for (int bpc : {1, 2, 4, 8, 16, 32}) {
         int bl = prop.multiProcessorCount * bpc;
