@@ -30,7 +30,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s measured cop
 # chip-wide rate of the MSM loop's unit of work — the lazy mixed addition on register-resident operands —
 # measured by tools/ubench (profiles/r01_j_ubench.json: g1_lazy_madd_Gops; fq_lazy_mul_Gops = 164.5)
 G1_MADD_CEILING_G = 13.5
-MSM_WINDOW_BITS = 10      # library default (csrc/msm.hip); 26 windows of signed 10-bit digits
+MSM_WINDOW_BITS = 10      # bucket-method default (csrc/msm.hip); 26 windows of signed 10-bit digits
 GROUP_ORDER = 2048
 PTAU = os.path.join(REPO, "tests", "golden", "srs_2048.ptau")
 
@@ -199,7 +199,10 @@ def main():
     gathered = D.gather_proofs(proofs[0], total, dist)
     n_results = len(gathered)
 
-    msm_ms, msm_launches, msm_bytes = ctx.profile_read("msm_accumulate")  # stream 0's launches
+    # the dominant kernel: the lookup MSM when the table fits in HBM (default), else the bucket method's accumulate
+    lookup_bits = setup.device_bases(ctx).lookup_bits
+    msm_kernel = "msm_lookup" if lookup_bits else "msm_accumulate"
+    msm_ms, msm_launches, msm_bytes = ctx.profile_read(msm_kernel)  # stream 0's launches
     total_proofs = args.steps * B * world
     line = {
         "metric": "proofs/sec at group_order=2^11 (PLONK prover hot path: NTT + quotient + KZG MSM)",
@@ -238,22 +241,25 @@ def main():
         avg_s = msm_ms * 1e-3 / msm_launches
         achieved = (msm_bytes / msm_launches) / avg_s / 1e9
         line["roofline"] = {
-            "kernel": "msm_accumulate_kernel",
+            "kernel": msm_kernel + "_kernel",
             "bound": "hbm",
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
-            "traffic": pmc_traffic("msm_accumulate_kernel", "bench")[0] if B // S == 512 else None,
+            "traffic": pmc_traffic(msm_kernel + "_kernel", "bench")[0] if B // S == 512 else None,
             "traffic_source": "profiles/r01_pmc_summary.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
                               "`bench.py --batch 512 --streams 1` (tools/pmc_collect.sh), 2*FETCH+WRITE, launch-weighted mean",
             "launches": msm_launches,
             "avg_launch_us": avg_s * 1e6,
-            "note": "algorithmic bytes = 96*N+64 per MSM; the kernel is integer-ALU bound (DESIGN.md 3/4.2), see `alu`",
+            "note": "algorithmic bytes = 96*N+64 per MSM (SURVEY.md 8(d)); the kernel is integer-ALU bound (DESIGN.md 3/4.2), "
+                    "see `alu`; with the lookup table every addition also reads 64 table bytes, i.e. `traffic` is the real demand",
+            "msm_method": ("lookup table, %d-bit windows" % lookup_bits) if lookup_bits else "bucket method, %d-bit windows" % MSM_WINDOW_BITS,
         }
         # the honest ceiling: W*N mixed additions per MSM against the rate of a bare mixed-addition loop
         n_msm = msm_bytes / (96.0 * GROUP_ORDER + 64.0)
-        windows = (256 + MSM_WINDOW_BITS - 1) // MSM_WINDOW_BITS
+        wbits = lookup_bits or MSM_WINDOW_BITS
+        windows = (256 + wbits - 1) // wbits
         gmadd = n_msm * windows * GROUP_ORDER / (msm_ms * 1e-3) / 1e9
         line["roofline"]["alu"] = {"achieved_g1_gmadd_per_s": gmadd, "ceiling_g1_gmadd_per_s": G1_MADD_CEILING_G,
                                    "frac": gmadd / G1_MADD_CEILING_G,

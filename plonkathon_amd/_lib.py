@@ -46,6 +46,8 @@ SIGNATURES = {
     "plonk_srs_load_affine": (ctypes.c_int, [ctypes.c_void_p, _u8p, ctypes.c_size_t, c_void_pp]),
     "plonk_srs_free": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "plonk_srs_size": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_size_t)]),
+    "plonk_srs_lookup_bits": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint)]),
+    "plonk_msm_lookup_configure": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint, ctypes.c_size_t]),
     "plonk_g1_msm": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]),
     "plonk_msm_configure": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint, ctypes.c_uint]),
     "plonk_prover_create": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint, _u8p, ctypes.c_size_t, c_void_pp]),

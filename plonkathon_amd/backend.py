@@ -58,6 +58,14 @@ class Context:
         check(self.L.plonk_timer_stop_ms(self.handle, ctypes.byref(ms)))
         return ms.value
 
+    def msm_configure(self, window_bits=0, groups=0):
+        """Bucket-method tuning knobs (0 = library default)."""
+        check(self.L.plonk_msm_configure(self.handle, window_bits, groups))
+
+    def msm_lookup(self, mode=0, window_bits=0, budget_bytes=0):
+        """Lookup-MSM policy (include/plonk_hip.h): mode 0 auto, 1 off, 2 force `window_bits` for every base set."""
+        check(self.L.plonk_msm_lookup_configure(self.handle, mode, window_bits, budget_bytes))
+
     def profile(self, on):
         check(self.L.plonk_profile_enable(self.handle, 1 if on else 0))
 

@@ -398,6 +398,7 @@ int plonk_srs_load_ptau(plonk_ctx* ctx, const uint8_t* g1_mont_le, size_t n_poin
         PLONK_CHECK_HIP(hipGetLastError());
     }
     PLONK_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    s->fixed = true;
     *out_srs = s;
     return PLONK_OK;
 }
@@ -426,6 +427,7 @@ int plonk_srs_free(plonk_ctx* ctx, plonk_srs* srs) {
     PLONK_CHECK_HIP(hipStreamSynchronize(ctx->stream));
     if (srs->bases) hipFree(srs->bases);
     if (srs->table) hipFree(srs->table);
+    if (srs->lookup) hipFree(srs->lookup);
     delete srs;
     return PLONK_OK;
 }
@@ -442,6 +444,24 @@ int plonk_msm_configure(plonk_ctx* ctx, unsigned window_bits, unsigned groups) {
                   "window_bits must be 0 (default) or in [2, 13]");
     ctx->msm_window_bits = window_bits;
     ctx->msm_groups = groups;
+    return PLONK_OK;
+}
+
+int plonk_srs_lookup_bits(const plonk_srs* srs, unsigned* out_bits) {
+    PLONK_REQUIRE(srs && out_bits, PLONK_ERR_ARG, "bad argument");
+    *out_bits = srs->lookup_bits;
+    return PLONK_OK;
+}
+
+int plonk_msm_lookup_configure(plonk_ctx* ctx, int mode, unsigned window_bits, size_t budget_bytes) {
+    PLONK_REQUIRE(ctx, PLONK_ERR_ARG, "ctx is NULL");
+    PLONK_REQUIRE(mode >= 0 && mode <= 2, PLONK_ERR_ARG, "mode must be 0 (auto), 1 (off) or 2 (force)");
+    PLONK_REQUIRE(window_bits == 0 || (window_bits >= 2 && window_bits <= 16), PLONK_ERR_ARG,
+                  "window_bits must be 0 (auto) or in [2, 16]");
+    PLONK_REQUIRE(mode != 2 || window_bits, PLONK_ERR_ARG, "mode 2 needs an explicit window_bits");
+    ctx->msm_lookup_mode = mode;
+    ctx->msm_lookup_bits = window_bits;
+    ctx->msm_lookup_budget = budget_bytes;
     return PLONK_OK;
 }
 

@@ -358,6 +358,126 @@ __global__ void __launch_bounds__(256) msm_bucket_reduce_kernel(const uint32_t* 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Lookup MSM.  MI355X has 288 GB of HBM; a reusable SRS of 2^11 points affords the table of EVERY multiple
+//     L[w][i][d] = d * 2^(c w) * P_i,   d = 1 .. 2^(c-1)      (68.7 GB at c = 16)
+// so that an MSM is just N * ceil(256 / c) mixed additions of looked-up points (32 768 at c = 16 against
+// 53 248 sorted bucket additions plus the bucket reduction): 64 random bytes from HBM per addition — the chip
+// sustains 20 G such reads/s (tools/ubench/gather.hip) against the 13.5 G additions/s its ALUs can do.
+// Signed digits as in the bucket method; a lane walks a flat range of (scalar, window) items.
+
+// tmp[i * half + d - 1] = d * wbase[w * n + i] for one window w, XYZZ (converted by g1_batch_to_affine_kernel)
+__global__ void msm_lookup_fill_kernel(const G1Affine* wbase, size_t n, unsigned c, unsigned w, G1Xyzz* tmp) {
+    const size_t half = (size_t)1 << (c - 1);
+    const size_t seg_len = half < 256 ? half : 256, nseg = half / seg_len;
+    for (size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x; id < n * nseg; id += (size_t)gridDim.x * blockDim.x) {
+        const size_t i = id / nseg, k = (id % nseg) * seg_len;  // this lane fills multiples k+1 .. k+seg_len
+        G1Affine b;
+        b.x = fp_load(&wbase[(size_t)w * n + i].x);
+        b.y = fp_load(&wbase[(size_t)w * n + i].y);
+        G1Xyzz acc = g1_xyzz_identity();
+        for (int bit = (int)c - 1; bit >= 0; bit--) {  // acc = k * b
+            g1_dbl(acc);
+            if ((k >> bit) & 1) g1_madd(acc, b);
+        }
+        G1Xyzz* out = tmp + i * half + k;
+        for (size_t j = 0; j < seg_len; j++) {
+            g1_madd(acc, b);
+            out[j] = acc;
+        }
+    }
+}
+
+// item = i * W + w; lane t of the MSM's 256 * G lanes adds items [t * per, (t + 1) * per)
+__global__ void __launch_bounds__(MSM_BLOCK, MSM_ACC_WAVES) msm_lookup_kernel(
+    const G1Affine* lookup, size_t table_n, unsigned c, unsigned W, const Fr* scalars, size_t n, size_t stride, size_t inner,
+    size_t outer_stride, MsmRecode rc, unsigned G, G1Xyzz* partial, MsmDeferred* deferred, size_t deferred_stride,
+    uint32_t* n_deferred) {
+    PLONK_DYN_SMEM(smem);  // MSM_BLOCK x 128 B: first each lane's recoded scalar (10 words), then the tree reduction
+    const unsigned m = blockIdx.x / G, g = blockIdx.x % G, tid = threadIdx.x;
+    uint32_t* row = reinterpret_cast<uint32_t*>(smem) + tid * 10;
+    G1Xyzz* red = reinterpret_cast<G1Xyzz*>(smem);
+    const Fr* sc = scalars + (m % inner) * stride + (m / inner) * outer_stride;
+    const uint32_t items = (uint32_t)(n * W), lanes = G * MSM_BLOCK;
+    const uint32_t per = (items + lanes - 1) / lanes;
+    const uint64_t lo64 = (uint64_t)(g * MSM_BLOCK + tid) * per;
+    const uint32_t lo = lo64 < items ? (uint32_t)lo64 : items;
+    const uint32_t hi = lo64 + per < items ? (uint32_t)(lo64 + per) : items;
+    const uint32_t mask = (1u << c) - 1, half = 1u << (c - 1);
+
+    G1XyzzL run = g1l_identity();
+    uint32_t i = lo / W, w = lo - i * W;
+    bool fresh = true;
+    for (uint32_t item = lo; item < hi; item++) {
+        if (fresh) {  // new scalar: canonical value + recoding constant, parked in this lane's LDS row
+            uint32_t limb[10];
+            msm_recode(sc, i, rc, limb);
+#pragma unroll
+            for (int j = 0; j < 10; j++) row[j] = limb[j];
+            fresh = false;
+        }
+        const unsigned bit = c * w, j = bit >> 5, sh = bit & 31;
+        const uint64_t two = (uint64_t)row[j] | ((uint64_t)row[j + 1] << 32);
+        const int d = (int)((uint32_t)(two >> sh) & mask) - (int)half;
+        if (d) {
+            const uint32_t ad = d < 0 ? (uint32_t)-d : (uint32_t)d;
+            const G1Affine* src = lookup + ((((size_t)w * table_n + i) << (c - 1)) + (ad - 1));
+            Fq x = fp_load(&src->x), y = fp_load(&src->y);
+            if (d < 0) y = fp_neg(y);
+            if (!g1l_madd_fast(run, x, y) && !(fp_is_zero(x) && fp_is_zero(y))) {  // see msm_accumulate_kernel
+                const uint32_t slot = atomicAdd(n_deferred + m, 1u);
+                deferred[(size_t)m * deferred_stride + slot] = MsmDeferred{item, (uint32_t)d};
+            }
+        }
+        if (++w == W) {
+            w = 0;
+            i++;
+            fresh = true;
+        }
+    }
+    __syncthreads();  // the scalar rows are dead: the same LDS now carries the reduction
+    red[tid] = g1l_to_piece(run);
+    red[tid] = g1_piece_load(&red[tid]);
+    __syncthreads();
+    for (unsigned s = MSM_BLOCK / 2; s > 0; s >>= 1) {
+        if (tid < s) {
+            G1Xyzz x = red[tid];
+            g1_add(x, red[tid + s]);
+            red[tid] = x;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) partial[(size_t)m * G + g] = red[0];
+}
+
+// out_xy[m] = canonical affine of sum_g partial[m][g] + the deferred additions; flags[m] = 1 for the identity
+__global__ void __launch_bounds__(64) msm_lookup_finalize_kernel(const G1Xyzz* partial, size_t M, unsigned G, const G1Affine* lookup,
+                                                                 size_t table_n, unsigned c, unsigned W, const MsmDeferred* deferred,
+                                                                 size_t deferred_stride, const uint32_t* n_deferred, Fq* out_xy,
+                                                                 uint8_t* flags) {
+    for (size_t m = (size_t)blockIdx.x * blockDim.x + threadIdx.x; m < M; m += (size_t)gridDim.x * blockDim.x) {
+        G1Xyzz acc = partial[m * G];
+        for (unsigned g = 1; g < G; g++) g1_add(acc, partial[m * G + g]);
+        const uint32_t nd = n_deferred[m];
+        for (uint32_t k = 0; k < nd; k++) {
+            const MsmDeferred e = deferred[m * deferred_stride + k];
+            const uint32_t i = e.bucket / W, w = e.bucket - i * W;  // `bucket` carries the item index here
+            const int d = (int)e.entry;
+            const uint32_t ad = d < 0 ? (uint32_t)-d : (uint32_t)d;
+            const G1Affine* src = lookup + ((((size_t)w * table_n + i) << (c - 1)) + (ad - 1));
+            G1Affine pt;
+            pt.x = fp_load(&src->x);
+            pt.y = fp_load(&src->y);
+            if (d < 0) pt.y = fp_neg(pt.y);
+            g1_madd(acc, pt);
+        }
+        G1Affine a = g1_to_affine(acc);
+        flags[m] = g1_affine_is_identity(a) ? 1 : 0;
+        fp_store(out_xy + 2 * m, fp_from_mont(a.x));
+        fp_store(out_xy + 2 * m + 1, fp_from_mont(a.y));
+    }
+}
+
 static unsigned windows_for(unsigned c) {
     // smallest W with 2^254 + K < 2^(c*W), K < 2^(c*W) * (1/2 + 2^-c): c*W >= 256 suffices
     return (256 + c - 1) / c;
@@ -393,13 +513,138 @@ int msm_build_table(plonk_ctx* ctx, plonk_srs* srs, unsigned c) {
     return PLONK_OK;
 }
 
+static void msm_recode_constant(unsigned c, unsigned W, MsmRecode* rc) {
+    memset(rc, 0, sizeof *rc);
+    for (unsigned w = 0; w < W; w++) {
+        unsigned bit = c * w + c - 1;
+        rc->k[bit >> 5] |= 1u << (bit & 31);
+    }
+}
+
+static size_t msm_lookup_bytes(size_t n, unsigned c) {  // table + the XYZZ staging buffer of one window
+    const size_t half = (size_t)1 << (c - 1);
+    return n * windows_for(c) * half * sizeof(G1Affine) + n * half * sizeof(G1Xyzz);
+}
+
+// Builds srs->lookup for window size c.  PLONK_ERR_NOMEM (nothing allocated, nothing changed) if it does not fit.
+static int msm_lookup_build(plonk_ctx* ctx, plonk_srs* srs, unsigned c) {
+    const unsigned W = windows_for(c);
+    const size_t n = srs->n_points, half = (size_t)1 << (c - 1);
+    void *wx = nullptr, *wb = nullptr, *tmp = nullptr, *tab = nullptr;
+    auto fail = [&]() {
+        if (wx) hipFree(wx);
+        if (wb) hipFree(wb);
+        if (tmp) hipFree(tmp);
+        if (tab) hipFree(tab);
+        (void)hipGetLastError();
+        plonk_set_error("the %u-bit lookup table (%zu MiB) does not fit in device memory", c, msm_lookup_bytes(n, c) >> 20);
+        return PLONK_ERR_NOMEM;
+    };
+    if (hipMalloc(&tab, n * W * half * sizeof(G1Affine)) != hipSuccess) return fail();
+    if (hipMalloc(&tmp, n * half * sizeof(G1Xyzz)) != hipSuccess) return fail();
+    if (hipMalloc(&wx, n * W * sizeof(G1Xyzz)) != hipSuccess) return fail();
+    if (hipMalloc(&wb, n * W * sizeof(G1Affine)) != hipSuccess) return fail();
+    // window bases 2^(c w) P_i, affine
+    unsigned grid = (unsigned)((n + 63) / 64);
+    if (grid > 2048) grid = 2048;
+    PLONK_LAUNCH(msm_table_kernel, dim3(grid), dim3(64), 0, ctx->stream, srs->bases, n, c, W, (G1Xyzz*)wx);
+    size_t chunks = (n * W + AFF_CHUNK - 1) / AFF_CHUNK;
+    unsigned g2 = (unsigned)((chunks + 63) / 64);
+    PLONK_LAUNCH(g1_batch_to_affine_kernel, dim3(g2 > 4096 ? 4096 : g2), dim3(64), 0, ctx->stream, (const G1Xyzz*)wx, (G1Affine*)wb,
+                 n * W);
+    const size_t seg_len = half < 256 ? half : 256, fill_lanes = n * (half / seg_len);
+    unsigned gf = (unsigned)((fill_lanes + 63) / 64);
+    if (gf > 65536) gf = 65536;
+    chunks = (n * half + AFF_CHUNK - 1) / AFF_CHUNK;
+    unsigned ga = (unsigned)((chunks + 63) / 64 > 65536 ? 65536 : (chunks + 63) / 64);
+    for (unsigned w = 0; w < W; w++) {
+        PLONK_LAUNCH(msm_lookup_fill_kernel, dim3(gf), dim3(64), 0, ctx->stream, (const G1Affine*)wb, n, c, w, (G1Xyzz*)tmp);
+        PLONK_LAUNCH(g1_batch_to_affine_kernel, dim3(ga), dim3(64), 0, ctx->stream, (const G1Xyzz*)tmp,
+                     (G1Affine*)tab + (size_t)w * n * half, n * half);
+    }
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) return fail();
+    hipFree(wx);
+    hipFree(wb);
+    hipFree(tmp);
+    if (srs->lookup) hipFree(srs->lookup);
+    srs->lookup = (G1Affine*)tab;
+    srs->lookup_bits = c;
+    srs->lookup_windows = W;
+    return PLONK_OK;
+}
+
+// Decides whether this call runs on the lookup table, building it on first use.
+static bool msm_lookup_prepare(plonk_ctx* ctx, plonk_srs* srs) {
+    if (ctx->msm_lookup_mode == 1) return false;
+    const unsigned want = ctx->msm_lookup_bits;
+    if (ctx->msm_lookup_mode == 2) {  // forced window size, any base set
+        if (srs->lookup && srs->lookup_bits == want) return true;
+        return msm_lookup_build(ctx, srs, want) == PLONK_OK;
+    }
+    if (!srs->fixed) return false;
+    if (srs->lookup && (!want || want == srs->lookup_bits)) return true;
+    if (srs->lookup_failed) return false;
+    size_t budget = ctx->msm_lookup_budget;
+#ifndef PLONK_EMU
+    if (!budget) {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            budget = (size_t)(0.45 * (double)free_b);
+            if (budget > (size_t)100e9) budget = (size_t)100e9;
+        }
+    }
+#endif
+    // more windows bits = fewer additions; below 8 bits the table no longer beats the bucket method
+    for (unsigned c = want ? want : 16; c >= (want ? want : 8); c--) {
+        if (msm_lookup_bytes(srs->n_points, c) > budget) continue;
+        if (msm_lookup_build(ctx, srs, c) == PLONK_OK) return true;
+    }
+    srs->lookup_failed = true;
+    return false;
+}
+
+static int msm_run_lookup(plonk_ctx* ctx, plonk_srs* srs, const Fr* d_scalars, size_t n, size_t M, size_t stride, Fq* d_out_xy,
+                          uint8_t* d_flags, size_t inner, size_t outer_stride) {
+    const unsigned c = srs->lookup_bits, W = srs->lookup_windows;
+    const size_t items = n * W;
+    PLONK_REQUIRE(items < ((size_t)1 << 32), PLONK_ERR_ARG, "MSM size %zu too large for the lookup path", n);
+    unsigned G = ctx->msm_groups;
+    if (!G) {
+        G = 1;
+        while (G < 64 && M * G < 1024) G *= 2;
+    }
+    while (G > 1 && (size_t)G * MSM_BLOCK * 2 > items) G /= 2;  // at least two additions per lane
+    const size_t part_bytes = (M * G * sizeof(G1Xyzz) + 255) & ~(size_t)255;
+    const size_t cnt_bytes = (M * 4 + 255) & ~(size_t)255;
+    const size_t dfr_bytes = M * items * sizeof(MsmDeferred);
+    void* s;
+    PLONK_TRY(ctx_scratch(ctx, 1, part_bytes + cnt_bytes + dfr_bytes, &s));
+    G1Xyzz* partial = (G1Xyzz*)s;
+    uint32_t* n_deferred = (uint32_t*)((uint8_t*)s + part_bytes);
+    MsmDeferred* deferred = (MsmDeferred*)((uint8_t*)s + part_bytes + cnt_bytes);
+    MsmRecode rc;
+    msm_recode_constant(c, W, &rc);
+    PLONK_CHECK_HIP(hipMemsetAsync(n_deferred, 0, M * 4, ctx->stream));
+    PLONK_TRY(prof_begin(ctx, "msm_lookup", (double)M * (96.0 * (double)n + 64.0)));
+    PLONK_LAUNCH(msm_lookup_kernel, dim3((unsigned)(M * G)), dim3(MSM_BLOCK), (size_t)MSM_BLOCK * sizeof(G1Xyzz), ctx->stream,
+                 (const G1Affine*)srs->lookup, srs->n_points, c, W, d_scalars, n, stride, inner, outer_stride, rc, G, partial,
+                 deferred, items, n_deferred);
+    PLONK_TRY(prof_end(ctx));
+    PLONK_LAUNCH(msm_lookup_finalize_kernel, dim3((unsigned)((M + 63) / 64)), dim3(64), 0, ctx->stream, (const G1Xyzz*)partial, M, G,
+                 (const G1Affine*)srs->lookup, srs->n_points, c, W, (const MsmDeferred*)deferred, items,
+                 (const uint32_t*)n_deferred, d_out_xy, d_flags);
+    PLONK_CHECK_HIP(hipGetLastError());
+    return PLONK_OK;
+}
+
 // Enqueue a batch of M MSMs; results land in device buffers (d_out_xy: 2*M Fq canonical, d_flags: M bytes).
 int msm_run_device(plonk_ctx* ctx, plonk_srs* srs, const Fr* d_scalars, size_t n, size_t M, size_t stride,
                    Fq* d_out_xy, uint8_t* d_flags, size_t inner, size_t outer_stride) {
     if (!inner) inner = M ? M : 1;
     PLONK_REQUIRE(n >= 1 && n <= srs->n_points, PLONK_ERR_ARG, "MSM size %zu exceeds the %zu loaded bases", n, srs->n_points);
-    PLONK_REQUIRE(n <= 32768, PLONK_ERR_ARG, "MSM size %zu > 32768 is not supported by the entry encoding", n);
     if (!M) return PLONK_OK;
+    if (msm_lookup_prepare(ctx, srs)) return msm_run_lookup(ctx, srs, d_scalars, n, M, stride, d_out_xy, d_flags, inner, outer_stride);
+    PLONK_REQUIRE(n <= 32768, PLONK_ERR_ARG, "MSM size %zu > 32768 is not supported by the bucket method's entry encoding", n);
     unsigned c = ctx->msm_window_bits ? ctx->msm_window_bits : MSM_DEFAULT_WINDOW_BITS;
     PLONK_TRY(msm_build_table(ctx, srs, c));
     const unsigned W = srs->n_windows, K = 1u << (c - 1);
@@ -429,11 +674,7 @@ int msm_run_device(plonk_ctx* ctx, plonk_srs* srs, const Fr* d_scalars, size_t n
     MsmDeferred* deferred = (MsmDeferred*)((uint8_t*)s + ent_bytes + st_bytes + piece_bytes + cnt_bytes);
 
     MsmRecode rc;
-    memset(&rc, 0, sizeof rc);
-    for (unsigned w = 0; w < W; w++) {
-        unsigned bit = c * w + c - 1;
-        rc.k[bit >> 5] |= 1u << (bit & 31);
-    }
+    msm_recode_constant(c, W, &rc);
     const size_t sort_lds = (size_t)(K + 2) * 4;
     static bool configured = false;
     if (!configured) {

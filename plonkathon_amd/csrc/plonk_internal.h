@@ -49,6 +49,12 @@ struct plonk_srs {
     unsigned window_bits = 0;   // c of the current window table (0 = not built)
     unsigned n_windows = 0;
     G1Affine* table = nullptr;  // device: table[w * n_points + i] = 2^(c*w) * bases[i]
+    // lookup MSM (msm.hip): every multiple d * 2^(c*w) * bases[i], d = 1 .. 2^(c-1), resident in HBM
+    bool fixed = false;          // a reusable SRS (plonk_srs_load_ptau): worth a big table
+    unsigned lookup_bits = 0;    // c of the lookup table (0 = none)
+    unsigned lookup_windows = 0;
+    bool lookup_failed = false;  // an automatic build did not fit: do not retry on every call
+    G1Affine* lookup = nullptr;  // lookup[((w * n_points + i) << (c - 1)) + d - 1]
 };
 
 #define PLONK_SCRATCH_SLOTS 4
@@ -62,6 +68,9 @@ struct plonk_ctx {
     size_t scratch_bytes[PLONK_SCRATCH_SLOTS] = {0, 0, 0, 0};
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
     unsigned msm_window_bits = 0, msm_groups = 0;
+    int msm_lookup_mode = 0;         // 0 auto (fixed SRS only), 1 off, 2 force msm_lookup_bits for every base set
+    unsigned msm_lookup_bits = 0;    // 0 = largest window whose table fits the budget
+    size_t msm_lookup_budget = 0;    // bytes; 0 = default (45 % of the free device memory, at most 100 GB)
     // per-kernel HIP-event profiling (bench.py roofline): one record per instrumented launch
     struct ProfRec { const char* name; hipEvent_t a, b; double algo_bytes; };
     bool profiling = false;

@@ -53,10 +53,17 @@ def _decode_points(xy: bytes, flags: bytes):
 
 
 class _DeviceBases:
-    """Owns a `plonk_srs*` (bases + window table in HBM)."""
+    """Owns a `plonk_srs*` (bases + window / lookup tables in HBM)."""
 
     def __init__(self, ctx, handle, n):
         self.ctx, self.handle, self.n = ctx, handle, n
+
+    @property
+    def lookup_bits(self):
+        """Window bits of the lookup table its MSMs run on (0: bucket method); built at the first MSM."""
+        out = ctypes.c_uint(0)
+        check(self.ctx.L.plonk_srs_lookup_bits(self.handle, ctypes.byref(out)))
+        return out.value
 
     def __del__(self):
         try:

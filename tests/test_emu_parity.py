@@ -84,6 +84,28 @@ def test_msm_window_configs(emu):
         check(ctx.L.plonk_msm_configure(ctx.handle, 0, 0))
 
 
+def test_msm_lookup_tables(emu):
+    """The lookup MSM (every multiple of every window base precomputed) against the oracle and the goldens, at
+    window sizes small enough for the emulator; includes the identity / duplicate / cancelling base cases."""
+    from plonkathon_amd import Setup, get_context
+
+    ctx = get_context()
+    try:
+        for c, groups in ((3, 0), (5, 2)):
+            ctx.msm_lookup(2, c)
+            ctx.msm_configure(0, groups)
+            setup = Setup.from_file(pc.PTAU)
+            pc.msm_vs_oracle(setup, 64, seed=40 + c)
+            if c == 5:
+                pc.lincomb_golden(setup, full_size=False)
+        ctx.msm_lookup(2, 4)
+        pc.prover_k6(Setup.from_file(pc.PTAU))
+        pc.batch_prover_k6(Setup.from_file(pc.PTAU))
+    finally:
+        ctx.msm_lookup(0)
+        ctx.msm_configure(0, 0)
+
+
 def test_prover_k6_golden_proof(emu):
     from plonkathon_amd import Setup
 

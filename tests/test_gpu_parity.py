@@ -98,11 +98,72 @@ def test_msm_window_configs(setup):
 
     ctx = get_context()
     try:
+        ctx.msm_lookup(1)  # the bucket method (the lookup table would otherwise serve every SRS commitment)
         for c, groups in ((4, 1), (5, 3), (6, 0), (7, 2), (8, 1), (8, 32), (9, 4), (11, 0), (12, 1), (12, 64), (13, 3)):
             check(ctx.L.plonk_msm_configure(ctx.handle, c, groups))
             pc.msm_vs_oracle(setup, 300, seed=20 + c)
     finally:
         check(ctx.L.plonk_msm_configure(ctx.handle, 0, 0))
+        ctx.msm_lookup(0)
+
+
+def test_msm_lookup_tables():
+    """Lookup MSM at several table sizes (forced), then the automatic choice (c = 16 on an idle MI355X)."""
+    from plonkathon_amd import Setup, get_context
+
+    ctx = get_context()
+    try:
+        for c, groups in ((6, 0), (11, 3), (14, 1)):
+            ctx.msm_lookup(2, c)
+            ctx.msm_configure(0, groups)
+            s = Setup.from_file(pc.PTAU)
+            pc.msm_vs_oracle(s, 300, seed=60 + c)
+            pc.lincomb_golden(s, full_size=(c == 11))
+            del s
+    finally:
+        ctx.msm_lookup(0)
+        ctx.msm_configure(0, 0)
+    s = Setup.from_file(pc.PTAU)
+    pc.msm_vs_oracle(s, 2048, seed=99)
+    pc.lincomb_golden(s, full_size=True)
+
+
+def test_lookup_and_bucket_methods_agree():
+    """512 commitments of 2^11 coefficients: byte-identical from the lookup table and from the bucket method."""
+    import ctypes
+
+    from plonkathon_amd import Setup, get_context
+    from plonkathon_amd._lib import check
+
+    ctx = get_context()
+    n, M = 2048, 512
+    sc = ctx.upload_ints(pc.rand_vec(4242, 4096))
+    buf = ctx.alloc(n * M + 4096)
+    for off in range(0, n * M + 4096, 4096):
+        check(ctx.L.plonk_mem_d2d(ctx.handle, buf.at(off), sc.ptr, 32 * 4096))
+    out = []
+    try:
+        for mode in (0, 1):
+            ctx.msm_lookup(mode)
+            s = Setup.from_file(pc.PTAU)
+            xy, fl = ctypes.create_string_buffer(64 * M), ctypes.create_string_buffer(M)
+            check(ctx.L.plonk_g1_msm(ctx.handle, s.device_bases().handle, buf.ptr, n, M, n + 7, xy, fl))
+            out.append((xy.raw, fl.raw))
+            del s
+    finally:
+        ctx.msm_lookup(0)
+    assert out[0] == out[1] and not any(out[0][1])
+
+
+def test_batch_prover_on_the_bucket_method():
+    from plonkathon_amd import Setup, get_context
+
+    ctx = get_context()
+    try:
+        ctx.msm_lookup(1)
+        pc.batch_prover_k6(Setup.from_file(pc.PTAU))
+    finally:
+        ctx.msm_lookup(0)
 
 
 def test_prover_k6_golden_proof(setup):
