@@ -130,6 +130,8 @@ def main():
     ap.add_argument("--batch", type=int, default=512, help="proofs per GPU per step")
     ap.add_argument("--streams", type=int, default=1, help="HIP streams per GPU: the batch is split into this many lock-step sub-batches that overlap each other")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI)")
+    ap.add_argument("--lookup-budget-gb", type=float, default=0.0,
+                    help="HBM budget for the MSM lookup table (0 = library default: 55 %% of free memory, at most 160 GB)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-microbench", action="store_true")
     args = ap.parse_args()
@@ -144,6 +146,8 @@ def main():
     dist = D.init_from_env(args.dist_backend) if world > 1 else None
     ctx = Context(local_rank)
     set_context(ctx)
+    if args.lookup_budget_gb:
+        ctx.msm_lookup(0, 0, int(args.lookup_budget_gb * 1e9))
     setup = Setup.from_file(PTAU)
     program = Program(chain_program_lines(GROUP_ORDER), GROUP_ORDER)
     B = args.batch
@@ -259,7 +263,7 @@ def main():
         # the honest ceiling: W*N mixed additions per MSM against the rate of a bare mixed-addition loop
         n_msm = msm_bytes / (96.0 * GROUP_ORDER + 64.0)
         wbits = lookup_bits or MSM_WINDOW_BITS
-        windows = (256 + wbits - 1) // wbits
+        windows = (255 + wbits - 1) // wbits
         gmadd = n_msm * windows * GROUP_ORDER / (msm_ms * 1e-3) / 1e9
         line["roofline"]["alu"] = {"achieved_g1_gmadd_per_s": gmadd, "ceiling_g1_gmadd_per_s": G1_MADD_CEILING_G,
                                    "frac": gmadd / G1_MADD_CEILING_G,

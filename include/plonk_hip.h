@@ -125,9 +125,10 @@ int plonk_g1_msm(plonk_ctx* ctx, plonk_srs* srs, const void* d_scalars, size_t n
 /* tuning knobs (0 = library default): window bits c and window-groups per MSM (bucket method) */
 int plonk_msm_configure(plonk_ctx* ctx, unsigned window_bits, unsigned groups);
 /* Lookup MSM: for a reusable SRS (plonk_srs_load_ptau) every multiple d * 2^(c w) * P_i, d <= 2^(c-1), is
- * precomputed once into HBM (68.7 GB for 2^11 points at c = 16), after which an MSM is N * ceil(256/c) mixed
- * additions of looked-up points: no sorting, no buckets, no doublings.  mode 0 (default): automatic — the
- * largest c (<= 16) whose table fits `budget_bytes` (0 = 45 % of the free device memory, at most 100 GB), bucket
+ * precomputed once into HBM (2^11 points: 128.8 GB at c = 17, 68.7 GB at c = 16), after which an MSM is
+ * N * ceil(255/c) mixed additions of looked-up points: no sorting, no buckets, no doublings.  mode 0 (default):
+ * automatic — the largest c (<= 17) whose table and its one-window staging buffer fit `budget_bytes` (0 = 55 %
+ * of the free device memory, at most 160 GB: c = 17 on an idle MI355X, smaller tables when memory is shared), bucket
  * method when nothing fits or for plonk_srs_load_affine bases; mode 1: never; mode 2: use `window_bits` for every
  * base set (tests).  Same results as the bucket method (curve.py:38-111), bit for bit.                        */
 int plonk_msm_lookup_configure(plonk_ctx* ctx, int mode, unsigned window_bits, size_t budget_bytes);

@@ -456,8 +456,8 @@ int plonk_srs_lookup_bits(const plonk_srs* srs, unsigned* out_bits) {
 int plonk_msm_lookup_configure(plonk_ctx* ctx, int mode, unsigned window_bits, size_t budget_bytes) {
     PLONK_REQUIRE(ctx, PLONK_ERR_ARG, "ctx is NULL");
     PLONK_REQUIRE(mode >= 0 && mode <= 2, PLONK_ERR_ARG, "mode must be 0 (auto), 1 (off) or 2 (force)");
-    PLONK_REQUIRE(window_bits == 0 || (window_bits >= 2 && window_bits <= 16), PLONK_ERR_ARG,
-                  "window_bits must be 0 (auto) or in [2, 16]");
+    PLONK_REQUIRE(window_bits == 0 || (window_bits >= 2 && window_bits <= 17), PLONK_ERR_ARG,
+                  "window_bits must be 0 (auto) or in [2, 17]");
     PLONK_REQUIRE(mode != 2 || window_bits, PLONK_ERR_ARG, "mode 2 needs an explicit window_bits");
     ctx->msm_lookup_mode = mode;
     ctx->msm_lookup_bits = window_bits;

@@ -360,8 +360,8 @@ __global__ void __launch_bounds__(256) msm_bucket_reduce_kernel(const uint32_t* 
 
 // ------------------------------------------------------------------------------------------------
 // Lookup MSM.  MI355X has 288 GB of HBM; a reusable SRS of 2^11 points affords the table of EVERY multiple
-//     L[w][i][d] = d * 2^(c w) * P_i,   d = 1 .. 2^(c-1)      (68.7 GB at c = 16)
-// so that an MSM is just N * ceil(256 / c) mixed additions of looked-up points (32 768 at c = 16 against
+//     L[w][i][d] = d * 2^(c w) * P_i,   d = 1 .. 2^(c-1)      (128.8 GB at c = 17, 68.7 GB at c = 16)
+// so that an MSM is just N * ceil(255 / c) mixed additions of looked-up points (30 720 at c = 17 against
 // 53 248 sorted bucket additions plus the bucket reduction): 64 random bytes from HBM per addition — the chip
 // sustains 20 G such reads/s (tools/ubench/gather.hip) against the 13.5 G additions/s its ALUs can do.
 // Signed digits as in the bucket method; a lane walks a flat range of (scalar, window) items.
@@ -479,8 +479,10 @@ __global__ void __launch_bounds__(64) msm_lookup_finalize_kernel(const G1Xyzz* p
 }
 
 static unsigned windows_for(unsigned c) {
-    // smallest W with 2^254 + K < 2^(c*W), K < 2^(c*W) * (1/2 + 2^-c): c*W >= 256 suffices
-    return (256 + c - 1) / c;
+    // Smallest W with  s + sum_w 2^(c w + c - 1) < 2^(c W)  for every canonical scalar s < r: the recoding
+    // constant is < 2^(cW-1) / (1 - 2^-c), and r < 0.76 * 2^254, so c W >= 255 is enough once c >= 3
+    // (17-bit windows need 15 of them, not 16).
+    return c >= 3 ? (255 + c - 1) / c : (256 + c - 1) / c;
 }
 
 int msm_build_table(plonk_ctx* ctx, plonk_srs* srs, unsigned c) {
@@ -589,13 +591,13 @@ static bool msm_lookup_prepare(plonk_ctx* ctx, plonk_srs* srs) {
     if (!budget) {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-            budget = (size_t)(0.45 * (double)free_b);
-            if (budget > (size_t)100e9) budget = (size_t)100e9;
+            budget = (size_t)(0.55 * (double)free_b);
+            if (budget > (size_t)160e9) budget = (size_t)160e9;
         }
     }
 #endif
     // more windows bits = fewer additions; below 8 bits the table no longer beats the bucket method
-    for (unsigned c = want ? want : 16; c >= (want ? want : 8); c--) {
+    for (unsigned c = want ? want : 17; c >= (want ? want : 8); c--) {
         if (msm_lookup_bytes(srs->n_points, c) > budget) continue;
         if (msm_lookup_build(ctx, srs, c) == PLONK_OK) return true;
     }

@@ -70,7 +70,7 @@ struct plonk_ctx {
     unsigned msm_window_bits = 0, msm_groups = 0;
     int msm_lookup_mode = 0;         // 0 auto (fixed SRS only), 1 off, 2 force msm_lookup_bits for every base set
     unsigned msm_lookup_bits = 0;    // 0 = largest window whose table fits the budget
-    size_t msm_lookup_budget = 0;    // bytes; 0 = default (45 % of the free device memory, at most 100 GB)
+    size_t msm_lookup_budget = 0;    // bytes; 0 = default (55 % of the free device memory, at most 160 GB)
     // per-kernel HIP-event profiling (bench.py roofline): one record per instrumented launch
     struct ProfRec { const char* name; hipEvent_t a, b; double algo_bytes; };
     bool profiling = false;

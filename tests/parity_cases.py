@@ -198,6 +198,14 @@ def msm_vs_oracle(setup, n, seed, batch=1):
         assert affine(setup.commit_coeffs(P(sc, Basis.MONOMIAL))) == want
 
 
+def msm_extreme_scalars(setup):
+    """Scalars at the top of the range: the signed-digit recoding must not overflow its last window."""
+    osetup = OSetup.from_file(PTAU)
+    sc = [R_MOD - 1, R_MOD - 2, 1, 0, 1 << 253, (R_MOD - 1) // 2, (1 << 254) % R_MOD, R_MOD - (1 << 200), R_MOD - 1]
+    want = og1.ec_lincomb([(osetup.powers_of_x[i], s) for i, s in enumerate(sc)])
+    assert affine(setup.commit_coeffs(P(sc, Basis.MONOMIAL))) == want
+
+
 # ------------------------------------------------------------------------------------------ transcript
 def transcript_golden():
     tv = load("transcript_vectors.json")

@@ -80,6 +80,7 @@ def test_msm_window_configs(emu):
         for c, groups in ((4, 1), (5, 3), (9, 2), (7, 0), (12, 1), (13, 4)):
             check(ctx.L.plonk_msm_configure(ctx.handle, c, groups))
             pc.msm_vs_oracle(Setup.from_file(pc.PTAU), 64, seed=20 + c)
+            pc.msm_extreme_scalars(Setup.from_file(pc.PTAU))
     finally:
         check(ctx.L.plonk_msm_configure(ctx.handle, 0, 0))
 
@@ -96,6 +97,7 @@ def test_msm_lookup_tables(emu):
             ctx.msm_configure(0, groups)
             setup = Setup.from_file(pc.PTAU)
             pc.msm_vs_oracle(setup, 64, seed=40 + c)
+            pc.msm_extreme_scalars(setup)
             if c == 5:
                 pc.lincomb_golden(setup, full_size=False)
         ctx.msm_lookup(2, 4)

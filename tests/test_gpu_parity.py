@@ -102,6 +102,7 @@ def test_msm_window_configs(setup):
         for c, groups in ((4, 1), (5, 3), (6, 0), (7, 2), (8, 1), (8, 32), (9, 4), (11, 0), (12, 1), (12, 64), (13, 3)):
             check(ctx.L.plonk_msm_configure(ctx.handle, c, groups))
             pc.msm_vs_oracle(setup, 300, seed=20 + c)
+            pc.msm_extreme_scalars(setup)
     finally:
         check(ctx.L.plonk_msm_configure(ctx.handle, 0, 0))
         ctx.msm_lookup(0)
@@ -118,6 +119,7 @@ def test_msm_lookup_tables():
             ctx.msm_configure(0, groups)
             s = Setup.from_file(pc.PTAU)
             pc.msm_vs_oracle(s, 300, seed=60 + c)
+            pc.msm_extreme_scalars(s)
             pc.lincomb_golden(s, full_size=(c == 11))
             del s
     finally:

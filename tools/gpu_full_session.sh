@@ -7,7 +7,8 @@ R=$GRAFT_REPO_ROOT
 tail -4 gpurun_out/pytest_gpu.log
 ( timeout 600 python bench.py > gpurun_out/bench.json 2> gpurun_out/bench.err; echo "bench rc=$?" )
 cat gpurun_out/bench.json; tail -5 gpurun_out/bench.err
-( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_bench -o bench -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $R/gpurun_out/prof_bench.log 2>&1; echo "rocprof rc=$?" )
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_bench -o bench -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-microbench > $R/gpurun_out/prof_bench.log 2>&1; echo "rocprof rc=$?" )
 head -6 gpurun_out/prof_bench/bench_kernel_stats.csv | cut -c1-160
 bash tools/pmc_collect.sh
+( timeout 120 ./tools/ubench/gather.bin 160 > gpurun_out/gather.json 2>/dev/null; cat gpurun_out/gather.json )
 ( timeout 120 ./tools/ubench/ubench.bin > gpurun_out/ubench.json 2> gpurun_out/ubench.err; echo "ubench rc=$?"; head -c 600 gpurun_out/ubench.json )

@@ -37,7 +37,7 @@ int main(int argc, char** argv) {
     uint32_t* out;
     hipMalloc(&out, (size_t)blocks * threads * 4);
     printf("{\"cus\": %d", prop.multiProcessorCount);
-    for (double gib : {0.0039, 0.25, 2.0, 8.0, 16.0, 32.0, 64.0, 96.0}) {
+    for (double gib : {0.0039, 0.25, 2.0, 8.0, 32.0, 64.0, 128.0, 160.0}) {
         if (gib > max_gib) break;
         const size_t bytes = (size_t)(gib * 1024.0 * 1024.0 * 1024.0) & ~(size_t)63;
         void* t = nullptr;
