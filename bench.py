@@ -158,13 +158,11 @@ def main():
     # kernel (transcript, field inversions), the others keep the ALUs busy with MSM / NTT work
     ctxs = [ctx] + [Context(local_rank) for _ in range(S - 1)]
     provers = [BatchProver(setup, program, c) for c in ctxs]
-    # synthetic witnesses, seeded by GLOBAL proof index; staged in HBM before the timed region
-    distinct = {}
-    for idx in mine:
-        distinct.setdefault(idx % 8, witness_for(program, idx % 8))
+    # synthetic witnesses, one per GLOBAL proof index (all distinct: identical proofs would turn the MSM's table
+    # look-ups into cache hits); staged in HBM before the timed region
     parts = [mine[k::S] for k in range(S)]
     for pr, part in zip(provers, parts):
-        pr.upload([distinct[idx % 8] for idx in part])
+        pr.upload([witness_for(program, idx) for idx in part])
 
     def step():
         for pr in provers:
