@@ -236,7 +236,6 @@ __global__ void __launch_bounds__(MSM_BLOCK, MSM_ACC_WAVES) msm_accumulate_kerne
     }
     unsigned k = a;
     G1Xyzz* out = pieces + (size_t)m * piece_stride + t - 1;  // out[k] = slot t + k - 1
-#ifndef PLONK_MSM_PACKED
     // Accumulator kept as 9 x 29-bit limbs with lazy reductions (fpl.h / g1l_madd_fast): the same 1548
     // multiplier instructions per mixed addition as the packed canonical form but ~2x fewer of everything
     // else.  The rare steps the fast formulas cannot take (the accumulator equals +-the table point, i.e.
@@ -254,19 +253,6 @@ __global__ void __launch_bounds__(MSM_BLOCK, MSM_ACC_WAVES) msm_accumulate_kerne
             deferred[(size_t)m * entry_stride + slot] = MsmDeferred{k, en};
         }
     };
-#else
-    G1Xyzz run = g1_xyzz_identity();
-    auto flush = [&](unsigned kk) {
-        out[kk] = run;
-        run = g1_xyzz_identity();
-    };
-    auto accumulate = [&](const Fq& x, const Fq& y, uint32_t) {
-        G1Affine pt;
-        pt.x = x;
-        pt.y = y;
-        g1_madd(run, pt);
-    };
-#endif
     auto step = [&](uint32_t e, uint32_t en) {
         if (e >= hi || e < lo) return;
         if (e < st[k]) {  // left bucket k: its partial sum is complete
