@@ -258,6 +258,9 @@ def main():
                     "see `alu`; with the lookup table every addition also reads 64 table bytes, i.e. `traffic` is the real demand",
             "msm_method": ("lookup table, %d-bit windows" % lookup_bits) if lookup_bits else "bucket method, %d-bit windows" % MSM_WINDOW_BITS,
         }
+        if line["roofline"]["traffic"]:  # what the kernel really asks of HBM (table look-ups), per the PMC passes
+            line["roofline"]["traffic_GBps"] = line["roofline"]["traffic"] / avg_s / 1e9
+            line["roofline"]["traffic_frac_of_peak"] = line["roofline"]["traffic_GBps"] / HBM_PEAK_GBS
         # the honest ceiling: W*N mixed additions per MSM against the rate of a bare mixed-addition loop
         n_msm = msm_bytes / (96.0 * GROUP_ORDER + 64.0)
         wbits = lookup_bits or MSM_WINDOW_BITS
