@@ -459,7 +459,7 @@ __global__ void quotient_degree_check_kernel(const Fr* tcoef, size_t n, size_t B
 #define EV_THREADS 256
 __global__ void __launch_bounds__(EV_THREADS) eval_kernel(const Fr* coef, const Fr* fixed_coef, Fr w, ProofState* st,
                                                           size_t n, size_t B) {
-    __shared__ Fr red[EV_THREADS];
+    __shared__ Fr red[NEVAL][EV_THREADS];
     const size_t b = blockIdx.x;
     const unsigned tid = threadIdx.x;
     const Fr zeta = st[b].zeta, zeta_w = fp_mul(zeta, w);
@@ -468,20 +468,23 @@ __global__ void __launch_bounds__(EV_THREADS) eval_kernel(const Fr* coef, const 
                               coef + (3 * B + b) * n};
     const size_t per = (n + EV_THREADS - 1) / EV_THREADS;
     const size_t lo = tid * per, hi = (lo + per < n) ? lo + per : n;
+    // x^(chunk start) once per evaluation point, not once per polynomial
+    const Fr shift_z = fp_pow_u64(zeta, (uint64_t)lo), shift_zw = fp_pow_u64(zeta_w, (uint64_t)lo);
+#pragma unroll 1
     for (int p = 0; p < NEVAL; p++) {
         const Fr x = (p == 5) ? zeta_w : zeta;
         Fr acc = fp_zero<FrParams>();
         for (size_t i = hi; i-- > lo;) acc = fp_add(fp_mul(acc, x), fp_load(polys[p] + i));
-        if (lo < hi) acc = fp_mul(acc, fp_pow_u64(x, (uint64_t)lo));
-        red[tid] = acc;
-        __syncthreads();
-        for (unsigned s = EV_THREADS / 2; s > 0; s >>= 1) {
-            if (tid < s) red[tid] = fp_add(red[tid], red[tid + s]);
-            __syncthreads();
-        }
-        if (tid == 0) st[b].evals[p] = red[0];
+        if (lo < hi) acc = fp_mul(acc, (p == 5) ? shift_zw : shift_z);
+        red[p][tid] = acc;
+    }
+    __syncthreads();
+    for (unsigned s = EV_THREADS / 2; s > 0; s >>= 1) {  // the seven sums share the barriers
+        if (tid < s)
+            for (int p = 0; p < NEVAL; p++) red[p][tid] = fp_add(red[p][tid], red[p][tid + s]);
         __syncthreads();
     }
+    if (tid < NEVAL) st[b].evals[tid] = red[tid][0];
 }
 
 // ------------------------------------------------------------------------------------------------
