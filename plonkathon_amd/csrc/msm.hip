@@ -1,14 +1,21 @@
-// msm.hip — batched fixed-base Pippenger multi-scalar multiplication on BN254 G1.
+// msm.hip — batched fixed-base multi-scalar multiplication on BN254 G1.
 //
 // Reference behaviour replaced: ec_lincomb -> lincomb -> multisubset
 // (/root/reference/curve.py:38-111), i.e. everything Setup.commit does after its ifft
 // (setup.py:66-72).  The reference bit-slices the scalars into 255 subsets and adds affine points
 // with one Fq inversion per addition (~109k additions for N = 2^11); the result is a group element,
-// so any correct schedule yields the same affine point.
+// so any correct schedule yields the same affine point.  Two schedules:
 //
-// Schedule.  The bases are fixed (the SRS), so a window table
-// T[w][i] = 2^(c*w) * P_i is built once per SRS; every window of every scalar then lands in ONE
-// shared bucket set and no doublings remain in the per-MSM work:
+// A. LOOKUP MSM — the default for a reusable SRS (plonk_srs_load_ptau).  Every multiple
+//    L[w][i][d] = d * 2^(c w) * P_i a signed c-bit digit can select is precomputed into HBM (128.8 GB
+//    at c = 17 for 2^11 points); an MSM is N * ceil(255 / c) mixed additions of looked-up points:
+//      msm_lookup_kernel           lanes walk flat ranges of (scalar, window) items, 64 random bytes per item
+//      msm_lookup_finalize_kernel  sum of the workgroup partials + deferred additions -> canonical affine
+//    See the section "Lookup MSM" below.
+//
+// B. BUCKET METHOD (Pippenger) — arbitrary bases (plonk_srs_load_affine), or when no table fits.
+//    A window table T[w][i] = 2^(c*w) * P_i is built once per base set; every window of every scalar then lands
+//    in ONE shared bucket set and no doublings remain in the per-MSM work:
 //   1. msm_sort_kernel        (one workgroup per MSM) scalar -> canonical -> + sum_w 2^(cw+c-1), signed
 //                             digits d_w in [-2^(c-1), 2^(c-1)); LDS counting sort (LDS atomics) of all
 //                             W*N (point, window) entries by bucket |d|; the sorted entry list and the
@@ -18,14 +25,16 @@
 //                             bucket sizes.  A lane sums its range top-down and stores one partial sum
 //                             ("piece") per bucket it touches: a bucket boundary costs a 128-byte store,
 //                             never a group operation, so the wave does not serialise on boundaries that
-//                             its lanes cross at different steps.  This kernel is >= 90 % of the MSM time
-//                             and runs at ~93 % of the measured Fq-multiplication ceiling.
+//                             its lanes cross at different steps.  >= 80 % of this method's time.
 //   3. msm_bucket_reduce_kernel (two waves per MSM) lane l owns K/128 consecutive buckets: walking them top-down,
 //                             run += pieces of bucket k, tot += run; its share is tot + (first bucket - 1) * run;
 //                             shares are tree-reduced through LDS ("wave-reduced bucket sum") and lane 0
 //                             converts the result to the unique affine representative, canonical x||y.
 //                             Buckets never exist in memory.
-// Table reads hit L2 / Infinity Cache (3.4 MiB table at c = 10); the kernels are integer-ALU bound.
+//    Window-table reads hit L2 / Infinity Cache (3.4 MiB at c = 10).
+//
+// Both inner loops keep the accumulator as 9 x 29-bit limbs with lazy reductions (fpl.h, g1l_madd_fast) and run
+// at the rate of a bare mixed-addition loop (13.4 G additions/s chip-wide): the kernels are integer-ALU bound.
 #include <string.h>
 
 #include "plonk_internal.h"
