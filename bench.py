@@ -5,16 +5,17 @@
 
 A "step" is one pass of the hot path over one batch: `--batch` independent PLONK proofs per GPU of
 the BASELINE configs[1] workload (group_order = 2^11, the powers-of-tau SRS slice, synthetic witness
-— a 2047-gate squaring chain + one public input, witness seeded per proof).  Proofs are independent,
+— a 2047-gate squaring chain + one public input, one distinct witness per proof).  Proofs are independent,
 so N GPUs shard by proof index with no data-path collective; the final (9 G1 + 6 Fr = 768 B) results
-are gathered with one RCCL all_gather ("scaling": "weak").  Inputs (circuit polynomials, SRS window
-table, witness columns) are resident in HBM before the timed region.
+are gathered with one RCCL all_gather ("scaling": "weak").  Inputs (circuit polynomials, the MSM lookup
+table of the SRS, witness columns) are resident in HBM before the timed region.
 
 Rank 0 prints ONE JSON line: the contract fields, plus
-  "roofline"      for the dominant kernel of the timed region (msm_accumulate), durations from HIP
-                  events recorded on the library's stream inside the timed region;
+  "roofline"      for the dominant kernel of the timed region (msm_lookup; msm_accumulate if no table fits),
+                  durations from HIP events recorded on the library's stream inside the timed region;
   "roofline_ntt"  the standalone Fr NTT at 2^20 (BASELINE configs[3]) against the HBM roofline;
   "ntt", "msm"    NTT GF-elems/s at 2^11 (batched) and 2^20; MSMs/s at 2^11 (512 x 9 commitments per call);
+                  N replicas for N GPUs;
   "cpu_baseline"  the oracle (pure-Python port of the reference path) timed on this box, rank 0, N=1.
 """
 import argparse
@@ -28,7 +29,7 @@ sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s measured copy)
 # chip-wide rate of the MSM loop's unit of work — the lazy mixed addition on register-resident operands —
-# measured by tools/ubench (profiles/r01_j_ubench.json: g1_lazy_madd_Gops; fq_lazy_mul_Gops = 164.5)
+# measured by tools/ubench (profiles/r01_k_ubench.json: g1_lazy_madd_Gops; fq_lazy_mul_Gops = 167)
 G1_MADD_CEILING_G = 13.5
 MSM_WINDOW_BITS = 10      # bucket-method default (csrc/msm.hip); 26 windows of signed 10-bit digits
 GROUP_ORDER = 2048
@@ -271,18 +272,21 @@ def main():
                                    "note": "%d mixed additions per MSM (8 Fq mul + 2 sqr + 8 add/sub each); ceiling = the same "
                                            "addition in a register-only loop (tools/ubench), i.e. the kernel adds no overhead "
                                            "beyond the arithmetic itself" % (windows * GROUP_ORDER)}
-    if rank == 0 and not args.no_microbench:
-        ms11 = ntt_microbench(ctx, 11, 512)
-        ms20 = ntt_microbench(ctx, 20, 1)
+    if not args.no_microbench:
+        # standalone NTT and MSM rates; with N GPUs every rank runs a replica and the whole-job
+        # rate is N x (work of one replica) / (time of the slowest rank)
+        ms11 = D.max_over_ranks(ntt_microbench(ctx, 11, 512), dist)
+        ms20 = D.max_over_ranks(ntt_microbench(ctx, 20, 1), dist)
+        ms_msm = D.max_over_ranks(msm_microbench(ctx, setup, 4608), dist)
         line["ntt"] = {
-            "gf_elems_per_s_2^11_x512": 512 * 2048 / (ms11 * 1e-3),
-            "gf_elems_per_s_2^20": (1 << 20) / (ms20 * 1e-3),
+            "gf_elems_per_s_2^11_x512": world * 512 * 2048 / (ms11 * 1e-3),
+            "gf_elems_per_s_2^20": world * (1 << 20) / (ms20 * 1e-3),
             "ms_2^11_x512": ms11,
             "ms_2^20": ms20,
+            "replicas": world,
         }
-        ms_msm = msm_microbench(ctx, setup, 4608)
-        line["msm"] = {"msms_per_s_2^11_x4608": 4608 / (ms_msm * 1e-3), "ms_4608": ms_msm}
-        ach = 64.0 * (1 << 20) / (ms20 * 1e-3) / 1e9
+        line["msm"] = {"msms_per_s_2^11_x4608": world * 4608 / (ms_msm * 1e-3), "ms_4608": ms_msm, "replicas": world}
+        ach = 64.0 * (1 << 20) / (ms20 * 1e-3) / 1e9  # per GPU
         line["roofline_ntt"] = {"kernel": "ntt_pass_kernel (2 passes, N=2^20)", "bound": "hbm", "achieved": ach,
                                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
