@@ -22,6 +22,7 @@
 #include "transcript.h"
 
 #define NEVAL 7  // a, b, c, s1, s2, z_shifted, PI(zeta)
+#define PI_SPARSE_MAX 8
 
 struct ProofState {
     Fr beta, gamma, alpha, fft_cofactor, zeta, v;
@@ -50,6 +51,12 @@ struct plonk_prover {
     Fr* ginv_pow;        // [4n]     g^-k / 4n
     const Fr* roots;     // [n]      w^i (owned by ctx)
     Fr zh_inv[4];        // 1 / (g^n * i^k - 1)
+    // Public inputs are the only non-zero entries of the PI column (prover.py:57-62): with few of them PI's
+    // coefficient and coset forms are cheaper from the Lagrange basis directly than through two transforms.
+    bool sparse_pi;      // n_public <= PI_SPARSE_MAX
+    Fr* li_big;          // [n_public][4n]  L_i on the coset: (w^i / n) Z_H(x_k) / (x_k - w^i)
+    const Fr* roots_inv; // [n]             w^-i (owned by ctx)
+    Fr* pub;             // [B][n_public]   public inputs of the resident batch (Montgomery)
     // per-batch buffers (capacity cap_b proofs)
     size_t cap_b;
     Fr *wit_lag;   // [4][B][n]  A, B, C, PI   Lagrange
@@ -81,6 +88,39 @@ __global__ void pi_fill_kernel(const Fr* pub, size_t n_public, size_t n, size_t 
         Fr v = fp_zero<FrParams>();
         if (i < n_public) v = fp_neg(fp_load(pub + b * n_public + i));
         fp_store(pi + gI, v);
+    }
+}
+
+// Sparse public inputs.  PI = sum_{i < l} (-pub_i) L_i with L_i the Lagrange basis of the n-th roots of unity:
+//   coefficient j of L_i is  w^(-ij) / n            (an inverse DFT of a unit vector)
+//   L_i(x) = (w^i / n) (x^n - 1) / (x - w^i)        (li_big holds it on the 4n coset points)
+__global__ void pi_coeffs_kernel(const Fr* pub, size_t l, const Fr* roots_inv, size_t n, size_t B, Fr n_inv, Fr* pic) {
+    const size_t total = B * n;
+    for (size_t gI = (size_t)blockIdx.x * blockDim.x + threadIdx.x; gI < total; gI += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = gI / n, j = gI - b * n;
+        Fr acc = fp_zero<FrParams>();
+        for (size_t i = 0; i < l; i++) acc = fp_add(acc, fp_mul(fp_load(pub + b * l + i), fp_load(roots_inv + ((i * j) & (n - 1)))));
+        fp_store(pic + gI, fp_neg(fp_mul(acc, n_inv)));
+    }
+}
+__global__ void pi_coset_kernel(const Fr* pub, size_t l, const Fr* li_big, size_t n4, size_t B, Fr* pi_big) {
+    const size_t total = B * n4;
+    for (size_t gI = (size_t)blockIdx.x * blockDim.x + threadIdx.x; gI < total; gI += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = gI / n4, k = gI - b * n4;
+        Fr acc = fp_zero<FrParams>();
+        for (size_t i = 0; i < l; i++) acc = fp_add(acc, fp_mul(fp_load(pub + b * l + i), fp_load(li_big + i * n4 + k)));
+        fp_store(pi_big + gI, fp_neg(acc));
+    }
+}
+// li[i][k] = (w^i / n) zh[k & 3] / (x_k - w^i); one field inversion per entry, once per circuit
+struct Zh4 { Fr v[4]; };
+__global__ void li_coset_kernel(const Fr* xs, const Fr* roots, size_t n4, size_t l, Zh4 zh, Fr n_inv, Fr* li) {
+    const size_t total = l * n4;
+    for (size_t gI = (size_t)blockIdx.x * blockDim.x + threadIdx.x; gI < total; gI += (size_t)gridDim.x * blockDim.x) {
+        const size_t i = gI / n4, k = gI - i * n4;
+        const Fr wi = fp_load(roots + i);
+        const Fr num = fp_mul(fp_mul(wi, n_inv), zh.v[k & 3]);
+        fp_store(li + gI, fp_mul(num, fp_inv(fp_sub(fp_load(xs + k), wi))));  // x_k is never an n-th root of unity
     }
 }
 
@@ -624,9 +664,10 @@ static Fr host_fr_u64(uint64_t x) {
 }
 
 static void free_batch(plonk_prover* p) {
-    void* bufs[] = {p->wit_lag, p->z_lag, p->coef, p->big, p->quot, p->num, p->den, p->wz, p->commit_xy, p->commit_flags, p->state};
+    void* bufs[] = {p->wit_lag, p->z_lag, p->coef, p->big, p->quot, p->num, p->den, p->wz, p->commit_xy, p->commit_flags, p->state, p->pub};
     for (void* q : bufs)
         if (q) hipFree(q);
+    p->pub = nullptr;
     p->wit_lag = p->z_lag = p->coef = p->big = p->quot = p->num = p->den = p->wz = nullptr;
     p->commit_xy = nullptr;
     p->commit_flags = nullptr;
@@ -650,6 +691,7 @@ static int ensure_batch(plonk_prover* p, size_t B) {
     PLONK_TRY(dev_alloc((void**)&p->commit_xy, 9 * B * 2 * sizeof(Fq)));
     PLONK_TRY(dev_alloc((void**)&p->commit_flags, 9 * B));
     PLONK_TRY(dev_alloc((void**)&p->state, B * sizeof(ProofState)));
+    PLONK_TRY(dev_alloc((void**)&p->pub, (B * p->n_public + 1) * e));
     p->cap_b = B;
     return PLONK_OK;
 }
@@ -710,9 +752,20 @@ int plonk_prover_create(plonk_ctx* ctx, plonk_srs* srs, unsigned log_n, const ui
     Fr gn = p->g;
     for (unsigned i = 0; i < log_n; i++) gn = fp_sqr(gn);
     Fr i4 = host_root_of_unity(2, false), cur = gn;
+    Zh4 zh4;
     for (int k = 0; k < 4; k++) {
-        p->zh_inv[k] = fp_inv(fp_sub(cur, one));
+        zh4.v[k] = fp_sub(cur, one);
+        p->zh_inv[k] = fp_inv(zh4.v[k]);
         cur = fp_mul(cur, i4);
+    }
+    p->sparse_pi = n_public <= PI_SPARSE_MAX;
+    if (p->sparse_pi && n_public) {
+        PLONK_TRY(ntt_get_roots(ctx, log_n, true, &p->roots_inv));
+        PLONK_TRY(dev_alloc((void**)&p->li_big, n_public * n4 * e));
+        PLONK_LAUNCH(li_coset_kernel, grid1(n_public * n4), dim3(256), 0, ctx->stream, (const Fr*)p->x_big, p->roots, n4, n_public,
+                     zh4, ninv, p->li_big);
+        PLONK_CHECK_HIP(hipGetLastError());
+        PLONK_CHECK_HIP(hipStreamSynchronize(ctx->stream));
     }
     PLONK_TRY(msm_build_table(ctx, srs, ctx->msm_window_bits ? ctx->msm_window_bits : 10));
     *out = p;
@@ -723,7 +776,7 @@ int plonk_prover_destroy(plonk_prover* p) {
     if (!p) return PLONK_OK;
     hipStreamSynchronize(p->ctx->stream);
     free_batch(p);
-    void* bufs[] = {p->fixed_lag, p->fixed_coef, p->fixed_big, p->l0_big, p->x_big, p->g_pow, p->ginv_pow};
+    void* bufs[] = {p->fixed_lag, p->fixed_coef, p->fixed_big, p->l0_big, p->x_big, p->g_pow, p->ginv_pow, p->li_big};
     for (void* q : bufs)
         if (q) hipFree(q);
     delete p;
@@ -738,11 +791,10 @@ int plonk_prover_upload_witness(plonk_prover* p, const uint8_t* abc_le32, const 
     const size_t n = p->n;
     PLONK_TRY(plonk_fr_upload(ctx, p->wit_lag, abc_le32, 3 * B * n));
     if (p->n_public) {
-        void* pub;
-        PLONK_TRY(ctx_scratch(ctx, 2, B * p->n_public * sizeof(Fr), &pub));
-        PLONK_TRY(plonk_fr_upload(ctx, pub, public_le32, B * p->n_public));
-        PLONK_LAUNCH(pi_fill_kernel, grid1(B * n), dim3(256), 0, ctx->stream, (const Fr*)pub, p->n_public, n, B,
-                     p->wit_lag + 3 * B * n);
+        PLONK_TRY(plonk_fr_upload(ctx, p->pub, public_le32, B * p->n_public));
+        if (!p->sparse_pi)
+            PLONK_LAUNCH(pi_fill_kernel, grid1(B * n), dim3(256), 0, ctx->stream, (const Fr*)p->pub, p->n_public, n, B,
+                         p->wit_lag + 3 * B * n);
     } else {
         PLONK_CHECK_HIP(hipMemsetAsync(p->wit_lag + 3 * B * n, 0, B * n * sizeof(Fr), ctx->stream));
     }
@@ -765,7 +817,17 @@ int plonk_prover_run(plonk_prover* p, size_t B) {
 
     PLONK_LAUNCH(transcript_kernel, dim3(tg), dim3(2 * TC_LANES), 0, s, 0, p->state, B, (const Fq*)cxy, (const uint8_t*)cfl, p->chal);
     // ---- round 1: coefficient forms of A, B, C, PI; commit A, B, C            prover.py:86-119
-    PLONK_TRY(ntt_run(ctx, p->wit_lag, p->coef, log_n, true, 4 * B, n, n, n, nullptr, nullptr, true));
+    const Fr n_inv = fp_inv(host_fr_u64((uint64_t)n));
+    if (p->sparse_pi) {
+        PLONK_TRY(ntt_run(ctx, p->wit_lag, p->coef, log_n, true, 3 * B, n, n, n, nullptr, nullptr, true));
+        if (p->n_public)
+            PLONK_LAUNCH(pi_coeffs_kernel, grid1(B * n), dim3(256), 0, s, (const Fr*)p->pub, p->n_public, p->roots_inv, n, B, n_inv,
+                         p->coef + 3 * B * n);
+        else
+            PLONK_CHECK_HIP(hipMemsetAsync(p->coef + 3 * B * n, 0, B * n * sizeof(Fr), s));
+    } else {
+        PLONK_TRY(ntt_run(ctx, p->wit_lag, p->coef, log_n, true, 4 * B, n, n, n, nullptr, nullptr, true));
+    }
     PLONK_TRY(msm_run_device(ctx, p->srs, p->coef, n, 3 * B, n, cxy, cfl));
     PLONK_LAUNCH(transcript_kernel, dim3(tg), dim3(2 * TC_LANES), 0, s, 1, p->state, B, (const Fq*)cxy, (const uint8_t*)cfl, p->chal);
     // ---- round 2: grand product Z, commit                                      prover.py:121-152
@@ -775,7 +837,17 @@ int plonk_prover_run(plonk_prover* p, size_t B) {
     PLONK_TRY(msm_run_device(ctx, p->srs, p->coef + 4 * B * n, n, B, n, cxy + 2 * 3 * B, cfl + 3 * B));
     PLONK_LAUNCH(transcript_kernel, dim3(tg), dim3(2 * TC_LANES), 0, s, 2, p->state, B, (const Fq*)cxy, (const uint8_t*)cfl, p->chal);
     // ---- round 3: coset extensions, fused quotient, back to coefficients, commit T1..T3   prover.py:154-226
-    PLONK_TRY(ntt_run(ctx, p->coef, p->big, log_n + 2, false, 5 * B, n, n, n4, p->g_pow, nullptr, false));
+    if (p->sparse_pi) {  // A, B, C and Z through the transform, PI from the Lagrange basis on the coset
+        PLONK_TRY(ntt_run(ctx, p->coef, p->big, log_n + 2, false, 3 * B, n, n, n4, p->g_pow, nullptr, false));
+        PLONK_TRY(ntt_run(ctx, p->coef + 4 * B * n, p->big + 4 * B * n4, log_n + 2, false, B, n, n, n4, p->g_pow, nullptr, false));
+        if (p->n_public)
+            PLONK_LAUNCH(pi_coset_kernel, grid1(B * n4), dim3(256), 0, s, (const Fr*)p->pub, p->n_public, (const Fr*)p->li_big, n4, B,
+                         p->big + 3 * B * n4);
+        else
+            PLONK_CHECK_HIP(hipMemsetAsync(p->big + 3 * B * n4, 0, B * n4 * sizeof(Fr), s));
+    } else {
+        PLONK_TRY(ntt_run(ctx, p->coef, p->big, log_n + 2, false, 5 * B, n, n, n4, p->g_pow, nullptr, false));
+    }
     ZhInv zh;
     for (int k = 0; k < 4; k++) zh.v[k] = p->zh_inv[k];
     PLONK_LAUNCH(quotient_kernel, grid1(B * n4), dim3(256), 0, s, (const Fr*)p->big, (const Fr*)p->fixed_big,

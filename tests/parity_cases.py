@@ -319,6 +319,17 @@ def batch_prover_vs_oracle(setup, lines, group_order, starts):
         assert g == want
 
 
+def batch_prover_public_input_counts(setup):
+    """0, 1, 3 and 8 public inputs take the sparse Lagrange-basis route for PI, 10 the dense transform route."""
+    for l in (0, 1, 3, 8, 10):
+        pubs = ["p%d public" % i for i in range(l)]
+        body = ["q%d <== p%d * p%d" % (i, i, (i + 1) % l) for i in range(l)] if l else []
+        lines = pubs + body + ["c <== a * b", "d <== c + a"]
+        start = {"a": 5, "b": 7}
+        start.update({"p%d" % i: 11 + 3 * i for i in range(l)})
+        batch_prover_vs_oracle(setup, lines, 32, [start, dict(start, a=9)])
+
+
 def batch_prover_rejects_bad_witness(setup):
     import pytest
 

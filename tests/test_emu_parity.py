@@ -126,6 +126,12 @@ def test_batch_prover_k6(emu):
     pc.batch_prover_k6(Setup.from_file(pc.PTAU))
 
 
+def test_batch_prover_public_input_counts(emu):
+    from plonkathon_amd import Setup
+
+    pc.batch_prover_public_input_counts(Setup.from_file(pc.PTAU))
+
+
 def test_batch_prover_vs_oracle(emu):
     from plonkathon_amd import Setup
 

@@ -190,6 +190,10 @@ def test_batch_prover_k6(setup):
     pc.batch_prover_k6(setup)
 
 
+def test_batch_prover_public_input_counts(setup):
+    pc.batch_prover_public_input_counts(setup)
+
+
 def test_batch_prover_vs_oracle_small(setup):
     pc.batch_prover_vs_oracle(setup, pc.FACTORIZATION, 16, [pc.FACTORIZATION_START])
     pc.batch_prover_vs_oracle(setup, pc.chain_lines(32), 32, [{"x0": 3}, {"x0": 4}, {"x0": 12345678901234567890}])
