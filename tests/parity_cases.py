@@ -198,6 +198,18 @@ def msm_vs_oracle(setup, n, seed, batch=1):
         assert affine(setup.commit_coeffs(P(sc, Basis.MONOMIAL))) == want
 
 
+def msm_linearity(setup, n, seed=314):
+    """commit(a) + commit(b) == commit(a + b) and commit(k a) == k commit(a): size-independent properties."""
+    a, b = rand_vec(seed, n), rand_vec(seed + 1, n)
+    k = rand_vec(seed + 2, 1)[0]
+    ca = affine(setup.commit_coeffs(P(a, Basis.MONOMIAL)))
+    cb = affine(setup.commit_coeffs(P(b, Basis.MONOMIAL)))
+    cab = affine(setup.commit_coeffs(P([(x + y) % R_MOD for x, y in zip(a, b)], Basis.MONOMIAL)))
+    cka = affine(setup.commit_coeffs(P([k * x % R_MOD for x in a], Basis.MONOMIAL)))
+    assert cab == og1.add(ca, cb)
+    assert cka == og1.multiply(ca, k)
+
+
 def msm_extreme_scalars(setup):
     """Scalars at the top of the range: the signed-digit recoding must not overflow its last window."""
     osetup = OSetup.from_file(PTAU)

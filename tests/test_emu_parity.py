@@ -69,6 +69,7 @@ def test_setup_commit_vkeys_lincomb(emu):
     pc.vkey_goldens(setup)
     pc.lincomb_golden(setup, full_size=False)
     pc.msm_vs_oracle(setup, 200, seed=11)
+    pc.msm_linearity(setup, 96)
 
 
 def test_msm_window_configs(emu):

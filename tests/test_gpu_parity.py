@@ -92,6 +92,10 @@ def test_msm_vs_oracle_sizes(setup):
         pc.msm_vs_oracle(setup, n, seed=n)
 
 
+def test_msm_linearity_full_size(setup):
+    pc.msm_linearity(setup, 2048)
+
+
 def test_msm_window_configs(setup):
     from plonkathon_amd import get_context
     from plonkathon_amd._lib import check
