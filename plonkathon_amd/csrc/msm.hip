@@ -591,8 +591,10 @@ static bool msm_lookup_prepare(plonk_ctx* ctx, plonk_srs* srs) {
         }
     }
 #endif
-    // more windows bits = fewer additions; below 8 bits the table no longer beats the bucket method
-    for (unsigned c = want ? want : 17; c >= (want ? want : 8); c--) {
+    // more windows bits = fewer additions; below 8 bits the table no longer beats the bucket method — which,
+    // however, cannot index more than 2^15 bases, so larger base sets accept any table that fits
+    const unsigned c_min = want ? want : (srs->n_points > 32768 ? 4 : 8);
+    for (unsigned c = want ? want : 17; c >= c_min; c--) {
         if (msm_lookup_bytes(srs->n_points, c) > budget) continue;
         if (msm_lookup_build(ctx, srs, c) == PLONK_OK) return true;
     }
