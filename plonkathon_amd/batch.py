@@ -7,6 +7,8 @@ the same `Proof` objects.  All five rounds and the Fiat-Shamir transcript run on
 """
 import ctypes
 
+import numpy as np
+
 from . import _lib
 from ._lib import check
 from .backend import get_context
@@ -37,6 +39,15 @@ class BatchProver:
         self._public_vars = program.get_public_assignments()
         self._wires = [w.as_list() for w in program.wires()]
         n = self.group_order
+        # wire cell -> variable index; one extra all-zero slot serves the empty cells and the padding rows
+        self._vars = sorted({v for row in self._wires for v in row if v is not None}, key=str)
+        pos = {v: i for i, v in enumerate(self._vars)}
+        zero = len(self._vars)
+        self._cell_index = np.full((3, n), zero, dtype=np.int64)
+        for i, row in enumerate(self._wires):
+            for j, v in enumerate(row):
+                if v is not None:
+                    self._cell_index[j, i] = pos[v]
         L, R, M, O, C = program.gate_columns()
         sigma = program.permutation_columns()
         sel = _le(M) + _le(L) + _le(R) + _le(O) + _le(C) + _le(sigma[1]) + _le(sigma[2]) + _le(sigma[3])
@@ -71,10 +82,18 @@ class BatchProver:
         return cols
 
     def upload(self, witnesses):
-        """Stage a batch of witnesses in HBM ([3][B][n] wire columns + public inputs)."""
+        """Stage a batch of witnesses in HBM ([3][B][n] wire columns + public inputs).  Each variable is
+        encoded once and scattered to its wire cells with a numpy gather (a KeyError names a missing variable)."""
         B = len(witnesses)
-        cols = [self.wire_columns(w) for w in witnesses]
-        abc = b"".join(_le(cols[b][j]) for j in range(3) for b in range(B))
+        n, V = self.group_order, len(self._vars)
+        abc = np.empty((3, B, n, 4), dtype=np.uint64)  # 32-byte little-endian elements as 4 x u64
+        flat_index = self._cell_index.ravel()
+        zero = bytes(32)
+        for b, w in enumerate(witnesses):
+            enc = b"".join([(w[v] % R_MOD).to_bytes(32, "little") for v in self._vars]) + zero
+            table = np.frombuffer(enc, dtype=np.uint64).reshape(V + 1, 4)
+            abc[:, b] = np.take(table, flat_index, axis=0).reshape(3, n, 4)
+        abc = abc.tobytes()
         pub = b"".join(_le([w[v] % R_MOD for v in self._public_vars]) for w in witnesses)
         check(self.ctx.L.plonk_prover_upload_witness(self._h, abc, pub if self._public_vars else None, B))
         self._resident = B
