@@ -259,6 +259,13 @@ def main():
                     "see `alu`; with the lookup table every addition also reads 64 table bytes, i.e. `traffic` is the real demand",
             "msm_method": ("lookup table, %d-bit windows" % lookup_bits) if lookup_bits else "bucket method, %d-bit windows" % MSM_WINDOW_BITS,
         }
+        if lookup_bits:  # the lookup method's own algorithmic bytes: one 64-byte table entry per addition + the scalars
+            windows_l = (255 + lookup_bits - 1) // lookup_bits
+            per_msm = GROUP_ORDER * windows_l * 64.0 + 32.0 * GROUP_ORDER + 64.0
+            n_msm_l = msm_bytes / (96.0 * GROUP_ORDER + 64.0)
+            line["roofline"]["method_bytes_per_msm"] = per_msm
+            line["roofline"]["method_GBps"] = per_msm * n_msm_l / (msm_ms * 1e-3) / 1e9
+            line["roofline"]["method_frac_of_peak"] = line["roofline"]["method_GBps"] / HBM_PEAK_GBS
         if line["roofline"]["traffic"]:  # what the kernel really asks of HBM (table look-ups), per the PMC passes
             line["roofline"]["traffic_GBps"] = line["roofline"]["traffic"] / avg_s / 1e9
             line["roofline"]["traffic_frac_of_peak"] = line["roofline"]["traffic_GBps"] / HBM_PEAK_GBS
