@@ -210,6 +210,28 @@ def msm_linearity(setup, n, seed=314):
     assert cka == og1.multiply(ca, k)
 
 
+def lincomb_fuzz(setup, rounds, seed=2024):
+    """Random small linear combinations drawn to hit the corner cases together: repeated and negated bases,
+    identity points, zero / tiny / top-of-range scalars, scalars that cancel."""
+    import random
+
+    rng = random.Random(seed)
+    Pts = setup.powers_of_x
+    special = [0, 1, 2, R_MOD - 1, R_MOD - 2, (R_MOD - 1) // 2, 1 << 253, (1 << 16) - 1, 1 << 17, (1 << 34) + 1]
+    for _ in range(rounds):
+        n = rng.randrange(1, 24)
+        pool = [Pts[rng.randrange(0, 12)] for _ in range(rng.randrange(1, 5))]
+        pairs = []
+        for _ in range(n):
+            p = None if rng.random() < 0.1 else rng.choice(pool)
+            k = rng.choice(special) if rng.random() < 0.5 else rng.randrange(R_MOD)
+            if pairs and rng.random() < 0.2:  # cancel or double the previous term
+                p, k = pairs[-1][0], (R_MOD - pairs[-1][1]) % R_MOD if rng.random() < 0.5 else pairs[-1][1]
+            pairs.append((p, k))
+        want = og1.ec_lincomb([(None if p is None else affine(p), k) for p, k in pairs])
+        assert affine(pa.ec_lincomb(pairs)) == want, pairs
+
+
 def msm_extreme_scalars(setup):
     """Scalars at the top of the range: the signed-digit recoding must not overflow its last window."""
     osetup = OSetup.from_file(PTAU)

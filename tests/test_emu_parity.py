@@ -70,6 +70,7 @@ def test_setup_commit_vkeys_lincomb(emu):
     pc.lincomb_golden(setup, full_size=False)
     pc.msm_vs_oracle(setup, 200, seed=11)
     pc.msm_linearity(setup, 96)
+    pc.lincomb_fuzz(setup, 12)
 
 
 def test_msm_window_configs(emu):
@@ -101,6 +102,7 @@ def test_msm_lookup_tables(emu):
             pc.msm_extreme_scalars(setup)
             if c == 5:
                 pc.lincomb_golden(setup, full_size=False)
+                pc.lincomb_fuzz(setup, 8, seed=77)
         ctx.msm_lookup(2, 4)
         pc.prover_k6(Setup.from_file(pc.PTAU))
         pc.batch_prover_k6(Setup.from_file(pc.PTAU))

@@ -96,6 +96,18 @@ def test_msm_linearity_full_size(setup):
     pc.msm_linearity(setup, 2048)
 
 
+def test_lincomb_fuzz_both_methods(setup):
+    from plonkathon_amd import get_context
+
+    ctx = get_context()
+    pc.lincomb_fuzz(setup, 25)  # arbitrary bases: bucket method
+    try:
+        ctx.msm_lookup(2, 9)    # the same through forced lookup tables
+        pc.lincomb_fuzz(setup, 25, seed=99)
+    finally:
+        ctx.msm_lookup(0)
+
+
 def test_msm_window_configs(setup):
     from plonkathon_amd import get_context
     from plonkathon_amd._lib import check
