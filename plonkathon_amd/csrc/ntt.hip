@@ -246,7 +246,7 @@ __global__ void __launch_bounds__(1024) ntt_pass_radix2_kernel(NttPass p) {
     const unsigned R = 1u << p.log_r, C = 1u << p.log_c;
     const unsigned T = R * C;
     // LDS index of tile element (r, c): column-interleaved for strided passes, padded rows for the
-    // row (last) pass so both the r-fastest load and the c-fastest store are conflict-free.
+    // row (last) pass so both the r-fastest and the c-fastest phases are conflict-free.
     const unsigned row_pitch = p.last ? (R + (C > 1 ? 1 : 0)) : 0;
     const unsigned t_pad = p.last ? row_pitch * C : T;
     u32x4* d_lo = reinterpret_cast<u32x4*>(smem);
@@ -274,98 +274,6 @@ __global__ void __launch_bounds__(1024) ntt_pass_radix2_kernel(NttPass p) {
         kb = tile & ((1u << log_kb) - 1);
         rest = tile >> log_kb;
     }
-
-    // stage the pass's small twiddles
-    for (unsigned i = tid; i < R / 2; i += nthr) lds_st(w_lo, w_hi, i, fp_load(p.small_tw + i));
-
-    // load the tile
-    for (unsigned e = tid; e < T; e += nthr) {
-        unsigned r, c;
-        size_t g;
-        if (!p.last) {
-            c = e & (C - 1);
-            r = e >> p.log_c;
-            g = base + ((size_t)r << p.log_s) + c;
-        } else {
-            r = e & (R - 1);
-            c = e >> p.log_r;
-            size_t row = p.nprev ? ((((size_t)(kb << p.log_c) + c) << (p.log_h - log_r1)) + rest) : 0;
-            g = (row << p.log_r) + r;
-        }
-        Fr v;
-        if (p.first && g >= p.in_len) {
-            v = fp_zero<FrParams>();
-        } else {
-            v = fp_load(in + g);
-            if (p.first && p.in_scale) v = fp_mul(v, fp_load(p.in_scale + g));
-        }
-        lds_st(d_lo, d_hi, LIDX(r, c), v);
-    }
-    __syncthreads();
-
-    // decimation-in-frequency stages, (a, b) -> (a + b, (a - b) * w).  Two levels (half sizes h and h/2) are
-    // done per LDS round trip: a thread owns rows {r0, r0 + h/2, r0 + h, r0 + 3h/2} of one column, which
-    // halves the LDS traffic and the barrier count of a level-at-a-time schedule; an odd level count starts
-    // with one plain radix-2 level.
-    int lh = (int)p.log_r - 1;
-    if (p.log_r & 1) {
-        const unsigned h = 1u << lh;
-        for (unsigned b = tid; b < T / 2; b += nthr) {
-            unsigned c, bf;
-            if (!p.last) {
-                c = b & (C - 1);
-                bf = b >> p.log_c;
-            } else {
-                bf = b & (R / 2 - 1);
-                c = b >> (p.log_r - 1);
-            }
-            const unsigned off = bf & (h - 1);
-            const unsigned r0 = ((bf >> lh) << (lh + 1)) + off;
-            const unsigned i0 = LIDX(r0, c), i1 = LIDX(r0 + h, c);
-            Fr x = lds_ld(d_lo, d_hi, i0), y = lds_ld(d_lo, d_hi, i1);
-            Fr s = fp_add(x, y), d = fp_sub(x, y);
-            if (lh != 0) d = fp_mul(d, lds_ld(w_lo, w_hi, off << (p.log_r - 1 - lh)));
-            lds_st(d_lo, d_hi, i0, s);
-            lds_st(d_lo, d_hi, i1, d);
-        }
-        __syncthreads();
-        lh--;
-    }
-    for (; lh >= 1; lh -= 2) {
-        const unsigned h = 1u << lh, q = h >> 1;
-        const unsigned sh_a = p.log_r - 1 - lh;  // twiddle index shift of the level with half size h
-        for (unsigned b = tid; b < T / 4; b += nthr) {
-            unsigned c, bf;
-            if (!p.last) {
-                c = b & (C - 1);
-                bf = b >> p.log_c;
-            } else {
-                bf = b & (R / 4 - 1);
-                c = b >> (p.log_r - 2);
-            }
-            const unsigned off = bf & (q - 1);
-            const unsigned r0 = ((bf >> (lh - 1)) << (lh + 1)) + off;
-            const unsigned i0 = LIDX(r0, c), i1 = LIDX(r0 + q, c), i2 = LIDX(r0 + h, c), i3 = LIDX(r0 + h + q, c);
-            const Fr x0 = lds_ld(d_lo, d_hi, i0), x1 = lds_ld(d_lo, d_hi, i1), x2 = lds_ld(d_lo, d_hi, i2),
-                     x3 = lds_ld(d_lo, d_hi, i3);
-            const Fr s0 = fp_add(x0, x2), s1 = fp_add(x1, x3);
-            const Fr d0 = fp_mul(fp_sub(x0, x2), lds_ld(w_lo, w_hi, off << sh_a));
-            const Fr d1 = fp_mul(fp_sub(x1, x3), lds_ld(w_lo, w_hi, (off + q) << sh_a));
-            Fr y1 = fp_sub(s0, s1), y3 = fp_sub(d0, d1);
-            if (lh != 1) {  // the level with half size 1 has unit twiddles
-                const Fr wb = lds_ld(w_lo, w_hi, off << (sh_a + 1));
-                y1 = fp_mul(y1, wb);
-                y3 = fp_mul(y3, wb);
-            }
-            lds_st(d_lo, d_hi, i0, fp_add(s0, s1));
-            lds_st(d_lo, d_hi, i1, y1);
-            lds_st(d_lo, d_hi, i2, fp_add(d0, d1));
-            lds_st(d_lo, d_hi, i3, y3);
-        }
-        __syncthreads();
-    }
-
-    // store: frequency k of column c sits at row bitrev(k)
     unsigned rev_rest = 0;
     if (p.last && p.nprev > 1) {
         unsigned rr = rest, weight = p.prev_log_r[0];
@@ -378,10 +286,23 @@ __global__ void __launch_bounds__(1024) ntt_pass_radix2_kernel(NttPass p) {
             rev_rest += kq << w_of[q];
         }
     }
-    for (unsigned e = tid; e < T; e += nthr) {
-        const unsigned c = e & (C - 1);
-        const unsigned k = e >> p.log_c;
-        Fr v = lds_ld(d_lo, d_hi, LIDX(bitrev(k, p.log_r), c));
+
+    // tile element (r, c) <- global memory (zero padding and the input scaling of the first pass fused in)
+    auto gload = [&](unsigned r, unsigned c) -> Fr {
+        size_t g;
+        if (!p.last) {
+            g = base + ((size_t)r << p.log_s) + c;
+        } else {
+            size_t row = p.nprev ? ((((size_t)(kb << p.log_c) + c) << (p.log_h - log_r1)) + rest) : 0;
+            g = (row << p.log_r) + r;
+        }
+        if (p.first && g >= p.in_len) return fp_zero<FrParams>();
+        Fr v = fp_load(in + g);
+        if (p.first && p.in_scale) v = fp_mul(v, fp_load(p.in_scale + g));
+        return v;
+    };
+    // frequency k of column c -> global memory (inter-pass twiddle, or the output scalings of the last pass)
+    auto gstore = [&](unsigned k, unsigned c, Fr v) {
         if (!p.last) {
             const size_t jrest = ((size_t)cb << p.log_c) + c;
             const size_t ex = (jrest * k) << p.log_h;  // < N
@@ -396,6 +317,123 @@ __global__ void __launch_bounds__(1024) ntt_pass_radix2_kernel(NttPass p) {
             if (p.out_scale) v = fp_mul(v, fp_load(p.out_scale + o));
             if (p.has_out_scalar) v = fp_mul(v, p.out_scalar);
             fp_store(out + o, v);
+        }
+    };
+
+    // stage the pass's small twiddles
+    for (unsigned i = tid; i < R / 2; i += nthr) lds_st(w_lo, w_hi, i, fp_load(p.small_tw + i));
+
+    // With at least four levels the first stage reads its operands straight from HBM and the last one writes
+    // its results straight to HBM (two LDS round trips and two barriers fewer per pass); tiny tiles keep the
+    // plain load / stages / store sequence.
+    const bool fuse = p.log_r >= 4;
+    if (!fuse) {
+        for (unsigned e = tid; e < T; e += nthr) {
+            unsigned r, c;
+            if (!p.last) {
+                c = e & (C - 1);
+                r = e >> p.log_c;
+            } else {
+                r = e & (R - 1);
+                c = e >> p.log_r;
+            }
+            lds_st(d_lo, d_hi, LIDX(r, c), gload(r, c));
+        }
+    }
+    __syncthreads();
+
+    // decimation-in-frequency stages, (a, b) -> (a + b, (a - b) * w).  Two levels (half sizes h and h/2) are
+    // done per LDS round trip: a thread owns rows {r0, r0 + h/2, r0 + h, r0 + 3h/2} of one column, which
+    // halves the LDS traffic and the barrier count of a level-at-a-time schedule; an odd level count starts
+    // with one plain radix-2 level.
+    int lh = (int)p.log_r - 1;
+    bool from_global = fuse;
+    if (p.log_r & 1) {
+        const unsigned h = 1u << lh;
+        for (unsigned b = tid; b < T / 2; b += nthr) {
+            unsigned c, bf;
+            if (!p.last) {
+                c = b & (C - 1);
+                bf = b >> p.log_c;
+            } else {
+                bf = b & (R / 2 - 1);
+                c = b >> (p.log_r - 1);
+            }
+            const unsigned off = bf & (h - 1);
+            const unsigned r0 = ((bf >> lh) << (lh + 1)) + off;
+            const unsigned i0 = LIDX(r0, c), i1 = LIDX(r0 + h, c);
+            const Fr x = from_global ? gload(r0, c) : lds_ld(d_lo, d_hi, i0);
+            const Fr y = from_global ? gload(r0 + h, c) : lds_ld(d_lo, d_hi, i1);
+            Fr s = fp_add(x, y), d = fp_sub(x, y);
+            if (lh != 0) d = fp_mul(d, lds_ld(w_lo, w_hi, off << (p.log_r - 1 - lh)));
+            lds_st(d_lo, d_hi, i0, s);
+            lds_st(d_lo, d_hi, i1, d);
+        }
+        __syncthreads();
+        lh--;
+        from_global = false;
+    }
+    for (; lh >= 1; lh -= 2) {
+        const unsigned h = 1u << lh, q = h >> 1;
+        const unsigned sh_a = p.log_r - 1 - lh;  // twiddle index shift of the level with half size h
+        const bool to_global = fuse && lh == 1;  // rows r0 .. r0 + 3 hold frequencies bitrev(r0 + j)
+        // the row pass walks rows fastest while it reads HBM and columns fastest when it finally writes
+        const bool c_fastest = !p.last || to_global;
+        for (unsigned b = tid; b < T / 4; b += nthr) {
+            unsigned c, bf;
+            if (c_fastest) {
+                c = b & (C - 1);
+                bf = b >> p.log_c;
+            } else {
+                bf = b & (R / 4 - 1);
+                c = b >> (p.log_r - 2);
+            }
+            const unsigned off = bf & (q - 1);
+            const unsigned r0 = ((bf >> (lh - 1)) << (lh + 1)) + off;
+            const unsigned i0 = LIDX(r0, c), i1 = LIDX(r0 + q, c), i2 = LIDX(r0 + h, c), i3 = LIDX(r0 + h + q, c);
+            Fr x0, x1, x2, x3;
+            if (from_global) {
+                x0 = gload(r0, c);
+                x1 = gload(r0 + q, c);
+                x2 = gload(r0 + h, c);
+                x3 = gload(r0 + h + q, c);
+            } else {
+                x0 = lds_ld(d_lo, d_hi, i0);
+                x1 = lds_ld(d_lo, d_hi, i1);
+                x2 = lds_ld(d_lo, d_hi, i2);
+                x3 = lds_ld(d_lo, d_hi, i3);
+            }
+            const Fr s0 = fp_add(x0, x2), s1 = fp_add(x1, x3);
+            const Fr d0 = fp_mul(fp_sub(x0, x2), lds_ld(w_lo, w_hi, off << sh_a));
+            const Fr d1 = fp_mul(fp_sub(x1, x3), lds_ld(w_lo, w_hi, (off + q) << sh_a));
+            Fr y1 = fp_sub(s0, s1), y3 = fp_sub(d0, d1);
+            if (lh != 1) {  // the level with half size 1 has unit twiddles
+                const Fr wb = lds_ld(w_lo, w_hi, off << (sh_a + 1));
+                y1 = fp_mul(y1, wb);
+                y3 = fp_mul(y3, wb);
+            }
+            const Fr y0 = fp_add(s0, s1), y2 = fp_add(d0, d1);
+            if (to_global) {
+                gstore(bitrev(r0, p.log_r), c, y0);
+                gstore(bitrev(r0 + 1, p.log_r), c, y1);
+                gstore(bitrev(r0 + 2, p.log_r), c, y2);
+                gstore(bitrev(r0 + 3, p.log_r), c, y3);
+            } else {
+                lds_st(d_lo, d_hi, i0, y0);
+                lds_st(d_lo, d_hi, i1, y1);
+                lds_st(d_lo, d_hi, i2, y2);
+                lds_st(d_lo, d_hi, i3, y3);
+            }
+        }
+        if (!to_global) __syncthreads();
+        from_global = false;
+    }
+
+    if (!fuse) {  // store: frequency k of column c sits at row bitrev(k)
+        for (unsigned e = tid; e < T; e += nthr) {
+            const unsigned c = e & (C - 1);
+            const unsigned k = e >> p.log_c;
+            gstore(k, c, lds_ld(d_lo, d_hi, LIDX(bitrev(k, p.log_r), c)));
         }
     }
 #undef LIDX
