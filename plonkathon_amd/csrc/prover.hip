@@ -374,7 +374,7 @@ __global__ void __launch_bounds__(2 * TC_LANES) transcript_kernel(int round, Pro
 #define GP_THREADS 256
 __global__ void __launch_bounds__(GP_THREADS) grand_product_kernel(const Fr* wit, const Fr* s_lag, const Fr* roots,
                                                                    const ProofState* st, size_t n, size_t B, Fr* z_out,
-                                                                   uint32_t* closes) {
+                                                                   uint32_t* closes, Fr* num_buf, Fr* den_buf) {
     __shared__ Fr sc_n[GP_THREADS], sc_d[GP_THREADS];
     __shared__ Fr tot_inv;
     const size_t b = blockIdx.x;
@@ -382,11 +382,12 @@ __global__ void __launch_bounds__(GP_THREADS) grand_product_kernel(const Fr* wit
     const Fr beta = st[b].beta, gamma = st[b].gamma;
     const Fr *A = wit + b * n, *Bv = wit + (B + b) * n, *C = wit + (2 * B + b) * n;
     const Fr *S1 = s_lag, *S2 = s_lag + n, *S3 = s_lag + 2 * n;
+    Fr *NUM = num_buf + b * n, *DEN = den_buf + b * n;  // this proof's factors; a lane only ever touches its own chunk
     const size_t per = (n + GP_THREADS - 1) / GP_THREADS;
     const size_t lo = tid * per, hi = (lo + per < n) ? lo + per : n;
     const Fr one = fp_one<FrParams>();
 
-    // pass 1: per-lane products
+    // pass 1: the factors, once; per-lane products
     Fr pn = one, pd = one;
     for (size_t i = lo; i < hi; i++) {
         Fr a = fp_load(A + i), bb = fp_load(Bv + i), c = fp_load(C + i);
@@ -395,8 +396,13 @@ __global__ void __launch_bounds__(GP_THREADS) grand_product_kernel(const Fr* wit
         Fr num = fp_mul(fp_mul(fp_add(ag, bw), fp_add(bg, fp_dbl(bw))), fp_add(cg, fp_mul3(bw)));
         Fr den = fp_mul(fp_mul(fp_add(ag, fp_mul(beta, fp_load(S1 + i))), fp_add(bg, fp_mul(beta, fp_load(S2 + i)))),
                         fp_add(cg, fp_mul(beta, fp_load(S3 + i))));
-        if (fp_is_zero(den)) num = fp_zero<FrParams>();  // ratio num/0 == 0
-        else pd = fp_mul(pd, den);
+        if (fp_is_zero(den)) {  // ratio num/0 == 0 (py_ecc): the factor leaves the denominator products
+            num = fp_zero<FrParams>();
+            den = one;
+        }
+        fp_store(NUM + i, num);
+        fp_store(DEN + i, den);
+        pd = fp_mul(pd, den);
         pn = fp_mul(pn, num);
     }
     sc_n[tid] = pn;
@@ -417,30 +423,15 @@ __global__ void __launch_bounds__(GP_THREADS) grand_product_kernel(const Fr* wit
     Fr run_n = tid ? sc_n[tid - 1] : one;                       // prod of num before this lane's chunk
     Fr after_d = (tid + 1 < GP_THREADS) ? sc_d[tid + 1] : one;  // prod of den after this lane's chunk
     const Fr tinv = tot_inv;
-    // pass 2: recompute the lane's factors, emit Z_i = PN_i * SD_i * tot_inv
-    // SD_i within the chunk needs the suffix product over the chunk: build it backwards first
-    Fr sd_local[16];  // per <= 16 (n <= 4096 per proof with 256 lanes)
-    {
-        Fr acc = after_d;
-        for (size_t k = hi; k-- > lo;) {
-            Fr a = fp_load(A + k), bb = fp_load(Bv + k), c = fp_load(C + k);
-            Fr ag = fp_add(a, gamma), bg = fp_add(bb, gamma), cg = fp_add(c, gamma);
-            Fr den = fp_mul(fp_mul(fp_add(ag, fp_mul(beta, fp_load(S1 + k))), fp_add(bg, fp_mul(beta, fp_load(S2 + k)))),
-                            fp_add(cg, fp_mul(beta, fp_load(S3 + k))));
-            if (!fp_is_zero(den)) acc = fp_mul(acc, den);
-            sd_local[k - lo] = acc;  // prod_{j >= k} den_j
-        }
+    // pass 2 (backwards): DEN[k] <- prod_{j >= k} den_j
+    for (size_t k = hi; k-- > lo;) {
+        after_d = fp_mul(after_d, fp_load(DEN + k));
+        fp_store(DEN + k, after_d);
     }
+    // pass 3: Z_i = PN_i * SD_i * tot_inv
     for (size_t i = lo; i < hi; i++) {
-        fp_store(z_out + b * n + i, fp_mul(fp_mul(run_n, sd_local[i - lo]), tinv));
-        Fr a = fp_load(A + i), bb = fp_load(Bv + i), c = fp_load(C + i);
-        Fr bw = fp_mul(beta, fp_load(roots + i));
-        Fr ag = fp_add(a, gamma), bg = fp_add(bb, gamma), cg = fp_add(c, gamma);
-        Fr num = fp_mul(fp_mul(fp_add(ag, bw), fp_add(bg, fp_dbl(bw))), fp_add(cg, fp_mul3(bw)));
-        Fr den = fp_mul(fp_mul(fp_add(ag, fp_mul(beta, fp_load(S1 + i))), fp_add(bg, fp_mul(beta, fp_load(S2 + i)))),
-                        fp_add(cg, fp_mul(beta, fp_load(S3 + i))));
-        if (fp_is_zero(den)) num = fp_zero<FrParams>();
-        run_n = fp_mul(run_n, num);
+        fp_store(z_out + b * n + i, fp_mul(fp_mul(run_n, fp_load(DEN + i)), tinv));
+        run_n = fp_mul(run_n, fp_load(NUM + i));
     }
     // prover.py:132 `assert Z_values.pop() == 1`: the full product of ratios must close to one
     if (tid == GP_THREADS - 1) closes[b] = fp_eq(fp_mul(run_n, tinv), fp_one<FrParams>()) ? 1u : 0u;
@@ -832,7 +823,8 @@ int plonk_prover_run(plonk_prover* p, size_t B) {
     PLONK_LAUNCH(transcript_kernel, dim3(tg), dim3(2 * TC_LANES), 0, s, 1, p->state, B, (const Fq*)cxy, (const uint8_t*)cfl, p->chal);
     // ---- round 2: grand product Z, commit                                      prover.py:121-152
     PLONK_LAUNCH(grand_product_kernel, dim3((unsigned)B), dim3(GP_THREADS), 0, s, (const Fr*)p->wit_lag,
-                 (const Fr*)(p->fixed_lag + FX_S1 * n), p->roots, (const ProofState*)p->state, n, B, p->z_lag, closes);
+                 (const Fr*)(p->fixed_lag + FX_S1 * n), p->roots, (const ProofState*)p->state, n, B, p->z_lag, closes, p->num,
+                 p->wz);  // num / wz: scratch until round 5
     PLONK_TRY(ntt_run(ctx, p->z_lag, p->coef + 4 * B * n, log_n, true, B, n, n, n, nullptr, nullptr, true));
     PLONK_TRY(msm_run_device(ctx, p->srs, p->coef + 4 * B * n, n, B, n, cxy + 2 * 3 * B, cfl + 3 * B));
     PLONK_LAUNCH(transcript_kernel, dim3(tg), dim3(2 * TC_LANES), 0, s, 2, p->state, B, (const Fq*)cxy, (const uint8_t*)cfl, p->chal);
