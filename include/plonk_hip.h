@@ -138,7 +138,7 @@ int plonk_srs_lookup_bits(const plonk_srs* srs, unsigned* out_bits);
 /* ---- batched GPU-resident prover ---------------------------------------------------------------------
  * Replaces Prover.__init__ / Prover.prove / round_1..round_5 (prover.py:45-306) for `batch`
  * independent proofs of ONE circuit proved in lock-step, Fiat-Shamir transcript included
- * (transcript.py:77-123 runs on the device, one lane per proof).
+ * (transcript.py:77-123 runs on the device, 32 lanes per proof).
  *   plonk_prover_create   Prover(setup, program): `selectors_le32` = the eight CommonPreprocessedInput
  *                         vectors QM, QL, QR, QO, QC, S1, S2, S3 (compiler/program.py:10-30), each
  *                         2^log_n canonical Fr values; n_public = len(program.get_public_assignments()).

@@ -95,7 +95,7 @@ int k_fr_rotate(plonk_ctx* ctx, const Fr* in, Fr* out, size_t n, size_t shift, s
 }
 
 // ------------------------------------------------------------------------------------------------
-// Batch inversion (Montgomery's trick) — one Fermat inversion per lane-chunk of INV_CHUNK elements.
+// Batch inversion (Montgomery's trick) — one field inversion (fp_inv) per lane-chunk of INV_CHUNK elements.
 // Zeros are skipped in the running product and map to zero (py_ecc: x / 0 == 0).
 #define INV_CHUNK 8
 __global__ void fr_batch_inverse_kernel(const Fr* in, Fr* out, size_t n) {

@@ -2,7 +2,7 @@
 //
 // Reference behaviour replaced: Prover.prove / round_1..round_5 (/root/reference/prover.py:51-306,
 // spec in SURVEY.md §3.2) for B independent proofs of one circuit run in lock-step, including the
-// Fiat-Shamir transcript (transcript.py:77-123), which runs on the device (one lane per proof) so
+// Fiat-Shamir transcript (transcript.py:77-123), which runs on the device (32 lanes per proof) so
 // that a whole batch is one uninterrupted stream of kernel launches with no host round trip.
 //
 // Every committed polynomial is uniquely determined by (circuit, witness, challenges) — the
