@@ -33,7 +33,7 @@ extern "C" {
 #define PLONK_ERR_NOMEM (-3) /* device allocation failed */
 #define PLONK_ERR_STATE (-4) /* object used in the wrong state */
 
-#define PLONK_ABI_VERSION 1
+#define PLONK_ABI_VERSION 2
 
 typedef struct plonk_ctx plonk_ctx; /* one per (process, device): stream, twiddle caches, scratch */
 typedef struct plonk_srs plonk_srs; /* device-resident G1 bases + fixed-base window table */
@@ -125,15 +125,21 @@ int plonk_g1_msm(plonk_ctx* ctx, plonk_srs* srs, const void* d_scalars, size_t n
 /* tuning knobs (0 = library default): window bits c and window-groups per MSM (bucket method) */
 int plonk_msm_configure(plonk_ctx* ctx, unsigned window_bits, unsigned groups);
 /* Lookup MSM: for a reusable SRS (plonk_srs_load_ptau) every multiple d * 2^(c w) * P_i, d <= 2^(c-1), is
- * precomputed once into HBM (2^11 points: 128.8 GB at c = 17, 68.7 GB at c = 16), after which an MSM is
- * N * ceil(255/c) mixed additions of looked-up points: no sorting, no buckets, no doublings.  mode 0 (default):
- * automatic — the largest c (<= 17) whose table and its one-window staging buffer fit `budget_bytes` (0 = 55 %
- * of the free device memory, at most 160 GB: c = 17 on an idle MI355X, smaller tables when memory is shared), bucket
- * method when nothing fits or for plonk_srs_load_affine bases; mode 1: never; mode 2: use `window_bits` for every
- * base set (tests).  Same results as the bucket method (curve.py:38-111), bit for bit.                        */
+ * precomputed once into HBM (2^11 points: 128.8 GB at c = 17, 68.7 GB at c = 16, 3.2 GB at c = 11), after which
+ * an MSM is N * ceil(255/c) mixed additions of looked-up points: no sorting, no buckets, no doublings.  mode 0
+ * (default): automatic — the largest c (<= 17) whose table and its one-window staging buffer fit `budget_bytes`;
+ * budget 0 = the library default of 4 GiB (or PLONK_MSM_TABLE_GB gigabytes if that variable is set): the big tables
+ * are a memory-for-time trade the caller opts into explicitly.  Bucket method when nothing fits or for
+ * plonk_srs_load_affine bases; mode 1: never; mode 2: use `window_bits` for every base set (tests).  Same results
+ * as the bucket method (curve.py:38-111), bit for bit.                                                          */
 int plonk_msm_lookup_configure(plonk_ctx* ctx, int mode, unsigned window_bits, size_t budget_bytes);
 /* window bits of the lookup table currently attached to `srs` (0 = none: its MSMs use the bucket method) */
 int plonk_srs_lookup_bits(const plonk_srs* srs, unsigned* out_bits);
+/* the same plus the table's size in bytes, the wall time its build took, and how many plonk_srs objects of this
+ * process share it: there is ONE table per (device, base set, window bits) whatever the number of contexts /
+ * streams / provers using that SRS on the device; it is freed with the last plonk_srs that references it.      */
+int plonk_srs_lookup_info(const plonk_srs* srs, unsigned* out_bits, size_t* out_bytes, double* out_build_s,
+                          int* out_sharers);
 
 /* ---- batched GPU-resident prover ---------------------------------------------------------------------
  * Replaces Prover.__init__ / Prover.prove / round_1..round_5 (prover.py:45-306) for `batch`
@@ -146,7 +152,8 @@ int plonk_srs_lookup_bits(const plonk_srs* srs, unsigned* out_bits);
  *   plonk_prover_upload_witness   the wire columns A, B, C of round 1 (prover.py:94-103) laid out
  *                         [3][batch][n] and the public inputs [batch][n_public] (PI = -public,
  *                         prover.py:57-62), canonical LE; they stay resident in HBM.
- *   plonk_prover_run      enqueue all five rounds for the resident witnesses (asynchronous).
+ *   plonk_prover_run      enqueue all five rounds for the resident witnesses (asynchronous); `batch` must be the
+ *                         batch size of the last upload (PLONK_ERR_STATE otherwise), also for download.
  *   plonk_prover_download wait, then per proof 768 bytes: a_1, b_1, c_1, z_1, t_lo_1, t_mid_1, t_hi_1,
  *                         W_z_1, W_zw_1 as canonical x||y LE (Proof.flatten order, prover.py:18-35) then
  *                         a_eval, b_eval, c_eval, s1_eval, s2_eval, z_shifted_eval canonical LE;
@@ -159,9 +166,34 @@ int plonk_prover_create(plonk_ctx* ctx, plonk_srs* srs, unsigned log_n, const ui
                         size_t n_public, plonk_prover** out);
 int plonk_prover_destroy(plonk_prover* p);
 int plonk_prover_upload_witness(plonk_prover* p, const uint8_t* abc_le32, const uint8_t* public_le32, size_t batch);
+/* The same inputs at n_vars * 32 bytes per proof instead of 3 * n * 32: the wiring is given once per circuit —
+ * cell_index[3][n] = index of the variable each wire cell (column L / R / O, row) carries, n_vars for an empty cell
+ * or a padding row (witness[None] = 0, prover.py:94-95); public_index[n_public] = the public variables in row
+ * order (prover.py:57-62) — and a batch is the variables' values, [batch][n_vars] canonical LE; the A, B, C columns
+ * (prover.py:97-103) and the public inputs are gathered from them on the device.                                */
+int plonk_prover_set_wiring(plonk_prover* p, const uint32_t* cell_index, const uint32_t* public_index, size_t n_vars);
+int plonk_prover_upload_variables(plonk_prover* p, const uint8_t* vars_le32, size_t batch);
 int plonk_prover_run(plonk_prover* p, size_t batch);
 int plonk_prover_download(plonk_prover* p, size_t batch, uint8_t* out_proofs, uint8_t* out_status);
 int plonk_prover_challenges(plonk_prover* p, size_t b, uint8_t out_le32[6 * 32]);
+
+/* ---- multi-GPU: gather of finished proofs, RCCL over xGMI ---------------------------------------------
+ * Proofs are independent (prover.py:51-84 has no cross-proof state), so N GPUs prove disjoint index sets with no
+ * data-path exchange; the one collective is an all-gather of the results, 768 bytes per proof.
+ * One process per GPU.  Rank 0 calls plonk_comm_unique_id and passes the 128 bytes to the other ranks out of band;
+ * every rank then calls plonk_comm_create (ncclCommInitRank on the context's device).  librccl is loaded on the
+ * first of these calls, never for single-GPU use.
+ *   plonk_gather_results  h_recv[r * bytes_per_rank ...] = rank r's h_send, for all ranks (ncclAllGather, uint8)
+ *   plonk_comm_max_f64    *inout = max over ranks (the benchmark clock: slowest rank); plonk_comm_barrier likewise */
+#define PLONK_COMM_ID_BYTES 128
+typedef struct plonk_comm plonk_comm;
+int plonk_comm_unique_id(uint8_t out_id[PLONK_COMM_ID_BYTES]);
+int plonk_comm_create(plonk_ctx* ctx, const uint8_t id[PLONK_COMM_ID_BYTES], int rank, int world, plonk_comm** out);
+int plonk_comm_destroy(plonk_comm* comm);
+int plonk_comm_size(const plonk_comm* comm, int* out_rank, int* out_world);
+int plonk_gather_results(plonk_comm* comm, const uint8_t* h_send, size_t bytes_per_rank, uint8_t* h_recv);
+int plonk_comm_max_f64(plonk_comm* comm, double* inout);
+int plonk_comm_barrier(plonk_comm* comm);
 
 /* ---- Fiat-Shamir transcript (host) ----------------------------------------------------------------
  * Replaces `merlin.MerlinTranscript` (third-party) as subclassed by transcript.py:58-60:

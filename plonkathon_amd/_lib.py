@@ -47,15 +47,25 @@ SIGNATURES = {
     "plonk_srs_free": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "plonk_srs_size": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_size_t)]),
     "plonk_srs_lookup_bits": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint)]),
+    "plonk_srs_lookup_info": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint), ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]),
     "plonk_msm_lookup_configure": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint, ctypes.c_size_t]),
     "plonk_g1_msm": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]),
     "plonk_msm_configure": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint, ctypes.c_uint]),
     "plonk_prover_create": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint, _u8p, ctypes.c_size_t, c_void_pp]),
     "plonk_prover_destroy": (ctypes.c_int, [ctypes.c_void_p]),
     "plonk_prover_upload_witness": (ctypes.c_int, [ctypes.c_void_p, _u8p, _u8p, ctypes.c_size_t]),
+    "plonk_prover_set_wiring": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]),
+    "plonk_prover_upload_variables": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]),
     "plonk_prover_run": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t]),
     "plonk_prover_download": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]),
     "plonk_prover_challenges": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "plonk_comm_unique_id": (ctypes.c_int, [ctypes.c_void_p]),
+    "plonk_comm_create": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, c_void_pp]),
+    "plonk_comm_destroy": (ctypes.c_int, [ctypes.c_void_p]),
+    "plonk_comm_size": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
+    "plonk_gather_results": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "plonk_comm_max_f64": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double)]),
+    "plonk_comm_barrier": (ctypes.c_int, [ctypes.c_void_p]),
     "plonk_transcript_new": (ctypes.c_int, [_u8p, ctypes.c_size_t, c_void_pp]),
     "plonk_transcript_clone": (ctypes.c_int, [ctypes.c_void_p, c_void_pp]),
     "plonk_transcript_free": (ctypes.c_int, [ctypes.c_void_p]),

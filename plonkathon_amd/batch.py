@@ -6,6 +6,7 @@ the same `Proof` objects.  All five rounds and the Fiat-Shamir transcript run on
 (plonk_prover_* in include/plonk_hip.h), with one host synchronisation per batch.
 """
 import ctypes
+import operator
 
 import numpy as np
 
@@ -26,6 +27,13 @@ class ProofError(AssertionError):
 
 def _le(vals):
     return b"".join(int(v).to_bytes(32, "little") for v in vals)
+
+
+try:  # host-side marshalling helper (csrc/pyext/pypack.c, built by __graft_entry__.build()); same bytes either way
+    from ._pypack import pack_le32 as _pack_mod_r
+except ImportError:  # pragma: no cover - pure-Python equivalent of the packer (not a compute fallback)
+    def _pack_mod_r(vals, modulus):
+        return b"".join([(int(v) % modulus).to_bytes(32, "little") for v in vals])
 
 
 class BatchProver:
@@ -56,6 +64,15 @@ class BatchProver:
         check(self.ctx.L.plonk_prover_create(self.ctx.handle, self._bases.handle, _log2_exact(n), sel,
                                              len(self._public_vars), ctypes.byref(self._h)))
         self._resident = 0
+        # the wiring goes to the device once; a batch is then only the variables' values (V x 32 B per proof)
+        self._getter = None
+        if self._vars:
+            cells = np.ascontiguousarray(self._cell_index, dtype=np.uint32)
+            pubs = np.ascontiguousarray([pos[v] for v in self._public_vars], dtype=np.uint32)
+            check(self.ctx.L.plonk_prover_set_wiring(self._h, cells.ctypes.data, pubs.ctypes.data if len(pubs) else None,
+                                                     len(self._vars)))
+            g = operator.itemgetter(*self._vars)
+            self._getter = g if len(self._vars) > 1 else (lambda w: (g(w),))
 
     def __del__(self):
         try:
@@ -82,8 +99,19 @@ class BatchProver:
         return cols
 
     def upload(self, witnesses):
-        """Stage a batch of witnesses in HBM ([3][B][n] wire columns + public inputs).  Each variable is
-        encoded once and scattered to its wire cells with a numpy gather (a KeyError names a missing variable)."""
+        """Stage a batch of witnesses in HBM: each variable's value is encoded once (V x 32 bytes per proof) and
+        the wire columns A, B, C + public inputs are gathered from them on the device (prover.py:94-103, 57-62).
+        A KeyError names a missing variable."""
+        B = len(witnesses)
+        if self._getter is None:
+            return self._upload_columns(witnesses)
+        get = self._getter
+        enc = b"".join([_pack_mod_r(get(w), R_MOD) for w in witnesses])
+        check(self.ctx.L.plonk_prover_upload_variables(self._h, enc, B))
+        self._resident = B
+
+    def _upload_columns(self, witnesses):
+        """The [3][B][n] column form of the same upload (circuits without variables; plonk_prover_upload_witness)."""
         B = len(witnesses)
         n, V = self.group_order, len(self._vars)
         abc = np.empty((3, B, n, 4), dtype=np.uint64)  # 32-byte little-endian elements as 4 x u64

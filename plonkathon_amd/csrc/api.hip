@@ -13,6 +13,14 @@ void plonk_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+int plonk_use_device(int device) {
+    static thread_local int current = -1;
+    if (current == device) return PLONK_OK;
+    PLONK_CHECK_HIP(hipSetDevice(device));
+    current = device;
+    return PLONK_OK;
+}
+
 int ctx_scratch(plonk_ctx* ctx, int slot, size_t bytes, void** out) {
     if (ctx->scratch_bytes[slot] < bytes) {
         if (ctx->scratch[slot]) {
@@ -63,6 +71,13 @@ int prof_end(plonk_ctx* ctx) {
     return PLONK_OK;
 }
 
+uint64_t plonk_fnv1a64(const void* data, size_t n) {
+    const uint8_t* p = (const uint8_t*)data;
+    uint64_t h = 0xcbf29ce484222325ull;
+    for (size_t i = 0; i < n; i++) h = (h ^ p[i]) * 0x100000001b3ull;
+    return h;
+}
+
 static Fr fr_from_le32(const uint8_t* b) {
     Fr a;
     memcpy(a.v, b, 32);
@@ -108,7 +123,7 @@ int plonk_ctx_create(int device, plonk_ctx** out_ctx) {
     int n = 0;
     PLONK_CHECK_HIP(hipGetDeviceCount(&n));
     PLONK_REQUIRE(device >= 0 && device < n, PLONK_ERR_ARG, "device %d out of range (%d visible)", device, n);
-    PLONK_CHECK_HIP(hipSetDevice(device));
+    PLONK_TRY(plonk_use_device(device));
     plonk_ctx* ctx = new plonk_ctx();
     ctx->device = device;
     PLONK_CHECK_HIP(hipStreamCreate(&ctx->stream));
@@ -120,7 +135,7 @@ int plonk_ctx_create(int device, plonk_ctx** out_ctx) {
 
 int plonk_ctx_destroy(plonk_ctx* ctx) {
     if (!ctx) return PLONK_OK;
-    hipSetDevice(ctx->device);
+    plonk_use_device(ctx->device);
     hipStreamSynchronize(ctx->stream);
     for (void* p : ctx->owned) hipFree(p);
     for (auto& kv : ctx->power_tables) hipFree(kv.second);
@@ -137,12 +152,14 @@ int plonk_ctx_destroy(plonk_ctx* ctx) {
 
 int plonk_ctx_sync(plonk_ctx* ctx) {
     PLONK_REQUIRE(ctx, PLONK_ERR_ARG, "ctx is NULL");
+    PLONK_ENTER(ctx);
     PLONK_CHECK_HIP(hipStreamSynchronize(ctx->stream));
     return PLONK_OK;
 }
 
 int plonk_ctx_device_name(plonk_ctx* ctx, char* buf, size_t buf_len) {
     PLONK_REQUIRE(ctx && buf && buf_len, PLONK_ERR_ARG, "bad argument");
+    PLONK_ENTER(ctx);
     hipDeviceProp_t prop;
     PLONK_CHECK_HIP(hipGetDeviceProperties(&prop, ctx->device));
     snprintf(buf, buf_len, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
@@ -152,6 +169,7 @@ int plonk_ctx_device_name(plonk_ctx* ctx, char* buf, size_t buf_len) {
 // ---- memory ------------------------------------------------------------------------------------
 int plonk_mem_alloc(plonk_ctx* ctx, size_t bytes, void** out_dptr) {
     PLONK_REQUIRE(ctx && out_dptr, PLONK_ERR_ARG, "bad argument");
+    PLONK_ENTER(ctx);
     void* p = nullptr;
     if (hipMalloc(&p, bytes ? bytes : 32) != hipSuccess) {
         plonk_set_error("hipMalloc(%zu) failed", bytes);
@@ -162,11 +180,13 @@ int plonk_mem_alloc(plonk_ctx* ctx, size_t bytes, void** out_dptr) {
 }
 int plonk_mem_free(plonk_ctx* ctx, void* dptr) {
     PLONK_REQUIRE(ctx, PLONK_ERR_ARG, "ctx is NULL");
+    PLONK_ENTER(ctx);
     if (dptr) PLONK_CHECK_HIP(hipFree(dptr));
     return PLONK_OK;
 }
 int plonk_mem_h2d(plonk_ctx* ctx, void* d_dst, const void* h_src, size_t bytes) {
     PLONK_REQUIRE(ctx && (bytes == 0 || (d_dst && h_src)), PLONK_ERR_ARG, "bad argument");
+    PLONK_ENTER(ctx);
     if (!bytes) return PLONK_OK;
     PLONK_CHECK_HIP(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
     PLONK_CHECK_HIP(hipStreamSynchronize(ctx->stream));  // the caller's buffer is not retained
@@ -174,6 +194,7 @@ int plonk_mem_h2d(plonk_ctx* ctx, void* d_dst, const void* h_src, size_t bytes) 
 }
 int plonk_mem_d2h(plonk_ctx* ctx, void* h_dst, const void* d_src, size_t bytes) {
     PLONK_REQUIRE(ctx && (bytes == 0 || (h_dst && d_src)), PLONK_ERR_ARG, "bad argument");
+    PLONK_ENTER(ctx);
     if (!bytes) return PLONK_OK;
     PLONK_CHECK_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     PLONK_CHECK_HIP(hipStreamSynchronize(ctx->stream));
@@ -181,12 +202,14 @@ int plonk_mem_d2h(plonk_ctx* ctx, void* h_dst, const void* d_src, size_t bytes) 
 }
 int plonk_mem_d2d(plonk_ctx* ctx, void* d_dst, const void* d_src, size_t bytes) {
     PLONK_REQUIRE(ctx && (bytes == 0 || (d_dst && d_src)), PLONK_ERR_ARG, "bad argument");
+    PLONK_ENTER(ctx);
     if (!bytes) return PLONK_OK;
     PLONK_CHECK_HIP(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
     return PLONK_OK;
 }
 int plonk_mem_zero(plonk_ctx* ctx, void* d_dst, size_t bytes) {
     PLONK_REQUIRE(ctx && (bytes == 0 || d_dst), PLONK_ERR_ARG, "bad argument");
+    PLONK_ENTER(ctx);
     if (!bytes) return PLONK_OK;
     PLONK_CHECK_HIP(hipMemsetAsync(d_dst, 0, bytes, ctx->stream));
     return PLONK_OK;
@@ -195,6 +218,7 @@ int plonk_mem_zero(plonk_ctx* ctx, void* d_dst, size_t bytes) {
 // ---- Fr vectors --------------------------------------------------------------------------------
 int plonk_fr_upload(plonk_ctx* ctx, void* d_dst, const uint8_t* h_src_le32, size_t count) {
     PLONK_REQUIRE(ctx && (count == 0 || (d_dst && h_src_le32)), PLONK_ERR_ARG, "bad argument");
+    PLONK_ENTER(ctx);
     if (!count) return PLONK_OK;
     for (size_t i = 0; i < count; i++)
         PLONK_REQUIRE(le32_below_modulus(h_src_le32 + 32 * i, false), PLONK_ERR_ARG,
@@ -207,6 +231,7 @@ int plonk_fr_upload(plonk_ctx* ctx, void* d_dst, const uint8_t* h_src_le32, size
 
 int plonk_fr_download(plonk_ctx* ctx, uint8_t* h_dst_le32, const void* d_src, size_t count) {
     PLONK_REQUIRE(ctx && (count == 0 || (h_dst_le32 && d_src)), PLONK_ERR_ARG, "bad argument");
+    PLONK_ENTER(ctx);
     if (!count) return PLONK_OK;
     void* tmp;
     PLONK_TRY(ctx_scratch(ctx, 3, count * 32, &tmp));
@@ -219,6 +244,7 @@ int plonk_fr_download(plonk_ctx* ctx, uint8_t* h_dst_le32, const void* d_src, si
 // ---- NTT family --------------------------------------------------------------------------------
 int plonk_ntt_configure(plonk_ctx* ctx, unsigned tile_log, unsigned single_pass_log, unsigned radix_log) {
     PLONK_REQUIRE(ctx, PLONK_ERR_ARG, "ctx is NULL");
+    PLONK_ENTER(ctx);
     if (!tile_log) tile_log = 12;
     if (!single_pass_log) single_pass_log = 11;
     if (!radix_log) radix_log = 10;
@@ -233,6 +259,7 @@ int plonk_ntt_configure(plonk_ctx* ctx, unsigned tile_log, unsigned single_pass_
 
 int plonk_ntt_select_kernel(plonk_ctx* ctx, unsigned kind) {
     PLONK_REQUIRE(ctx, PLONK_ERR_ARG, "ctx is NULL");
+    PLONK_ENTER(ctx);
     PLONK_REQUIRE(kind <= 2, PLONK_ERR_ARG, "kernel kind must be 0 (auto), 1 (radix-2 stages) or 2 (Stockham radix-8)");
     ctx->ntt_kind = kind;
     return PLONK_OK;
@@ -240,6 +267,7 @@ int plonk_ntt_select_kernel(plonk_ctx* ctx, unsigned kind) {
 
 int plonk_fr_ntt(plonk_ctx* ctx, const void* d_in, void* d_out, unsigned log_n, int inverse, size_t batch) {
     PLONK_REQUIRE(ctx && d_in && d_out, PLONK_ERR_ARG, "bad argument");
+    PLONK_ENTER(ctx);
     const size_t N = (size_t)1 << log_n;
     return ntt_run(ctx, (const Fr*)d_in, (Fr*)d_out, log_n, inverse != 0, batch, N, N, N, nullptr, nullptr, inverse != 0);
 }
@@ -271,6 +299,7 @@ static int get_power_table(plonk_ctx* ctx, const Fr& base, const Fr& first, size
 int plonk_fr_coset_ntt_from_coeffs(plonk_ctx* ctx, const void* d_coeffs, void* d_out, unsigned log_n,
                                    unsigned log_expand, const uint8_t offset_le32[32], size_t batch) {
     PLONK_REQUIRE(ctx && d_coeffs && d_out && offset_le32, PLONK_ERR_ARG, "bad argument");
+    PLONK_ENTER(ctx);
     PLONK_REQUIRE(le32_below_modulus(offset_le32, false), PLONK_ERR_ARG, "offset is not a canonical Fr value");
     const size_t n = (size_t)1 << log_n, big = n << log_expand;
     const Fr* pw;
@@ -282,6 +311,7 @@ int plonk_fr_coset_ntt_from_coeffs(plonk_ctx* ctx, const void* d_coeffs, void* d
 int plonk_fr_coset_extend(plonk_ctx* ctx, const void* d_in, void* d_out, unsigned log_n,
                           const uint8_t offset_le32[32], size_t batch) {
     PLONK_REQUIRE(ctx && d_in && d_out && offset_le32, PLONK_ERR_ARG, "bad argument");
+    PLONK_ENTER(ctx);
     const size_t n = (size_t)1 << log_n;
     void* coeffs;
     PLONK_TRY(ctx_scratch(ctx, 2, batch * n * sizeof(Fr), &coeffs));
@@ -293,6 +323,7 @@ int plonk_fr_coset_extend(plonk_ctx* ctx, const void* d_in, void* d_out, unsigne
 int plonk_fr_coset_to_coeffs(plonk_ctx* ctx, const void* d_in, void* d_out, unsigned log_m,
                              const uint8_t offset_le32[32], size_t batch) {
     PLONK_REQUIRE(ctx && d_in && d_out && offset_le32, PLONK_ERR_ARG, "bad argument");
+    PLONK_ENTER(ctx);
     PLONK_REQUIRE(le32_below_modulus(offset_le32, false), PLONK_ERR_ARG, "offset is not a canonical Fr value");
     const size_t M = (size_t)1 << log_m;
     // poly.py:172-176 — ifft, then v_i * (1/offset)^i; the 1/M of the ifft is folded into the table
@@ -309,6 +340,7 @@ int plonk_fr_coset_to_coeffs(plonk_ctx* ctx, const void* d_in, void* d_out, unsi
 // ---- pointwise ---------------------------------------------------------------------------------
 int plonk_fr_pointwise(plonk_ctx* ctx, int op, const void* d_a, const void* d_b, void* d_out, size_t count) {
     PLONK_REQUIRE(ctx && (count == 0 || (d_a && d_b && d_out)), PLONK_ERR_ARG, "bad argument");
+    PLONK_ENTER(ctx);
     PLONK_REQUIRE(op >= PLONK_OP_ADD && op <= PLONK_OP_DIV, PLONK_ERR_ARG, "unknown pointwise op %d", op);
     if (op == PLONK_OP_DIV) {
         void* inv;
@@ -322,6 +354,7 @@ int plonk_fr_pointwise(plonk_ctx* ctx, int op, const void* d_a, const void* d_b,
 int plonk_fr_scalar_op(plonk_ctx* ctx, int op, const void* d_a, const uint8_t scalar_le32[32], void* d_out,
                        size_t count, int constant_term_only) {
     PLONK_REQUIRE(ctx && scalar_le32 && (count == 0 || (d_a && d_out)), PLONK_ERR_ARG, "bad argument");
+    PLONK_ENTER(ctx);
     PLONK_REQUIRE(op >= PLONK_OP_ADD && op <= PLONK_OP_DIV, PLONK_ERR_ARG, "unknown scalar op %d", op);
     PLONK_REQUIRE(le32_below_modulus(scalar_le32, false), PLONK_ERR_ARG, "scalar is not a canonical Fr value");
     Fr s = fr_from_le32(scalar_le32);
@@ -334,18 +367,21 @@ int plonk_fr_scalar_op(plonk_ctx* ctx, int op, const void* d_a, const uint8_t sc
 
 int plonk_fr_rotate(plonk_ctx* ctx, const void* d_in, void* d_out, size_t count, size_t shift) {
     PLONK_REQUIRE(ctx && d_in && d_out && d_in != d_out, PLONK_ERR_ARG, "bad argument (rotate is out-of-place)");
+    PLONK_ENTER(ctx);
     PLONK_REQUIRE(shift < count, PLONK_ERR_ARG, "shift %zu must be < length %zu", shift, count);
     return k_fr_rotate(ctx, (const Fr*)d_in, (Fr*)d_out, count, shift, 1);
 }
 
 int plonk_fr_batch_inverse(plonk_ctx* ctx, const void* d_in, void* d_out, size_t count) {
     PLONK_REQUIRE(ctx && (count == 0 || (d_in && d_out)), PLONK_ERR_ARG, "bad argument");
+    PLONK_ENTER(ctx);
     return k_fr_batch_inverse(ctx, (const Fr*)d_in, (Fr*)d_out, count);
 }
 
 int plonk_fr_barycentric(plonk_ctx* ctx, const void* d_vals, unsigned log_n, const uint8_t x_le32[32],
                          uint8_t out_le32[32]) {
     PLONK_REQUIRE(ctx && d_vals && x_le32 && out_le32, PLONK_ERR_ARG, "bad argument");
+    PLONK_ENTER(ctx);
     PLONK_REQUIRE(log_n <= PLONK_FR_TWO_ADICITY, PLONK_ERR_ARG, "size 2^%u exceeds the 2-adicity of Fr", log_n);
     PLONK_REQUIRE(le32_below_modulus(x_le32, false), PLONK_ERR_ARG, "x is not a canonical Fr value");
     const Fr* roots;
@@ -370,6 +406,7 @@ int plonk_fr_barycentric(plonk_ctx* ctx, const void* d_vals, unsigned log_n, con
 static int srs_alloc(plonk_ctx* ctx, size_t n_points, plonk_srs** out) {
     plonk_srs* s = new plonk_srs();
     s->n_points = n_points;
+    s->device = ctx->device;
     void* p = nullptr;
     if (hipMalloc(&p, n_points * sizeof(G1Affine)) != hipSuccess) {
         delete s;
@@ -384,6 +421,7 @@ static int srs_alloc(plonk_ctx* ctx, size_t n_points, plonk_srs** out) {
 
 int plonk_srs_load_ptau(plonk_ctx* ctx, const uint8_t* g1_mont_le, size_t n_points, plonk_srs** out_srs) {
     PLONK_REQUIRE(ctx && g1_mont_le && out_srs && n_points, PLONK_ERR_ARG, "bad argument");
+    PLONK_ENTER(ctx);
     for (size_t i = 0; i < 2 * n_points; i++)  // setup.py:36 `assert max(values) < b.field_modulus`
         PLONK_REQUIRE(le32_below_modulus(g1_mont_le + 32 * i, true), PLONK_ERR_ARG,
                       "SRS coordinate %zu is >= the BN254 base-field modulus", i);
@@ -399,12 +437,14 @@ int plonk_srs_load_ptau(plonk_ctx* ctx, const uint8_t* g1_mont_le, size_t n_poin
     }
     PLONK_CHECK_HIP(hipStreamSynchronize(ctx->stream));
     s->fixed = true;
+    s->content_key = plonk_fnv1a64(g1_mont_le, n_points * 64);
     *out_srs = s;
     return PLONK_OK;
 }
 
 int plonk_srs_load_affine(plonk_ctx* ctx, const uint8_t* xy_le, size_t n_points, plonk_srs** out_srs) {
     PLONK_REQUIRE(ctx && xy_le && out_srs && n_points, PLONK_ERR_ARG, "bad argument");
+    PLONK_ENTER(ctx);
     std::vector<Fq> host(2 * n_points);
     for (size_t i = 0; i < 2 * n_points; i++) {
         PLONK_REQUIRE(le32_below_modulus(xy_le + 32 * i, true), PLONK_ERR_ARG,
@@ -417,17 +457,20 @@ int plonk_srs_load_affine(plonk_ctx* ctx, const uint8_t* xy_le, size_t n_points,
     PLONK_TRY(srs_alloc(ctx, n_points, &s));
     PLONK_CHECK_HIP(hipMemcpyAsync(s->bases, host.data(), n_points * 64, hipMemcpyHostToDevice, ctx->stream));
     PLONK_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    s->content_key = plonk_fnv1a64(xy_le, n_points * 64) ^ 0x9e3779b97f4a7c15ull;  // canonical bytes: a different key space
     *out_srs = s;
     return PLONK_OK;
 }
 
 int plonk_srs_free(plonk_ctx* ctx, plonk_srs* srs) {
     PLONK_REQUIRE(ctx, PLONK_ERR_ARG, "ctx is NULL");
+    PLONK_ENTER(ctx);
     if (!srs) return PLONK_OK;
     PLONK_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    for (auto& kv : srs->lagrange) plonk_srs_free(ctx, kv.second);
     if (srs->bases) hipFree(srs->bases);
     if (srs->table) hipFree(srs->table);
-    if (srs->lookup) hipFree(srs->lookup);
+    msm_srs_release(srs);  // the lookup table is shared: freed with its last user
     delete srs;
     return PLONK_OK;
 }
@@ -440,6 +483,7 @@ int plonk_srs_size(const plonk_srs* srs, size_t* out_n) {
 
 int plonk_msm_configure(plonk_ctx* ctx, unsigned window_bits, unsigned groups) {
     PLONK_REQUIRE(ctx, PLONK_ERR_ARG, "ctx is NULL");
+    PLONK_ENTER(ctx);
     PLONK_REQUIRE(window_bits == 0 || (window_bits >= 2 && window_bits <= 13), PLONK_ERR_ARG,
                   "window_bits must be 0 (default) or in [2, 13]");
     ctx->msm_window_bits = window_bits;
@@ -453,8 +497,14 @@ int plonk_srs_lookup_bits(const plonk_srs* srs, unsigned* out_bits) {
     return PLONK_OK;
 }
 
+int plonk_srs_lookup_info(const plonk_srs* srs, unsigned* out_bits, size_t* out_bytes, double* out_build_s, int* out_sharers) {
+    PLONK_REQUIRE(srs && out_bits && out_bytes && out_build_s && out_sharers, PLONK_ERR_ARG, "bad argument");
+    return msm_lookup_info(srs, out_bits, out_bytes, out_build_s, out_sharers);
+}
+
 int plonk_msm_lookup_configure(plonk_ctx* ctx, int mode, unsigned window_bits, size_t budget_bytes) {
     PLONK_REQUIRE(ctx, PLONK_ERR_ARG, "ctx is NULL");
+    PLONK_ENTER(ctx);
     PLONK_REQUIRE(mode >= 0 && mode <= 2, PLONK_ERR_ARG, "mode must be 0 (auto), 1 (off) or 2 (force)");
     PLONK_REQUIRE(window_bits == 0 || (window_bits >= 2 && window_bits <= 17), PLONK_ERR_ARG,
                   "window_bits must be 0 (auto) or in [2, 17]");
@@ -468,6 +518,7 @@ int plonk_msm_lookup_configure(plonk_ctx* ctx, int mode, unsigned window_bits, s
 int plonk_g1_msm(plonk_ctx* ctx, plonk_srs* srs, const void* d_scalars, size_t n, size_t batch,
                  size_t scalar_stride, uint8_t* h_out_xy_le, uint8_t* h_out_is_identity) {
     PLONK_REQUIRE(ctx && srs && d_scalars && h_out_xy_le && h_out_is_identity, PLONK_ERR_ARG, "bad argument");
+    PLONK_ENTER(ctx);
     if (!batch) return PLONK_OK;
     void* res;
     PLONK_TRY(ctx_scratch(ctx, 2, batch * 64 + batch + 64, &res));
@@ -483,12 +534,14 @@ int plonk_g1_msm(plonk_ctx* ctx, plonk_srs* srs, const void* d_scalars, size_t n
 // ---- per-kernel profiling ------------------------------------------------------------------------
 int plonk_profile_enable(plonk_ctx* ctx, int on) {
     PLONK_REQUIRE(ctx, PLONK_ERR_ARG, "ctx is NULL");
+    PLONK_ENTER(ctx);
     ctx->profiling = on != 0;
     return PLONK_OK;
 }
 
 int plonk_profile_read(plonk_ctx* ctx, const char* kernel, double* total_ms, uint64_t* launches, double* algo_bytes) {
     PLONK_REQUIRE(ctx && kernel && total_ms && launches && algo_bytes, PLONK_ERR_ARG, "bad argument");
+    PLONK_ENTER(ctx);
     PLONK_CHECK_HIP(hipStreamSynchronize(ctx->stream));
     double ms = 0, bytes = 0;
     uint64_t n = 0;
@@ -508,6 +561,7 @@ int plonk_profile_read(plonk_ctx* ctx, const char* kernel, double* total_ms, uin
 
 int plonk_profile_reset(plonk_ctx* ctx) {
     PLONK_REQUIRE(ctx, PLONK_ERR_ARG, "ctx is NULL");
+    PLONK_ENTER(ctx);
     PLONK_CHECK_HIP(hipStreamSynchronize(ctx->stream));
     for (auto& r : ctx->prof) {
         ctx->event_pool.push_back(r.a);
@@ -520,11 +574,13 @@ int plonk_profile_reset(plonk_ctx* ctx) {
 // ---- timing ------------------------------------------------------------------------------------
 int plonk_timer_start(plonk_ctx* ctx) {
     PLONK_REQUIRE(ctx, PLONK_ERR_ARG, "ctx is NULL");
+    PLONK_ENTER(ctx);
     PLONK_CHECK_HIP(hipEventRecord(ctx->ev_a, ctx->stream));
     return PLONK_OK;
 }
 int plonk_timer_stop_ms(plonk_ctx* ctx, float* out_ms) {
     PLONK_REQUIRE(ctx && out_ms, PLONK_ERR_ARG, "bad argument");
+    PLONK_ENTER(ctx);
     PLONK_CHECK_HIP(hipEventRecord(ctx->ev_b, ctx->stream));
     PLONK_CHECK_HIP(hipEventSynchronize(ctx->ev_b));
     PLONK_CHECK_HIP(hipEventElapsedTime(out_ms, ctx->ev_a, ctx->ev_b));

@@ -1,0 +1,169 @@
+// comm.hip — the one collective on the path: gathering the finished proofs (768 bytes each: 9 affine G1 +
+// 6 Fr) of independently proving GPUs, RCCL over xGMI (SURVEY.md §8(b) `plonk_gather_results`, §8(e)).
+//
+// The reference is a single Python process and has no counterpart; proofs shard by index across the GPUs of a
+// node with no data-path exchange, so this all-gather (384 KiB for 512 proofs, latency-bound) plus a barrier and
+// a max-reduction for the benchmark clock are everything that ever crosses xGMI.  One process per GPU; rank 0
+// draws the ncclUniqueId (plonk_comm_unique_id) and hands its 128 bytes to the other ranks out of band
+// (plonkathon_amd/distributed.py does it over a loopback socket).  librccl is dlopen'ed on first use so that
+// single-GPU users never load it.
+#include <dlfcn.h>
+#include <string.h>
+
+#include <rccl/rccl.h>  // types and enums only: every call goes through the dlsym table below
+
+#include "plonk_internal.h"
+
+namespace {
+struct Rccl {
+    void* handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+Rccl g_rccl;
+
+int rccl_load() {
+    if (g_rccl.handle) return PLONK_OK;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void* h = nullptr;
+    for (const char* nm : names)
+        if ((h = dlopen(nm, RTLD_NOW | RTLD_LOCAL))) break;
+    PLONK_REQUIRE(h, PLONK_ERR_STATE, "librccl could not be loaded: %s", dlerror());
+#define PLONK_RCCL_SYM(field, sym)                                                        \
+    *(void**)(&g_rccl.field) = dlsym(h, sym);                                             \
+    PLONK_REQUIRE(g_rccl.field, PLONK_ERR_STATE, "librccl does not export %s", sym)
+    PLONK_RCCL_SYM(GetUniqueId, "ncclGetUniqueId");
+    PLONK_RCCL_SYM(CommInitRank, "ncclCommInitRank");
+    PLONK_RCCL_SYM(CommDestroy, "ncclCommDestroy");
+    PLONK_RCCL_SYM(AllGather, "ncclAllGather");
+    PLONK_RCCL_SYM(AllReduce, "ncclAllReduce");
+    PLONK_RCCL_SYM(GetErrorString, "ncclGetErrorString");
+#undef PLONK_RCCL_SYM
+    g_rccl.handle = h;
+    return PLONK_OK;
+}
+}  // namespace
+
+#define PLONK_CHECK_RCCL(expr)                                                                              \
+    do {                                                                                                    \
+        ncclResult_t r_ = (expr);                                                                           \
+        if (r_ != ncclSuccess) {                                                                            \
+            plonk_set_error("%s failed: %s (%s:%d)", #expr, g_rccl.GetErrorString(r_), __FILE__, __LINE__); \
+            return PLONK_ERR_HIP;                                                                           \
+        }                                                                                                   \
+    } while (0)
+
+struct plonk_comm {
+    plonk_ctx* ctx = nullptr;
+    ncclComm_t comm = nullptr;
+    int rank = 0, world = 1;
+    uint8_t* d_buf = nullptr;  // [send | recv] staging in HBM
+    size_t cap = 0;
+};
+
+static int comm_staging(plonk_comm* c, size_t bytes) {
+    if (c->cap >= bytes) return PLONK_OK;
+    if (c->d_buf) {
+        PLONK_CHECK_HIP(hipStreamSynchronize(c->ctx->stream));
+        hipFree(c->d_buf);
+        c->d_buf = nullptr;
+        c->cap = 0;
+    }
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess) {
+        plonk_set_error("hipMalloc of %zu gather-staging bytes failed", bytes);
+        return PLONK_ERR_NOMEM;
+    }
+    c->d_buf = (uint8_t*)p;
+    c->cap = bytes;
+    return PLONK_OK;
+}
+
+extern "C" {
+
+int plonk_comm_unique_id(uint8_t out_id[PLONK_COMM_ID_BYTES]) {
+    PLONK_REQUIRE(out_id, PLONK_ERR_ARG, "out_id is NULL");
+    static_assert(sizeof(ncclUniqueId) == PLONK_COMM_ID_BYTES, "ncclUniqueId size");
+    PLONK_TRY(rccl_load());
+    ncclUniqueId id;
+    PLONK_CHECK_RCCL(g_rccl.GetUniqueId(&id));
+    memcpy(out_id, &id, sizeof id);
+    return PLONK_OK;
+}
+
+int plonk_comm_create(plonk_ctx* ctx, const uint8_t id_bytes[PLONK_COMM_ID_BYTES], int rank, int world, plonk_comm** out) {
+    PLONK_REQUIRE(ctx && id_bytes && out && world >= 1 && rank >= 0 && rank < world, PLONK_ERR_ARG, "bad argument");
+    PLONK_ENTER(ctx);
+    PLONK_TRY(rccl_load());
+    ncclUniqueId id;
+    memcpy(&id, id_bytes, sizeof id);
+    plonk_comm* c = new plonk_comm();
+    c->ctx = ctx;
+    c->rank = rank;
+    c->world = world;
+    ncclResult_t r = g_rccl.CommInitRank(&c->comm, world, id, rank);
+    if (r != ncclSuccess) {
+        plonk_set_error("ncclCommInitRank(rank %d of %d, device %d) failed: %s", rank, world, ctx->device, g_rccl.GetErrorString(r));
+        delete c;
+        return PLONK_ERR_HIP;
+    }
+    *out = c;
+    return PLONK_OK;
+}
+
+int plonk_comm_destroy(plonk_comm* c) {
+    if (!c) return PLONK_OK;
+    plonk_use_device(c->ctx->device);
+    hipStreamSynchronize(c->ctx->stream);
+    if (c->comm) g_rccl.CommDestroy(c->comm);
+    if (c->d_buf) hipFree(c->d_buf);
+    delete c;
+    return PLONK_OK;
+}
+
+int plonk_comm_size(const plonk_comm* c, int* out_rank, int* out_world) {
+    PLONK_REQUIRE(c && out_rank && out_world, PLONK_ERR_ARG, "bad argument");
+    *out_rank = c->rank;
+    *out_world = c->world;
+    return PLONK_OK;
+}
+
+// h_recv[r * bytes_per_rank ..] = rank r's h_send, for every r: one ncclAllGather of uint8 on the context's stream
+int plonk_gather_results(plonk_comm* c, const uint8_t* h_send, size_t bytes_per_rank, uint8_t* h_recv) {
+    PLONK_REQUIRE(c && h_send && h_recv && bytes_per_rank, PLONK_ERR_ARG, "bad argument");
+    PLONK_ENTER(c->ctx);
+    const size_t total = bytes_per_rank * (size_t)c->world;
+    PLONK_TRY(comm_staging(c, bytes_per_rank + total));
+    hipStream_t s = c->ctx->stream;
+    uint8_t *d_send = c->d_buf, *d_recv = c->d_buf + bytes_per_rank;
+    PLONK_CHECK_HIP(hipMemcpyAsync(d_send, h_send, bytes_per_rank, hipMemcpyHostToDevice, s));
+    PLONK_CHECK_RCCL(g_rccl.AllGather(d_send, d_recv, bytes_per_rank, ncclUint8, c->comm, s));
+    PLONK_CHECK_HIP(hipMemcpyAsync(h_recv, d_recv, total, hipMemcpyDeviceToHost, s));
+    PLONK_CHECK_HIP(hipStreamSynchronize(s));
+    return PLONK_OK;
+}
+
+// *inout = max over ranks (bench.py: the step time is the slowest rank's); also serves as the barrier
+int plonk_comm_max_f64(plonk_comm* c, double* inout) {
+    PLONK_REQUIRE(c && inout, PLONK_ERR_ARG, "bad argument");
+    PLONK_ENTER(c->ctx);
+    PLONK_TRY(comm_staging(c, 64));
+    hipStream_t s = c->ctx->stream;
+    double* d = (double*)c->d_buf;
+    PLONK_CHECK_HIP(hipMemcpyAsync(d, inout, sizeof(double), hipMemcpyHostToDevice, s));
+    PLONK_CHECK_RCCL(g_rccl.AllReduce(d, d, 1, ncclDouble, ncclMax, c->comm, s));
+    PLONK_CHECK_HIP(hipMemcpyAsync(inout, d, sizeof(double), hipMemcpyDeviceToHost, s));
+    PLONK_CHECK_HIP(hipStreamSynchronize(s));
+    return PLONK_OK;
+}
+
+int plonk_comm_barrier(plonk_comm* c) {
+    double zero = 0;
+    return plonk_comm_max_f64(c, &zero);
+}
+
+}  // extern "C"

@@ -35,7 +35,10 @@
 //
 // Both inner loops keep the accumulator as 9 x 29-bit limbs with lazy reductions (fpl.h, g1l_madd_fast) and run
 // at the rate of a bare mixed-addition loop (13.4 G additions/s chip-wide): the kernels are integer-ALU bound.
+#include <stdlib.h>
 #include <string.h>
+
+#include <chrono>
 
 #include "plonk_internal.h"
 
@@ -45,6 +48,10 @@
 #ifndef MSM_ACC_WAVES
 #define MSM_ACC_WAVES 4  // waves per SIMD the accumulate kernel is compiled for (register budget 512 / waves)
 #endif
+// Additions the fast formulas cannot take (accumulator == +-addend: duplicate bases, or the 2^-25 false positive
+// of the cheap filter) are deferred to a per-MSM list of this many slots.  An MSM that overflows it (pathological
+// input: many equal bases) is recomputed from scratch with the general formulas by msm_*_slow_kernel.
+#define MSM_DEFER_CAP 256
 
 // ------------------------------------------------------------------------------------------------
 // Window table: table[w*n + i] = 2^(c*w) * bases[i], affine.
@@ -259,7 +266,7 @@ __global__ void __launch_bounds__(MSM_BLOCK, MSM_ACC_WAVES) msm_accumulate_kerne
     auto accumulate = [&](const Fq& x, const Fq& y, uint32_t en) {
         if (!g1l_madd_fast(run, x, y) && !(fp_is_zero(x) && fp_is_zero(y))) {
             const uint32_t slot = atomicAdd(n_deferred + m, 1u);
-            deferred[(size_t)m * entry_stride + slot] = MsmDeferred{k, en};
+            if (slot < MSM_DEFER_CAP) deferred[(size_t)m * MSM_DEFER_CAP + slot] = MsmDeferred{k, en};
         }
     };
     auto step = [&](uint32_t e, uint32_t en) {
@@ -306,7 +313,9 @@ __global__ void __launch_bounds__(256) msm_bucket_reduce_kernel(const uint32_t* 
     const G1Xyzz* pc = pieces + (size_t)m * piece_stride - 1;  // pc[t + k] = piece of lane t for bucket k
     G1Xyzz run = g1_xyzz_identity(), tot = g1_xyzz_identity();
     const MsmDeferred* dfr = deferred + (size_t)m * deferred_stride;
-    const uint32_t n_dfr = n_deferred[m];  // additions msm_accumulate_kernel left to the general formulas (normally 0)
+    // additions msm_accumulate_kernel left to the general formulas (normally 0); past the cap the MSM is redone by
+    // msm_bucket_slow_kernel, which overwrites this kernel's output
+    const uint32_t n_dfr = n_deferred[m] < MSM_DEFER_CAP ? n_deferred[m] : MSM_DEFER_CAP;
     uint32_t s_hi = gst[b_hi + 1];
     for (unsigned k = b_hi; k > b_lo; k--) {
         const uint32_t s_lo = gst[k];
@@ -421,7 +430,7 @@ __global__ void __launch_bounds__(MSM_BLOCK, MSM_ACC_WAVES) msm_lookup_kernel(
             if (d < 0) y = fp_neg(y);
             if (!g1l_madd_fast(run, x, y) && !(fp_is_zero(x) && fp_is_zero(y))) {  // see msm_accumulate_kernel
                 const uint32_t slot = atomicAdd(n_deferred + m, 1u);
-                deferred[(size_t)m * deferred_stride + slot] = MsmDeferred{item, (uint32_t)d};
+                if (slot < MSM_DEFER_CAP) deferred[(size_t)m * deferred_stride + slot] = MsmDeferred{item, (uint32_t)d};
             }
         }
         if (++w == W) {
@@ -453,7 +462,7 @@ __global__ void __launch_bounds__(64) msm_lookup_finalize_kernel(const G1Xyzz* p
     for (size_t m = (size_t)blockIdx.x * blockDim.x + threadIdx.x; m < M; m += (size_t)gridDim.x * blockDim.x) {
         G1Xyzz acc = partial[m * G];
         for (unsigned g = 1; g < G; g++) g1_add(acc, partial[m * G + g]);
-        const uint32_t nd = n_deferred[m];
+        const uint32_t nd = n_deferred[m] < MSM_DEFER_CAP ? n_deferred[m] : MSM_DEFER_CAP;  // past the cap: msm_lookup_slow_kernel
         for (uint32_t k = 0; k < nd; k++) {
             const MsmDeferred e = deferred[m * deferred_stride + k];
             const uint32_t i = e.bucket / W, w = e.bucket - i * W;  // `bucket` carries the item index here
@@ -471,6 +480,107 @@ __global__ void __launch_bounds__(64) msm_lookup_finalize_kernel(const G1Xyzz* p
         fp_store(out_xy + 2 * m, fp_from_mont(a.x));
         fp_store(out_xy + 2 * m + 1, fp_from_mont(a.y));
     }
+}
+
+// Recovery path (see MSM_DEFER_CAP): MSM m is recomputed with the general addition formulas, which handle every
+// exceptional case (identity, P == Q, P == -Q), and its output overwritten.  One workgroup per MSM; it exits at
+// once unless the MSM overflowed its deferred list, so the launch costs a few microseconds on the normal path.
+// kind 0: lookup table (entry |d| of item (i, w));  kind 1: window table T[w][i] (|d| * T by double-and-add).
+__global__ void __launch_bounds__(256) msm_slow_kernel(int kind, const G1Affine* tab, size_t table_n, unsigned c, unsigned W,
+                                                       const Fr* scalars, size_t n, size_t stride, size_t inner,
+                                                       size_t outer_stride, MsmRecode rc, const uint32_t* n_deferred,
+                                                       Fq* out_xy, uint8_t* flags) {
+    __shared__ G1Xyzz red[256];
+    const unsigned m = blockIdx.x, tid = threadIdx.x;
+    if (n_deferred[m] <= MSM_DEFER_CAP) return;
+    const Fr* sc = scalars + (m % inner) * stride + (m / inner) * outer_stride;
+    G1Xyzz acc = g1_xyzz_identity();
+    for (size_t i = tid; i < n; i += 256) {
+        uint32_t limb[10];
+        msm_recode(sc, i, rc, limb);
+        msm_for_each_digit(limb, c, W, [&](unsigned w, int d) {
+            if (!d) return;
+            const uint32_t ad = d < 0 ? (uint32_t)-d : (uint32_t)d;
+            const G1Affine* src = kind == 0 ? tab + ((((size_t)w * table_n + i) << (c - 1)) + (ad - 1)) : tab + (size_t)w * table_n + i;
+            G1Affine pt;
+            pt.x = fp_load(&src->x);
+            pt.y = fp_load(&src->y);
+            if (d < 0) pt.y = fp_neg(pt.y);
+            if (kind == 0) {
+                g1_madd(acc, pt);
+            } else {
+                G1Xyzz t = g1_xyzz_identity();
+                for (int bit = (int)c - 1; bit >= 0; bit--) {
+                    g1_dbl(t);
+                    if ((ad >> bit) & 1) g1_madd(t, pt);
+                }
+                g1_add(acc, t);
+            }
+        });
+    }
+    red[tid] = acc;
+    __syncthreads();
+    for (unsigned s = 128; s > 0; s >>= 1) {
+        if (tid < s) {
+            G1Xyzz x = red[tid];
+            g1_add(x, red[tid + s]);
+            red[tid] = x;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        G1Affine a = g1_to_affine(red[0]);
+        flags[m] = g1_affine_is_identity(a) ? 1 : 0;
+        fp_store(out_xy + 2 * m, fp_from_mont(a.x));
+        fp_store(out_xy + 2 * m + 1, fp_from_mont(a.y));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Registry of lookup tables: one per (process, device, base set, window bits), shared by every plonk_srs that
+// was loaded from the same bytes — several contexts / streams / BatchProvers of one GPU use ONE table.
+#include <mutex>
+static std::mutex g_lut_mu;
+static std::vector<MsmLookupTable*> g_luts;
+
+static void lut_attach(plonk_srs* srs, MsmLookupTable* t) {  // g_lut_mu held
+    if (srs->shared == t) return;
+    if (srs->shared && --srs->shared->refs == 0) {
+        for (size_t k = 0; k < g_luts.size(); k++)
+            if (g_luts[k] == srs->shared) g_luts.erase(g_luts.begin() + k);
+        hipFree(srs->shared->data);
+        delete srs->shared;
+    }
+    srs->shared = t;
+    srs->lookup = t ? t->data : nullptr;
+    srs->lookup_bits = t ? t->bits : 0;
+    srs->lookup_windows = t ? t->windows : 0;
+    if (t) t->refs++;
+}
+
+// the registered table of this base set with `bits` window bits (0: the one with the most)
+static MsmLookupTable* lut_find(const plonk_srs* srs, unsigned bits) {  // g_lut_mu held
+    MsmLookupTable* best = nullptr;
+    for (MsmLookupTable* t : g_luts) {
+        if (t->device != srs->device || t->key != srs->content_key || t->n_points != srs->n_points) continue;
+        if (bits ? t->bits == bits : (!best || t->bits > best->bits)) best = t;
+    }
+    return best;
+}
+
+void msm_srs_release(plonk_srs* srs) {
+    std::lock_guard<std::mutex> lk(g_lut_mu);
+    lut_attach(srs, nullptr);
+}
+
+int msm_lookup_info(const plonk_srs* srs, unsigned* bits, size_t* bytes, double* build_s, int* sharers) {
+    std::lock_guard<std::mutex> lk(g_lut_mu);
+    const MsmLookupTable* t = srs->shared;
+    *bits = t ? t->bits : 0;
+    *bytes = t ? t->bytes : 0;
+    *build_s = t ? t->build_s : 0;
+    *sharers = t ? t->refs : 0;
+    return PLONK_OK;
 }
 
 static unsigned windows_for(unsigned c) {
@@ -524,7 +634,8 @@ static size_t msm_lookup_bytes(size_t n, unsigned c) {  // table + the XYZZ stag
 }
 
 // Builds srs->lookup for window size c.  PLONK_ERR_NOMEM (nothing allocated, nothing changed) if it does not fit.
-static int msm_lookup_build(plonk_ctx* ctx, plonk_srs* srs, unsigned c) {
+static int msm_lookup_build(plonk_ctx* ctx, plonk_srs* srs, unsigned c) {  // g_lut_mu held
+    const auto t0 = std::chrono::steady_clock::now();
     const unsigned W = windows_for(c);
     const size_t n = srs->n_points, half = (size_t)1 << (c - 1);
     void *wx = nullptr, *wb = nullptr, *tmp = nullptr, *tab = nullptr;
@@ -563,34 +674,50 @@ static int msm_lookup_build(plonk_ctx* ctx, plonk_srs* srs, unsigned c) {
     hipFree(wx);
     hipFree(wb);
     hipFree(tmp);
-    if (srs->lookup) hipFree(srs->lookup);
-    srs->lookup = (G1Affine*)tab;
-    srs->lookup_bits = c;
-    srs->lookup_windows = W;
+    MsmLookupTable* t = new MsmLookupTable();
+    t->device = srs->device;
+    t->key = srs->content_key;
+    t->n_points = n;
+    t->bits = c;
+    t->windows = W;
+    t->data = (G1Affine*)tab;
+    t->bytes = n * W * half * sizeof(G1Affine);
+    t->build_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    g_luts.push_back(t);
+    lut_attach(srs, t);
     return PLONK_OK;
 }
 
-// Decides whether this call runs on the lookup table, building it on first use.
+static size_t msm_default_lookup_budget() {
+    // The table is a memory-for-time trade the CALLER must opt into: 4 GiB by default (c = 11 for 2^11 bases), more
+    // only through plonk_msm_lookup_configure(budget) or PLONK_MSM_TABLE_GB (bench.py asks for the 129 GB c = 17 table).
+    const char* e = getenv("PLONK_MSM_TABLE_GB");
+    if (e && atof(e) > 0) return (size_t)(atof(e) * 1e9);
+    return (size_t)4 << 30;
+}
+
+// Decides whether this call runs on a lookup table: attaches the table another context of this device already
+// built for the same bases, or builds one on first use.
 static bool msm_lookup_prepare(plonk_ctx* ctx, plonk_srs* srs) {
     if (ctx->msm_lookup_mode == 1) return false;
     const unsigned want = ctx->msm_lookup_bits;
+    std::lock_guard<std::mutex> lk(g_lut_mu);
     if (ctx->msm_lookup_mode == 2) {  // forced window size, any base set
-        if (srs->lookup && srs->lookup_bits == want) return true;
+        if (srs->shared && srs->lookup_bits == want) return true;
+        if (MsmLookupTable* t = lut_find(srs, want)) {
+            lut_attach(srs, t);
+            return true;
+        }
         return msm_lookup_build(ctx, srs, want) == PLONK_OK;
     }
     if (!srs->fixed) return false;
-    if (srs->lookup && (!want || want == srs->lookup_bits)) return true;
-    if (srs->lookup_failed) return false;
-    size_t budget = ctx->msm_lookup_budget;
-#ifndef PLONK_EMU
-    if (!budget) {
-        size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-            budget = (size_t)(0.55 * (double)free_b);
-            if (budget > (size_t)160e9) budget = (size_t)160e9;
-        }
+    if (srs->shared && (!want || want == srs->lookup_bits)) return true;
+    if (MsmLookupTable* t = lut_find(srs, want)) {
+        lut_attach(srs, t);
+        return true;
     }
-#endif
+    if (srs->lookup_failed) return false;
+    const size_t budget = ctx->msm_lookup_budget ? ctx->msm_lookup_budget : msm_default_lookup_budget();
     // more windows bits = fewer additions; below 8 bits the table no longer beats the bucket method — which,
     // however, cannot index more than 2^15 bases, so larger base sets accept any table that fits
     const unsigned c_min = want ? want : (srs->n_points > 32768 ? 4 : 8);
@@ -615,7 +742,7 @@ static int msm_run_lookup(plonk_ctx* ctx, plonk_srs* srs, const Fr* d_scalars, s
     while (G > 1 && (size_t)G * MSM_BLOCK * 2 > items) G /= 2;  // at least two additions per lane
     const size_t part_bytes = (M * G * sizeof(G1Xyzz) + 255) & ~(size_t)255;
     const size_t cnt_bytes = (M * 4 + 255) & ~(size_t)255;
-    const size_t dfr_bytes = M * items * sizeof(MsmDeferred);
+    const size_t dfr_bytes = M * MSM_DEFER_CAP * sizeof(MsmDeferred);
     void* s;
     PLONK_TRY(ctx_scratch(ctx, 1, part_bytes + cnt_bytes + dfr_bytes, &s));
     G1Xyzz* partial = (G1Xyzz*)s;
@@ -627,11 +754,13 @@ static int msm_run_lookup(plonk_ctx* ctx, plonk_srs* srs, const Fr* d_scalars, s
     PLONK_TRY(prof_begin(ctx, "msm_lookup", (double)M * (96.0 * (double)n + 64.0)));
     PLONK_LAUNCH(msm_lookup_kernel, dim3((unsigned)(M * G)), dim3(MSM_BLOCK), (size_t)MSM_BLOCK * sizeof(G1Xyzz), ctx->stream,
                  (const G1Affine*)srs->lookup, srs->n_points, c, W, d_scalars, n, stride, inner, outer_stride, rc, G, partial,
-                 deferred, items, n_deferred);
+                 deferred, (size_t)MSM_DEFER_CAP, n_deferred);
     PLONK_TRY(prof_end(ctx));
     PLONK_LAUNCH(msm_lookup_finalize_kernel, dim3((unsigned)((M + 63) / 64)), dim3(64), 0, ctx->stream, (const G1Xyzz*)partial, M, G,
-                 (const G1Affine*)srs->lookup, srs->n_points, c, W, (const MsmDeferred*)deferred, items,
+                 (const G1Affine*)srs->lookup, srs->n_points, c, W, (const MsmDeferred*)deferred, (size_t)MSM_DEFER_CAP,
                  (const uint32_t*)n_deferred, d_out_xy, d_flags);
+    PLONK_LAUNCH(msm_slow_kernel, dim3((unsigned)M), dim3(256), 0, ctx->stream, 0, (const G1Affine*)srs->lookup, srs->n_points, c, W,
+                 d_scalars, n, stride, inner, outer_stride, rc, (const uint32_t*)n_deferred, d_out_xy, d_flags);
     PLONK_CHECK_HIP(hipGetLastError());
     return PLONK_OK;
 }
@@ -663,7 +792,7 @@ int msm_run_device(plonk_ctx* ctx, plonk_srs* srs, const Fr* d_scalars, size_t n
     const size_t st_bytes = (M * (size_t)(K + 2) * 4 + 255) & ~(size_t)255;
     const size_t piece_bytes = (M * piece_stride * sizeof(G1Xyzz) + 255) & ~(size_t)255;
     const size_t cnt_bytes = (M * 4 + 255) & ~(size_t)255;
-    const size_t dfr_bytes = M * entry_stride * sizeof(MsmDeferred);  // worst case: every addition deferred (all bases equal)
+    const size_t dfr_bytes = M * MSM_DEFER_CAP * sizeof(MsmDeferred);  // bounded: an MSM that overflows is redone by msm_slow_kernel
     void* s;
     PLONK_TRY(ctx_scratch(ctx, 1, ent_bytes + st_bytes + piece_bytes + cnt_bytes + dfr_bytes, &s));
     uint32_t* entries = (uint32_t*)s;
@@ -675,11 +804,10 @@ int msm_run_device(plonk_ctx* ctx, plonk_srs* srs, const Fr* d_scalars, size_t n
     MsmRecode rc;
     msm_recode_constant(c, W, &rc);
     const size_t sort_lds = (size_t)(K + 2) * 4;
-    static bool configured = false;
-    if (!configured) {
+    if (!ctx->msm_attr_set) {  // a per-device attribute: tracked per context, not per process
         PLONK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(msm_sort_kernel),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)(128 * 1024)));
-        configured = true;
+        ctx->msm_attr_set = true;
     }
     PLONK_TRY(prof_begin(ctx, "msm_sort", (double)M * 32.0 * (double)n));
     PLONK_LAUNCH(msm_sort_kernel, dim3((unsigned)M), dim3(MSM_BLOCK), sort_lds, ctx->stream, d_scalars, n, stride, inner, outer_stride, c, W, rc,
@@ -694,9 +822,11 @@ int msm_run_device(plonk_ctx* ctx, plonk_srs* srs, const Fr* d_scalars, size_t n
     PLONK_TRY(prof_begin(ctx, "msm_bucket_reduce", (double)M * (double)piece_stride * sizeof(G1Xyzz)));
     PLONK_LAUNCH(msm_bucket_reduce_kernel, dim3((unsigned)M), dim3(red_lanes), (size_t)red_lanes * sizeof(G1Xyzz), ctx->stream,
                  (const uint32_t*)starts, c, G * MSM_BLOCK, (const G1Xyzz*)pieces, piece_stride,
-                 (const G1Affine*)srs->table, srs->n_points, (const MsmDeferred*)deferred, entry_stride, (const uint32_t*)n_deferred,
+                 (const G1Affine*)srs->table, srs->n_points, (const MsmDeferred*)deferred, (size_t)MSM_DEFER_CAP, (const uint32_t*)n_deferred,
                  d_out_xy, d_flags);
     PLONK_TRY(prof_end(ctx));
+    PLONK_LAUNCH(msm_slow_kernel, dim3((unsigned)M), dim3(256), 0, ctx->stream, 1, (const G1Affine*)srs->table, srs->n_points, c, W,
+                 d_scalars, n, stride, inner, outer_stride, rc, (const uint32_t*)n_deferred, d_out_xy, d_flags);
     PLONK_CHECK_HIP(hipGetLastError());
     return PLONK_OK;
 }

@@ -610,13 +610,12 @@ int ntt_run(plonk_ctx* ctx, const Fr* in, Fr* out, unsigned log_n, bool inverse,
         p.tw_in_lds = !stockham || ((32 * t_pad + tw_bytes <= 80 * 1024 || 32 * t_pad > 80 * 1024) && (32 * t_pad + tw_bytes <= 160 * 1024));
         const size_t shmem = 32 * t_pad + (p.tw_in_lds ? tw_bytes : 32);
         const size_t tiles = N / T;
-        static size_t configured = 0;
-        if (shmem > configured) {
+        if (!ctx->ntt_attr_set) {  // a per-device attribute: tracked per context, not per process
             PLONK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ntt_pass_stockham_kernel),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
             PLONK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ntt_pass_radix2_kernel),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
-            configured = 160 * 1024;
+            ctx->ntt_attr_set = true;
         }
         // algorithmic bytes of a size-N transform: 64 * N (read once, write once), split over its passes
         PLONK_TRY(prof_begin(ctx, "ntt_pass", 64.0 * (double)N * (double)batch / (double)P));

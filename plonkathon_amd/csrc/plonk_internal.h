@@ -30,6 +30,15 @@ void plonk_set_error(const char* fmt, ...);
         }                                 \
     } while (0)
 
+// HIP's current device is per thread; every entry point that touches a context makes its device current first
+// (a process may hold contexts on several GPUs).
+int plonk_use_device(int device);
+#define PLONK_ENTER(ctx)                                                  \
+    do {                                                                  \
+        int rc_enter_ = plonk_use_device((ctx)->device);                  \
+        if (rc_enter_ != PLONK_OK) return rc_enter_;                      \
+    } while (0)
+
 #define PLONK_TRY(expr)          \
     do {                         \
         int rc_ = (expr);        \
@@ -43,7 +52,22 @@ struct NttTables {
     std::map<unsigned, Fr*> full;    // w_N^k, k < N                 (barycentric / permutation argument)
 };
 
+// One lookup table per (process, device, base set), shared by every plonk_srs / context / stream that
+// loads the same bases (msm.hip keeps the registry; reference counted, freed with its last plonk_srs).
+struct MsmLookupTable {
+    int device = 0;
+    uint64_t key = 0;        // FNV-1a of the host bytes the bases were loaded from
+    size_t n_points = 0;
+    unsigned bits = 0, windows = 0;
+    G1Affine* data = nullptr;
+    size_t bytes = 0;
+    double build_s = 0;      // wall time of the build (reported by bench.py)
+    int refs = 0;
+};
+
 struct plonk_srs {
+    int device = 0;
+    uint64_t content_key = 0;   // FNV-1a of the loaded bytes: identifies the base set in the lookup-table registry
     size_t n_points = 0;
     G1Affine* bases = nullptr;  // device, Montgomery coordinates (.ptau layout)
     unsigned window_bits = 0;   // c of the current window table (0 = not built)
@@ -54,7 +78,11 @@ struct plonk_srs {
     unsigned lookup_bits = 0;    // c of the lookup table (0 = none)
     unsigned lookup_windows = 0;
     bool lookup_failed = false;  // an automatic build did not fit: do not retry on every call
-    G1Affine* lookup = nullptr;  // lookup[((w * n_points + i) << (c - 1)) + d - 1]
+    G1Affine* lookup = nullptr;  // lookup[((w * n_points + i) << (c - 1)) + d - 1]   (= shared->data)
+    MsmLookupTable* shared = nullptr;
+    // Lagrange-basis SRS (setup.py:66-72 without the ifft): lagrange[log_n] = [L_i(tau)]_1, i < 2^log_n, built on
+    // demand by an EC inverse NTT of the first 2^log_n bases (msm.hip); each is a plonk_srs of its own.
+    std::map<unsigned, plonk_srs*> lagrange;
 };
 
 #define PLONK_SCRATCH_SLOTS 4
@@ -70,7 +98,8 @@ struct plonk_ctx {
     unsigned msm_window_bits = 0, msm_groups = 0;
     int msm_lookup_mode = 0;         // 0 auto (fixed SRS only), 1 off, 2 force msm_lookup_bits for every base set
     unsigned msm_lookup_bits = 0;    // 0 = largest window whose table fits the budget
-    size_t msm_lookup_budget = 0;    // bytes; 0 = default (55 % of the free device memory, at most 160 GB)
+    size_t msm_lookup_budget = 0;    // bytes; 0 = default (PLONK_MSM_TABLE_GB if set, else 4 GiB)
+    bool ntt_attr_set = false, msm_attr_set = false;  // hipFuncSetAttribute is per device: tracked per context
     // per-kernel HIP-event profiling (bench.py roofline): one record per instrumented launch
     struct ProfRec { const char* name; hipEvent_t a, b; double algo_bytes; };
     bool profiling = false;
@@ -104,6 +133,9 @@ int ntt_run(plonk_ctx*, const Fr* in, Fr* out, unsigned log_n, bool inverse, siz
 int ntt_get_roots(plonk_ctx*, unsigned log_n, bool inverse, const Fr** table_full);
 // msm.hip
 int msm_build_table(plonk_ctx*, plonk_srs*, unsigned c);
+void msm_srs_release(plonk_srs*);  // drops the reference on the shared lookup table
+int msm_lookup_info(const plonk_srs*, unsigned* bits, size_t* bytes, double* build_s, int* sharers);
+uint64_t plonk_fnv1a64(const void* data, size_t n);
 // MSM m reads its scalars at d_scalars + (m % inner) * stride + (m / inner) * outer_stride (inner = 0: inner = M)
 int msm_run_device(plonk_ctx*, plonk_srs*, const Fr* d_scalars, size_t n, size_t M, size_t stride, Fq* d_out_xy,
                    uint8_t* d_flags, size_t inner = 0, size_t outer_stride = 0);

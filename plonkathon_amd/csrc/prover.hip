@@ -66,6 +66,14 @@ struct plonk_prover {
     Fr *quot;      // [B][4n]    quotient evaluations, then its coefficients (in place)
     Fr *num, *den; // [B][n] scratch (round 2), reused as W_z numerator
     Fr *wz;        // [2][B][n]  W_z, W_zw coefficient forms
+    struct LinWeights* lin_w;  // [B]   round-5 linearisation weights (own allocation: 480 B per proof)
+    // wiring (plonk_prover_set_wiring): the wire cells are scattered from per-variable values on the device
+    uint32_t* cell_index;      // [3][n]  variable index of each wire cell; n_vars = empty cell / padding row
+    uint32_t* pub_index;       // [n_public]
+    size_t n_vars;
+    Fr* vars;                  // [B][n_vars] values of the resident batch (Montgomery)
+    size_t vars_cap;           // elements
+    size_t resident_b;         // batch size of the witnesses currently resident (run / download must match it)
     Fq *commit_xy; // [9][B] x||y canonical
     uint8_t* commit_flags;  // [9][B]
     ProofState* state;      // [B]
@@ -88,6 +96,24 @@ __global__ void pi_fill_kernel(const Fr* pub, size_t n_public, size_t n, size_t 
         Fr v = fp_zero<FrParams>();
         if (i < n_public) v = fp_neg(fp_load(pub + b * n_public + i));
         fp_store(pi + gI, v);
+    }
+}
+
+// prover.py:94-103 on the device: A[i], B[i], C[i] = witness[wires[i].L / R / O], witness[None] = 0, zero padded to n.
+// vars = [B][V] variable values; cell[3][n] = variable index of each wire cell (V: empty); out = wit_lag [3][B][n].
+__global__ void witness_scatter_kernel(const Fr* vars, const uint32_t* cell, size_t V, size_t n, size_t B, Fr* out) {
+    const size_t total = 3 * B * n;
+    for (size_t gI = (size_t)blockIdx.x * blockDim.x + threadIdx.x; gI < total; gI += (size_t)gridDim.x * blockDim.x) {
+        const size_t j = gI / (B * n), r = gI - j * B * n, b = r / n, i = r - b * n;
+        const uint32_t idx = cell[j * n + i];
+        fp_store(out + gI, idx < V ? fp_load(vars + b * V + idx) : fp_zero<FrParams>());
+    }
+}
+__global__ void public_gather_kernel(const Fr* vars, const uint32_t* pub_index, size_t V, size_t l, size_t B, Fr* pub) {
+    const size_t total = B * l;
+    for (size_t gI = (size_t)blockIdx.x * blockDim.x + threadIdx.x; gI < total; gI += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = gI / l, k = gI - b * l;
+        fp_store(pub + gI, fp_load(vars + b * V + pub_index[k]));
     }
 }
 
@@ -655,10 +681,15 @@ static Fr host_fr_u64(uint64_t x) {
 }
 
 static void free_batch(plonk_prover* p) {
-    void* bufs[] = {p->wit_lag, p->z_lag, p->coef, p->big, p->quot, p->num, p->den, p->wz, p->commit_xy, p->commit_flags, p->state, p->pub};
+    void* bufs[] = {p->wit_lag, p->z_lag, p->coef, p->big, p->quot, p->num, p->den, p->wz, p->commit_xy, p->commit_flags, p->state, p->pub,
+                    p->lin_w, p->vars};
     for (void* q : bufs)
         if (q) hipFree(q);
     p->pub = nullptr;
+    p->lin_w = nullptr;
+    p->vars = nullptr;
+    p->vars_cap = 0;
+    p->resident_b = 0;
     p->wit_lag = p->z_lag = p->coef = p->big = p->quot = p->num = p->den = p->wz = nullptr;
     p->commit_xy = nullptr;
     p->commit_flags = nullptr;
@@ -683,22 +714,40 @@ static int ensure_batch(plonk_prover* p, size_t B) {
     PLONK_TRY(dev_alloc((void**)&p->commit_flags, 9 * B));
     PLONK_TRY(dev_alloc((void**)&p->state, B * sizeof(ProofState)));
     PLONK_TRY(dev_alloc((void**)&p->pub, (B * p->n_public + 1) * e));
+    PLONK_TRY(dev_alloc((void**)&p->lin_w, B * sizeof(LinWeights)));
     p->cap_b = B;
     return PLONK_OK;
 }
+
+static int prover_init(plonk_prover* p, plonk_ctx* ctx, plonk_srs* srs, unsigned log_n, const uint8_t* selectors_le32, size_t n_public);
 
 extern "C" {
 
 int plonk_prover_create(plonk_ctx* ctx, plonk_srs* srs, unsigned log_n, const uint8_t* selectors_le32,
                         size_t n_public, plonk_prover** out) {
     PLONK_REQUIRE(ctx && srs && selectors_le32 && out, PLONK_ERR_ARG, "bad argument");
+    PLONK_ENTER(ctx);
     PLONK_REQUIRE(log_n >= 1 && log_n + 2 <= PLONK_FR_TWO_ADICITY, PLONK_ERR_ARG, "group_order 2^%u out of range", log_n);
-    const size_t n = (size_t)1 << log_n, n4 = 4 * n;
+    const size_t n = (size_t)1 << log_n;
     PLONK_REQUIRE(n <= 4096, PLONK_ERR_ARG, "the batched prover supports group_order <= 4096 (got %zu)", n);
     PLONK_REQUIRE(srs->n_points >= n, PLONK_ERR_ARG, "SRS has %zu powers, group_order is %zu", srs->n_points, n);
     PLONK_REQUIRE(n_public <= n, PLONK_ERR_ARG, "more public inputs than rows");
     plonk_prover* p = new plonk_prover();
     memset((void*)p, 0, sizeof *p);
+    const int rc = prover_init(p, ctx, srs, log_n, selectors_le32, n_public);
+    if (rc != PLONK_OK) {  // a single cleanup path: everything allocated so far goes with the half-built object
+        plonk_prover_destroy(p);
+        return rc;
+    }
+    *out = p;
+    return PLONK_OK;
+}
+
+}  // extern "C"
+
+static int prover_init(plonk_prover* p, plonk_ctx* ctx, plonk_srs* srs, unsigned log_n, const uint8_t* selectors_le32,
+                       size_t n_public) {
+    const size_t n = (size_t)1 << log_n, n4 = 4 * n;
     p->ctx = ctx;
     p->srs = srs;
     p->log_n = log_n;
@@ -733,12 +782,12 @@ int plonk_prover_create(plonk_ctx* ctx, plonk_srs* srs, unsigned log_n, const ui
     PLONK_TRY(ntt_run(ctx, p->fixed_coef, p->fixed_big, log_n + 2, false, 8, n, n, n4, p->g_pow, nullptr, false));
     // L0: Lagrange vector e_0 has coefficient form (1/n, 1/n, ...)          prover.py:184-186
     Fr ninv = fp_inv(host_fr_u64((uint64_t)n));
-    Fr* tmp;
-    PLONK_TRY(dev_alloc((void**)&tmp, n * e));
+    void* tmpv;
+    PLONK_TRY(ctx_scratch(ctx, 2, n * e, &tmpv));  // context-owned scratch: nothing to leak on an error path
+    Fr* tmp = (Fr*)tmpv;
     PLONK_TRY(k_fr_powers(ctx, one, ninv, tmp, n));
     PLONK_TRY(ntt_run(ctx, tmp, p->l0_big, log_n + 2, false, 1, n, n, n4, p->g_pow, nullptr, false));
     PLONK_CHECK_HIP(hipStreamSynchronize(ctx->stream));
-    hipFree(tmp);
     // Z_H on the coset takes 4 values: (g mu^k)^n - 1 = g^n i^k - 1, i = mu^n            prover.py:178
     Fr gn = p->g;
     for (unsigned i = 0; i < log_n; i++) gn = fp_sqr(gn);
@@ -758,16 +807,19 @@ int plonk_prover_create(plonk_ctx* ctx, plonk_srs* srs, unsigned log_n, const ui
         PLONK_CHECK_HIP(hipGetLastError());
         PLONK_CHECK_HIP(hipStreamSynchronize(ctx->stream));
     }
-    PLONK_TRY(msm_build_table(ctx, srs, ctx->msm_window_bits ? ctx->msm_window_bits : 10));
-    *out = p;
-    return PLONK_OK;
+    return PLONK_OK;  // (the MSM tables are built by the first commitment: lookup table or bucket-method window table)
 }
+
+extern "C" {
 
 int plonk_prover_destroy(plonk_prover* p) {
     if (!p) return PLONK_OK;
-    hipStreamSynchronize(p->ctx->stream);
+    if (p->ctx) {
+        plonk_use_device(p->ctx->device);
+        hipStreamSynchronize(p->ctx->stream);
+    }
     free_batch(p);
-    void* bufs[] = {p->fixed_lag, p->fixed_coef, p->fixed_big, p->l0_big, p->x_big, p->g_pow, p->ginv_pow, p->li_big};
+    void* bufs[] = {p->fixed_lag, p->fixed_coef, p->fixed_big, p->l0_big, p->x_big, p->g_pow, p->ginv_pow, p->li_big, p->cell_index, p->pub_index};
     for (void* q : bufs)
         if (q) hipFree(q);
     delete p;
@@ -777,6 +829,7 @@ int plonk_prover_destroy(plonk_prover* p) {
 // witness columns [3][B][n] (A, B, C) and public inputs [B][n_public], canonical LE
 int plonk_prover_upload_witness(plonk_prover* p, const uint8_t* abc_le32, const uint8_t* public_le32, size_t B) {
     PLONK_REQUIRE(p && abc_le32 && B && (public_le32 || !p->n_public), PLONK_ERR_ARG, "bad argument");
+    PLONK_ENTER(p->ctx);
     PLONK_TRY(ensure_batch(p, B));
     plonk_ctx* ctx = p->ctx;
     const size_t n = p->n;
@@ -791,12 +844,70 @@ int plonk_prover_upload_witness(plonk_prover* p, const uint8_t* abc_le32, const 
     }
     PLONK_CHECK_HIP(hipGetLastError());
     PLONK_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    p->resident_b = B;
+    return PLONK_OK;
+}
+
+// cell_index[3][n]: variable index carried by each wire cell (column L/R/O, row), n_vars for an empty cell or a
+// padding row; public_index[n_public]: the public variables, in the order of the public rows (prover.py:57-62).
+int plonk_prover_set_wiring(plonk_prover* p, const uint32_t* cell_index, const uint32_t* public_index, size_t n_vars) {
+    PLONK_REQUIRE(p && cell_index && n_vars && (public_index || !p->n_public), PLONK_ERR_ARG, "bad argument");
+    PLONK_ENTER(p->ctx);
+    for (size_t k = 0; k < 3 * p->n; k++)
+        PLONK_REQUIRE(cell_index[k] <= n_vars, PLONK_ERR_ARG, "wire cell %zu names variable %u of %zu", k, cell_index[k], n_vars);
+    for (size_t k = 0; k < p->n_public; k++)
+        PLONK_REQUIRE(public_index[k] < n_vars, PLONK_ERR_ARG, "public input %zu names variable %u of %zu", k, public_index[k], n_vars);
+    if (!p->cell_index) PLONK_TRY(dev_alloc((void**)&p->cell_index, 3 * p->n * sizeof(uint32_t)));
+    if (!p->pub_index) PLONK_TRY(dev_alloc((void**)&p->pub_index, (p->n_public + 1) * sizeof(uint32_t)));
+    PLONK_CHECK_HIP(hipMemcpyAsync(p->cell_index, cell_index, 3 * p->n * sizeof(uint32_t), hipMemcpyHostToDevice, p->ctx->stream));
+    if (p->n_public)
+        PLONK_CHECK_HIP(hipMemcpyAsync(p->pub_index, public_index, p->n_public * sizeof(uint32_t), hipMemcpyHostToDevice, p->ctx->stream));
+    PLONK_CHECK_HIP(hipStreamSynchronize(p->ctx->stream));
+    p->n_vars = n_vars;
+    return PLONK_OK;
+}
+
+// values of the n_vars variables of each witness, [B][n_vars] canonical LE (n_vars * 32 bytes per proof instead of
+// 3 * n * 32): the wire columns and the public inputs are gathered from them on the device (prover.py:94-103, 57-62)
+int plonk_prover_upload_variables(plonk_prover* p, const uint8_t* vars_le32, size_t B) {
+    PLONK_REQUIRE(p && vars_le32 && B, PLONK_ERR_ARG, "bad argument");
+    PLONK_ENTER(p->ctx);
+    PLONK_REQUIRE(p->n_vars, PLONK_ERR_STATE, "plonk_prover_set_wiring has not been called");
+    PLONK_TRY(ensure_batch(p, B));
+    plonk_ctx* ctx = p->ctx;
+    const size_t n = p->n, V = p->n_vars;
+    if (p->vars_cap < B * V) {
+        PLONK_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+        if (p->vars) hipFree(p->vars);
+        p->vars = nullptr;
+        p->vars_cap = 0;
+        PLONK_TRY(dev_alloc((void**)&p->vars, B * V * sizeof(Fr)));
+        p->vars_cap = B * V;
+    }
+    PLONK_TRY(plonk_fr_upload(ctx, p->vars, vars_le32, B * V));
+    PLONK_LAUNCH(witness_scatter_kernel, grid1(3 * B * n), dim3(256), 0, ctx->stream, (const Fr*)p->vars, (const uint32_t*)p->cell_index, V,
+                 n, B, p->wit_lag);
+    if (p->n_public) {
+        PLONK_LAUNCH(public_gather_kernel, grid1(B * p->n_public), dim3(256), 0, ctx->stream, (const Fr*)p->vars,
+                     (const uint32_t*)p->pub_index, V, p->n_public, B, p->pub);
+        if (!p->sparse_pi)
+            PLONK_LAUNCH(pi_fill_kernel, grid1(B * n), dim3(256), 0, ctx->stream, (const Fr*)p->pub, p->n_public, n, B,
+                         p->wit_lag + 3 * B * n);
+    } else {
+        PLONK_CHECK_HIP(hipMemsetAsync(p->wit_lag + 3 * B * n, 0, B * n * sizeof(Fr), ctx->stream));
+    }
+    PLONK_CHECK_HIP(hipGetLastError());
+    PLONK_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    p->resident_b = B;
     return PLONK_OK;
 }
 
 // Enqueue all five rounds for the B resident witnesses.  Asynchronous.
 int plonk_prover_run(plonk_prover* p, size_t B) {
-    PLONK_REQUIRE(p && B && B <= p->cap_b, PLONK_ERR_ARG, "run: batch %zu exceeds the uploaded capacity", B);
+    PLONK_REQUIRE(p && B, PLONK_ERR_ARG, "bad argument");
+    // every buffer is laid out [k][B][n] with the B of the upload: another B would read the wrong strides
+    PLONK_REQUIRE(B == p->resident_b, PLONK_ERR_STATE, "run: batch %zu, but %zu witnesses are resident", B, p->resident_b);
+    PLONK_ENTER(p->ctx);
     plonk_ctx* ctx = p->ctx;
     const size_t n = p->n, n4 = 4 * n;
     const unsigned log_n = p->log_n;
@@ -858,7 +969,7 @@ int plonk_prover_run(plonk_prover* p, size_t B) {
     // ---- round 5: opening polynomials in coefficient form, commit              prover.py:241-306
     Fr ninv = fp_inv(host_fr_u64((uint64_t)n));
     unsigned gx = (unsigned)((n + 255) / 256);
-    LinWeights* lw = reinterpret_cast<LinWeights*>(p->wz);  // W_z buffer is free until divide_linear writes it
+    LinWeights* lw = p->lin_w;
     PLONK_LAUNCH(linearisation_weights_kernel, dim3(tb), dim3(64), 0, s, (const ProofState*)p->state, log_n, ninv, B, lw);
     PLONK_LAUNCH(linearisation_kernel, dim3(gx, (unsigned)B), dim3(256), 0, s, (const Fr*)p->coef,
                  (const Fr*)p->fixed_coef, (const Fr*)p->quot, (const LinWeights*)lw, log_n, B, p->num);
@@ -875,7 +986,9 @@ int plonk_prover_run(plonk_prover* p, size_t B) {
 // not close to 1, i.e. the witness breaks the copy constraints — prover.py:132; bit2: the quotient has
 // degree >= 3n, i.e. the witness breaks a gate constraint — prover.py:108-116, 205-208).
 int plonk_prover_download(plonk_prover* p, size_t B, uint8_t* out_proofs, uint8_t* out_status) {
-    PLONK_REQUIRE(p && B && B <= p->cap_b && out_proofs && out_status, PLONK_ERR_ARG, "bad argument");
+    PLONK_REQUIRE(p && B && out_proofs && out_status, PLONK_ERR_ARG, "bad argument");
+    PLONK_REQUIRE(B == p->resident_b, PLONK_ERR_STATE, "download: batch %zu, but %zu witnesses are resident", B, p->resident_b);
+    PLONK_ENTER(p->ctx);
     plonk_ctx* ctx = p->ctx;
     void* packed;
     PLONK_TRY(ctx_scratch(ctx, 2, B * 768, &packed));
@@ -903,7 +1016,8 @@ int plonk_prover_download(plonk_prover* p, size_t B, uint8_t* out_proofs, uint8_
 
 // Debug / test access: the six challenges of proof b, canonical LE (beta, gamma, alpha, fft_cofactor, zeta, v)
 int plonk_prover_challenges(plonk_prover* p, size_t b, uint8_t out_le32[6 * 32]) {
-    PLONK_REQUIRE(p && b < p->cap_b && out_le32, PLONK_ERR_ARG, "bad argument");
+    PLONK_REQUIRE(p && b < p->resident_b && out_le32, PLONK_ERR_ARG, "bad argument");
+    PLONK_ENTER(p->ctx);
     ProofState st;
     PLONK_CHECK_HIP(hipStreamSynchronize(p->ctx->stream));
     PLONK_CHECK_HIP(hipMemcpy(&st, p->state + b, sizeof st, hipMemcpyDeviceToHost));

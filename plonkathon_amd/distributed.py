@@ -1,13 +1,27 @@
 """Proof-level data parallelism over the GPUs of one node.
 
-Proofs are independent, so the path shards by proof index with NO data-path collective: rank r of W
-proves indices r, r+W, r+2W, ... on its own GPU (circuit polynomials, SRS window table and twiddles
-are replicated per GPU).  The only exchange is one all_gather of the finished proofs — 768 bytes each
-(9 affine G1 + 6 Fr) — over RCCL/xGMI (`backend="nccl"` on ROCm) or gloo in the CPU tests.
+Proofs are independent (the reference's `Prover.prove`, /root/reference/prover.py:51-84, keeps no
+cross-proof state), so the path shards by proof index with NO data-path collective: rank r of W proves
+indices r, r+W, r+2W, ... on its own GPU (circuit polynomials, SRS tables and twiddles are replicated per
+GPU).  The only exchange is one all-gather of the finished proofs — 768 bytes each (9 affine G1 + 6 Fr).
+
+Transports (all expose `rank`, `world`, `all_gather(bytes) -> [bytes] * world`, `max(float)`, `barrier()`):
+  * `RcclComm`   — the product path: `plonk_comm_*` / `plonk_gather_results` of the C-ABI (include/plonk_hip.h),
+                   i.e. RCCL over xGMI, one process per GPU.  The 128-byte ncclUniqueId travels from rank 0 to
+                   the other ranks over a loopback TCP socket (`_rendezvous`); no PyTorch anywhere.
+  * `SocketComm` — plain TCP through rank 0, for CPU tests and for several ranks sharing one GPU (RCCL refuses
+                   two ranks on one device).  Never selected implicitly on a multi-GPU run.
+Environment (the torchrun convention): RANK, WORLD_SIZE, LOCAL_RANK, MASTER_ADDR, MASTER_PORT; the rendezvous
+socket listens on PLONK_RDZV_PORT (default MASTER_PORT + 1: torchrun's own store owns MASTER_PORT).
 """
+import ctypes
 import os
+import socket
+import struct
+import time
 
 PROOF_BYTES = 768
+_ID_BYTES = 128
 
 
 def shard_indices(total: int, rank: int, world: int):
@@ -15,56 +29,206 @@ def shard_indices(total: int, rank: int, world: int):
     return list(range(rank, total, world))
 
 
-def init_from_env(backend=None):
-    """torch.distributed initialisation from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun)."""
-    import torch
-    import torch.distributed as dist
+def env_rank_world():
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+
+def _rdzv_addr():
+    host = os.environ.get("MASTER_ADDR", "127.0.0.1")
+    port = int(os.environ.get("PLONK_RDZV_PORT", int(os.environ.get("MASTER_PORT", "29500")) + 1))
+    return host, port
+
+
+def _recv_exact(sock, n):
+    buf = bytearray()
+    while len(buf) < n:
+        chunk = sock.recv(n - len(buf))
+        if not chunk:
+            raise ConnectionError("peer closed the rendezvous socket")
+        buf += chunk
+    return bytes(buf)
+
+
+def _send_msg(sock, payload: bytes):
+    sock.sendall(struct.pack("<Q", len(payload)) + payload)
+
+
+def _recv_msg(sock):
+    (n,) = struct.unpack("<Q", _recv_exact(sock, 8))
+    return _recv_exact(sock, n)
+
+
+class _Star:
+    """Rank 0 listens, ranks 1..W-1 connect and introduce themselves; the sockets stay open."""
+
+    def __init__(self, rank, world, timeout=120.0):
+        self.rank, self.world = rank, world
+        host, port = _rdzv_addr()
+        self.peers = {}
+        if world == 1:
+            return
+        if rank == 0:
+            srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+            srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            srv.bind((host, port))
+            srv.listen(world)
+            srv.settimeout(timeout)
+            while len(self.peers) < world - 1:
+                conn, _ = srv.accept()
+                conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                (r,) = struct.unpack("<I", _recv_exact(conn, 4))
+                self.peers[r] = conn
+            srv.close()
+        else:
+            deadline = time.time() + timeout
+            while True:
+                try:
+                    s = socket.create_connection((host, port), timeout=5.0)
+                    break
+                except OSError:
+                    if time.time() > deadline:
+                        raise
+                    time.sleep(0.05)
+            s.settimeout(timeout)
+            s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+            s.sendall(struct.pack("<I", rank))
+            self.peers[0] = s
+
+    def broadcast(self, payload):
+        """rank 0's bytes -> every rank"""
+        if self.world == 1:
+            return payload
+        if self.rank == 0:
+            for r in range(1, self.world):
+                _send_msg(self.peers[r], payload)
+            return payload
+        return _recv_msg(self.peers[0])
+
+    def all_gather(self, payload):
+        if self.world == 1:
+            return [payload]
+        if self.rank == 0:
+            parts = [payload] + [_recv_msg(self.peers[r]) for r in range(1, self.world)]
+            blob = b"".join(struct.pack("<Q", len(p)) + p for p in parts)
+            for r in range(1, self.world):
+                _send_msg(self.peers[r], blob)
+            return parts
+        _send_msg(self.peers[0], payload)
+        blob, parts, o = _recv_msg(self.peers[0]), [], 0
+        for _ in range(self.world):
+            (n,) = struct.unpack_from("<Q", blob, o)
+            parts.append(blob[o + 8 : o + 8 + n])
+            o += 8 + n
+        return parts
+
+    def close(self):
+        for s in self.peers.values():
+            try:
+                s.close()
+            except OSError:
+                pass
+        self.peers = {}
+
+
+class SocketComm:
+    """TCP star through rank 0 (tests; several ranks on one GPU)."""
+
+    kind = "sockets"
+
+    def __init__(self, rank, world):
+        self.rank, self.world = rank, world
+        self._star = _Star(rank, world)
+
+    def all_gather(self, payload: bytes):
+        return self._star.all_gather(payload)
+
+    def max(self, value: float) -> float:
+        return max(struct.unpack("<d", p)[0] for p in self._star.all_gather(struct.pack("<d", value)))
+
+    def barrier(self):
+        self._star.all_gather(b"")
+
+    def close(self):
+        self._star.close()
+
+
+class RcclComm:
+    """RCCL over xGMI through the C-ABI (`plonk_comm_*`): the product's multi-GPU path."""
+
+    kind = "rccl"
+
+    def __init__(self, ctx, rank, world):
+        from ._lib import check
+
+        self.ctx, self.rank, self.world = ctx, rank, world
+        self._check = check
+        star = _Star(rank, world)  # only to hand out the unique id
+        try:
+            ident = ctypes.create_string_buffer(_ID_BYTES)
+            if rank == 0:
+                check(ctx.L.plonk_comm_unique_id(ident))
+            ident = ctypes.create_string_buffer(star.broadcast(ident.raw), _ID_BYTES)
+        finally:
+            star.close()
+        self._h = ctypes.c_void_p()
+        check(ctx.L.plonk_comm_create(ctx.handle, ident, rank, world, ctypes.byref(self._h)))
+
+    def all_gather(self, payload: bytes):
+        """Equal-sized payloads (the caller pads): one ncclAllGather."""
+        n = len(payload)
+        out = ctypes.create_string_buffer(n * self.world)
+        self._check(self.ctx.L.plonk_gather_results(self._h, payload, n, out))
+        raw = out.raw
+        return [raw[n * r : n * (r + 1)] for r in range(self.world)]
+
+    def max(self, value: float) -> float:
+        v = ctypes.c_double(value)
+        self._check(self.ctx.L.plonk_comm_max_f64(self._h, ctypes.byref(v)))
+        return v.value
+
+    def barrier(self):
+        self._check(self.ctx.L.plonk_comm_barrier(self._h))
+
+    def close(self):
+        if self._h:
+            self.ctx.L.plonk_comm_destroy(self._h)
+            self._h = None
+
+
+def init_from_env(ctx=None, backend="rccl"):
+    """The communicator for this process (None for a single rank).  `backend`: "rccl" (default) or "sockets"."""
+    rank, world, _ = env_rank_world()
     if world == 1:
         return None
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if backend is None:
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
-    if backend == "nccl":
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    else:
-        dist.init_process_group(backend)
-    return dist
+    if backend == "rccl":
+        if ctx is None:
+            from .backend import get_context
+
+            ctx = get_context()
+        return RcclComm(ctx, rank, world)
+    if backend == "sockets":
+        return SocketComm(rank, world)
+    raise ValueError("unknown distributed backend %r (rccl | sockets)" % (backend,))
 
 
-def gather_proofs(local_blob: bytes, total: int, dist=None):
-    """all_gather the per-rank proof blobs and return all `total` proofs in global index order.
+def gather_proofs(local_blob: bytes, total: int, comm=None):
+    """All-gather the per-rank proof blobs and return all `total` proofs in global index order.
 
-    `local_blob` holds this rank's proofs (768 B each) in the order of `shard_indices`.  Ranks may
-    own different counts (total % world != 0), so blobs are padded to the largest shard."""
-    if dist is None:
+    `local_blob` holds this rank's proofs (768 B each) in the order of `shard_indices`.  Ranks may own different
+    counts (total % world != 0), so blobs are padded to the largest shard."""
+    if comm is None:
         assert len(local_blob) == PROOF_BYTES * total
         return [local_blob[PROOF_BYTES * i : PROOF_BYTES * (i + 1)] for i in range(total)]
-    import torch
-
-    rank, world = dist.get_rank(), dist.get_world_size()
+    world = comm.world
     per = (total + world - 1) // world
-    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
-    buf = bytearray(local_blob) + bytearray(PROOF_BYTES * per - len(local_blob))
-    mine = torch.frombuffer(buf, dtype=torch.uint8).to(dev)
-    parts = [torch.empty_like(mine) for _ in range(world)]
-    dist.all_gather(parts, mine)
+    parts = comm.all_gather(bytes(local_blob) + bytes(PROOF_BYTES * per - len(local_blob)))
     out = [None] * total
     for r in range(world):
-        raw = bytes(parts[r].cpu().numpy().tobytes())
+        raw = parts[r]
         for j, idx in enumerate(shard_indices(total, r, world)):
             out[idx] = raw[PROOF_BYTES * j : PROOF_BYTES * (j + 1)]
     return out
 
 
-def max_over_ranks(value: float, dist=None) -> float:
-    if dist is None:
-        return value
-    import torch
-
-    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
-    t = torch.tensor([value], dtype=torch.float64, device=dev)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    return float(t.item())
+def max_over_ranks(value: float, comm=None) -> float:
+    return value if comm is None else comm.max(value)

@@ -65,6 +65,14 @@ class _DeviceBases:
         check(self.ctx.L.plonk_srs_lookup_bits(self.handle, ctypes.byref(out)))
         return out.value
 
+    def lookup_info(self):
+        """{bits, bytes, build_s, sharers} of the lookup table attached to these bases (one table per device and
+        base set, shared by every context / stream / prover that loaded the same SRS)."""
+        bits, nbytes, secs, sharers = ctypes.c_uint(0), ctypes.c_size_t(0), ctypes.c_double(0), ctypes.c_int(0)
+        check(self.ctx.L.plonk_srs_lookup_info(self.handle, ctypes.byref(bits), ctypes.byref(nbytes), ctypes.byref(secs),
+                                               ctypes.byref(sharers)))
+        return {"bits": bits.value, "bytes": nbytes.value, "build_s": secs.value, "sharers": sharers.value}
+
     def __del__(self):
         try:
             if self.handle and self.ctx.handle:

@@ -15,6 +15,19 @@ EMU_DIR = os.path.join(REPO, "tests", "emu")
 EMU_LIB = os.path.join(EMU_DIR, "libplonk_emu.so")
 
 
+# CPU runs go through the fiber emulation, where building even the default 4 GiB lookup table would take
+# minutes: without a GPU the automatic policy gets a budget nothing fits in (bucket method); the lookup path is
+# covered by the forced-size tests (mode 2).  GPU runs keep the library default.
+try:
+    import subprocess as _sp
+
+    _HAS_GPU = _sp.run(["rocminfo"], capture_output=True, timeout=30).returncode == 0 and os.path.exists("/dev/kfd")
+except Exception:  # pragma: no cover
+    _HAS_GPU = False
+if not _HAS_GPU:
+    os.environ.setdefault("PLONK_MSM_TABLE_GB", "0.0001")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

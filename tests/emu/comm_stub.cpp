@@ -1,0 +1,23 @@
+// TEST INFRASTRUCTURE ONLY — the emulation build has no RCCL: plonk_comm_* exist so the C-ABI table binds, and
+// work for a single rank (a gather of one rank is a copy).  Multi-rank CPU tests use a socket / gloo transport
+// above the C-ABI (tests/test_distributed_*.py); the RCCL calls themselves are exercised on the GPU box.
+#include <string.h>
+
+#include "../../include/plonk_hip.h"
+
+struct plonk_comm { int rank, world; };
+void plonk_set_error(const char* fmt, ...);
+
+extern "C" {
+int plonk_comm_unique_id(uint8_t out_id[PLONK_COMM_ID_BYTES]) { memset(out_id, 0x5a, PLONK_COMM_ID_BYTES); return PLONK_OK; }
+int plonk_comm_create(plonk_ctx*, const uint8_t*, int rank, int world, plonk_comm** out) {
+    if (world != 1 || rank != 0) { plonk_set_error("the emulation build has no RCCL: world must be 1"); return PLONK_ERR_STATE; }
+    *out = new plonk_comm{0, 1};
+    return PLONK_OK;
+}
+int plonk_comm_destroy(plonk_comm* c) { delete c; return PLONK_OK; }
+int plonk_comm_size(const plonk_comm* c, int* r, int* w) { *r = c->rank; *w = c->world; return PLONK_OK; }
+int plonk_gather_results(plonk_comm*, const uint8_t* s, size_t n, uint8_t* r) { memcpy(r, s, n); return PLONK_OK; }
+int plonk_comm_max_f64(plonk_comm*, double*) { return PLONK_OK; }
+int plonk_comm_barrier(plonk_comm*) { return PLONK_OK; }
+}

@@ -11,6 +11,7 @@ import os
 from helpers import GOLDEN, check_summary, digest, load, pt, rand_vec, R_MOD
 
 import plonkathon_amd as pa
+from plonkathon_amd.field import Fq, Q_MOD
 from plonkathon_amd import Basis, Polynomial, Program, Prover, Scalar, Setup, Transcript
 from oracle import field as ofield, g1 as og1
 from oracle.circuit import Program as OProgram
@@ -441,6 +442,100 @@ def edge_and_error_paths(setup):
         assert flat(proofs[i]) == OProver(osetup, OProgram(["e public", "c <== a * b", "e <== c * d"], 8)).prove(dict(wits[i])).flatten()
     proofs2 = bp.prove_batch(wits[:5])  # smaller batch on the same prover: buffers are reused
     assert [flat(p) for p in proofs2] == [flat(p) for p in proofs[:5]]
+
+
+def batch_prover_tiny_group_orders(setup):
+    """group_order 2 and 4 (the round-5 weights used to alias a buffer that is too small below n = 8)."""
+    import pytest
+
+    batch_prover_vs_oracle(setup, ["c <== a * b", "d <== c + a"], 4, [{"a": 3 + i, "b": 4 + i} for i in range(16)])
+    # group_order 2: a commitment is the identity, where the reference's transcript raises (transcript.py:65-67 on
+    # None; the oracle reproduces that TypeError) -> the batched prover reports it per proof instead of crashing
+    lines = ["c <== a * b"]
+    with pytest.raises(TypeError):
+        OProver(OSetup.from_file(PTAU), OProgram(lines, 2)).prove(OProgram(lines, 2).fill_variable_assignments({"a": 3, "b": 4}))
+    bp = pa.BatchProver(setup, Program(lines, 2))
+    bp.upload([Program(lines, 2).fill_variable_assignments({"a": 3 + i, "b": 4}) for i in range(16)])
+    bp.run()
+    assert all(st & 1 for st in bp.download_raw()[1])
+    with pytest.raises(pa.ProofError):
+        bp.download()
+
+
+def batch_prover_resident_batch_is_checked(setup):
+    """run / download with a batch size other than the resident one must fail (the buffers are laid out for the
+    uploaded B), not read the wrong strides."""
+    import ctypes
+    import pytest
+    from plonkathon_amd import _lib
+
+    bp = pa.BatchProver(setup, Program(["e public", "c <== a * b", "e <== c * d"], 8))
+    wits = [{"a": 3 + i, "b": 4, "c": (3 + i) * 4, "d": 5, "e": (3 + i) * 20} for i in range(4)]
+    bp.upload(wits)
+    with pytest.raises(_lib.BackendError, match="resident"):
+        bp.run(3)
+    bp.run()
+    with pytest.raises(_lib.BackendError, match="resident"):
+        bp.download_raw(2)
+    assert len(bp.download()) == 4
+    # the column form of the upload (plonk_prover_upload_witness) gives the same proofs as the per-variable form
+    want = bp.download_raw()[0]
+    bp._upload_columns(wits)
+    bp.run()
+    assert bp.download_raw()[0] == want
+
+
+def msm_deferred_overflow(setup_unused=None):
+    """More exceptional additions than the per-MSM deferred list holds (all bases equal: every step after the
+    first is a doubling): the MSM must be recomputed by the general-formula kernel, on both methods."""
+    from plonkathon_amd import get_context
+
+    ctx = get_context()
+    g = (1, 2)
+    n = 700  # > MSM_DEFER_CAP = 256 deferred additions in one window
+    pairs = [((Fq(1), Fq(2)), 1 + (i % 3)) for i in range(n)]
+    want = og1.multiply(g, sum(k for _, k in pairs))
+    try:
+        ctx.msm_lookup(1)  # bucket method
+        assert affine(pa.ec_lincomb(pairs)) == want
+        ctx.msm_lookup(2, 4)  # forced 4-bit lookup table over these bases
+        assert affine(pa.ec_lincomb(pairs)) == want
+        # cancelling pairs: the sum is the identity
+        pairs2 = [((Fq(1), Fq(2)), 5)] * 300 + [((Fq(1), Fq(Q_MOD - 2)), 5)] * 300
+        assert pa.ec_lincomb(pairs2) is None
+    finally:
+        ctx.msm_lookup(0)
+
+
+def lookup_table_is_shared_across_contexts():
+    """One lookup table per (device, SRS): a second context / Setup over the same bytes attaches to it."""
+    from plonkathon_amd import Context, Setup
+
+    a, b = Context(0), Context(0)
+    sa, sb = Setup.from_file(PTAU), Setup.from_file(PTAU)
+    try:
+        a.msm_lookup(2, 5)
+        b.msm_lookup(2, 5)
+        coeffs = list(range(1, 9))
+        pa_ = P(coeffs, Basis.MONOMIAL)
+        da, db = sa.device_bases(a), sb.device_bases(b)
+        import ctypes
+        from plonkathon_amd.kzg import _msm
+
+        ra = _msm(da, a.upload_ints(coeffs).ptr, 8, 1, 8)[0]
+        rb = _msm(db, b.upload_ints(coeffs).ptr, 8, 1, 8)[0]
+        assert affine(ra) == affine(rb)
+        ia, ib = da.lookup_info(), db.lookup_info()
+        assert ia["bits"] == ib["bits"] == 5 and ia["bytes"] == ib["bytes"] > 0
+        assert ia["sharers"] == ib["sharers"] == 2, (ia, ib)
+        del db, sb
+        import gc
+
+        gc.collect()
+        assert da.lookup_info()["sharers"] == 1
+    finally:
+        a.msm_lookup(0)
+        b.msm_lookup(0)
 
 
 # ------------------------------------------------------------------------------------------ proofs verify

@@ -35,7 +35,7 @@ def test_hip_library_exports_the_abi():
     for name in _declared_symbols():
         assert hasattr(cdll, name), name
     cdll.plonk_abi_version.restype = ctypes.c_int
-    assert cdll.plonk_abi_version() == 1
+    assert cdll.plonk_abi_version() == 2
 
 
 def test_product_has_no_cpu_fallback():

@@ -1,6 +1,8 @@
-"""N>1 path on CPU: two gloo ranks shard a batch of proofs by index, each proves its shard through the
-product's BatchProver (over the emulated kernels, injected from the test side), the 768-byte results
-are all_gathered, and rank 0 checks every proof against the oracle."""
+"""N>1 path on CPU: two ranks shard a batch of proofs by index, each proves its shard through the product's
+BatchProver (over the emulated kernels, injected from the test side), the 768-byte results are all-gathered and
+rank 0 checks every proof against the oracle.  The gather runs over BOTH CPU transports: the product's
+`SocketComm` (plonkathon_amd/distributed.py) and a gloo communicator defined here, test-side (`TorchComm`: the
+product itself never imports torch; RCCL — the transport of a real multi-GPU run — is exercised on the GPU box)."""
 import ctypes
 import os
 import sys
@@ -14,6 +16,39 @@ LINES = ["e public", "c <== a * b", "e <== c * d"]
 WITS = [{"a": 3 + i, "b": 4, "c": (3 + i) * 4, "d": 5, "e": (3 + i) * 20} for i in range(5)]
 
 
+class TorchComm:
+    """gloo all_gather / all_reduce behind the transport interface of plonkathon_amd.distributed (test-side only)."""
+
+    kind = "gloo"
+
+    def __init__(self):
+        import torch.distributed as dist
+
+        dist.init_process_group("gloo")
+        self.dist, self.rank, self.world = dist, dist.get_rank(), dist.get_world_size()
+
+    def all_gather(self, payload):
+        import torch
+
+        mine = torch.frombuffer(bytearray(payload), dtype=torch.uint8)
+        parts = [torch.empty_like(mine) for _ in range(self.world)]
+        self.dist.all_gather(parts, mine)
+        return [bytes(p.numpy().tobytes()) for p in parts]
+
+    def max(self, value):
+        import torch
+
+        t = torch.tensor([value], dtype=torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def barrier(self):
+        self.dist.barrier()
+
+    def close(self):
+        self.dist.destroy_process_group()
+
+
 def _worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     sys.path.insert(0, REPO)
@@ -24,7 +59,6 @@ def _worker(rank, world, port, q):
     from plonkathon_amd import BatchProver, Program, Setup
     from plonkathon_amd import distributed as D
 
-    dist = D.init_from_env("gloo")
     setup = Setup.from_file(os.path.join(REPO, "tests", "golden", "srs_2048.ptau"))
     prover = BatchProver(setup, Program(LINES, 8))
     mine = D.shard_indices(len(WITS), rank, world)
@@ -32,12 +66,16 @@ def _worker(rank, world, port, q):
     prover.run()
     blob, status = prover.download_raw()
     assert not any(status)
-    allp = D.gather_proofs(blob, len(WITS), dist)
-    slowest = D.max_over_ranks(float(rank), dist)
+    results = {}
+    for name, comm in (("sockets", D.init_from_env(backend="sockets")), ("gloo", TorchComm())):
+        assert (comm.rank, comm.world) == (rank, world)
+        allp = D.gather_proofs(blob, len(WITS), comm)
+        slowest = D.max_over_ranks(float(rank), comm)
+        comm.barrier()
+        results[name] = ([p.hex() for p in allp], slowest)
+        comm.close()
     if rank == 0:
-        q.put(([p.hex() for p in allp], slowest))
-    dist.barrier()
-    dist.destroy_process_group()
+        q.put(results)
 
 
 def test_two_rank_sharding_and_gather(emu_cdll):
@@ -52,10 +90,12 @@ def test_two_rank_sharding_and_gather(emu_cdll):
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    hexes, slowest = q.get(timeout=300)
+    results = q.get(timeout=300)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
+    assert results["sockets"] == results["gloo"]
+    hexes, slowest = results["sockets"]
     assert slowest == 1.0 and len(hexes) == len(WITS)
     osetup = OSetup.from_file(os.path.join(REPO, "tests", "golden", "srs_2048.ptau"))
     for w, hx in zip(WITS, hexes):
@@ -64,6 +104,23 @@ def test_two_rank_sharding_and_gather(emu_cdll):
         for k, v in want.items():
             g = got[k]
             assert ((g[0].n, g[1].n) if isinstance(g, tuple) else g.n) == v, k
+
+
+def test_rccl_transport_refuses_to_degrade(emu_cdll, monkeypatch):
+    """WORLD_SIZE=2 with the default backend must create an RCCL communicator or fail loudly — never fall back to
+    a single rank (the emulation build has no RCCL, so here it must raise)."""
+    from plonkathon_amd import _lib, distributed as D
+    from plonkathon_amd.backend import Context
+
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    assert D.init_from_env() is None
+    ctx = Context(0)
+    comm = D.RcclComm(ctx, 0, 1)  # single rank: the id exchange and the C-ABI round trip
+    assert comm.all_gather(b"abc") == [b"abc"] and comm.max(2.5) == 2.5
+    comm.close()
+    h = ctypes.c_void_p()
+    ident = ctypes.create_string_buffer(128)
+    assert ctx.L.plonk_comm_create(ctx.handle, ident, 0, 2, ctypes.byref(h)) == _lib.PLONK_ERR_STATE
 
 
 def test_shard_indices_cover_everything():

@@ -156,3 +156,19 @@ def test_proofs_verify_under_the_pairing_check(emu):
     setup = Setup.from_file(pc.PTAU)
     pc.proofs_verify(setup, ["e public", "c <== a * b", "e <== c * d"], 8, {"a": 3, "b": 4, "d": 5}, ["e"])
     pc.proofs_verify(setup, pc.FACTORIZATION, 16, pc.FACTORIZATION_START, ["n"])
+
+
+def test_batch_prover_tiny_group_orders_and_resident_batch(emu):
+    from plonkathon_amd import Setup
+
+    setup = Setup.from_file(pc.PTAU)
+    pc.batch_prover_tiny_group_orders(setup)
+    pc.batch_prover_resident_batch_is_checked(setup)
+
+
+def test_msm_deferred_overflow_is_recomputed(emu):
+    pc.msm_deferred_overflow()
+
+
+def test_lookup_table_is_shared_across_contexts(emu):
+    pc.lookup_table_is_shared_across_contexts()

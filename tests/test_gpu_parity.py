@@ -302,3 +302,19 @@ def test_gpu_proofs_verify_under_the_pairing_check(setup):
 
     pc.proofs_verify(setup, pc.chain_lines(2048), 2048, {"x0": 5}, ["x0"])
     pc.proofs_verify(setup, poseidon_program_lines(), 2048, {"L0": 1, "M0": 2}, ["L0", "M0", "M64"])
+
+
+@pytest.mark.gpu
+def test_batch_prover_tiny_group_orders_and_resident_batch(setup):
+    pc.batch_prover_tiny_group_orders(setup)
+    pc.batch_prover_resident_batch_is_checked(setup)
+
+
+@pytest.mark.gpu
+def test_msm_deferred_overflow_is_recomputed():
+    pc.msm_deferred_overflow()
+
+
+@pytest.mark.gpu
+def test_lookup_table_is_shared_across_contexts():
+    pc.lookup_table_is_shared_across_contexts()
