@@ -1,26 +1,35 @@
 #!/usr/bin/env python3
 """bench.py — proofs/sec of the plonkathon prover hot path on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W        (N>1 via torch.distributed.run, one rank/GPU)
+    python bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the hot path over one batch: `--batch` independent PLONK proofs per GPU of
-the BASELINE configs[1] workload (group_order = 2^11, the powers-of-tau SRS slice, synthetic witness
-— a 2047-gate squaring chain + one public input, one distinct witness per proof).  Proofs are independent,
-so N GPUs shard by proof index with no data-path collective; the final (9 G1 + 6 Fr = 768 B) results
-are gathered with one RCCL all_gather ("scaling": "weak").  Inputs (circuit polynomials, the MSM lookup
-table of the SRS, witness columns) are resident in HBM before the timed region.
+N > 1: either launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (RANK /
+LOCAL_RANK / WORLD_SIZE / MASTER_* come from the environment), or — when WORLD_SIZE is not set — bench.py spawns the
+N ranks itself, one process per GPU.  Either way the ranks talk RCCL over xGMI through the library's own C-ABI
+(`plonk_comm_*`, no PyTorch), and a run that cannot get N ranks on N GPUs fails instead of degrading.
+
+A "step" is one pass of the hot path over one batch of synthetic input: `--batches-per-step` lock-step batches of
+`--batch` independent PLONK proofs per GPU of the BASELINE configs[1] workload (group_order = 2^11, the powers-of-tau
+SRS slice, synthetic witness — a 2047-gate squaring chain + one public input, ONE DISTINCT WITNESS PER PROOF).  With
+the defaults a step is 16 x 512 = 8192 proofs per GPU (~0.27 s), so that the driver's 20 timed steps last > 5 s.
+Proofs are independent, so N GPUs shard by proof index with no data-path collective; every step ends with the one
+collective of the path, an all-gather of the finished proofs (768 B each) over RCCL ("scaling": "weak").  Inputs
+(circuit polynomials, the MSM lookup table of the SRS, witness columns) are resident in HBM before the timed region.
 
 Rank 0 prints ONE JSON line: the contract fields, plus
-  "roofline"      for the dominant kernel of the timed region (msm_lookup; msm_accumulate if no table fits),
-                  durations from HIP events recorded on the library's stream inside the timed region;
+  "roofline"      the dominant kernel of the timed region (msm_lookup; msm_accumulate if no table fits): durations from
+                  HIP events recorded on the library's stream inside the timed region;
   "roofline_ntt"  the standalone Fr NTT at 2^20 (BASELINE configs[3]) against the HBM roofline;
-  "ntt", "msm"    NTT GF-elems/s at 2^11 (batched) and 2^20; MSMs/s at 2^11 (512 x 9 commitments per call);
-                  N replicas for N GPUs;
-  "cpu_baseline"  the oracle (pure-Python port of the reference path) timed on this box, rank 0, N=1.
+  "ntt", "msm"    NTT GF-elems/s at 2^11 (batched), 2^16, 2^20; MSMs/s at 2^11; N replicas for N GPUs;
+  "fallbacks"     the same prover on a 40 GB table budget and on the bucket method (no table);
+  "host"          host-side cost of staging witnesses from Python dictionaries, end-to-end rate including it;
+  "cpu_baseline"  the oracle (pure-Python port of the reference path) timed on this box, rank 0, N = 1: one full
+                  proof, and per primitive fft/ifft at 2^11, 2^13, 2^16 and ec_lincomb at 2^11 (3 samples each).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -33,7 +42,9 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s measured cop
 G1_MADD_CEILING_G = 13.5
 MSM_WINDOW_BITS = 10      # bucket-method default (csrc/msm.hip); 26 windows of signed 10-bit digits
 GROUP_ORDER = 2048
+R_MOD = 21888242871839275222246405745257275088548364400416034343698204186575808495617
 PTAU = os.path.join(REPO, "tests", "golden", "srs_2048.ptau")
+DEFAULT_TABLE_GB = 150.0  # opt-in budget for the MSM lookup table: the c = 17 table of 2^11 bases is 128.8 GB + 17.2 GB of build staging
 
 
 def chain_program_lines(n):
@@ -41,34 +52,59 @@ def chain_program_lines(n):
     return ["x0 public"] + ["x%d <== x%d * x%d" % (i + 1, i, i) for i in range(n - 1)]
 
 
-def witness_for(program, proof_index):
-    return program.fill_variable_assignments({"x0": 3 + proof_index})
+def witness_for(proof_index):
+    """The witness dictionary fill_variable_assignments({"x0": 3 + index}) produces for the chain circuit."""
+    vals, x = [], 3 + proof_index
+    for _ in range(GROUP_ORDER):
+        vals.append(x)
+        x = x * x % R_MOD
+    return dict(zip(["x%d" % i for i in range(GROUP_ORDER)], vals))
 
 
-def proof_bytes(proof):
-    out = b""
-    for k, v in proof.flatten().items():
-        if isinstance(v, tuple):
-            out += v[0].n.to_bytes(32, "big") + v[1].n.to_bytes(32, "big")
-        else:
-            out += v.n.to_bytes(32, "big")
-    return out
+def lookup_table_bytes(n, c):
+    windows = (255 + c - 1) // c
+    return n * windows * (1 << (c - 1)) * 64 + n * (1 << (c - 1)) * 128  # table + one window of XYZZ staging
 
 
 def cpu_baseline():
-    """One full proof of the same workload by the oracle on one host core (the reference is
-    single-threaded pure Python)."""
+    """The oracle on one host core (the reference is single-threaded pure Python): one full proof of the same
+    workload, and the path's primitives one by one (BASELINE.md §3 / SURVEY.md §8(d))."""
+    import random
+
     from oracle.circuit import Program as OProgram
+    from oracle.fr_poly import fft_ints
+    from oracle.g1 import ec_lincomb
     from oracle.plonk_prover import Prover as OProver
     from oracle.srs import Setup as OSetup
 
+    osetup = OSetup.from_file(PTAU)
     prog = OProgram(chain_program_lines(GROUP_ORDER), GROUP_ORDER)
     wit = prog.fill_variable_assignments({"x0": 3})
-    prover = OProver(OSetup.from_file(PTAU), prog)
+    prover = OProver(osetup, prog)
     t0 = time.perf_counter()
     proof = prover.prove(dict(wit))
     dt = time.perf_counter() - t0
-    return dt, proof
+
+    def best_of(fn, reps=3):
+        ts = []
+        for _ in range(reps):
+            t = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t)
+        return min(ts), ts
+
+    rng = random.Random(11)
+    prim = {}
+    for log_n in (11, 13, 16):
+        vals = [rng.randrange(R_MOD) for _ in range(1 << log_n)]
+        prim["fft_2^%d_ms" % log_n] = 1e3 * best_of(lambda: fft_ints(vals))[0]
+        prim["ifft_2^%d_ms" % log_n] = 1e3 * best_of(lambda: fft_ints(vals, True))[0]
+    scal = [rng.randrange(R_MOD) for _ in range(GROUP_ORDER)]
+    pts = osetup.powers_of_x[:GROUP_ORDER]
+    prim["ec_lincomb_2^11_s"] = best_of(lambda: ec_lincomb(list(zip(pts, scal))))[0]
+    prim["samples"] = 3
+    prim["note"] = "best of 3; oracle/fr_poly.py (poly.py:113-148 restated) and oracle/g1.py (curve.py:38-111 restated), 1 core"
+    return dt, proof, prim
 
 
 def ntt_microbench(ctx, log_n, batch, reps=5):
@@ -96,7 +132,7 @@ def ntt_microbench(ctx, log_n, batch, reps=5):
     return best
 
 
-def msm_microbench(ctx, setup, batch, reps=3):
+def msm_microbench(ctx, bases, batch, reps=3):
     """`batch` commitments of 2^11 random coefficients in one plonk_g1_msm call -> ms (best of reps)."""
     import ctypes
     import random
@@ -109,7 +145,6 @@ def msm_microbench(ctx, setup, batch, reps=3):
     sc = ctx.alloc(n * batch + 4096)
     for off in range(0, n * batch + 4096, 4096):
         check(ctx.L.plonk_mem_d2d(ctx.handle, sc.at(off), src.ptr, 32 * 4096))
-    bases = setup.device_bases(ctx)
     xy, fl = ctypes.create_string_buffer(64 * batch), ctypes.create_string_buffer(batch)
     call = lambda: check(ctx.L.plonk_g1_msm(ctx.handle, bases.handle, sc.ptr, n, batch, n + 1, xy, fl))  # stride n+1: distinct vectors
     call()
@@ -123,70 +158,112 @@ def msm_microbench(ctx, setup, batch, reps=3):
     return best
 
 
+def spawn_ranks(args):
+    """`--gpus N` without a launcher: one child process per GPU, rank 0's JSON line is ours."""
+    import socket
+
+    from plonkathon_amd import _lib
+    import ctypes
+
+    n_dev = ctypes.c_int(0)
+    _lib.check(_lib.lib().plonk_device_count(ctypes.byref(n_dev)))
+    if args.dist_backend == "rccl" and n_dev.value < args.gpus:
+        sys.exit("bench.py: --gpus %d but only %d HIP device(s) are visible; refusing to run fewer ranks than asked "
+                 "(use --dist-backend sockets to share a GPU between ranks for a functional test)" % (args.gpus, n_dev.value))
+    with socket.socket() as s:  # a free port pair for the rendezvous
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), PLONK_RDZV_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    if any(rcs):
+        sys.exit("bench.py: rank exit codes %s" % rcs)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=512, help="proofs per GPU per step")
-    ap.add_argument("--streams", type=int, default=1, help="HIP streams per GPU: the batch is split into this many lock-step sub-batches that overlap each other")
-    ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI)")
-    ap.add_argument("--lookup-budget-gb", type=float, default=0.0,
-                    help="HBM budget for the MSM lookup table (0 = library default: 55 %% of free memory, at most 160 GB)")
+    ap.add_argument("--batch", type=int, default=512, help="proofs per lock-step batch (BASELINE configs[4]: 512)")
+    ap.add_argument("--batches-per-step", type=int, default=16, help="lock-step batches per GPU per step (all witnesses distinct)")
+    ap.add_argument("--streams", type=int, default=1, help="HIP streams per GPU: the lock-step batches of a step are dealt round-robin to this many contexts")
+    ap.add_argument("--dist-backend", default="rccl", choices=["rccl", "sockets"],
+                    help="transport of the final gather for N > 1: rccl = RCCL over xGMI through the C-ABI (default); sockets = TCP, lets ranks share one GPU")
+    ap.add_argument("--lookup-budget-gb", type=float, default=DEFAULT_TABLE_GB,
+                    help="HBM budget for the MSM lookup table (the library's own default is 4 GiB; the c = 17 table of 2^11 bases is 128.8 GB)")
+    ap.add_argument("--no-lookup", action="store_true", help="bucket-method MSM only")
+    ap.add_argument("--lagrange-commits", action="store_true", help="commit rounds 1-2 from Lagrange values over the Lagrange-basis SRS (a second lookup table)")
+    ap.add_argument("--log-n", type=int, default=11, help="log2(group_order); 11 = the BASELINE workload, smaller values are for functional tests only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-microbench", action="store_true")
+    ap.add_argument("--no-fallbacks", action="store_true")
     args = ap.parse_args()
 
+    global GROUP_ORDER
+    GROUP_ORDER = 1 << args.log_n
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return spawn_ranks(args)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
 
     from plonkathon_amd import BatchProver, Context, Program, Setup, set_context
     from plonkathon_amd import distributed as D
 
-    dist = D.init_from_env(args.dist_backend) if world > 1 else None
     ctx = Context(local_rank)
     set_context(ctx)
-    if args.lookup_budget_gb:
-        ctx.msm_lookup(0, 0, int(args.lookup_budget_gb * 1e9))
+    comm = D.init_from_env(ctx, args.dist_backend) if world > 1 else None
+    if comm is not None and comm.world != world:
+        sys.exit("bench.py: communicator has %d ranks, expected %d" % (comm.world, world))
+    budget = 0 if args.no_lookup else int(args.lookup_budget_gb * 1e9)
+    B, S, NS = args.batch, args.batches_per_step, max(1, args.streams)
+    ctxs = [ctx] + [Context(local_rank) for _ in range(NS - 1)]
+    for c in ctxs:
+        c.msm_lookup(1 if args.no_lookup else 0, 0, budget)
     setup = Setup.from_file(PTAU)
     program = Program(chain_program_lines(GROUP_ORDER), GROUP_ORDER)
-    B = args.batch
-    S = max(1, min(args.streams, B))
-    total = B * world  # weak scaling: every GPU proves B proofs per step
+    per_gpu = B * S
+    total = per_gpu * world  # weak scaling: every GPU proves B * S proofs per step
     mine = D.shard_indices(total, rank, world)
-    # S lock-step sub-batches on S HIP streams of the same GPU: while one sub-batch sits in a latency-bound
-    # kernel (transcript, field inversions), the others keep the ALUs busy with MSM / NTT work
-    ctxs = [ctx] + [Context(local_rank) for _ in range(S - 1)]
-    provers = [BatchProver(setup, program, c) for c in ctxs]
-    # synthetic witnesses, one per GLOBAL proof index (all distinct: identical proofs would turn the MSM's table
-    # look-ups into cache hits); staged in HBM before the timed region
-    parts = [mine[k::S] for k in range(S)]
+    # S lock-step batches per step, dealt round-robin to NS contexts (HIP streams) of this GPU; every proof of a step has
+    # its own witness (identical proofs would turn the MSM's table look-ups into cache hits), staged in HBM beforehand
+    provers = [BatchProver(setup, program, ctxs[k % NS], lagrange_commits=args.lagrange_commits) for k in range(S)]
+    parts = [mine[k * B : (k + 1) * B] for k in range(S)]
+    t_gen = t_up = 0.0
     for pr, part in zip(provers, parts):
-        pr.upload([witness_for(program, idx) for idx in part])
+        t0 = time.perf_counter()
+        wits = [witness_for(idx) for idx in part]
+        t1 = time.perf_counter()
+        pr.upload(wits)  # dicts -> V x 32 B per proof -> HBM; wire columns gathered on the device
+        t2 = time.perf_counter()
+        t_gen += t1 - t0
+        t_up += t2 - t1
+    host_upload_ms = 1e3 * t_up / per_gpu
 
     def step():
         for pr in provers:
             pr.run()                   # five rounds + transcript: one stream of kernel launches each
         blobs = [pr.download_raw() for pr in provers]   # sync + 768 B per proof back to the host
-        if S == 1:
-            return blobs[0][0], bytes(blobs[0][1])
-        out, status = [None] * len(mine), [0] * len(mine)
-        for k, (raw, st) in enumerate(blobs):
-            for j in range(len(parts[k])):
-                out[k + S * j] = raw[768 * j : 768 * (j + 1)]
-                status[k + S * j] = st[j]
-        return b"".join(out), bytes(status)
+        local = b"".join(b[0] for b in blobs)
+        status = b"".join(b[1] for b in blobs)
+        gathered = D.gather_proofs(local, total, comm) if comm is not None else None  # the path's one collective
+        return local, status, gathered
 
     def barrier():
         for c in ctxs:
             c.sync()
-        if dist is not None:
-            if dist.get_backend() == "nccl":
-                import torch
-
-                torch.cuda.synchronize()
-            dist.barrier()
+        if comm is not None:
+            comm.barrier()
 
     for _ in range(args.warmup):
         proofs = step()
@@ -197,20 +274,21 @@ def main():
     for _ in range(args.steps):
         proofs = step()
     barrier()
-    elapsed = D.max_over_ranks(time.perf_counter() - t0, dist)
+    elapsed = D.max_over_ranks(time.perf_counter() - t0, comm)
     ctx.profile(False)
     assert not any(proofs[1]), "a proof in the batch reported a failure status"
-    # the only collective on the path: all_gather of the finished proofs (768 B each) over RCCL/xGMI
-    gathered = D.gather_proofs(proofs[0], total, dist)
+    gathered = proofs[2] if comm is not None else D.gather_proofs(proofs[0], total, None)
     n_results = len(gathered)
+    assert n_results == total and all(g is not None for g in gathered)
 
     # the dominant kernel: the lookup MSM when the table fits in HBM (default), else the bucket method's accumulate
-    lookup_bits = setup.device_bases(ctx).lookup_bits
+    info = setup.device_bases(ctx).lookup_info()
+    lookup_bits = info["bits"]
     msm_kernel = "msm_lookup" if lookup_bits else "msm_accumulate"
     msm_ms, msm_launches, msm_bytes = ctx.profile_read(msm_kernel)  # stream 0's launches
-    total_proofs = args.steps * B * world
+    total_proofs = args.steps * total
     line = {
-        "metric": "proofs/sec at group_order=2^11 (PLONK prover hot path: NTT + quotient + KZG MSM)",
+        "metric": "proofs/sec at group_order=2^%d (PLONK prover hot path: NTT + quotient + KZG MSM)" % args.log_n,
         "value": total_proofs / elapsed,
         "unit": "proofs/s",
         "n_gpus": world,
@@ -223,28 +301,51 @@ def main():
         "dtype": "u32x8 (254-bit Montgomery integers, BN254 Fr/Fq)",
         "data": "synthetic",
         "config": {
-            "workload": "configs[1]: group_order=2^11, powersOfTau28_hez_final_11 SRS slice, synthetic squaring-chain witness",
-            "proofs_per_gpu_per_step": B,
+            "workload": "configs[1]: group_order=2^%d, powersOfTau28_hez_final_11 SRS slice, synthetic squaring-chain witness, one distinct witness per proof" % args.log_n,
+            "proofs_per_gpu_per_step": per_gpu,
+            "lockstep_batch": B,
+            "batches_per_step": S,
             "prover": "BatchProver (lock-step, GPU-resident transcript)",
-            "streams_per_gpu": S,
-            "results_gathered": n_results,
+            "streams_per_gpu": NS,
+            "results_gathered_per_step": n_results,
             "parallelism": "proof-sharded x%d" % world,
+            "ranks_in_communicator": comm.world if comm is not None else 1,
+            "gather_transport": comm.kind if comm is not None else "none (single rank)",
+            "gather_in_timed_region": comm is not None,
+            "msm_method": ("lookup table, %d-bit windows" % lookup_bits) if lookup_bits else "bucket method, %d-bit windows" % MSM_WINDOW_BITS,
+            "msm_table_bits": lookup_bits,
+            "msm_table_bytes": info["bytes"],
+            "msm_table_build_s": info["build_s"],
+            "msm_table_budget_bytes": budget,
+            "msm_table_shared_by": info["sharers"],
+            "lagrange_commits": bool(args.lagrange_commits),
+            "timed_region_s": elapsed,
+        },
+        "host": {
+            "host_upload_ms_per_proof": host_upload_ms,
+            "witness_generation_ms_per_proof": 1e3 * t_gen / per_gpu,
+            "note": "BatchProver.upload: Python witness dictionaries -> 32-byte words (V x 32 B per proof) -> HBM, wire columns "
+                    "gathered on the device; outside `value` (inputs are resident before the timed region)",
         },
     }
+    line["host"]["end_to_end_proofs_per_s_from_dicts_per_gpu"] = per_gpu / (t_up + per_gpu * elapsed / total_proofs * world)
+
     def pmc_traffic(kernel, run):
         """HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside this process)."""
-        path = os.path.join(REPO, "profiles", "r01_pmc_summary.json")
-        if not os.path.exists(path):
-            return None, None
-        ks = [k for k in json.load(open(path))["kernels"] if k["kernel"] == kernel and k["run"] == run]
-        n = sum(k["launches"] for k in ks)
-        if not n:
-            return None, None
-        return sum(k["traffic_bytes"] * k["launches"] for k in ks) / n, "profiles/r01_pmc_summary.json"
+        for name in ("r02_pmc_summary.json", "r01_pmc_summary.json"):
+            path = os.path.join(REPO, "profiles", name)
+            if not os.path.exists(path):
+                continue
+            ks = [k for k in json.load(open(path))["kernels"] if k["kernel"] == kernel and k["run"] == run]
+            n = sum(k["launches"] for k in ks)
+            if n:
+                return sum(k["traffic_bytes"] * k["launches"] for k in ks) / n, "profiles/" + name
+        return None, None
 
     if msm_launches:
         avg_s = msm_ms * 1e-3 / msm_launches
         achieved = (msm_bytes / msm_launches) / avg_s / 1e9
+        traffic, traffic_src = pmc_traffic(msm_kernel + "_kernel", "bench") if B == 512 and NS == 1 else (None, None)
         line["roofline"] = {
             "kernel": msm_kernel + "_kernel",
             "bound": "hbm",
@@ -252,14 +353,13 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
-            "traffic": pmc_traffic(msm_kernel + "_kernel", "bench")[0] if B // S == 512 else None,
-            "traffic_source": "profiles/r01_pmc_summary.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
-                              "`bench.py --batch 512 --streams 1` (tools/pmc_collect.sh), 2*FETCH+WRITE, launch-weighted mean",
+            "traffic": traffic,
+            "traffic_source": "%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --batch 512` (tools/pmc_collect.sh), "
+                              "2*FETCH+WRITE, launch-weighted mean" % traffic_src,
             "launches": msm_launches,
             "avg_launch_us": avg_s * 1e6,
             "note": "algorithmic bytes = 96*N+64 per MSM (SURVEY.md 8(d)); the kernel is integer-ALU bound (DESIGN.md 3/4.2), "
                     "see `alu`; with the lookup table every addition also reads 64 table bytes, i.e. `traffic` is the real demand",
-            "msm_method": ("lookup table, %d-bit windows" % lookup_bits) if lookup_bits else "bucket method, %d-bit windows" % MSM_WINDOW_BITS,
         }
         if lookup_bits:  # the lookup method's own algorithmic bytes: one 64-byte table entry per addition + the scalars
             windows_l = (255 + lookup_bits - 1) // lookup_bits
@@ -268,8 +368,8 @@ def main():
             line["roofline"]["method_bytes_per_msm"] = per_msm
             line["roofline"]["method_GBps"] = per_msm * n_msm_l / (msm_ms * 1e-3) / 1e9
             line["roofline"]["method_frac_of_peak"] = line["roofline"]["method_GBps"] / HBM_PEAK_GBS
-        if line["roofline"]["traffic"]:  # what the kernel really asks of HBM (table look-ups), per the PMC passes
-            line["roofline"]["traffic_GBps"] = line["roofline"]["traffic"] / avg_s / 1e9
+        if traffic:  # what the kernel really asks of HBM (table look-ups), per the PMC passes
+            line["roofline"]["traffic_GBps"] = traffic / avg_s / 1e9
             line["roofline"]["traffic_frac_of_peak"] = line["roofline"]["traffic_GBps"] / HBM_PEAK_GBS
         # the honest ceiling: W*N mixed additions per MSM against the rate of a bare mixed-addition loop
         n_msm = msm_bytes / (96.0 * GROUP_ORDER + 64.0)
@@ -281,32 +381,74 @@ def main():
                                    "note": "%d mixed additions per MSM (8 Fq mul + 2 sqr + 8 add/sub each); ceiling = the same "
                                            "addition in a register-only loop (tools/ubench), i.e. the kernel adds no overhead "
                                            "beyond the arithmetic itself" % (windows * GROUP_ORDER)}
+    ntt_ms, ntt_launches, ntt_bytes = ctx.profile_read("ntt_pass")
+    if ntt_launches:
+        line["prover_ntt"] = {"kernel": "ntt passes inside the timed prover steps", "launches": ntt_launches, "total_ms": ntt_ms,
+                              "achieved_GBps": ntt_bytes / (ntt_ms * 1e-3) / 1e9, "frac_of_hbm_peak": ntt_bytes / (ntt_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+
+    if not args.no_fallbacks and lookup_bits and world == 1:
+        # the same prover when the HBM for the big table is not available: a 40 GB budget, and no table at all
+        fb = {}
+        c40 = max(c for c in range(8, 18) if lookup_table_bytes(GROUP_ORDER, c) <= 40e9)
+        for name, conf in (("table_budget_40GB", (0, c40, int(40e9))), ("bucket_method", (1, 0, 0))):
+            c2 = Context(local_rank)
+            c2.msm_lookup(*conf)
+            pr = BatchProver(setup, program, c2)
+            pr.upload([witness_for(idx) for idx in mine[:B]])
+            for _ in range(2):
+                pr.run()
+                pr.download_raw()
+            t = time.perf_counter()
+            for _ in range(3):
+                pr.run()
+                st = pr.download_raw()[1]
+            dt = (time.perf_counter() - t) / 3
+            assert not any(st)
+            i2 = setup.device_bases(c2).lookup_info()
+            fb[name] = {"proofs_per_s": B / dt, "ms_per_batch_of_%d" % B: 1e3 * dt, "msm_table_bits": i2["bits"],
+                        "msm_table_bytes": i2["bytes"], "msm_table_build_s": i2["build_s"]}
+            del pr
+            c2.close()
+        line["fallbacks"] = fb
+
     if not args.no_microbench:
         # standalone NTT and MSM rates; with N GPUs every rank runs a replica and the whole-job
         # rate is N x (work of one replica) / (time of the slowest rank)
-        ms11 = D.max_over_ranks(ntt_microbench(ctx, 11, 512), dist)
-        ms20 = D.max_over_ranks(ntt_microbench(ctx, 20, 1), dist)
-        ms_msm = D.max_over_ranks(msm_microbench(ctx, setup, 4608), dist)
+        ms11 = D.max_over_ranks(ntt_microbench(ctx, 11, 512), comm)
+        ms13 = D.max_over_ranks(ntt_microbench(ctx, 13, 512), comm)
+        ms16 = D.max_over_ranks(ntt_microbench(ctx, 16, 1), comm)
+        ms20 = D.max_over_ranks(ntt_microbench(ctx, 20, 1), comm)
+        ms_msm = D.max_over_ranks(msm_microbench(ctx, setup.device_bases(ctx), 4608), comm)
         line["ntt"] = {
             "gf_elems_per_s_2^11_x512": world * 512 * 2048 / (ms11 * 1e-3),
+            "gf_elems_per_s_2^13_x512": world * 512 * 8192 / (ms13 * 1e-3),
+            "gf_elems_per_s_2^16": world * (1 << 16) / (ms16 * 1e-3),
             "gf_elems_per_s_2^20": world * (1 << 20) / (ms20 * 1e-3),
             "ms_2^11_x512": ms11,
+            "ms_2^13_x512": ms13,
+            "ms_2^16": ms16,
             "ms_2^20": ms20,
             "replicas": world,
         }
         line["msm"] = {"msms_per_s_2^11_x4608": world * 4608 / (ms_msm * 1e-3), "ms_4608": ms_msm, "replicas": world}
         ach = 64.0 * (1 << 20) / (ms20 * 1e-3) / 1e9  # per GPU
-        line["roofline_ntt"] = {"kernel": "ntt_pass_kernel (2 passes, N=2^20)", "bound": "hbm", "achieved": ach,
-                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None}
+        tr20, tr20_src = pmc_traffic("ntt_2^20", "ntt")
+        line["roofline_ntt"] = {"kernel": "ntt pass kernels (N=2^20)", "bound": "hbm", "achieved": ach,
+                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": tr20,
+                                "traffic_source": tr20_src,
+                                "note": "ALU-bound on the 254-bit multiplication: 5 N multiplications at ~140 G/s chip-wide bound the "
+                                        "transform at ~10 % of HBM peak (DESIGN.md 4.1)"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        dt, oproof = cpu_baseline()
+        dt, oproof, prim = cpu_baseline()
         line["cpu_baseline"] = {
             "value": 1.0 / dt,
             "unit": "proofs/s",
             "cores": 1,
             "host_cores_total": os.cpu_count(),
             "kind": "port",
-            "sample": "1 full proof of the same group_order=2^11 circuit by oracle/plonk_prover.py (pure Python), %.1f s" % dt,
+            "sample": "1 full proof of the same group_order=2^11 circuit by oracle/plonk_prover.py (pure Python), %.1f s; "
+                      "primitives: best of 3 each" % dt,
+            "primitives": prim,
         }
         # the GPU proof of the same witness must be bit-identical to the oracle's
         got = BatchProver.decode(gathered[0]).flatten()
@@ -315,10 +457,14 @@ def main():
             ((got[k][0].n, got[k][1].n) if isinstance(got[k], tuple) else got[k].n) == want[k] for k in want
         )
         line["cpu_baseline"]["gpu_proof_bit_identical"] = bool(same)
+        if "ntt" in line:
+            line["cpu_baseline"]["gpu_speedup_fft_2^11"] = prim["fft_2^11_ms"] / (line["ntt"]["ms_2^11_x512"] / 512)
+            line["cpu_baseline"]["gpu_speedup_ec_lincomb_2^11"] = prim["ec_lincomb_2^11_s"] * 1e3 / (line["msm"]["ms_4608"] / 4608)
     if rank == 0:
         print(json.dumps(line), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
+    if comm is not None:
+        comm.barrier()
+        comm.close()
 
 
 if __name__ == "__main__":

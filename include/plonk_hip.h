@@ -119,6 +119,12 @@ int plonk_fr_barycentric(plonk_ctx* ctx, const void* d_vals, unsigned log_n, con
 int plonk_srs_load_ptau(plonk_ctx* ctx, const uint8_t* g1_mont_le, size_t n_points, plonk_srs** out_srs);
 int plonk_srs_load_affine(plonk_ctx* ctx, const uint8_t* xy_le, size_t n_points, plonk_srs** out_srs);
 int plonk_srs_free(plonk_ctx* ctx, plonk_srs* srs);
+/* Lagrange-basis view of an SRS: the 2^log_n points [L_i(tau)]_1 = sum_j (w^-ij / n) [tau^j]_1 (an inverse DFT of
+ * the SRS over the group, run once per size on the device and cached), so that Setup.commit(values)
+ * (setup.py:66-72: ifft, then lincomb with powers_of_x) is ONE MSM of the Lagrange values with no ifft in front, and
+ * Setup.verification_key (setup.py:75-77) eight of them.  The view is owned by `srs` and freed with it; it is a
+ * plonk_srs like any other (plonk_g1_msm, lookup tables).                                                        */
+int plonk_srs_lagrange(plonk_ctx* ctx, plonk_srs* srs, unsigned log_n, plonk_srs** out_view);
 int plonk_srs_size(const plonk_srs* srs, size_t* out_n);
 int plonk_g1_msm(plonk_ctx* ctx, plonk_srs* srs, const void* d_scalars, size_t n, size_t batch,
                  size_t scalar_stride, uint8_t* h_out_xy_le, uint8_t* h_out_is_identity);
@@ -165,6 +171,10 @@ typedef struct plonk_prover plonk_prover;
 int plonk_prover_create(plonk_ctx* ctx, plonk_srs* srs, unsigned log_n, const uint8_t* selectors_le32,
                         size_t n_public, plonk_prover** out);
 int plonk_prover_destroy(plonk_prover* p);
+/* options (0 = default): PLONK_PROVER_LAGRANGE_COMMITS commits a_1, b_1, c_1 and z_1 (rounds 1-2) from their
+ * Lagrange values over plonk_srs_lagrange instead of from coefficient forms — same group elements, same proof. */
+#define PLONK_PROVER_LAGRANGE_COMMITS 1u
+int plonk_prover_set_options(plonk_prover* p, unsigned flags);
 int plonk_prover_upload_witness(plonk_prover* p, const uint8_t* abc_le32, const uint8_t* public_le32, size_t batch);
 /* The same inputs at n_vars * 32 bytes per proof instead of 3 * n * 32: the wiring is given once per circuit —
  * cell_index[3][n] = index of the variable each wire cell (column L / R / O, row) carries, n_vars for an empty cell

@@ -44,6 +44,7 @@ SIGNATURES = {
     "plonk_fr_barycentric": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint, _u8p, ctypes.c_void_p]),
     "plonk_srs_load_ptau": (ctypes.c_int, [ctypes.c_void_p, _u8p, ctypes.c_size_t, c_void_pp]),
     "plonk_srs_load_affine": (ctypes.c_int, [ctypes.c_void_p, _u8p, ctypes.c_size_t, c_void_pp]),
+    "plonk_srs_lagrange": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint, c_void_pp]),
     "plonk_srs_free": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "plonk_srs_size": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_size_t)]),
     "plonk_srs_lookup_bits": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint)]),
@@ -52,6 +53,7 @@ SIGNATURES = {
     "plonk_g1_msm": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]),
     "plonk_msm_configure": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint, ctypes.c_uint]),
     "plonk_prover_create": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint, _u8p, ctypes.c_size_t, c_void_pp]),
+    "plonk_prover_set_options": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint]),
     "plonk_prover_destroy": (ctypes.c_int, [ctypes.c_void_p]),
     "plonk_prover_upload_witness": (ctypes.c_int, [ctypes.c_void_p, _u8p, _u8p, ctypes.c_size_t]),
     "plonk_prover_set_wiring": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]),

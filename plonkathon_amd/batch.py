@@ -37,9 +37,11 @@ except ImportError:  # pragma: no cover - pure-Python equivalent of the packer (
 
 
 class BatchProver:
-    def __init__(self, setup: Setup, program: Program, ctx=None):
+    def __init__(self, setup: Setup, program: Program, ctx=None, lagrange_commits=False):
         """`ctx`: the Context (HIP stream) to run on; several BatchProvers on distinct contexts of one
-        GPU overlap each other's latency-bound kernels (transcript, inversions) with MSM work."""
+        GPU overlap each other's latency-bound kernels (transcript, inversions) with MSM work.
+        `lagrange_commits`: commit a_1, b_1, c_1, z_1 from Lagrange values over the Lagrange-basis SRS
+        (PLONK_PROVER_LAGRANGE_COMMITS) instead of from coefficient forms; same proofs."""
         self.group_order = program.group_order
         self.setup = setup
         self.program = program
@@ -64,6 +66,8 @@ class BatchProver:
         check(self.ctx.L.plonk_prover_create(self.ctx.handle, self._bases.handle, _log2_exact(n), sel,
                                              len(self._public_vars), ctypes.byref(self._h)))
         self._resident = 0
+        if lagrange_commits:
+            check(self.ctx.L.plonk_prover_set_options(self._h, 1))
         # the wiring goes to the device once; a batch is then only the variables' values (V x 32 B per proof)
         self._getter = None
         if self._vars:

@@ -475,6 +475,12 @@ int plonk_srs_free(plonk_ctx* ctx, plonk_srs* srs) {
     return PLONK_OK;
 }
 
+int plonk_srs_lagrange(plonk_ctx* ctx, plonk_srs* srs, unsigned log_n, plonk_srs** out_view) {
+    PLONK_REQUIRE(ctx && srs && out_view, PLONK_ERR_ARG, "bad argument");
+    PLONK_ENTER(ctx);
+    return msm_lagrange_srs(ctx, srs, log_n, out_view);
+}
+
 int plonk_srs_size(const plonk_srs* srs, size_t* out_n) {
     PLONK_REQUIRE(srs && out_n, PLONK_ERR_ARG, "bad argument");
     *out_n = srs->n_points;

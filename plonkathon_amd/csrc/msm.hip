@@ -765,6 +765,82 @@ static int msm_run_lookup(plonk_ctx* ctx, plonk_srs* srs, const Fr* d_scalars, s
     return PLONK_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Lagrange-basis SRS (setup.py:66-72 says commit = ifft + lincomb with powers_of_x): the points
+//     [L_i(tau)]_1 = sum_j (w^(-ij) / n) [tau^j]_1,      i < n = 2^log_n,
+// i.e. the inverse DFT of the SRS over the group, computed once per (SRS, n) — as n batched MSMs over the
+// monomial bases whose scalar rows are the inverse NTT of the identity matrix (row i = coefficients of L_i), so the
+// "EC-iNTT" reuses the NTT and MSM kernels as they are (2^11 rows: a few milliseconds on the lookup table).
+// commit(values) = sum_i values_i [L_i(tau)]_1 is then one MSM with no inverse NTT in front of it.
+__global__ void fr_identity_rows_kernel(Fr* out, size_t n, size_t row0, size_t rows) {
+    const size_t total = rows * n;
+    const Fr one = fp_one<FrParams>(), zero = fp_zero<FrParams>();
+    for (size_t gI = (size_t)blockIdx.x * blockDim.x + threadIdx.x; gI < total; gI += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = gI / n, j = gI - r * n;
+        fp_store(out + gI, j == row0 + r ? one : zero);
+    }
+}
+__global__ void fq_to_mont_kernel(const Fq* in, Fq* out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        fp_store(out + i, fp_to_mont(fp_load(in + i)));
+}
+
+int msm_lagrange_srs(plonk_ctx* ctx, plonk_srs* srs, unsigned log_n, plonk_srs** out) {
+    auto it = srs->lagrange.find(log_n);
+    if (it != srs->lagrange.end()) {
+        *out = it->second;
+        return PLONK_OK;
+    }
+    const size_t n = (size_t)1 << log_n;
+    PLONK_REQUIRE(n <= srs->n_points, PLONK_ERR_ARG, "Lagrange basis of size %zu needs %zu powers, the SRS has %zu", n, n, srs->n_points);
+    PLONK_REQUIRE(log_n <= PLONK_FR_TWO_ADICITY, PLONK_ERR_ARG, "size 2^%u exceeds the 2-adicity of Fr", log_n);
+    const size_t rows = n < 1024 ? n : 1024;  // rows per round: bounds the scalar matrix at 1024 * n elements
+    void *mat = nullptr, *res = nullptr, *bases = nullptr;
+    auto cleanup = [&]() {
+        if (mat) hipFree(mat);
+        if (res) hipFree(res);
+    };
+    if (hipMalloc(&mat, rows * n * sizeof(Fr)) != hipSuccess || hipMalloc(&res, rows * (2 * sizeof(Fq) + 1) + 64) != hipSuccess ||
+        hipMalloc(&bases, n * sizeof(G1Affine)) != hipSuccess) {
+        cleanup();
+        if (bases) hipFree(bases);
+        plonk_set_error("hipMalloc failed while building the Lagrange-basis SRS of size %zu", n);
+        return PLONK_ERR_NOMEM;
+    }
+    Fq* d_xy = (Fq*)res;
+    uint8_t* d_fl = (uint8_t*)res + rows * 2 * sizeof(Fq);
+    int rc = PLONK_OK;
+    for (size_t row0 = 0; row0 < n && rc == PLONK_OK; row0 += rows) {
+        unsigned g = (unsigned)((rows * n + 255) / 256);
+        PLONK_LAUNCH(fr_identity_rows_kernel, dim3(g > 4096 ? 4096 : g), dim3(256), 0, ctx->stream, (Fr*)mat, n, row0, rows);
+        rc = ntt_run(ctx, (const Fr*)mat, (Fr*)mat, log_n, true, rows, n, n, n, nullptr, nullptr, true);
+        if (rc == PLONK_OK) rc = msm_run_device(ctx, srs, (const Fr*)mat, n, rows, n, d_xy, d_fl);
+        if (rc == PLONK_OK) {  // canonical x||y -> Montgomery bases; the identity stays (0, 0)
+            unsigned g2 = (unsigned)((2 * rows + 255) / 256);
+            PLONK_LAUNCH(fq_to_mont_kernel, dim3(g2), dim3(256), 0, ctx->stream, (const Fq*)d_xy, (Fq*)((G1Affine*)bases + row0), 2 * rows);
+        }
+    }
+    if (rc == PLONK_OK && (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess)) {
+        plonk_set_error("building the Lagrange-basis SRS failed on the device");
+        rc = PLONK_ERR_HIP;
+    }
+    cleanup();
+    if (rc != PLONK_OK) {
+        hipFree(bases);
+        return rc;
+    }
+    plonk_srs* child = new plonk_srs();
+    child->device = srs->device;
+    child->n_points = n;
+    child->bases = (G1Affine*)bases;
+    child->fixed = srs->fixed;
+    const uint64_t tag[2] = {srs->content_key, 0x4c61677200000000ull | log_n};  // "Lagr" | log_n
+    child->content_key = plonk_fnv1a64(tag, sizeof tag);
+    srs->lagrange[log_n] = child;
+    *out = child;
+    return PLONK_OK;
+}
+
 // Enqueue a batch of M MSMs; results land in device buffers (d_out_xy: 2*M Fq canonical, d_flags: M bytes).
 int msm_run_device(plonk_ctx* ctx, plonk_srs* srs, const Fr* d_scalars, size_t n, size_t M, size_t stride,
                    Fq* d_out_xy, uint8_t* d_flags, size_t inner, size_t outer_stride) {

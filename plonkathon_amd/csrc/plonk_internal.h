@@ -133,6 +133,7 @@ int ntt_run(plonk_ctx*, const Fr* in, Fr* out, unsigned log_n, bool inverse, siz
 int ntt_get_roots(plonk_ctx*, unsigned log_n, bool inverse, const Fr** table_full);
 // msm.hip
 int msm_build_table(plonk_ctx*, plonk_srs*, unsigned c);
+int msm_lagrange_srs(plonk_ctx*, plonk_srs*, unsigned log_n, plonk_srs** out);  // owned by (and freed with) the parent
 void msm_srs_release(plonk_srs*);  // drops the reference on the shared lookup table
 int msm_lookup_info(const plonk_srs*, unsigned* bits, size_t* bytes, double* build_s, int* sharers);
 uint64_t plonk_fnv1a64(const void* data, size_t n);

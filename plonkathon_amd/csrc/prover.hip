@@ -73,6 +73,7 @@ struct plonk_prover {
     size_t n_vars;
     Fr* vars;                  // [B][n_vars] values of the resident batch (Montgomery)
     size_t vars_cap;           // elements
+    plonk_srs* lag_srs;        // Lagrange-basis view of srs (PLONK_PROVER_LAGRANGE_COMMITS), owned by srs
     size_t resident_b;         // batch size of the witnesses currently resident (run / download must match it)
     Fq *commit_xy; // [9][B] x||y canonical
     uint8_t* commit_flags;  // [9][B]
@@ -812,6 +813,14 @@ static int prover_init(plonk_prover* p, plonk_ctx* ctx, plonk_srs* srs, unsigned
 
 extern "C" {
 
+int plonk_prover_set_options(plonk_prover* p, unsigned flags) {
+    PLONK_REQUIRE(p && !(flags & ~PLONK_PROVER_LAGRANGE_COMMITS), PLONK_ERR_ARG, "unknown prover option bits %#x", flags);
+    PLONK_ENTER(p->ctx);
+    p->lag_srs = nullptr;
+    if (flags & PLONK_PROVER_LAGRANGE_COMMITS) PLONK_TRY(msm_lagrange_srs(p->ctx, p->srs, p->log_n, &p->lag_srs));
+    return PLONK_OK;
+}
+
 int plonk_prover_destroy(plonk_prover* p) {
     if (!p) return PLONK_OK;
     if (p->ctx) {
@@ -930,14 +939,16 @@ int plonk_prover_run(plonk_prover* p, size_t B) {
     } else {
         PLONK_TRY(ntt_run(ctx, p->wit_lag, p->coef, log_n, true, 4 * B, n, n, n, nullptr, nullptr, true));
     }
-    PLONK_TRY(msm_run_device(ctx, p->srs, p->coef, n, 3 * B, n, cxy, cfl));
+    if (p->lag_srs) PLONK_TRY(msm_run_device(ctx, p->lag_srs, p->wit_lag, n, 3 * B, n, cxy, cfl));  // same points from Lagrange values
+    else PLONK_TRY(msm_run_device(ctx, p->srs, p->coef, n, 3 * B, n, cxy, cfl));
     PLONK_LAUNCH(transcript_kernel, dim3(tg), dim3(2 * TC_LANES), 0, s, 1, p->state, B, (const Fq*)cxy, (const uint8_t*)cfl, p->chal);
     // ---- round 2: grand product Z, commit                                      prover.py:121-152
     PLONK_LAUNCH(grand_product_kernel, dim3((unsigned)B), dim3(GP_THREADS), 0, s, (const Fr*)p->wit_lag,
                  (const Fr*)(p->fixed_lag + FX_S1 * n), p->roots, (const ProofState*)p->state, n, B, p->z_lag, closes, p->num,
                  p->wz);  // num / wz: scratch until round 5
     PLONK_TRY(ntt_run(ctx, p->z_lag, p->coef + 4 * B * n, log_n, true, B, n, n, n, nullptr, nullptr, true));
-    PLONK_TRY(msm_run_device(ctx, p->srs, p->coef + 4 * B * n, n, B, n, cxy + 2 * 3 * B, cfl + 3 * B));
+    if (p->lag_srs) PLONK_TRY(msm_run_device(ctx, p->lag_srs, p->z_lag, n, B, n, cxy + 2 * 3 * B, cfl + 3 * B));
+    else PLONK_TRY(msm_run_device(ctx, p->srs, p->coef + 4 * B * n, n, B, n, cxy + 2 * 3 * B, cfl + 3 * B));
     PLONK_LAUNCH(transcript_kernel, dim3(tg), dim3(2 * TC_LANES), 0, s, 2, p->state, B, (const Fq*)cxy, (const uint8_t*)cfl, p->chal);
     // ---- round 3: coset extensions, fused quotient, back to coefficients, commit T1..T3   prover.py:154-226
     if (p->sparse_pi) {  // A, B, C and Z through the transform, PI from the Lagrange basis on the coset

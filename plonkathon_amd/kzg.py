@@ -55,8 +55,19 @@ def _decode_points(xy: bytes, flags: bytes):
 class _DeviceBases:
     """Owns a `plonk_srs*` (bases + window / lookup tables in HBM)."""
 
-    def __init__(self, ctx, handle, n):
+    def __init__(self, ctx, handle, n, owner=None):
         self.ctx, self.handle, self.n = ctx, handle, n
+        self._owner = owner  # a Lagrange view is owned by (and keeps alive) its parent
+        self._views = {}
+
+    def lagrange(self, log_n):
+        """The Lagrange-basis view [L_i(tau)]_1, i < 2^log_n (plonk_srs_lagrange; built once, cached on the device)."""
+        v = self._views.get(log_n)
+        if v is None:
+            h = ctypes.c_void_p()
+            check(self.ctx.L.plonk_srs_lagrange(self.ctx.handle, self.handle, log_n, ctypes.byref(h)))
+            v = self._views[log_n] = _DeviceBases(self.ctx, h, 1 << log_n, owner=self)
+        return v
 
     @property
     def lookup_bits(self):
@@ -75,6 +86,10 @@ class _DeviceBases:
 
     def __del__(self):
         try:
+            if self._owner is not None:  # a view: freed with its parent
+                self.handle = None
+                return
+            self._views = {}
             if self.handle and self.ctx.handle:
                 self.ctx.L.plonk_srs_free(self.ctx.handle, self.handle)
                 self.handle = None
@@ -161,10 +176,14 @@ class Setup:
 
     # setup.py:66-72
     def commit(self, values: Polynomial):
+        """KZG commitment of Lagrange values.  The reference runs an ifft and then a lincomb with powers_of_x; here the
+        SRS itself is taken to the Lagrange basis once per size (an inverse DFT over the group, on the device) and the
+        commitment is a single MSM of the values — the same group element."""
         assert values.basis == Basis.LAGRANGE
-        coeffs = values.ifft()
-        assert len(coeffs) <= self._n
-        return self.commit_coeffs(coeffs)
+        n = len(values)
+        assert n <= self._n  # setup.py:70
+        lag = self.device_bases().lagrange(_log2_exact(n))
+        return _msm(lag, values.device().ptr, n, 1, n)[0]
 
     def commit_coeffs(self, coeffs: Polynomial):
         """KZG commitment of a polynomial already in MONOMIAL basis (skips the ifft)."""

@@ -507,6 +507,28 @@ def msm_deferred_overflow(setup_unused=None):
         ctx.msm_lookup(0)
 
 
+def lagrange_srs_paths(setup):
+    """Setup.commit goes through the Lagrange-basis SRS: it must equal ifft + coefficient-basis MSM (setup.py:66-72) at
+    several sizes, and a BatchProver committing rounds 1-2 from Lagrange values must produce the same proofs."""
+    import random
+
+    rng = random.Random(77)
+    for log_n in (0, 1, 3, 6):
+        n = 1 << log_n
+        vals = [rng.randrange(R_MOD) for _ in range(n)]
+        a = setup.commit(P(vals))
+        b = setup.commit_coeffs(P(vals).ifft())
+        assert affine(a) == affine(b)
+        want = og1.ec_lincomb(list(zip([affine(p) for p in setup.powers_of_x[:n]], OPoly(vals, OBasis.LAGRANGE).ifft().values)))
+        assert affine(a) == want
+    assert setup.commit(P([0] * 8)) is None
+    lines, n = ["e public", "c <== a * b", "e <== c * d"], 8
+    wits = [{"a": 3 + i, "b": 4, "c": (3 + i) * 4, "d": 5, "e": (3 + i) * 20} for i in range(5)]
+    ref = [flat(p) for p in pa.BatchProver(setup, Program(lines, n)).prove_batch(wits)]
+    got = [flat(p) for p in pa.BatchProver(setup, Program(lines, n), lagrange_commits=True).prove_batch(wits)]
+    assert got == ref
+
+
 def lookup_table_is_shared_across_contexts():
     """One lookup table per (device, SRS): a second context / Setup over the same bytes attaches to it."""
     from plonkathon_amd import Context, Setup

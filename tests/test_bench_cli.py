@@ -1,0 +1,37 @@
+"""bench.py's launch contract on CPU (emulated kernels, tiny circuit): `--gpus N` without a launcher spawns N ranks
+that really form an N-rank communicator, and asking for more RCCL ranks than there are devices fails loudly."""
+import json
+import os
+import subprocess
+import sys
+
+from conftest import EMU_LIB, REPO
+
+
+def _run(extra, timeout=600):
+    env = dict(os.environ, PLONK_HIP_LIB=EMU_LIB, PLONK_MSM_TABLE_GB="0.0001")
+    env.pop("WORLD_SIZE", None)
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--log-n", "4", "--batch", "3", "--batches-per-step", "2", "--steps", "2",
+           "--warmup", "1", "--no-cpu-baseline", "--no-microbench", "--no-fallbacks", "--no-lookup"] + extra
+    return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_gpus_flag_spawns_that_many_ranks(emu_cdll):
+    r = _run(["--gpus", "2", "--dist-backend", "sockets"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["config"]["ranks_in_communicator"] == 2
+    assert line["config"]["results_gathered_per_step"] == 2 * 3 * 2 and line["config"]["gather_in_timed_region"]
+    assert line["scaling"] == "weak" and line["unit"] == "proofs/s" and line["value"] > 0
+
+
+def test_more_rccl_ranks_than_devices_is_an_error(emu_cdll):
+    r = _run(["--gpus", "3"])  # the emulation reports one device
+    assert r.returncode != 0 and "refusing" in r.stderr
+
+
+def test_world_size_must_match_gpus(emu_cdll):
+    env = dict(os.environ, PLONK_HIP_LIB=EMU_LIB, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "4", "--log-n", "4"], env=env,
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE" in r.stderr

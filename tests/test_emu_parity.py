@@ -172,3 +172,9 @@ def test_msm_deferred_overflow_is_recomputed(emu):
 
 def test_lookup_table_is_shared_across_contexts(emu):
     pc.lookup_table_is_shared_across_contexts()
+
+
+def test_lagrange_srs_paths(emu):
+    from plonkathon_amd import Setup
+
+    pc.lagrange_srs_paths(Setup.from_file(pc.PTAU))
