@@ -194,13 +194,14 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=512, help="proofs per lock-step batch (BASELINE configs[4]: 512)")
     ap.add_argument("--batches-per-step", type=int, default=16, help="lock-step batches per GPU per step (all witnesses distinct)")
-    ap.add_argument("--streams", type=int, default=1, help="HIP streams per GPU: the lock-step batches of a step are dealt round-robin to this many contexts")
+    ap.add_argument("--streams", type=int, default=2, help="HIP streams per GPU: the lock-step batches of a step are dealt round-robin to this many contexts, so one batch's latency-bound kernels (transcript, inversions, scans) overlap another's MSMs")
     ap.add_argument("--dist-backend", default="rccl", choices=["rccl", "sockets"],
                     help="transport of the final gather for N > 1: rccl = RCCL over xGMI through the C-ABI (default); sockets = TCP, lets ranks share one GPU")
     ap.add_argument("--lookup-budget-gb", type=float, default=DEFAULT_TABLE_GB,
                     help="HBM budget for the MSM lookup table (the library's own default is 4 GiB; the c = 17 table of 2^11 bases is 128.8 GB)")
     ap.add_argument("--no-lookup", action="store_true", help="bucket-method MSM only")
     ap.add_argument("--lagrange-commits", action="store_true", help="commit rounds 1-2 from Lagrange values over the Lagrange-basis SRS (a second lookup table)")
+    ap.add_argument("--ntt-kind", type=int, default=0, help="plonk_ntt_select_kernel: 0 auto, 1 radix-2 stages, 2 Stockham, 3 wave, 4 auto without the wave kernel (A/B)")
     ap.add_argument("--log-n", type=int, default=11, help="log2(group_order); 11 = the BASELINE workload, smaller values are for functional tests only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-microbench", action="store_true")
@@ -230,6 +231,10 @@ def main():
     ctxs = [ctx] + [Context(local_rank) for _ in range(NS - 1)]
     for c in ctxs:
         c.msm_lookup(1 if args.no_lookup else 0, 0, budget)
+        if args.ntt_kind:
+            from plonkathon_amd._lib import check as _check
+
+            _check(c.L.plonk_ntt_select_kernel(c.handle, args.ntt_kind))
     setup = Setup.from_file(PTAU)
     program = Program(chain_program_lines(GROUP_ORDER), GROUP_ORDER)
     per_gpu = B * S
@@ -267,15 +272,22 @@ def main():
 
     for _ in range(args.warmup):
         proofs = step()
-    ctx.profile_reset()
-    ctx.profile(True)
+    for c in ctxs:
+        c.profile_reset()
+        c.profile(True)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         proofs = step()
     barrier()
     elapsed = D.max_over_ranks(time.perf_counter() - t0, comm)
-    ctx.profile(False)
+    for c in ctxs:
+        c.profile(False)
+
+    def profile_sum(kernel):  # over every stream of this GPU
+        parts = [c.profile_read(kernel) for c in ctxs]
+        return sum(p[0] for p in parts), sum(p[1] for p in parts), sum(p[2] for p in parts)
+
     assert not any(proofs[1]), "a proof in the batch reported a failure status"
     gathered = proofs[2] if comm is not None else D.gather_proofs(proofs[0], total, None)
     n_results = len(gathered)
@@ -285,7 +297,7 @@ def main():
     info = setup.device_bases(ctx).lookup_info()
     lookup_bits = info["bits"]
     msm_kernel = "msm_lookup" if lookup_bits else "msm_accumulate"
-    msm_ms, msm_launches, msm_bytes = ctx.profile_read(msm_kernel)  # stream 0's launches
+    msm_ms, msm_launches, msm_bytes = profile_sum(msm_kernel)
     total_proofs = args.steps * total
     line = {
         "metric": "proofs/sec at group_order=2^%d (PLONK prover hot path: NTT + quotient + KZG MSM)" % args.log_n,
@@ -345,7 +357,7 @@ def main():
     if msm_launches:
         avg_s = msm_ms * 1e-3 / msm_launches
         achieved = (msm_bytes / msm_launches) / avg_s / 1e9
-        traffic, traffic_src = pmc_traffic(msm_kernel + "_kernel", "bench") if B == 512 and NS == 1 else (None, None)
+        traffic, traffic_src = pmc_traffic(msm_kernel + "_kernel", "bench") if B == 512 else (None, None)
         line["roofline"] = {
             "kernel": msm_kernel + "_kernel",
             "bound": "hbm",
@@ -358,8 +370,10 @@ def main():
                               "2*FETCH+WRITE, launch-weighted mean" % traffic_src,
             "launches": msm_launches,
             "avg_launch_us": avg_s * 1e6,
+            "concurrent_streams": NS,
             "note": "algorithmic bytes = 96*N+64 per MSM (SURVEY.md 8(d)); the kernel is integer-ALU bound (DESIGN.md 3/4.2), "
-                    "see `alu`; with the lookup table every addition also reads 64 table bytes, i.e. `traffic` is the real demand",
+                    "see `alu`; with the lookup table every addition also reads 64 table bytes, i.e. `traffic` is the real demand; "
+                    "with concurrent_streams > 1 a launch shares the chip with the other stream's kernels for part of its duration",
         }
         if lookup_bits:  # the lookup method's own algorithmic bytes: one 64-byte table entry per addition + the scalars
             windows_l = (255 + lookup_bits - 1) // lookup_bits
@@ -376,12 +390,16 @@ def main():
         wbits = lookup_bits or MSM_WINDOW_BITS
         windows = (255 + wbits - 1) // wbits
         gmadd = n_msm * windows * GROUP_ORDER / (msm_ms * 1e-3) / 1e9
+        # whole-step view: every mixed addition of the timed region over its wall time — with several streams the per-launch
+        # durations above include the time a launch shares the chip with another stream's kernels, this figure does not care
+        step_gmadd = n_msm * windows * GROUP_ORDER / elapsed / 1e9
         line["roofline"]["alu"] = {"achieved_g1_gmadd_per_s": gmadd, "ceiling_g1_gmadd_per_s": G1_MADD_CEILING_G,
                                    "frac": gmadd / G1_MADD_CEILING_G,
+                                   "whole_step_g1_gmadd_per_s": step_gmadd, "whole_step_frac": step_gmadd / G1_MADD_CEILING_G,
                                    "note": "%d mixed additions per MSM (8 Fq mul + 2 sqr + 8 add/sub each); ceiling = the same "
                                            "addition in a register-only loop (tools/ubench), i.e. the kernel adds no overhead "
                                            "beyond the arithmetic itself" % (windows * GROUP_ORDER)}
-    ntt_ms, ntt_launches, ntt_bytes = ctx.profile_read("ntt_pass")
+    ntt_ms, ntt_launches, ntt_bytes = profile_sum("ntt_pass")
     if ntt_launches:
         line["prover_ntt"] = {"kernel": "ntt passes inside the timed prover steps", "launches": ntt_launches, "total_ms": ntt_ms,
                               "achieved_GBps": ntt_bytes / (ntt_ms * 1e-3) / 1e9, "frac_of_hbm_peak": ntt_bytes / (ntt_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}

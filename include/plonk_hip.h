@@ -76,8 +76,10 @@ int plonk_fr_coset_to_coeffs(plonk_ctx* ctx, const void* d_in, void* d_out, unsi
 /* tuning / test knob (0 = default): LDS tile = 2^tile_log elements (<= 12), sizes <= 2^single_pass_log
  * (<= 11) run as one pass, larger sizes split into passes of radix <= 2^radix_log (<= 10). */
 int plonk_ntt_configure(plonk_ctx* ctx, unsigned tile_log, unsigned single_pass_log, unsigned radix_log);
-/* in-LDS butterfly schedule: 0 = auto (Stockham radix-8 register butterflies for single-pass sizes <= 2^11,
- * radix-2 stages for multi-pass sizes: what measures fastest on MI355X), 1 = radix-2 stages, 2 = Stockham radix-8 */
+/* kernel family: 0 = auto (what measures fastest on MI355X: the in-register "wave" kernel — digits exchanged inside a
+ * wave by DPP / ds_swizzle / v_permlane32_swap, LDS only across waves — for 2^9, 2^11, 2^13 and the two-pass sizes
+ * built from them; Stockham radix-8 for other single-pass sizes; radix-2 stages otherwise), 1 = radix-2 stages,
+ * 2 = Stockham radix-8, 3 = wave kernel where it applies, 4 = auto without the wave kernel (A/B measurements) */
 int plonk_ntt_select_kernel(plonk_ctx* ctx, unsigned kind);
 /* Lower-level pieces used by the batched prover: coefficient form in, fixed offset table. */
 int plonk_fr_coset_ntt_from_coeffs(plonk_ctx* ctx, const void* d_coeffs, void* d_out, unsigned log_n,

@@ -440,6 +440,180 @@ __global__ void __launch_bounds__(1024) ntt_pass_radix2_kernel(NttPass p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Variant C ("wave" kernel): the whole transform in registers, exchanges INSIDE a wave by cross-lane moves.
+// plonk_ntt_select_kernel(kind = 3); the default for the single-pass sizes it covers (2^9, 2^11, 2^13).
+//
+// N = 2^(9 + 2 L) points, L = 0, 1, 2; N / 8 threads (64, 256, 1024), each holding 8 elements in registers.
+// Decimation in frequency by digits: a radix-8 stage, L radix-4 stages, two radix-8 stages.  The bits of the element
+// index live in three places — the register index (3 bits), the lane (6 bits) and, for L > 0, the wave (2 L bits).  A
+// stage works on the digit currently held in the register index; between stages that digit is swapped with
+//   * two WAVE bits: the only exchange that needs LDS, run in two rounds of 4 elements per thread (16 KiB per 64
+//     lanes, so LDS no longer limits occupancy: the Stockham kernel's 64 KiB tile held it to 2 waves per SIMD);
+//   * three LANE bits: an 8 x 8 transpose inside groups of 8 lanes as three single-bit swaps, each a cross-lane move
+//     (DPP quad_perm / row_ror for lane ^ 1, 2, 8; ds_swizzle for lane ^ 4, 16; v_permlane32_swap for lane ^ 32)
+//     plus two selects per dword — no LDS, no barrier for the last six levels of every transform.
+// After a stage on digit q of a sub-transform of size S (S / 8 or S / 4 remaining points indexed by `low`), output f is
+// multiplied by w_S^(low f) = roots[(N / S) low f]  (the Cooley-Tukey twiddle between the digit DFT and the remaining
+// sub-transforms).  Outputs appear at frequency k = d_A + 8 d_B + ... (first digit least significant), which the
+// final store turns into a natural-order write.  Coset scaling, zero padding n -> 4n, 1/N and the inverse-coset
+// scaling are fused into the first load / last store as in the other kernels.
+struct NttWave {
+    const Fr* in;
+    Fr* out;
+    size_t in_bstride, out_bstride;
+    unsigned in_len;
+    const Fr* roots;      // w_N^k, k < N (direction of the transform)
+    const Fr* in_scale;   // per-element factor at load (coset offset powers) or null
+    const Fr* out_scale;  // per-element factor at store or null
+    Fr out_scalar;
+    unsigned has_out_scalar;
+    Fr w8_1, w8_2, w8_3;
+};
+
+// f(0) .. f(7) with compile-time arguments: the element array must never be indexed by a run-time value, or it moves
+// from VGPRs to scratch memory (clang gives up unrolling loops whose bodies hold two field multiplications)
+template <unsigned J> struct WaveIdx { static constexpr unsigned value = J; };
+template <unsigned N, class F> PLONK_DEV void wave_for(F f) {
+    if constexpr (N > 0) {
+        wave_for<N - 1>(f);
+        f(WaveIdx<N - 1>{});
+    }
+}
+template <class F> PLONK_DEV void wave_for8(F f) { wave_for<8>(f); }
+
+template <unsigned MASK> PLONK_DEV uint32_t wave_lane_xor(uint32_t v, unsigned lane) {
+    if (MASK == 1) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
+    if (MASK == 2) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, false);   // quad_perm [2,3,0,1]
+    if (MASK == 4) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, (4 << 10) | 0x1f);           // bit mode: lane ^ 4
+    if (MASK == 8) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, false);  // row_ror:8
+    if (MASK == 16) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, (16 << 10) | 0x1f);         // bit mode: lane ^ 16
+    // lane ^ 32: v_permlane32_swap exchanges the upper half of its first operand with the lower half of the second
+    auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    return lane < 32 ? r[1] : r[0];
+}
+
+// swap register-index bit RB with the lane bit of MASK: lanes with the bit clear keep x[r] and trade x[r | 1 << RB],
+// lanes with the bit set keep x[r | 1 << RB] and trade x[r]
+template <unsigned RB, unsigned MASK> PLONK_DEV void wave_swap_bit(Fr (&x)[8], unsigned lane) {
+    const bool hi = (lane & MASK) != 0;
+    wave_for<4>([&](auto I) {
+        constexpr unsigned i4 = decltype(I)::value;
+        constexpr unsigned r = ((i4 >> RB) << (RB + 1)) | (i4 & ((1u << RB) - 1)), r1 = r | (1u << RB);  // the 4 indices with bit RB clear
+        wave_for<8>([&](auto W) {
+            constexpr unsigned i = decltype(W)::value;
+            const uint32_t send = hi ? x[r].v[i] : x[r1].v[i];
+            const uint32_t recv = wave_lane_xor<MASK>(send, lane);
+            if (hi) x[r].v[i] = recv;
+            else x[r1].v[i] = recv;
+        });
+    });
+}
+
+// x[BASE + f] *= roots[(low * f * mult) mod N], f = 1 .. COUNT-1   (compile-time register indices: x stays in VGPRs)
+template <unsigned LOG_N, unsigned BASE, unsigned COUNT> PLONK_DEV void wave_twiddle(Fr (&x)[8], unsigned low, unsigned mult, const Fr* roots) {
+    wave_for<COUNT - 1>([&](auto F) {
+        constexpr unsigned f = decltype(F)::value + 1;
+        x[BASE + f] = fp_mul(x[BASE + f], fp_load(roots + ((low * f * mult) & ((1u << LOG_N) - 1))));
+    });
+}
+PLONK_DEV void dft4r(Fr& x0, Fr& x1, Fr& x2, Fr& x3, const Fr& w2) {
+    Fr a0 = fp_add(x0, x2), a1 = fp_add(x1, x3), d0 = fp_sub(x0, x2), d1 = fp_mul(fp_sub(x1, x3), w2);
+    x0 = fp_add(a0, a1); x2 = fp_sub(a0, a1); x1 = fp_add(d0, d1); x3 = fp_sub(d0, d1);
+}
+
+#ifndef NTT_WAVE_MIN_WAVES
+#define NTT_WAVE_MIN_WAVES 4  // waves per SIMD the register allocation aims for (128 VGPRs)
+#endif
+template <unsigned NLDS>
+__global__ void __launch_bounds__(64u << (2 * NLDS), NTT_WAVE_MIN_WAVES) ntt_wave_kernel(NttWave p) {
+    constexpr unsigned LOG_N = 9 + 2 * NLDS, NT = 64u << (2 * NLDS);
+    PLONK_DYN_SMEM(smem);
+    u32x4* l_lo = reinterpret_cast<u32x4*>(smem);  // 4 * NT elements as two 16-byte planes
+    u32x4* l_hi = l_lo + 4 * NT;
+    const unsigned tid = threadIdx.x, lane = tid & 63;
+    const Fr* in = p.in + (size_t)blockIdx.x * p.in_bstride;
+    Fr* out = p.out + (size_t)blockIdx.x * p.out_bstride;
+
+    Fr x[8];
+    wave_for8([&](auto J) {  // element index j * NT + tid: consecutive lanes read consecutive elements
+        constexpr unsigned j = decltype(J)::value;
+        const unsigned g = j * NT + tid;
+        x[j] = g < p.in_len ? fp_load(in + g) : fp_zero<FrParams>();
+    });
+    if (p.in_scale) {
+        wave_for8([&](auto J) {
+            constexpr unsigned j = decltype(J)::value;
+            const unsigned g = j * NT + tid;
+            if (g < p.in_len) x[j] = fp_mul(x[j], fp_load(p.in_scale + g));
+        });
+    }
+    // stage A: digit = index bits LOG_N-1 .. LOG_N-3, low = tid
+    dft8(x, p.w8_1, p.w8_2, p.w8_3);
+    wave_twiddle<LOG_N, 0, 8>(x, tid, 1, p.roots);
+    // L radix-4 stages on the wave bits: swap register bits (1, 0) with thread bits (tb + 1, tb)
+    wave_for<NLDS>([&](auto S) {
+        constexpr unsigned s = decltype(S)::value;
+        constexpr unsigned tb = 6 + 2 * (NLDS - 1 - s);
+        const unsigned mine = (tid >> tb) & 3u, rest = tid & ~(3u << tb);
+        wave_for<2>([&](auto R2) {
+            constexpr unsigned r2 = decltype(R2)::value;
+            wave_for<4>([&](auto Q) { lds_st(l_lo, l_hi, decltype(Q)::value * NT + tid, x[4 * r2 + decltype(Q)::value]); });
+            __syncthreads();
+            wave_for<4>([&](auto Q) { x[4 * r2 + decltype(Q)::value] = lds_ld(l_lo, l_hi, mine * NT + (rest | (decltype(Q)::value << tb))); });
+            __syncthreads();
+        });
+        const unsigned low = tid & ((1u << tb) - 1);
+        const unsigned mult = 1u << (LOG_N - (tb + 2));  // N / S, S = 2^(tb + 2)
+        dft4r(x[0], x[1], x[2], x[3], p.w8_2);
+        dft4r(x[4], x[5], x[6], x[7], p.w8_2);
+        wave_twiddle<LOG_N, 0, 4>(x, low, mult, p.roots);
+        wave_twiddle<LOG_N, 4, 4>(x, low, mult, p.roots);
+    });
+    // stage on lane bits 5..3
+    wave_swap_bit<2, 32>(x, lane);
+    wave_swap_bit<1, 16>(x, lane);
+    wave_swap_bit<0, 8>(x, lane);
+    dft8(x, p.w8_1, p.w8_2, p.w8_3);
+    wave_twiddle<LOG_N, 0, 8>(x, lane & 7u, 1u << (LOG_N - 6), p.roots);
+    // stage on lane bits 2..0
+    wave_swap_bit<2, 4>(x, lane);
+    wave_swap_bit<1, 2>(x, lane);
+    wave_swap_bit<0, 1>(x, lane);
+    dft8(x, p.w8_1, p.w8_2, p.w8_3);
+    // frequency of register j: digits in processing order, first digit least significant
+    //   d_A = (lane bit 5) * 4 + thread bits (top pair);  then the remaining wave pairs;  (lane bits 4, 3);  (lane bits 2..0);  j
+    //   (without wave stages the first digit is simply lane bits 5..3)
+    unsigned k, shift = 3;
+    if (NLDS) {
+        k = (((lane >> 5) & 1u) << 2) | ((tid >> (6 + 2 * (NLDS > 0 ? NLDS - 1 : 0))) & 3u);
+        for (unsigned s = 1; s < NLDS; s++) {
+            k |= ((tid >> (6 + 2 * (NLDS - 1 - s))) & 3u) << shift;
+            shift += 2;
+        }
+        k |= ((lane >> 3) & 3u) << shift;
+        shift += 2;
+    } else {
+        k = (lane >> 3) & 7u;
+    }
+    k |= (lane & 7u) << shift;
+    shift += 3;
+    if (p.out_scale) {
+        wave_for8([&](auto J) {
+            constexpr unsigned j = decltype(J)::value;
+            x[j] = fp_mul(x[j], fp_load(p.out_scale + (k | (j << shift))));
+        });
+    }
+    if (p.has_out_scalar) {
+        const Fr sc = p.out_scalar;
+        wave_for8([&](auto J) { x[decltype(J)::value] = fp_mul(x[decltype(J)::value], sc); });
+    }
+    wave_for8([&](auto J) {
+        constexpr unsigned j = decltype(J)::value;
+        fp_store(out + (k | (j << shift)), x[j]);
+    });
+}
+
+// ------------------------------------------------------------------------------------------------
 // host side: roots of unity, cached tables, pass planning
 
 static Fr host_fr_from_u64(uint64_t x) {
@@ -531,12 +705,60 @@ static unsigned plan_passes(const plonk_ctx* ctx, unsigned log_n, unsigned radic
     return P;
 }
 
+// the wave kernel (variant C) for N = 2^9, 2^11, 2^13: one workgroup of N / 8 threads per transform, one pass
+static int ntt_run_wave(plonk_ctx* ctx, const Fr* in, Fr* out, unsigned log_n, bool inverse, size_t batch, size_t in_len,
+                        size_t in_bstride, size_t out_bstride, const Fr* in_scale, const Fr* out_scale, bool scale_by_n_inv) {
+    const size_t N = (size_t)1 << log_n;
+    NttWave p;
+    memset(&p, 0, sizeof p);
+    p.in = in;
+    p.out = out;
+    p.in_bstride = in_bstride;
+    p.out_bstride = out_bstride;
+    p.in_len = (unsigned)(in_len < N ? in_len : N);
+    PLONK_TRY(ntt_get_roots(ctx, log_n, inverse, &p.roots));
+    p.in_scale = in_scale;
+    p.out_scale = out_scale;
+    if (scale_by_n_inv) {
+        p.out_scalar = fp_inv(host_fr_from_u64((uint64_t)N));
+        p.has_out_scalar = 1;
+    }
+    const Fr w8 = host_root_of_unity(3, inverse);
+    p.w8_1 = w8;
+    p.w8_2 = fp_sqr(w8);
+    p.w8_3 = fp_mul(p.w8_2, w8);
+    const unsigned nlds = (log_n - 9) / 2, nt = 64u << (2 * nlds);
+    const size_t shmem = (size_t)4 * nt * 32;
+    if (!ctx->ntt_wave_attr_set) {  // a per-device attribute: tracked per context
+        PLONK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ntt_wave_kernel<2>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)(128 * 1024)));
+        ctx->ntt_wave_attr_set = true;
+    }
+    // an in-place transform is safe: every thread has read all of its inputs before any thread stores (the stages in
+    // between are separated by barriers for L > 0; for L = 0 the single wave runs in lock step)
+    PLONK_TRY(prof_begin(ctx, "ntt_pass", 64.0 * (double)N * (double)batch));
+    for (size_t b0 = 0; b0 < batch; b0 += 65535 * 16) {  // grid.x carries the batch
+        const size_t nb = batch - b0 < 65535 * 16 ? batch - b0 : 65535 * 16;
+        NttWave q = p;
+        q.in = in + b0 * in_bstride;
+        q.out = out + b0 * out_bstride;
+        if (nlds == 0) PLONK_LAUNCH(ntt_wave_kernel<0>, dim3((unsigned)nb), dim3(nt), shmem, ctx->stream, q);
+        else if (nlds == 1) PLONK_LAUNCH(ntt_wave_kernel<1>, dim3((unsigned)nb), dim3(nt), shmem, ctx->stream, q);
+        else PLONK_LAUNCH(ntt_wave_kernel<2>, dim3((unsigned)nb), dim3(nt), shmem, ctx->stream, q);
+    }
+    PLONK_TRY(prof_end(ctx));
+    PLONK_CHECK_HIP(hipGetLastError());
+    return PLONK_OK;
+}
+
 int ntt_run(plonk_ctx* ctx, const Fr* in, Fr* out, unsigned log_n, bool inverse, size_t batch, size_t in_len,
             size_t in_bstride, size_t out_bstride, const Fr* in_scale, const Fr* out_scale, bool scale_by_n_inv) {
     PLONK_REQUIRE(log_n <= PLONK_FR_TWO_ADICITY, PLONK_ERR_ARG, "NTT size 2^%u exceeds the 2-adicity (28) of BN254 Fr", log_n);
     if (!batch) return PLONK_OK;
-    PLONK_REQUIRE(batch <= 65535, PLONK_ERR_ARG, "NTT batch %zu exceeds 65535", batch);
     const size_t N = (size_t)1 << log_n;
+    if ((ctx->ntt_kind == 0 || ctx->ntt_kind == 3) && (log_n == 9 || log_n == 11 || log_n == 13) && ctx->ntt_single_log >= 11)
+        return ntt_run_wave(ctx, in, out, log_n, inverse, batch, in_len, in_bstride, out_bstride, in_scale, out_scale, scale_by_n_inv);
+    PLONK_REQUIRE(batch <= 65535, PLONK_ERR_ARG, "NTT batch %zu exceeds 65535", batch);
     unsigned radices[4];
     const unsigned P = plan_passes(ctx, log_n, radices);
     PLONK_REQUIRE(P <= 4, PLONK_ERR_ARG, "NTT of size 2^%u needs %u passes at radix 2^%u (max 4)", log_n, P, ctx->ntt_radix_log);
@@ -599,7 +821,7 @@ int ntt_run(plonk_ctx* ctx, const Fr* in, Fr* out, unsigned log_n, bool inverse,
         p.w8_1 = w8;
         p.w8_2 = fp_sqr(w8);
         p.w8_3 = fp_mul(p.w8_2, w8);
-        const bool stockham = ctx->ntt_kind == 2 || (ctx->ntt_kind == 0 && P == 1);
+        const bool stockham = ctx->ntt_kind == 2 || ((ctx->ntt_kind == 0 || ctx->ntt_kind >= 3) && P == 1);
         unsigned nthr = stockham ? T / 8 : T / 4;
         if (nthr < 64) nthr = 64;
         if (nthr > (stockham ? 512u : 1024u)) nthr = stockham ? 512 : 1024;

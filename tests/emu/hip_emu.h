@@ -64,6 +64,31 @@ template <class T> inline T __shfl_down(T v, unsigned d, int = 64) {
 template <class T> inline T __shfl_up(T v, unsigned d, int = 64) {
     int l = (int)(threadIdx.x & 63) - (int)d; return __shfl(v, l >= 0 ? l : (int)(threadIdx.x & 63));
 }
+// cross-lane builtins of the NTT wave kernels (csrc/ntt_wave.hip), emulated on top of the wave shuffle: the three DPP
+// controls in use (quad_perm, row_ror), ds_swizzle in bit mode, and the v_permlane32_swap half exchange
+inline int __builtin_amdgcn_update_dpp(int, int src, int ctrl, int, int, bool) {
+    const int lane = (int)(threadIdx.x & 63);
+    int from = lane;
+    if (ctrl < 0x100) from = (lane & ~3) | ((ctrl >> (2 * (lane & 3))) & 3);        // quad_perm
+    else if (ctrl >= 0x121 && ctrl <= 0x12f) from = (lane & ~15) | ((lane + (ctrl - 0x120)) & 15);  // row_ror:n (n = 8: lane ^ 8)
+    else abort();
+    return __shfl(src, from);
+}
+inline int __builtin_amdgcn_ds_swizzle(int src, int pattern) {
+    const int lane = (int)(threadIdx.x & 63);
+    if (pattern & 0x8000) abort();  // only bit mode is used
+    const int a = pattern & 31, o = (pattern >> 5) & 31, x = (pattern >> 10) & 31;
+    return __shfl(src, (lane & 32) | ((((lane & 31) & a) | o) ^ x));
+}
+struct hipemu_u2 { unsigned v[2]; unsigned operator[](int i) const { return v[i]; } };
+inline hipemu_u2 __builtin_amdgcn_permlane32_swap(unsigned vdst, unsigned src, bool, bool) {
+    const int lane = (int)(threadIdx.x & 63);
+    const unsigned src_lo = __shfl(src, lane & 31), dst_hi = __shfl(vdst, lane | 32);
+    hipemu_u2 r;
+    r.v[0] = lane < 32 ? vdst : src_lo;   // new vdst: lanes 32-63 take src[0..31]
+    r.v[1] = lane < 32 ? dst_hi : src;    // new src:  lanes 0-31 take vdst[32..63]
+    return r;
+}
 inline unsigned long long __ballot(int pred) { return ::hipemu::ballot(pred); }
 inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 inline int __popc(unsigned x) { return __builtin_popcount(x); }
