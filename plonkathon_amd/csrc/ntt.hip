@@ -462,7 +462,14 @@ struct NttWave {
     Fr* out;
     size_t in_bstride, out_bstride;
     unsigned in_len;
-    const Fr* roots;      // w_N^k, k < N (direction of the transform)
+    // mode 0: the whole transform, blockIdx.x = batch index.  Two-pass transforms N = R1 R2 (index i1 R2 + c -> frequency
+    // k1 + R1 k2): mode 1 = R1-point transforms down the R2 columns (element i1 of column c at in[i1 R2 + c], output k1
+    // times w_N^(c k1) to out[k1 R2 + c]); mode 2 = R2-point transforms along the R1 rows (row k1 at in[k1 R2 ..],
+    // output k2 to out[k1 + R1 k2]).  blockIdx.x = column / row (XCD-aware order), blockIdx.y = batch index.
+    unsigned mode, log_n, log_other;  // log2 of the whole transform and of the OTHER pass's size
+    const Fr* tw_lo;      // inter-pass twiddles w_N^e = tw_lo[e & 1023] * tw_hi[e >> 10]   (mode 1)
+    const Fr* tw_hi;
+    const Fr* roots;      // w_R^k, k < R, R = this kernel's transform size (direction of the transform)
     const Fr* in_scale;   // per-element factor at load (coset offset powers) or null
     const Fr* out_scale;  // per-element factor at store or null
     Fr out_scalar;
@@ -521,29 +528,37 @@ PLONK_DEV void dft4r(Fr& x0, Fr& x1, Fr& x2, Fr& x3, const Fr& w2) {
     x0 = fp_add(a0, a1); x2 = fp_sub(a0, a1); x1 = fp_add(d0, d1); x3 = fp_sub(d0, d1);
 }
 
-#ifndef NTT_WAVE_MIN_WAVES
-#define NTT_WAVE_MIN_WAVES 4  // waves per SIMD the register allocation aims for (128 VGPRs)
-#endif
+// register budget: 1024-thread workgroups (L = 2) must fit 128 VGPRs (a few dwords spill); the smaller ones run faster
+// without spills at 3 waves per SIMD (measured: 18.1 vs 16.8 G elements/s at 2^11 x 2048)
 template <unsigned NLDS>
-__global__ void __launch_bounds__(64u << (2 * NLDS), NTT_WAVE_MIN_WAVES) ntt_wave_kernel(NttWave p) {
+__global__ void __launch_bounds__(64u << (2 * NLDS), NLDS == 2 ? 4 : 3) ntt_wave_kernel(NttWave p) {
     constexpr unsigned LOG_N = 9 + 2 * NLDS, NT = 64u << (2 * NLDS);
     PLONK_DYN_SMEM(smem);
     u32x4* l_lo = reinterpret_cast<u32x4*>(smem);  // 4 * NT elements as two 16-byte planes
     u32x4* l_hi = l_lo + 4 * NT;
     const unsigned tid = threadIdx.x, lane = tid & 63;
-    const Fr* in = p.in + (size_t)blockIdx.x * p.in_bstride;
-    Fr* out = p.out + (size_t)blockIdx.x * p.out_bstride;
+    const unsigned bidx = p.mode ? blockIdx.y : blockIdx.x;
+    const Fr* in = p.in + (size_t)bidx * p.in_bstride;
+    Fr* out = p.out + (size_t)bidx * p.out_bstride;
+    // column / row of a two-pass transform.  Workgroup b runs on XCD b % 8 (each XCD has its own L2): the remap gives
+    // every XCD four ADJACENT columns (rows) per group of 32, so the 32-byte elements it touches share 128-byte lines.
+    const unsigned b = blockIdx.x;
+    const unsigned sub = p.mode ? ((b & ~31u) | ((b & 7u) << 2) | ((b >> 3) & 3u)) : 0;
+    // global index of sub-transform position pos on the input side, of frequency o on the output side
+    const unsigned in_shift = p.mode == 1 ? p.log_other : 0, out_shift = p.mode ? p.log_other : 0;
+    const unsigned in_off = p.mode == 1 ? sub : (p.mode == 2 ? sub << LOG_N : 0);
+    const unsigned out_off = p.mode ? sub : 0;
 
     Fr x[8];
-    wave_for8([&](auto J) {  // element index j * NT + tid: consecutive lanes read consecutive elements
+    wave_for8([&](auto J) {  // position j * NT + tid: consecutive lanes read consecutive positions
         constexpr unsigned j = decltype(J)::value;
-        const unsigned g = j * NT + tid;
+        const unsigned g = ((j * NT + tid) << in_shift) + in_off;
         x[j] = g < p.in_len ? fp_load(in + g) : fp_zero<FrParams>();
     });
     if (p.in_scale) {
         wave_for8([&](auto J) {
             constexpr unsigned j = decltype(J)::value;
-            const unsigned g = j * NT + tid;
+            const unsigned g = ((j * NT + tid) << in_shift) + in_off;
             if (g < p.in_len) x[j] = fp_mul(x[j], fp_load(p.in_scale + g));
         });
     }
@@ -597,10 +612,21 @@ __global__ void __launch_bounds__(64u << (2 * NLDS), NTT_WAVE_MIN_WAVES) ntt_wav
     }
     k |= (lane & 7u) << shift;
     shift += 3;
+    if (p.mode == 1) {  // inter-pass twiddle w_N^(column * frequency)
+        wave_for8([&](auto J) {
+            constexpr unsigned j = decltype(J)::value;
+            const unsigned e = sub * (k | (j << shift));  // < N
+            if (e) {
+                Fr tw = fp_load(p.tw_lo + (e & ((1u << NTT_TW_LO_LOG) - 1)));
+                if (p.log_n > NTT_TW_LO_LOG) tw = fp_mul(tw, fp_load(p.tw_hi + (e >> NTT_TW_LO_LOG)));
+                x[j] = fp_mul(x[j], tw);
+            }
+        });
+    }
     if (p.out_scale) {
         wave_for8([&](auto J) {
             constexpr unsigned j = decltype(J)::value;
-            x[j] = fp_mul(x[j], fp_load(p.out_scale + (k | (j << shift))));
+            x[j] = fp_mul(x[j], fp_load(p.out_scale + (((k | (j << shift)) << out_shift) + out_off)));
         });
     }
     if (p.has_out_scalar) {
@@ -609,7 +635,7 @@ __global__ void __launch_bounds__(64u << (2 * NLDS), NTT_WAVE_MIN_WAVES) ntt_wav
     }
     wave_for8([&](auto J) {
         constexpr unsigned j = decltype(J)::value;
-        fp_store(out + (k | (j << shift)), x[j]);
+        fp_store(out + (((k | (j << shift)) << out_shift) + out_off), x[j]);
     });
 }
 
@@ -705,47 +731,107 @@ static unsigned plan_passes(const plonk_ctx* ctx, unsigned log_n, unsigned radic
     return P;
 }
 
-// the wave kernel (variant C) for N = 2^9, 2^11, 2^13: one workgroup of N / 8 threads per transform, one pass
-static int ntt_run_wave(plonk_ctx* ctx, const Fr* in, Fr* out, unsigned log_n, bool inverse, size_t batch, size_t in_len,
-                        size_t in_bstride, size_t out_bstride, const Fr* in_scale, const Fr* out_scale, bool scale_by_n_inv) {
-    const size_t N = (size_t)1 << log_n;
-    NttWave p;
-    memset(&p, 0, sizeof p);
-    p.in = in;
-    p.out = out;
-    p.in_bstride = in_bstride;
-    p.out_bstride = out_bstride;
-    p.in_len = (unsigned)(in_len < N ? in_len : N);
-    PLONK_TRY(ntt_get_roots(ctx, log_n, inverse, &p.roots));
-    p.in_scale = in_scale;
-    p.out_scale = out_scale;
-    if (scale_by_n_inv) {
-        p.out_scalar = fp_inv(host_fr_from_u64((uint64_t)N));
-        p.has_out_scalar = 1;
+// the wave kernel (variant C): N = 2^9, 2^11, 2^13 in one pass (one workgroup of N / 8 threads per transform), and
+// N = R1 R2 with R1, R2 from that set in two passes (columns, then rows)
+static bool ntt_wave_plan(unsigned log_n, unsigned* log_r1, unsigned* log_r2) {
+    switch (log_n) {
+        case 9: case 11: case 13: *log_r1 = log_n; *log_r2 = 0; return true;
+        case 18: *log_r1 = 9; *log_r2 = 9; return true;
+        case 20: *log_r1 = 11; *log_r2 = 9; return true;
+        case 22: *log_r1 = 11; *log_r2 = 11; return true;
+        case 24: *log_r1 = 13; *log_r2 = 11; return true;
+        case 26: *log_r1 = 13; *log_r2 = 13; return true;
+        default: return false;
     }
-    const Fr w8 = host_root_of_unity(3, inverse);
-    p.w8_1 = w8;
-    p.w8_2 = fp_sqr(w8);
-    p.w8_3 = fp_mul(p.w8_2, w8);
-    const unsigned nlds = (log_n - 9) / 2, nt = 64u << (2 * nlds);
+}
+
+static int ntt_wave_launch(plonk_ctx* ctx, const NttWave& p, unsigned log_r, unsigned grid_x, unsigned grid_y) {
+    const unsigned nlds = (log_r - 9) / 2, nt = 64u << (2 * nlds);
     const size_t shmem = (size_t)4 * nt * 32;
     if (!ctx->ntt_wave_attr_set) {  // a per-device attribute: tracked per context
         PLONK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ntt_wave_kernel<2>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)(128 * 1024)));
         ctx->ntt_wave_attr_set = true;
     }
-    // an in-place transform is safe: every thread has read all of its inputs before any thread stores (the stages in
-    // between are separated by barriers for L > 0; for L = 0 the single wave runs in lock step)
-    PLONK_TRY(prof_begin(ctx, "ntt_pass", 64.0 * (double)N * (double)batch));
-    for (size_t b0 = 0; b0 < batch; b0 += 65535 * 16) {  // grid.x carries the batch
-        const size_t nb = batch - b0 < 65535 * 16 ? batch - b0 : 65535 * 16;
-        NttWave q = p;
-        q.in = in + b0 * in_bstride;
-        q.out = out + b0 * out_bstride;
-        if (nlds == 0) PLONK_LAUNCH(ntt_wave_kernel<0>, dim3((unsigned)nb), dim3(nt), shmem, ctx->stream, q);
-        else if (nlds == 1) PLONK_LAUNCH(ntt_wave_kernel<1>, dim3((unsigned)nb), dim3(nt), shmem, ctx->stream, q);
-        else PLONK_LAUNCH(ntt_wave_kernel<2>, dim3((unsigned)nb), dim3(nt), shmem, ctx->stream, q);
+    if (nlds == 0) PLONK_LAUNCH(ntt_wave_kernel<0>, dim3(grid_x, grid_y), dim3(nt), shmem, ctx->stream, p);
+    else if (nlds == 1) PLONK_LAUNCH(ntt_wave_kernel<1>, dim3(grid_x, grid_y), dim3(nt), shmem, ctx->stream, p);
+    else PLONK_LAUNCH(ntt_wave_kernel<2>, dim3(grid_x, grid_y), dim3(nt), shmem, ctx->stream, p);
+    return PLONK_OK;
+}
+
+static int ntt_run_wave(plonk_ctx* ctx, const Fr* in, Fr* out, unsigned log_n, bool inverse, size_t batch, size_t in_len,
+                        size_t in_bstride, size_t out_bstride, const Fr* in_scale, const Fr* out_scale, bool scale_by_n_inv) {
+    const size_t N = (size_t)1 << log_n;
+    unsigned log_r1 = 0, log_r2 = 0;
+    ntt_wave_plan(log_n, &log_r1, &log_r2);
+    NttWave p;
+    memset(&p, 0, sizeof p);
+    p.log_n = log_n;
+    const Fr w8 = host_root_of_unity(3, inverse);
+    p.w8_1 = w8;
+    p.w8_2 = fp_sqr(w8);
+    p.w8_3 = fp_mul(p.w8_2, w8);
+    Fr n_inv = fp_zero<FrParams>();
+    if (scale_by_n_inv) n_inv = fp_inv(host_fr_from_u64((uint64_t)N));
+    const unsigned in_len32 = (unsigned)(in_len < N ? in_len : N);
+    if (!log_r2) {
+        p.in = in;
+        p.out = out;
+        p.in_bstride = in_bstride;
+        p.out_bstride = out_bstride;
+        p.in_len = in_len32;
+        PLONK_TRY(ntt_get_roots(ctx, log_n, inverse, &p.roots));
+        p.in_scale = in_scale;
+        p.out_scale = out_scale;
+        p.out_scalar = n_inv;
+        p.has_out_scalar = scale_by_n_inv;
+        // an in-place transform is safe: every thread has read all of its inputs before any thread stores (the stages
+        // in between are separated by barriers for L > 0; for L = 0 the single wave runs in lock step)
+        PLONK_TRY(prof_begin(ctx, "ntt_pass", 64.0 * (double)N * (double)batch));
+        for (size_t b0 = 0; b0 < batch; b0 += (size_t)1 << 30) {  // grid.x carries the batch
+            const size_t nb = batch - b0 < ((size_t)1 << 30) ? batch - b0 : (size_t)1 << 30;
+            NttWave q = p;
+            q.in = in + b0 * in_bstride;
+            q.out = out + b0 * out_bstride;
+            PLONK_TRY(ntt_wave_launch(ctx, q, log_n, (unsigned)nb, 1));
+        }
+        PLONK_TRY(prof_end(ctx));
+        PLONK_CHECK_HIP(hipGetLastError());
+        return PLONK_OK;
     }
+    // two passes through a scratch copy: columns (R1 points each, stride R2), then rows (R2 points each)
+    PLONK_REQUIRE(batch <= 65535, PLONK_ERR_ARG, "NTT batch %zu exceeds 65535", batch);
+    void* sc;
+    PLONK_TRY(ctx_scratch(ctx, 0, batch * N * sizeof(Fr), &sc));
+    Fr* tmp = (Fr*)sc;
+    PLONK_TRY(get_lo_hi(ctx, log_n, inverse, &p.tw_lo, &p.tw_hi));
+    NttWave a = p;
+    a.mode = 1;
+    a.log_other = log_r2;
+    a.in = in;
+    a.out = tmp;
+    a.in_bstride = in_bstride;
+    a.out_bstride = N;
+    a.in_len = in_len32;
+    a.in_scale = in_scale;
+    PLONK_TRY(ntt_get_roots(ctx, log_r1, inverse, &a.roots));
+    PLONK_TRY(prof_begin(ctx, "ntt_pass", 32.0 * (double)N * (double)batch));
+    PLONK_TRY(ntt_wave_launch(ctx, a, log_r1, 1u << log_r2, (unsigned)batch));
+    PLONK_TRY(prof_end(ctx));
+    NttWave c = p;
+    c.mode = 2;
+    c.log_other = log_r1;
+    c.in = tmp;
+    c.out = out;
+    c.in_bstride = N;
+    c.out_bstride = out_bstride;
+    c.in_len = (unsigned)N;
+    c.out_scale = out_scale;
+    c.out_scalar = n_inv;
+    c.has_out_scalar = scale_by_n_inv;
+    PLONK_TRY(ntt_get_roots(ctx, log_r2, inverse, &c.roots));
+    PLONK_TRY(prof_begin(ctx, "ntt_pass", 32.0 * (double)N * (double)batch));
+    PLONK_TRY(ntt_wave_launch(ctx, c, log_r2, 1u << log_r1, (unsigned)batch));
     PLONK_TRY(prof_end(ctx));
     PLONK_CHECK_HIP(hipGetLastError());
     return PLONK_OK;
@@ -756,8 +842,15 @@ int ntt_run(plonk_ctx* ctx, const Fr* in, Fr* out, unsigned log_n, bool inverse,
     PLONK_REQUIRE(log_n <= PLONK_FR_TWO_ADICITY, PLONK_ERR_ARG, "NTT size 2^%u exceeds the 2-adicity (28) of BN254 Fr", log_n);
     if (!batch) return PLONK_OK;
     const size_t N = (size_t)1 << log_n;
-    if ((ctx->ntt_kind == 0 || ctx->ntt_kind == 3) && (log_n == 9 || log_n == 11 || log_n == 13) && ctx->ntt_single_log >= 11)
-        return ntt_run_wave(ctx, in, out, log_n, inverse, batch, in_len, in_bstride, out_bstride, in_scale, out_scale, scale_by_n_inv);
+    unsigned wr1, wr2;
+    if ((ctx->ntt_kind == 0 || ctx->ntt_kind == 3) && ntt_wave_plan(log_n, &wr1, &wr2) && ctx->ntt_single_log >= 11 && ctx->ntt_radix_log >= 10) {
+        // measured on MI355X (profiles/r02_e_ntt_kinds.json): the one-pass sizes always win (+22 % at 2^11 / 2^13); the
+        // two-pass form wins when there is enough work to fill the chip several times over (2^18 x 16, 2^20 x 8, 2^22) and for
+        // a lone 2^18 (latency), but a lone 2^20 is faster on the 1024-thread radix-2 passes and 2^24 on three of those
+        const bool two_pass_ok = log_n == 18 || ((log_n == 20 || log_n == 22) && ((size_t)batch << log_n) >= ((size_t)1 << 22));
+        if (!wr2 || two_pass_ok || ctx->ntt_kind == 3)
+            return ntt_run_wave(ctx, in, out, log_n, inverse, batch, in_len, in_bstride, out_bstride, in_scale, out_scale, scale_by_n_inv);
+    }
     PLONK_REQUIRE(batch <= 65535, PLONK_ERR_ARG, "NTT batch %zu exceeds 65535", batch);
     unsigned radices[4];
     const unsigned P = plan_passes(ctx, log_n, radices);

@@ -178,3 +178,12 @@ def test_lagrange_srs_paths(emu):
     from plonkathon_amd import Setup
 
     pc.lagrange_srs_paths(Setup.from_file(pc.PTAU))
+
+
+def test_ntt_two_pass_wave_kernel(emu):
+    """2^18 = 2^9 x 2^9 through the wave kernel's column and row passes (auto), exact against the C oracle."""
+    from oracle import c_oracle
+    from plonkathon_amd import Basis
+
+    v = pc.rand_vec(4018, 1 << 18)
+    assert pc.ints(pc.P(v, Basis.MONOMIAL).fft()) == c_oracle.fr_ntt(v)

@@ -241,7 +241,7 @@ def test_api_prover_matches_batch_prover_2_11(setup):
     assert pc.flat(p1.prove(dict(wit))) == pc.flat(BatchProver(setup, program).prove(dict(wit)))
 
 
-@pytest.mark.parametrize("log_n", [17, 20])
+@pytest.mark.parametrize("log_n", [17, 18, 20, 22])
 def test_ntt_exact_vs_c_oracle(log_n):
     """Bit-exact forward and inverse transforms at microbench sizes against the C half of the oracle."""
     from oracle import c_oracle
