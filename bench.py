@@ -11,7 +11,7 @@ N ranks itself, one process per GPU.  Either way the ranks talk RCCL over xGMI t
 A "step" is one pass of the hot path over one batch of synthetic input: `--batches-per-step` lock-step batches of
 `--batch` independent PLONK proofs per GPU of the BASELINE configs[1] workload (group_order = 2^11, the powers-of-tau
 SRS slice, synthetic witness — a 2047-gate squaring chain + one public input, ONE DISTINCT WITNESS PER PROOF).  With
-the defaults a step is 16 x 512 = 8192 proofs per GPU (~0.27 s), so that the driver's 20 timed steps last > 5 s.
+the defaults a step is 20 x 512 = 10240 proofs per GPU (~0.3 s), so that the driver's 20 timed steps last > 5 s.
 Proofs are independent, so N GPUs shard by proof index with no data-path collective; every step ends with the one
 collective of the path, an all-gather of the finished proofs (768 B each) over RCCL ("scaling": "weak").  Inputs
 (circuit polynomials, the MSM lookup table of the SRS, witness columns) are resident in HBM before the timed region.
@@ -193,7 +193,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=512, help="proofs per lock-step batch (BASELINE configs[4]: 512)")
-    ap.add_argument("--batches-per-step", type=int, default=16, help="lock-step batches per GPU per step (all witnesses distinct)")
+    ap.add_argument("--batches-per-step", type=int, default=20, help="lock-step batches per GPU per step (all witnesses distinct)")
     ap.add_argument("--streams", type=int, default=2, help="HIP streams per GPU: the lock-step batches of a step are dealt round-robin to this many contexts, so one batch's latency-bound kernels (transcript, inversions, scans) overlap another's MSMs")
     ap.add_argument("--dist-backend", default="rccl", choices=["rccl", "sockets"],
                     help="transport of the final gather for N > 1: rccl = RCCL over xGMI through the C-ABI (default); sockets = TCP, lets ranks share one GPU")
@@ -201,6 +201,7 @@ def main():
                     help="HBM budget for the MSM lookup table (the library's own default is 4 GiB; the c = 17 table of 2^11 bases is 128.8 GB)")
     ap.add_argument("--no-lookup", action="store_true", help="bucket-method MSM only")
     ap.add_argument("--lagrange-commits", action="store_true", help="commit rounds 1-2 from Lagrange values over the Lagrange-basis SRS (a second lookup table)")
+    ap.add_argument("--msm-groups", type=int, default=0, help="plonk_msm_configure groups: workgroups per MSM (0 = library default)")
     ap.add_argument("--ntt-kind", type=int, default=0, help="plonk_ntt_select_kernel: 0 auto, 1 radix-2 stages, 2 Stockham, 3 wave, 4 auto without the wave kernel (A/B)")
     ap.add_argument("--log-n", type=int, default=11, help="log2(group_order); 11 = the BASELINE workload, smaller values are for functional tests only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -231,6 +232,8 @@ def main():
     ctxs = [ctx] + [Context(local_rank) for _ in range(NS - 1)]
     for c in ctxs:
         c.msm_lookup(1 if args.no_lookup else 0, 0, budget)
+        if args.msm_groups:
+            c.msm_configure(0, args.msm_groups)
         if args.ntt_kind:
             from plonkathon_amd._lib import check as _check
 
@@ -254,6 +257,12 @@ def main():
         t_gen += t1 - t0
         t_up += t2 - t1
     host_upload_ms = 1e3 * t_up / per_gpu
+    # the same staging from pre-packed values (callers that generate witnesses natively): [B][V] x 32 B, no per-value Python
+    from plonkathon_amd.batch import _pack_witnesses
+    blob = _pack_witnesses([witness_for(idx) for idx in parts[0]], provers[0].variables, R_MOD)
+    t0 = time.perf_counter()
+    provers[0].upload_values(blob, len(parts[0]))
+    host_upload_packed_ms = 1e3 * (time.perf_counter() - t0) / len(parts[0])
 
     def step():
         for pr in provers:
@@ -335,6 +344,7 @@ def main():
         },
         "host": {
             "host_upload_ms_per_proof": host_upload_ms,
+            "host_upload_prepacked_ms_per_proof": host_upload_packed_ms,
             "witness_generation_ms_per_proof": 1e3 * t_gen / per_gpu,
             "note": "BatchProver.upload: Python witness dictionaries -> 32-byte words (V x 32 B per proof) -> HBM, wire columns "
                     "gathered on the device; outside `value` (inputs are resident before the timed region)",

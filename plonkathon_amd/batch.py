@@ -6,7 +6,6 @@ the same `Proof` objects.  All five rounds and the Fiat-Shamir transcript run on
 (plonk_prover_* in include/plonk_hip.h), with one host synchronisation per batch.
 """
 import ctypes
-import operator
 
 import numpy as np
 
@@ -30,10 +29,10 @@ def _le(vals):
 
 
 try:  # host-side marshalling helper (csrc/pyext/pypack.c, built by __graft_entry__.build()); same bytes either way
-    from ._pypack import pack_le32 as _pack_mod_r
+    from ._pypack import pack_dicts_le32 as _pack_witnesses
 except ImportError:  # pragma: no cover - pure-Python equivalent of the packer (not a compute fallback)
-    def _pack_mod_r(vals, modulus):
-        return b"".join([(int(v) % modulus).to_bytes(32, "little") for v in vals])
+    def _pack_witnesses(witnesses, keys, modulus):
+        return b"".join([(int(w[k]) % modulus).to_bytes(32, "little") for w in witnesses for k in keys])
 
 
 class BatchProver:
@@ -75,8 +74,8 @@ class BatchProver:
             pubs = np.ascontiguousarray([pos[v] for v in self._public_vars], dtype=np.uint32)
             check(self.ctx.L.plonk_prover_set_wiring(self._h, cells.ctypes.data, pubs.ctypes.data if len(pubs) else None,
                                                      len(self._vars)))
-            g = operator.itemgetter(*self._vars)
-            self._getter = g if len(self._vars) > 1 else (lambda w: (g(w),))
+            self._getter = True
+            self._var_keys = tuple(self._vars)
 
     def __del__(self):
         try:
@@ -109,10 +108,22 @@ class BatchProver:
         B = len(witnesses)
         if self._getter is None:
             return self._upload_columns(witnesses)
-        get = self._getter
-        enc = b"".join([_pack_mod_r(get(w), R_MOD) for w in witnesses])
+        enc = _pack_witnesses(witnesses, self._var_keys, R_MOD)
         check(self.ctx.L.plonk_prover_upload_variables(self._h, enc, B))
         self._resident = B
+
+    def upload_values(self, blob, B):
+        """The same staging for callers that produce witnesses natively: `blob` = [B][V] canonical 32-byte little-endian
+        values in the order of `self.variables` (64 KiB per proof at 2^11; no Python work per value)."""
+        if len(blob) != 32 * B * len(self._vars):
+            raise ValueError("upload_values: expected %d bytes" % (32 * B * len(self._vars)))
+        check(self.ctx.L.plonk_prover_upload_variables(self._h, blob, B))
+        self._resident = B
+
+    @property
+    def variables(self):
+        """Variable names in the column order `upload_values` expects."""
+        return tuple(self._vars)
 
     def _upload_columns(self, witnesses):
         """The [3][B][n] column form of the same upload (circuits without variables; plonk_prover_upload_witness)."""

@@ -41,6 +41,7 @@
 #include <chrono>
 
 #include "plonk_internal.h"
+#include "wave.h"
 
 #define MSM_BLOCK 256
 #define MSM_DEFAULT_WINDOW_BITS 10
@@ -344,9 +345,10 @@ __global__ void __launch_bounds__(256) msm_bucket_reduce_kernel(const uint32_t* 
         }
         g1_add(tot, kr);
     }
+    // shares: across waves through LDS, then the last six levels inside wave 0 by cross-lane moves (wave.h)
     red[tid] = tot;
     __syncthreads();
-    for (unsigned s = nl / 2; s > 0; s >>= 1) {
+    for (unsigned s = nl / 2; s >= 64; s >>= 1) {
         if (tid < s) {
             G1Xyzz x = red[tid];
             g1_add(x, red[tid + s]);
@@ -354,8 +356,11 @@ __global__ void __launch_bounds__(256) msm_bucket_reduce_kernel(const uint32_t* 
         }
         __syncthreads();
     }
+    if (tid >= 64) return;
+    G1Xyzz total = red[tid];
+    g1_wave_reduce(total, tid);
     if (tid == 0) {  // the unique affine representative, canonical x||y; identity reported out of band
-        G1Affine a = g1_to_affine(red[0]);
+        G1Affine a = g1_to_affine(total);
         flags[m] = g1_affine_is_identity(a) ? 1 : 0;
         fp_store(out_xy + 2 * m, fp_from_mont(a.x));
         fp_store(out_xy + 2 * m + 1, fp_from_mont(a.y));
@@ -443,6 +448,9 @@ __global__ void __launch_bounds__(MSM_BLOCK, MSM_ACC_WAVES) msm_lookup_kernel(
     red[tid] = g1l_to_piece(run);
     red[tid] = g1_piece_load(&red[tid]);
     __syncthreads();
+    // Tree reduction through LDS.  (A wave-level butterfly for the last six levels — wave.h, as in the bucket reduction
+    // below — was measured here and is 1.7 % slower end to end: inlined it costs the 128-VGPR loop 51 spilled registers,
+    // out of line the accumulator travels through scratch; profiles/r02_g_msm_reduce_ab.txt.)
     for (unsigned s = MSM_BLOCK / 2; s > 0; s >>= 1) {
         if (tid < s) {
             G1Xyzz x = red[tid];
@@ -520,7 +528,7 @@ __global__ void __launch_bounds__(256) msm_slow_kernel(int kind, const G1Affine*
     }
     red[tid] = acc;
     __syncthreads();
-    for (unsigned s = 128; s > 0; s >>= 1) {
+    for (unsigned s = 128; s >= 64; s >>= 1) {
         if (tid < s) {
             G1Xyzz x = red[tid];
             g1_add(x, red[tid + s]);
@@ -528,8 +536,11 @@ __global__ void __launch_bounds__(256) msm_slow_kernel(int kind, const G1Affine*
         }
         __syncthreads();
     }
+    if (tid >= 64) return;
+    G1Xyzz total = red[tid];
+    g1_wave_reduce(total, tid);
     if (tid == 0) {
-        G1Affine a = g1_to_affine(red[0]);
+        G1Affine a = g1_to_affine(total);
         flags[m] = g1_affine_is_identity(a) ? 1 : 0;
         fp_store(out_xy + 2 * m, fp_from_mont(a.x));
         fp_store(out_xy + 2 * m + 1, fp_from_mont(a.y));

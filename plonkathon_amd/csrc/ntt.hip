@@ -18,6 +18,7 @@
 #include <string.h>
 
 #include "plonk_internal.h"
+#include "wave.h"
 
 // defaults live in plonk_ctx (ntt_tile_log = 12: 4096 elements = 128 KiB of LDS; ntt_single_log = 11;
 // ntt_radix_log = 10) and can be changed with plonk_ntt_configure for tuning / small-size tests.
@@ -487,17 +488,6 @@ template <unsigned N, class F> PLONK_DEV void wave_for(F f) {
     }
 }
 template <class F> PLONK_DEV void wave_for8(F f) { wave_for<8>(f); }
-
-template <unsigned MASK> PLONK_DEV uint32_t wave_lane_xor(uint32_t v, unsigned lane) {
-    if (MASK == 1) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
-    if (MASK == 2) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, false);   // quad_perm [2,3,0,1]
-    if (MASK == 4) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, (4 << 10) | 0x1f);           // bit mode: lane ^ 4
-    if (MASK == 8) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, false);  // row_ror:8
-    if (MASK == 16) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, (16 << 10) | 0x1f);         // bit mode: lane ^ 16
-    // lane ^ 32: v_permlane32_swap exchanges the upper half of its first operand with the lower half of the second
-    auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
-    return lane < 32 ? r[1] : r[0];
-}
 
 // swap register-index bit RB with the lane bit of MASK: lanes with the bit clear keep x[r] and trade x[r | 1 << RB],
 // lanes with the bit set keep x[r | 1 << RB] and trade x[r]

@@ -59,7 +59,80 @@ fail:
     return NULL;
 }
 
-static PyMethodDef methods[] = {{"pack_le32", pack_le32, METH_VARARGS, "ints -> 32-byte little-endian words, reduced mod modulus"},
+/* one value -> 32 bytes at dst (reduced mod modulus); 0 on success */
+static int pack_one(PyObject* v, PyObject* modulus, const unsigned char* mod, unsigned char* dst) {
+    PyObject* as_int = NULL;
+    if (!PyLong_Check(v)) {
+        as_int = PyNumber_Long(v);
+        if (!as_int) return -1;
+        v = as_int;
+    }
+    int ok = 0;
+    if (Py_SIZE(v) >= 0 && _PyLong_NumBits(v) <= 256) {
+        if (_PyLong_AsByteArray((PyLongObject*)v, dst, 32, 1, 0) == 0 && below(dst, mod)) ok = 1;
+        else PyErr_Clear();
+    }
+    if (!ok) {
+        PyObject* r = PyNumber_Remainder(v, modulus);
+        if (!r) { Py_XDECREF(as_int); return -1; }
+        int rc = _PyLong_AsByteArray((PyLongObject*)r, dst, 32, 1, 0);
+        Py_DECREF(r);
+        if (rc < 0) { Py_XDECREF(as_int); return -1; }
+    }
+    Py_XDECREF(as_int);
+    return 0;
+}
+
+/* pack_dicts_le32(witnesses, keys, modulus) -> bytes: for every dict of `witnesses`, the values of `keys` in order, each
+ * reduced mod modulus, 32 bytes little-endian: the [B][V] buffer plonk_prover_upload_variables takes.  A missing key
+ * raises KeyError(key), as witness[key] would. */
+static PyObject* pack_dicts_le32(PyObject* self, PyObject* args) {
+    PyObject *wits, *keys, *modulus;
+    if (!PyArg_ParseTuple(args, "OOO!", &wits, &keys, &PyLong_Type, &modulus)) return NULL;
+    unsigned char mod[32];
+    if (_PyLong_AsByteArray((PyLongObject*)modulus, mod, 32, 1, 0) < 0) return NULL;
+    PyObject* wf = PySequence_Fast(wits, "pack_dicts_le32 expects a sequence of dicts");
+    if (!wf) return NULL;
+    PyObject* kf = PySequence_Fast(keys, "pack_dicts_le32 expects a sequence of keys");
+    if (!kf) { Py_DECREF(wf); return NULL; }
+    const Py_ssize_t B = PySequence_Fast_GET_SIZE(wf), V = PySequence_Fast_GET_SIZE(kf);
+    PyObject* out = PyBytes_FromStringAndSize(NULL, 32 * B * V);
+    if (!out) { Py_DECREF(wf); Py_DECREF(kf); return NULL; }
+    unsigned char* dst = (unsigned char*)PyBytes_AS_STRING(out);
+    for (Py_ssize_t b = 0; b < B; b++) {
+        PyObject* w = PySequence_Fast_GET_ITEM(wf, b);
+        const int is_dict = PyDict_CheckExact(w);
+        for (Py_ssize_t i = 0; i < V; i++, dst += 32) {
+            PyObject* key = PySequence_Fast_GET_ITEM(kf, i);
+            PyObject* v;
+            if (is_dict) {
+                v = PyDict_GetItemWithError(w, key); /* borrowed */
+                if (!v) {
+                    if (!PyErr_Occurred()) PyErr_SetObject(PyExc_KeyError, key);
+                    goto fail;
+                }
+                if (pack_one(v, modulus, mod, dst) < 0) goto fail;
+            } else {
+                v = PyObject_GetItem(w, key); /* new reference */
+                if (!v) goto fail;
+                int rc = pack_one(v, modulus, mod, dst);
+                Py_DECREF(v);
+                if (rc < 0) goto fail;
+            }
+        }
+    }
+    Py_DECREF(wf);
+    Py_DECREF(kf);
+    return out;
+fail:
+    Py_DECREF(wf);
+    Py_DECREF(kf);
+    Py_DECREF(out);
+    return NULL;
+}
+
+static PyMethodDef methods[] = {{"pack_dicts_le32", pack_dicts_le32, METH_VARARGS, "dicts x keys -> [B][V] 32-byte little-endian words, reduced mod modulus"},
+                                {"pack_le32", pack_le32, METH_VARARGS, "ints -> 32-byte little-endian words, reduced mod modulus"},
                                 {NULL, NULL, 0, NULL}};
 static struct PyModuleDef moddef = {PyModuleDef_HEAD_INIT, "_pypack", "host-side int packing for plonkathon_amd", -1, methods};
 PyMODINIT_FUNC PyInit__pypack(void) { return PyModule_Create(&moddef); }

@@ -544,8 +544,9 @@ def lookup_table_is_shared_across_contexts():
         import ctypes
         from plonkathon_amd.kzg import _msm
 
-        ra = _msm(da, a.upload_ints(coeffs).ptr, 8, 1, 8)[0]
-        rb = _msm(db, b.upload_ints(coeffs).ptr, 8, 1, 8)[0]
+        buf_a, buf_b = a.upload_ints(coeffs), b.upload_ints(coeffs)  # (kept alive across the calls)
+        ra = _msm(da, buf_a.ptr, 8, 1, 8)[0]
+        rb = _msm(db, buf_b.ptr, 8, 1, 8)[0]
         assert affine(ra) == affine(rb)
         ia, ib = da.lookup_info(), db.lookup_info()
         assert ia["bits"] == ib["bits"] == 5 and ia["bytes"] == ib["bytes"] > 0

@@ -4,7 +4,7 @@
 HBM traffic per launch = FETCH_SIZE * 2 * 1024 + WRITE_SIZE * 1024 bytes: on gfx950 FETCH_SIZE counts 128-byte
 requests as 64 B (MI355X_MICROARCH.md §HBM); the factor is calibrated here on our own kernels — a 2^20-point NTT
 pass must read its 32 MiB tile set exactly once, and reports 16.3 MiB.  WRITE_SIZE needs no correction (the same
-pass writes 32 MiB and reports 32.0).  usage: python tools/pmc_summary.py gpurun_out/pmc profiles/r01_pmc_summary.json"""
+pass writes 32 MiB and reports 32.0).  usage: python tools/pmc_summary.py gpurun_out/pmc profiles/r02_pmc_summary.json"""
 import collections
 import csv
 import json
@@ -37,6 +37,13 @@ for tag, algo in (("ntt", None), ("bench", None)):
             "fetch_size_kb_raw": round(fk[1], 1), "write_size_kb": round(wk[1], 1),
             "traffic_bytes": int(2 * fk[1] * 1024 + wk[1] * 1024),
         })
+# the standalone 2^20 transform as a whole: tools/ntt_only.py runs NTT_REPS of them and no other NTT
+NTT_REPS = 4
+ntt_total = sum(k["traffic_bytes"] * k["launches"] for k in res["kernels"] if k["run"] == "ntt" and k["kernel"].find("ntt_") >= 0)
+if ntt_total:
+    res["kernels"].append({"run": "ntt", "kernel": "ntt_2^20", "grid_threads": 0, "launches": NTT_REPS,
+                           "fetch_size_kb_raw": 0, "write_size_kb": 0, "traffic_bytes": int(ntt_total / NTT_REPS),
+                           "note": "all pass kernels of one 2^20-point transform (algorithmic 64 MiB)"})
 json.dump(res, open(out, "w"), indent=1)
 for k in res["kernels"]:
     print("%-6s %-30s grid=%-9d n=%-3d fetch_raw=%10.0f KB write=%10.0f KB traffic=%8.1f MiB" % (
