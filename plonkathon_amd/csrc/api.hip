@@ -1,5 +1,6 @@
 // api.hip — the extern "C" surface declared in include/plonk_hip.h: context, device memory,
 // conversions and the thin wrappers that turn one reference-level operation into kernel launches.
+#include <stdlib.h>
 #include <string.h>
 
 #include "plonk_internal.h"
@@ -126,6 +127,7 @@ int plonk_ctx_create(int device, plonk_ctx** out_ctx) {
     PLONK_TRY(plonk_use_device(device));
     plonk_ctx* ctx = new plonk_ctx();
     ctx->device = device;
+    if (const char* e = getenv("PLONK_NTT_ADAPTIVE_TILES")) ctx->ntt_adaptive_tiles = atoi(e) != 0;  // A/B knob (default on)
     PLONK_CHECK_HIP(hipStreamCreate(&ctx->stream));
     PLONK_CHECK_HIP(hipEventCreate(&ctx->ev_a));
     PLONK_CHECK_HIP(hipEventCreate(&ctx->ev_b));
@@ -220,12 +222,16 @@ int plonk_fr_upload(plonk_ctx* ctx, void* d_dst, const uint8_t* h_src_le32, size
     PLONK_REQUIRE(ctx && (count == 0 || (d_dst && h_src_le32)), PLONK_ERR_ARG, "bad argument");
     PLONK_ENTER(ctx);
     if (!count) return PLONK_OK;
-    for (size_t i = 0; i < count; i++)
-        PLONK_REQUIRE(le32_below_modulus(h_src_le32 + 32 * i, false), PLONK_ERR_ARG,
-                      "element %zu is not a canonical Fr value (>= r)", i);
+    // the range check `value < r` runs on the device, fused with the Montgomery conversion (a host loop over a
+    // batch of witnesses cost as much as packing them)
+    void* flag;
+    PLONK_TRY(ctx_scratch(ctx, 3, 64, &flag));
     PLONK_CHECK_HIP(hipMemcpyAsync(d_dst, h_src_le32, count * 32, hipMemcpyHostToDevice, ctx->stream));
-    PLONK_TRY(k_fr_to_mont(ctx, (const Fr*)d_dst, (Fr*)d_dst, count));
+    PLONK_TRY(k_fr_to_mont_checked(ctx, (Fr*)d_dst, count, (unsigned long long*)flag));
+    unsigned long long first_bad = 0;
+    PLONK_CHECK_HIP(hipMemcpyAsync(&first_bad, flag, sizeof first_bad, hipMemcpyDeviceToHost, ctx->stream));
     PLONK_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    PLONK_REQUIRE(first_bad == ~0ull, PLONK_ERR_ARG, "element %llu is not a canonical Fr value (>= r)", first_bad);
     return PLONK_OK;
 }
 

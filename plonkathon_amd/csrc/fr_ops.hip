@@ -24,6 +24,27 @@ __global__ void fr_convert_kernel(const Fr* in, Fr* out, size_t n, int to_mont) 
     }
 }
 
+// canonical-range check fused with the conversion: first offending index (or ~0) lands in *bad
+__global__ void fr_to_mont_checked_kernel(const Fr* in, Fr* out, size_t n, unsigned long long* bad) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        Fr a = fp_load(in + i);
+        uint32_t br = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) (void)fp_sbb(a.v[k], FrParams::mod(k), br);  // a - r borrows  <=>  a < r
+        if (!br) atomicMin(bad, (unsigned long long)i);
+        fp_store(out + i, fp_to_mont(a));
+    }
+}
+
+// in-place Montgomery conversion of freshly uploaded values; *first_bad = index of the first element >= r, or ~0
+int k_fr_to_mont_checked(plonk_ctx* ctx, Fr* data, size_t n, unsigned long long* d_first_bad) {
+    if (!n) return PLONK_OK;
+    PLONK_CHECK_HIP(hipMemsetAsync(d_first_bad, 0xff, sizeof(unsigned long long), ctx->stream));
+    PLONK_LAUNCH(fr_to_mont_checked_kernel, grid_for(n), dim3(256), 0, ctx->stream, (const Fr*)data, data, n, d_first_bad);
+    PLONK_CHECK_HIP(hipGetLastError());
+    return PLONK_OK;
+}
+
 int k_fr_to_mont(plonk_ctx* ctx, const Fr* in, Fr* out, size_t n) {
     if (!n) return PLONK_OK;
     PLONK_LAUNCH(fr_convert_kernel, grid_for(n), dim3(256), 0, ctx->stream, in, out, n, 1);

@@ -835,9 +835,9 @@ int ntt_run(plonk_ctx* ctx, const Fr* in, Fr* out, unsigned log_n, bool inverse,
     unsigned wr1, wr2;
     if ((ctx->ntt_kind == 0 || ctx->ntt_kind == 3) && ntt_wave_plan(log_n, &wr1, &wr2) && ctx->ntt_single_log >= 11 && ctx->ntt_radix_log >= 10) {
         // measured on MI355X (profiles/r02_e_ntt_kinds.json): the one-pass sizes always win (+22 % at 2^11 / 2^13); the
-        // two-pass form wins when there is enough work to fill the chip several times over (2^18 x 16, 2^20 x 8, 2^22) and for
-        // a lone 2^18 (latency), but a lone 2^20 is faster on the 1024-thread radix-2 passes and 2^24 on three of those
-        const bool two_pass_ok = log_n == 18 || ((log_n == 20 || log_n == 22) && ((size_t)batch << log_n) >= ((size_t)1 << 22));
+        // two-pass form wins when there is enough work to fill the chip several times over (2^18 x 16, 2^20 x 8, 2^22), but a
+        // lone 2^18 / 2^20 is faster on the radix-2 passes (smaller per-thread chains) and 2^24 on three of those
+        const bool two_pass_ok = (log_n == 18 || log_n == 20 || log_n == 22) && ((size_t)batch << log_n) >= ((size_t)1 << 22);
         if (!wr2 || two_pass_ok || ctx->ntt_kind == 3)
             return ntt_run_wave(ctx, in, out, log_n, inverse, batch, in_len, in_bstride, out_bstride, in_scale, out_scale, scale_by_n_inv);
     }
@@ -873,7 +873,14 @@ int ntt_run(plonk_ctx* ctx, const Fr* in, Fr* out, unsigned log_n, bool inverse,
         p.in_len = (unsigned)(in_len < N ? in_len : N);
         // three-pass transforms (N >= 2^21) run faster with 2048-element tiles (two workgroups per CU):
         // measured 2.40 ms vs 2.90 ms at 2^24 (profiles/r01_h_sweep.jsonl); 2^12..2^20 prefer 4096
-        const unsigned tile_log = (ctx->ntt_tile_log == 12 && P >= 3) ? 11 : ctx->ntt_tile_log;
+        unsigned tile_log = (ctx->ntt_tile_log == 12 && P >= 3) ? 11 : ctx->ntt_tile_log;
+        // small jobs: shrink the tile until the pass has >= 512 workgroups (two per CU) or one column per tile — a lone
+        // 2^16 transform used to run on 16 workgroups of 4096 elements.  Narrow tiles give up 128-byte chunks, but such
+        // a job's data (<= 32 MiB) sits in L2 / MALL anyway.
+        // Measured (profiles/r02_h_ntt_adaptive_tiles.json): 2^16 0.096 -> 0.042 ms, 2^14 0.088 -> 0.040, 2^18 0.113 -> 0.075,
+        // 2^19 0.122 -> 0.087; from 2^20 elements up the 4096-element tiles win (2^20: 0.139 vs 0.151 ms).
+        if (ctx->ntt_tile_log == 12 && ctx->ntt_adaptive_tiles && ((size_t)batch << log_n) < ((size_t)1 << 20))
+            while (tile_log > p.log_r && (((size_t)batch << log_n) >> tile_log) < 512) tile_log--;
         unsigned log_c = tile_log > p.log_r ? tile_log - p.log_r : 0;
         unsigned avail = last ? (P > 1 ? radices[0] : 0) : p.log_s;
         if (log_c > avail) log_c = avail;

@@ -106,6 +106,7 @@ struct plonk_ctx {
     std::vector<ProfRec> prof;
     std::vector<hipEvent_t> event_pool;
     unsigned ntt_tile_log = 12, ntt_single_log = 11, ntt_radix_log = 10;
+    bool ntt_adaptive_tiles = true;
     unsigned ntt_kind = 0;  // 0 = auto (Stockham radix-8 for single-pass sizes, radix-2 stages otherwise), 1 / 2 = force
 };
 
@@ -119,6 +120,7 @@ int prof_end(plonk_ctx* ctx);
 // fr_ops.hip
 int k_fr_to_mont(plonk_ctx*, const Fr* in, Fr* out, size_t n);
 int k_fr_from_mont(plonk_ctx*, const Fr* in, Fr* out, size_t n);
+int k_fr_to_mont_checked(plonk_ctx*, Fr* data, size_t n, unsigned long long* d_first_bad);
 int k_fr_pointwise(plonk_ctx*, int op, const Fr* a, const Fr* b, Fr* out, size_t n);
 int k_fr_pointwise_scalar(plonk_ctx*, int op, const Fr* a, const Fr& s_mont, Fr* out, size_t n, size_t limit);
 int k_fr_batch_inverse(plonk_ctx*, const Fr* in, Fr* out, size_t n);

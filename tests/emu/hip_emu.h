@@ -103,6 +103,7 @@ inline unsigned __brev(unsigned x) {
 template <class T> inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
 template <class T> inline T atomicExch(T* p, T v) { T o = *p; *p = v; return o; }
 template <class T> inline T atomicMax(T* p, T v) { T o = *p; if (v > o) *p = v; return o; }
+template <class T> inline T atomicMin(T* p, T v) { T o = *p; if (v < o) *p = v; return o; }
 template <class T> inline T atomicOr(T* p, T v) { T o = *p; *p = o | v; return o; }
 
 #define PLONK_LAUNCH(kern, grid, block, shmem, stream, ...) \
