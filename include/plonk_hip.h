@@ -207,6 +207,14 @@ int plonk_gather_results(plonk_comm* comm, const uint8_t* h_send, size_t bytes_p
 int plonk_comm_max_f64(plonk_comm* comm, double* inout);
 int plonk_comm_barrier(plonk_comm* comm);
 
+/* ---- verifier support: pairing-product check (host CPU) ------------------------------------------------
+ * Replaces the `b.pairing(...)` comparisons of the verifier, TESTING_verifier_DO_NOT_OPEN.py:148-160, 237-262 /
+ * verifier.py:40-92 (py_ecc.bn128.pairing): out_ok = 1 iff prod_i e(P_i, Q_i) == 1 in GT.  P_i in G1: affine
+ * canonical x||y LE (64 B) + identity flag; Q_i in G2: affine canonical x.c0||x.c1||y.c0||y.c1 LE (128 B, py_ecc's FQ2
+ * coefficient order; all zero = identity).  A check e(A, X) == e(B, Y) is asked as e(A, X) e(-B, Y) == 1.  Runs on the
+ * host (the verifier is off the prover hot path); no context needed.                          */
+int plonk_pairing_check(const uint8_t* g1_xy_le, const uint8_t* g1_is_identity, const uint8_t* g2_le, size_t count, int* out_ok);
+
 /* ---- Fiat-Shamir transcript (host) ----------------------------------------------------------------
  * Replaces `merlin.MerlinTranscript` (third-party) as subclassed by transcript.py:58-60:
  *   plonk_transcript_new              MerlinTranscript(label)             (prover.py:53 uses b"plonk")

@@ -23,8 +23,11 @@ SETUP_FILE_POWERS_POS = 60  # setup.py:12
 
 G1 = (Fq(1), Fq(2))
 Z1 = None
-# x.c0 of py_ecc.bn128.G2 (published generator of the BN254 twist subgroup)
+# py_ecc.bn128.G2: the published generator of the BN254 twist subgroup, (x.c0, x.c1), (y.c0, y.c1)
 _G2_X_C0 = 10857046999023057135944570762232829481370756359578518086990519993285655852781
+_G2_COORDS = ((_G2_X_C0, 11559732032986387107991004021392285783925812861821192530917403151452391805634),
+              (8495653923123431417604973247489272438418190587263600148770280649306958101930,
+               4082367875863433681332203403145435568316851327593401208105741076214120093531))
 _MONT_R_Q = (1 << 256) % Q_MOD
 
 
@@ -39,6 +42,23 @@ class Fq2:
 
     def __repr__(self):
         return repr(self.coeffs)
+
+
+G2 = None  # set below, once Fq2 exists
+
+
+def pairing_check(pairs) -> bool:
+    """True iff prod e(P_i, Q_i) == 1 for `pairs` = [(G1 point or None, G2 point)]: the question every
+    `b.pairing(...) == b.pairing(...)` of the reference's verifier asks (TESTING_verifier_DO_NOT_OPEN.py:148-160,
+    237-262), answered by plonk_pairing_check on the host CPU."""
+    pairs = list(pairs)
+    g1 = b"".join(bytes(64) if p is None else le32(int(p[0])) + le32(int(p[1])) for p, _ in pairs)
+    flags = bytes(1 if p is None else 0 for p, _ in pairs)
+    g2 = b"".join(le32(int(q[0].coeffs[0])) + le32(int(q[0].coeffs[1])) + le32(int(q[1].coeffs[0])) + le32(int(q[1].coeffs[1]))
+                  for _, q in pairs)
+    ok = ctypes.c_int(0)
+    check(_lib.lib().plonk_pairing_check(g1, flags, g2, len(pairs), ctypes.byref(ok)))
+    return bool(ok.value)
 
 
 def _decode_points(xy: bytes, flags: bytes):
@@ -107,7 +127,10 @@ def _msm(bases: _DeviceBases, scalars_ptr, n, batch, stride):
 
 @dataclass
 class VerificationKey:
-    """verifier.py:9-34 (fields only; pairing-based verification is outside the prover hot path)."""
+    """verifier.py:9-34, with the verification the reference leaves blank (verifier.py:40-92) following its complete
+    test verifier, TESTING_verifier_DO_NOT_OPEN.py:39-277.  Group arithmetic = `ec_lincomb` on the GPU, the evaluation of
+    PI = `Polynomial.barycentric_eval` on the GPU, challenges = the native transcript, pairings = `pairing_check`
+    (host CPU).  Off the prover hot path."""
 
     group_order: int
     Qm: object
@@ -120,6 +143,83 @@ class VerificationKey:
     S3: object
     X_2: object
     w: Scalar
+
+    # TESTING_verifier_DO_NOT_OPEN.py:266-277 / verifier.py:95-105
+    def compute_challenges(self, proof):
+        from .fiat_shamir import Transcript
+
+        transcript = Transcript(b"plonk")
+        beta, gamma = transcript.round_1(proof.msg_1)
+        alpha, _fft_cofactor = transcript.round_2(proof.msg_2)
+        zeta = transcript.round_3(proof.msg_3)
+        v = transcript.round_4(proof.msg_4)
+        u = transcript.round_5(proof.msg_5)
+        return beta, gamma, alpha, zeta, v, u
+
+    def _common(self, group_order, zeta, public):
+        ZH_ev = zeta**group_order - 1
+        L0_ev = ZH_ev / (group_order * (zeta - 1))
+        PI = Polynomial([Scalar(-x) for x in public] + [Scalar(0) for _ in range(group_order - len(public))], Basis.LAGRANGE)
+        return ZH_ev, L0_ev, PI.barycentric_eval(zeta)
+
+    # TESTING_verifier_DO_NOT_OPEN.py:39-163: one pairing check
+    def verify_proof(self, group_order: int, pf, public=[]) -> bool:
+        beta, gamma, alpha, zeta, v, u = self.compute_challenges(pf)
+        proof = pf.flatten()
+        root_of_unity = Scalar.root_of_unity(group_order)
+        ZH_ev, L0_ev, PI_ev = self._common(group_order, zeta, public)
+        a, b_, c = proof["a_eval"], proof["b_eval"], proof["c_eval"]
+        s1, s2, zw = proof["s1_eval"], proof["s2_eval"], proof["z_shifted_eval"]
+        r0 = PI_ev - L0_ev * alpha**2 - alpha * (a + beta * s1 + gamma) * (b_ + beta * s2 + gamma) * (c + gamma) * zw
+        D_pt = ec_lincomb([
+            (self.Qm, a * b_), (self.Ql, a), (self.Qr, b_), (self.Qo, c), (self.Qc, 1),
+            (proof["z_1"], (a + beta * zeta + gamma) * (b_ + beta * 2 * zeta + gamma) * (c + beta * 3 * zeta + gamma) * alpha
+             + L0_ev * alpha**2 + u),
+            (self.S3, -(a + beta * s1 + gamma) * (b_ + beta * s2 + gamma) * alpha * beta * zw),
+            (proof["t_lo_1"], -ZH_ev), (proof["t_mid_1"], -ZH_ev * zeta**group_order),
+            (proof["t_hi_1"], -ZH_ev * zeta ** (group_order * 2)),
+        ])
+        F_pt = ec_lincomb([(D_pt, 1), (proof["a_1"], v), (proof["b_1"], v**2), (proof["c_1"], v**3), (self.S1, v**4), (self.S2, v**5)])
+        E_pt = ec_mul(G1, -r0 + v * a + v**2 * b_ + v**3 * c + v**4 * s1 + v**5 * s2 + u * zw)
+        lhs = ec_lincomb([(proof["W_z_1"], 1), (proof["W_zw_1"], u)])
+        rhs = ec_lincomb([(proof["W_z_1"], zeta), (proof["W_zw_1"], u * zeta * root_of_unity), (F_pt, 1), (E_pt, -1)])
+        # e(lhs, [x]_2) == e(rhs, [1]_2)
+        return pairing_check([(lhs, self.X_2), (_g1_neg(rhs), G2)])
+
+    # TESTING_verifier_DO_NOT_OPEN.py:166-264: the two opening checks separately.  e(Y, [1]_2) == e(W, [x]_2 - z [1]_2) is
+    # asked as e(Y + z W, [1]_2) e(-W, [x]_2) == 1, so no arithmetic in G2 is needed.
+    def verify_proof_unoptimized(self, group_order: int, pf, public=[]) -> bool:
+        beta, gamma, alpha, zeta, v, _ = self.compute_challenges(pf)
+        proof = pf.flatten()
+        root_of_unity = Scalar.root_of_unity(group_order)
+        ZH_ev, L0_ev, PI_ev = self._common(group_order, zeta, public)
+        a, b_, c = proof["a_eval"], proof["b_eval"], proof["c_eval"]
+        s1, s2, zw = proof["s1_eval"], proof["s2_eval"], proof["z_shifted_eval"]
+        R_pt = ec_lincomb([
+            (self.Qm, a * b_), (self.Ql, a), (self.Qr, b_), (self.Qo, c), (G1, PI_ev), (self.Qc, 1),
+            (proof["z_1"], (a + beta * zeta + gamma) * (b_ + beta * 2 * zeta + gamma) * (c + beta * 3 * zeta + gamma) * alpha),
+            (self.S3, -(a + beta * s1 + gamma) * (b_ + beta * s2 + gamma) * beta * alpha * zw),
+            (G1, -(a + beta * s1 + gamma) * (b_ + beta * s2 + gamma) * (c + gamma) * alpha * zw),
+            (proof["z_1"], L0_ev * alpha**2), (G1, -L0_ev * alpha**2),
+            (proof["t_lo_1"], -ZH_ev), (proof["t_mid_1"], -ZH_ev * zeta**group_order),
+            (proof["t_hi_1"], -ZH_ev * zeta ** (group_order * 2)),
+        ])
+        Y1 = ec_lincomb([
+            (R_pt, 1), (proof["a_1"], v), (G1, -v * a), (proof["b_1"], v**2), (G1, -(v**2) * b_), (proof["c_1"], v**3),
+            (G1, -(v**3) * c), (self.S1, v**4), (G1, -(v**4) * s1), (self.S2, v**5), (G1, -(v**5) * s2),
+            (proof["W_z_1"], zeta),
+        ])
+        if not pairing_check([(Y1, G2), (_g1_neg(proof["W_z_1"]), self.X_2)]):
+            return False
+        Y2 = ec_lincomb([(proof["z_1"], 1), (G1, -zw), (proof["W_zw_1"], zeta * root_of_unity)])
+        return pairing_check([(Y2, G2), (_g1_neg(proof["W_zw_1"]), self.X_2)])
+
+
+def _g1_neg(pt):
+    return None if pt is None else (pt[0], Fq(-int(pt[1])))
+
+
+G2 = (Fq2(_G2_COORDS[0]), Fq2(_G2_COORDS[1]))
 
 
 class Setup:

@@ -561,6 +561,76 @@ def lookup_table_is_shared_across_contexts():
         b.msm_lookup(0)
 
 
+# ------------------------------------------------------------------------------------------ product-side verifier
+def verifier_cases(setup, full_size=False):
+    """The reference's own verifier tests on the product's `VerificationKey` (plonk_pairing_check on the host):
+    `verifier_test_unoptimized` / `verifier_test_full` on test/proof.pickle (test.py:59-67, 149-168, 272-275),
+    prove -> verify for the factorisation circuit (test.py:171-213), rejection of tampered proofs and wrong public inputs,
+    and the pairing itself through bilinearity against oracle-computed multiples."""
+    from oracle import pairing as opairing
+
+    g = load("k6_proof.json")
+
+    def Pt(k):
+        return (pa.Fq(int(g["proof"][k][0])), pa.Fq(int(g["proof"][k][1])))
+
+    def S(k):
+        return Scalar(int(g["proof"][k]))
+
+    golden = pa.Proof(pa.Message1(Pt("a_1"), Pt("b_1"), Pt("c_1")), pa.Message2(Pt("z_1")),
+                      pa.Message3(Pt("t_lo_1"), Pt("t_mid_1"), Pt("t_hi_1")),
+                      pa.Message4(S("a_eval"), S("b_eval"), S("c_eval"), S("s1_eval"), S("s2_eval"), S("z_shifted_eval")),
+                      pa.Message5(Pt("W_z_1"), Pt("W_zw_1")))
+    program = Program(g["program"], g["group_order"])
+    vk = setup.verification_key(program.common_preprocessed_input())
+    public = [int(g["witness"]["e"])]
+    assert vk.verify_proof_unoptimized(8, golden, public)  # test.py:59-67
+    assert vk.verify_proof(8, golden, public)              # test.py:149-168
+    assert not vk.verify_proof(8, golden, [public[0] + 1])
+    assert not vk.verify_proof_unoptimized(8, golden, [public[0] + 1])
+    import copy
+
+    bad = copy.deepcopy(golden)
+    bad.msg_4.b_eval = bad.msg_4.b_eval + 1
+    assert not vk.verify_proof(8, bad, public) and not vk.verify_proof_unoptimized(8, bad, public)
+    bad = copy.deepcopy(golden)
+    bad.msg_5.W_zw_1 = golden.msg_5.W_z_1
+    assert not vk.verify_proof(8, bad, public)
+    # the same challenges as the prover drew
+    tv = load("transcript_vectors.json")["k6_challenges"]
+    beta, gamma, alpha, zeta, v, u = vk.compute_challenges(golden)
+    assert [str(x.n) for x in (beta, gamma, alpha, zeta, v, u)] == [tv[k] for k in ("beta", "gamma", "alpha", "zeta", "v", "u")]
+    # prove -> verify (test.py:171-213)
+    fprog = Program(FACTORIZATION, 16)
+    fwit = fprog.fill_variable_assignments(FACTORIZATION_START)
+    fproof = pa.BatchProver(setup, fprog).prove(dict(fwit))
+    fvk = setup.verification_key(fprog.common_preprocessed_input())
+    assert fvk.verify_proof(16, fproof, [fwit["n"]]) and fvk.verify_proof_unoptimized(16, fproof, [fwit["n"]])
+    assert not fvk.verify_proof(16, fproof, [fwit["n"] + 1])
+    # bilinearity: e(aP, bQ) e(-(ab)P, Q) == 1, and non-degeneracy
+    a, b = 0x1234567890ABCDEF1234567, R_MOD - 5
+    Pa, Pab = og1.multiply((1, 2), a), og1.multiply((1, 2), a * b % R_MOD)
+    Qb = opairing.multiply(opairing.G2, b)
+    fq2 = lambda q: (pa.kzg.Fq2(q[0].c), pa.kzg.Fq2(q[1].c))
+    neg = lambda p: (p[0], (-p[1]) % Q_MOD)
+    assert pa.pairing_check([(Pa, fq2(Qb)), (neg(Pab), pa.G2)])
+    assert not pa.pairing_check([(Pa, fq2(Qb)), (neg(Pa), pa.G2)])
+    assert not pa.pairing_check([((1, 2), pa.G2)])
+    assert pa.pairing_check([(None, pa.G2), ((1, 2), pa.G2), (neg((1, 2)), pa.G2)])
+    import pytest
+
+    with pytest.raises(AssertionError, match="curve"):
+        pa.pairing_check([((1, 3), pa.G2)])
+    if full_size:  # Poseidon at group_order 2^10 (test.py:242-259): prove on the GPU, verify with the product's verifier
+        lines = poseidon_program_lines()
+        pprog = Program(lines, 1024)
+        pwit = pprog.fill_variable_assignments({"L0": 1, "M0": 2})
+        pproof = pa.BatchProver(setup, pprog).prove(dict(pwit))
+        pvk = setup.verification_key(pprog.common_preprocessed_input())
+        pub = [pwit[v] for v in pprog.get_public_assignments()]
+        assert pvk.verify_proof(1024, pproof, pub) and pvk.verify_proof_unoptimized(1024, pproof, pub)
+
+
 # ------------------------------------------------------------------------------------------ proofs verify
 def proofs_verify(setup, lines, group_order, start, public):
     """Independent acceptance: the GPU's proof passes the oracle's pairing-based verifier against a

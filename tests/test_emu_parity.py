@@ -187,3 +187,9 @@ def test_ntt_two_pass_wave_kernel(emu):
 
     v = pc.rand_vec(4018, 1 << 18)
     assert pc.ints(pc.P(v, Basis.MONOMIAL).fft()) == c_oracle.fr_ntt(v)
+
+
+def test_product_verifier(emu):
+    from plonkathon_amd import Setup
+
+    pc.verifier_cases(Setup.from_file(pc.PTAU))

@@ -402,3 +402,8 @@ def test_lagrange_srs_paths(setup):
         got = pc.flat(proofs[b])
         for k, v in fx[name]["proof"].items():
             assert got[k] == (pc.pt(v) if isinstance(v, list) else int(v)), (name, k)
+
+
+@pytest.mark.gpu
+def test_product_verifier(setup):
+    pc.verifier_cases(setup, full_size=True)
