@@ -206,6 +206,19 @@ int plonk_comm_size(const plonk_comm* comm, int* out_rank, int* out_world);
 int plonk_gather_results(plonk_comm* comm, const uint8_t* h_send, size_t bytes_per_rank, uint8_t* h_recv);
 int plonk_comm_max_f64(plonk_comm* comm, double* inout);
 int plonk_comm_barrier(plonk_comm* comm);
+/* ---- one transform across the GPUs of a communicator (four-step NTT) ----------------------
+ * Polynomial.fft / ifft (poly.py:113-148) for N = 2^log_n = R1 R2 points that need not fit one GPU (log_n = 18, 20, 22,
+ * 24, 26: R1 x R2 = 2^9 x 2^9, 2^11 x 2^9, 2^11 x 2^11, 2^13 x 2^11, 2^13 x 2^13), over W = 2^k ranks, W <= min(R1, R2) / 32.
+ *   input   rank g holds the columns c = g R2/W .. (g+1) R2/W - 1 of x[i1 R2 + c], stored [R1][R2/W]   (N / W elements)
+ *   output  rank g holds the frequencies k = k1 + R1 k2 with k1 = g R1/W .. (g+1) R1/W - 1, stored [R2][R1/W]
+ * (the inverse transform includes 1/N).  plonk_fr_ntt_distributed = plonk_fr_ntt_dist_columns (local R1-point transforms
+ * and the w_N^(c k1) twiddles) -> plonk_comm_all_to_all (d_recv block r = block `rank` of rank r's d_send: grouped
+ * ncclSend / ncclRecv over xGMI, N / W^2 elements per pair) -> plonk_fr_ntt_dist_rows (local R2-point transforms).
+ * The two local steps are exported so the exchange can run over another transport (tests: sockets on CPU).        */
+int plonk_fr_ntt_dist_columns(plonk_ctx* ctx, const void* d_in, void* d_out, unsigned log_n, unsigned log_world, unsigned rank, int inverse);
+int plonk_fr_ntt_dist_rows(plonk_ctx* ctx, const void* d_in, void* d_out, unsigned log_n, unsigned log_world, unsigned rank, int inverse);
+int plonk_comm_all_to_all(plonk_comm* comm, const void* d_send, void* d_recv, size_t bytes_per_peer);
+int plonk_fr_ntt_distributed(plonk_comm* comm, const void* d_in, void* d_out, unsigned log_n, int inverse);
 
 /* ---- verifier support: pairing-product check (host CPU) ------------------------------------------------
  * Replaces the `b.pairing(...)` comparisons of the verifier, TESTING_verifier_DO_NOT_OPEN.py:148-160, 237-262 /

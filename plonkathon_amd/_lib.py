@@ -68,6 +68,10 @@ SIGNATURES = {
     "plonk_gather_results": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "plonk_comm_max_f64": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double)]),
     "plonk_comm_barrier": (ctypes.c_int, [ctypes.c_void_p]),
+    "plonk_fr_ntt_dist_columns": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint, ctypes.c_uint, ctypes.c_uint, ctypes.c_int]),
+    "plonk_fr_ntt_dist_rows": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint, ctypes.c_uint, ctypes.c_uint, ctypes.c_int]),
+    "plonk_comm_all_to_all": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]),
+    "plonk_fr_ntt_distributed": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint, ctypes.c_int]),
     "plonk_pairing_check": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_int)]),
     "plonk_transcript_new": (ctypes.c_int, [_u8p, ctypes.c_size_t, c_void_pp]),
     "plonk_transcript_clone": (ctypes.c_int, [ctypes.c_void_p, c_void_pp]),

@@ -278,6 +278,18 @@ int plonk_fr_ntt(plonk_ctx* ctx, const void* d_in, void* d_out, unsigned log_n, 
     return ntt_run(ctx, (const Fr*)d_in, (Fr*)d_out, log_n, inverse != 0, batch, N, N, N, nullptr, nullptr, inverse != 0);
 }
 
+int plonk_fr_ntt_dist_columns(plonk_ctx* ctx, const void* d_in, void* d_out, unsigned log_n, unsigned log_world, unsigned rank, int inverse) {
+    PLONK_REQUIRE(ctx && d_in && d_out && d_in != d_out && rank < (1u << log_world), PLONK_ERR_ARG, "bad argument");
+    PLONK_ENTER(ctx);
+    return ntt_dist_columns(ctx, (const Fr*)d_in, (Fr*)d_out, log_n, log_world, rank, inverse != 0);
+}
+
+int plonk_fr_ntt_dist_rows(plonk_ctx* ctx, const void* d_in, void* d_out, unsigned log_n, unsigned log_world, unsigned rank, int inverse) {
+    PLONK_REQUIRE(ctx && d_in && d_out && d_in != d_out && rank < (1u << log_world), PLONK_ERR_ARG, "bad argument");
+    PLONK_ENTER(ctx);
+    return ntt_dist_rows(ctx, (const Fr*)d_in, (Fr*)d_out, log_n, log_world, rank, inverse != 0);
+}
+
 // power table first * base^i, i < n, cached per (base, first, n)
 static int get_power_table(plonk_ctx* ctx, const Fr& base, const Fr& first, size_t n, const Fr** out) {
     std::string key((const char*)base.v, 32);

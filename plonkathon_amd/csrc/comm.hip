@@ -1,9 +1,10 @@
-// comm.hip — the one collective on the path: gathering the finished proofs (768 bytes each: 9 affine G1 +
-// 6 Fr) of independently proving GPUs, RCCL over xGMI (SURVEY.md §8(b) `plonk_gather_results`, §8(e)).
-//
-// The reference is a single Python process and has no counterpart; proofs shard by index across the GPUs of a
-// node with no data-path exchange, so this all-gather (384 KiB for 512 proofs, latency-bound) plus a barrier and
-// a max-reduction for the benchmark clock are everything that ever crosses xGMI.  One process per GPU; rank 0
+// comm.hip — everything that crosses xGMI, RCCL behind the C-ABI:
+//   * the one collective of the prover path: gathering the finished proofs (768 bytes each: 9 affine G1 + 6 Fr) of
+//     independently proving GPUs (SURVEY.md §8(b) `plonk_gather_results`, §8(e)), plus a barrier and a max-reduction
+//     for the benchmark clock;
+//   * the transpose step of a transform split across GPUs (`plonk_comm_all_to_all`, `plonk_fr_ntt_distributed`,
+//     SURVEY.md §8(f) N4): grouped point-to-point ncclSend / ncclRecv, since xGMI is point-to-point anyway.
+// The reference is a single Python process and has no counterpart.  One process per GPU; rank 0
 // draws the ncclUniqueId (plonk_comm_unique_id) and hands its 128 bytes to the other ranks out of band
 // (plonkathon_amd/distributed.py does it over a loopback socket).  librccl is dlopen'ed on first use so that
 // single-GPU users never load it.
@@ -22,6 +23,10 @@ struct Rccl {
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 Rccl g_rccl;
@@ -41,6 +46,10 @@ int rccl_load() {
     PLONK_RCCL_SYM(CommDestroy, "ncclCommDestroy");
     PLONK_RCCL_SYM(AllGather, "ncclAllGather");
     PLONK_RCCL_SYM(AllReduce, "ncclAllReduce");
+    PLONK_RCCL_SYM(Send, "ncclSend");
+    PLONK_RCCL_SYM(Recv, "ncclRecv");
+    PLONK_RCCL_SYM(GroupStart, "ncclGroupStart");
+    PLONK_RCCL_SYM(GroupEnd, "ncclGroupEnd");
     PLONK_RCCL_SYM(GetErrorString, "ncclGetErrorString");
 #undef PLONK_RCCL_SYM
     g_rccl.handle = h;
@@ -159,6 +168,45 @@ int plonk_comm_max_f64(plonk_comm* c, double* inout) {
     PLONK_CHECK_HIP(hipMemcpyAsync(inout, d, sizeof(double), hipMemcpyDeviceToHost, s));
     PLONK_CHECK_HIP(hipStreamSynchronize(s));
     return PLONK_OK;
+}
+
+// d_recv[r * bytes_per_peer ..] = block `rank` of rank r's d_send, for every r: the transpose step of the distributed
+// NTT, as one group of point-to-point ncclSend / ncclRecv pairs over xGMI (device buffers, the context's stream)
+int plonk_comm_all_to_all(plonk_comm* c, const void* d_send, void* d_recv, size_t bytes_per_peer) {
+    PLONK_REQUIRE(c && d_send && d_recv && bytes_per_peer, PLONK_ERR_ARG, "bad argument");
+    PLONK_ENTER(c->ctx);
+    hipStream_t s = c->ctx->stream;
+    if (c->world == 1) {
+        PLONK_CHECK_HIP(hipMemcpyAsync(d_recv, d_send, bytes_per_peer, hipMemcpyDeviceToDevice, s));
+        return PLONK_OK;
+    }
+    PLONK_CHECK_RCCL(g_rccl.GroupStart());
+    for (int r = 0; r < c->world; r++) {
+        PLONK_CHECK_RCCL(g_rccl.Send((const uint8_t*)d_send + (size_t)r * bytes_per_peer, bytes_per_peer, ncclUint8, r, c->comm, s));
+        PLONK_CHECK_RCCL(g_rccl.Recv((uint8_t*)d_recv + (size_t)r * bytes_per_peer, bytes_per_peer, ncclUint8, r, c->comm, s));
+    }
+    PLONK_CHECK_RCCL(g_rccl.GroupEnd());
+    return PLONK_OK;
+}
+
+// One transform of 2^log_n points across the communicator's W = 2^k GPUs (four-step): local column
+// transforms with the inter-pass twiddles, ONE all-to-all, local row transforms.  Layouts: see plonk_hip.h.
+int plonk_fr_ntt_distributed(plonk_comm* c, const void* d_in, void* d_out, unsigned log_n, int inverse) {
+    PLONK_REQUIRE(c && d_in && d_out, PLONK_ERR_ARG, "bad argument");
+    PLONK_ENTER(c->ctx);
+    unsigned log_w = 0;
+    while ((1 << log_w) < c->world) log_w++;
+    PLONK_REQUIRE((1 << log_w) == c->world, PLONK_ERR_ARG, "the communicator has %d ranks: a power of two is needed", c->world);
+    unsigned r1, r2;
+    PLONK_TRY(ntt_dist_plan(log_n, log_w, &r1, &r2));
+    const size_t local = (size_t)1 << (log_n - log_w);
+    void* sc;
+    PLONK_TRY(ctx_scratch(c->ctx, 0, 2 * local * sizeof(Fr), &sc));
+    Fr* cols = (Fr*)sc;
+    Fr* recv = cols + local;
+    PLONK_TRY(ntt_dist_columns(c->ctx, (const Fr*)d_in, cols, log_n, log_w, (unsigned)c->rank, inverse != 0));
+    PLONK_TRY(plonk_comm_all_to_all(c, cols, recv, (local >> log_w) * sizeof(Fr)));
+    return ntt_dist_rows(c->ctx, recv, (Fr*)d_out, log_n, log_w, (unsigned)c->rank, inverse != 0);
 }
 
 int plonk_comm_barrier(plonk_comm* c) {

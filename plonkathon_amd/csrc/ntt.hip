@@ -467,7 +467,12 @@ struct NttWave {
     // k1 + R1 k2): mode 1 = R1-point transforms down the R2 columns (element i1 of column c at in[i1 R2 + c], output k1
     // times w_N^(c k1) to out[k1 R2 + c]); mode 2 = R2-point transforms along the R1 rows (row k1 at in[k1 R2 ..],
     // output k2 to out[k1 + R1 k2]).  blockIdx.x = column / row (XCD-aware order), blockIdx.y = batch index.
-    unsigned mode, log_n, log_other;  // log2 of the whole transform and of the OTHER pass's size
+    unsigned mode, log_n, log_other;  // log2 of the whole transform and of the stride between successive positions
+    // Distributed (multi-GPU) transforms run the same two passes on a slice: rank g of W owns R2 / W columns for the
+    // column pass (twiddle column = sub + sub_base) and R1 / W rows for the row pass, whose input arrives from the
+    // all-to-all as W chunks [source rank][local row][source's columns]: position c of a row sits at
+    // (c >> chunk_log) * chunk_stride + row * 2^chunk_log + (c & (2^chunk_log - 1)).  chunk_log = 0 means contiguous rows.
+    unsigned sub_base, chunk_log, chunk_stride;
     const Fr* tw_lo;      // inter-pass twiddles w_N^e = tw_lo[e & 1023] * tw_hi[e >> 10]   (mode 1)
     const Fr* tw_hi;
     const Fr* roots;      // w_R^k, k < R, R = this kernel's transform size (direction of the transform)
@@ -533,16 +538,18 @@ __global__ void __launch_bounds__(64u << (2 * NLDS), NLDS == 2 ? 4 : 3) ntt_wave
     // column / row of a two-pass transform.  Workgroup b runs on XCD b % 8 (each XCD has its own L2): the remap gives
     // every XCD four ADJACENT columns (rows) per group of 32, so the 32-byte elements it touches share 128-byte lines.
     const unsigned b = blockIdx.x;
-    const unsigned sub = p.mode ? ((b & ~31u) | ((b & 7u) << 2) | ((b >> 3) & 3u)) : 0;
+    const unsigned sub = !p.mode ? 0 : ((gridDim.x & 31u) ? b : ((b & ~31u) | ((b & 7u) << 2) | ((b >> 3) & 3u)));
     // global index of sub-transform position pos on the input side, of frequency o on the output side
     const unsigned in_shift = p.mode == 1 ? p.log_other : 0, out_shift = p.mode ? p.log_other : 0;
-    const unsigned in_off = p.mode == 1 ? sub : (p.mode == 2 ? sub << LOG_N : 0);
+    const unsigned in_off = p.mode == 1 ? sub : (p.mode == 2 ? (p.chunk_log ? sub << p.chunk_log : sub << LOG_N) : 0);
     const unsigned out_off = p.mode ? sub : 0;
+    const unsigned chunk_mask = (1u << p.chunk_log) - 1;
 
     Fr x[8];
     wave_for8([&](auto J) {  // position j * NT + tid: consecutive lanes read consecutive positions
         constexpr unsigned j = decltype(J)::value;
-        const unsigned g = ((j * NT + tid) << in_shift) + in_off;
+        const unsigned pos = j * NT + tid;
+        const unsigned g = p.chunk_log ? (pos >> p.chunk_log) * p.chunk_stride + (pos & chunk_mask) + in_off : (pos << in_shift) + in_off;
         x[j] = g < p.in_len ? fp_load(in + g) : fp_zero<FrParams>();
     });
     if (p.in_scale) {
@@ -605,7 +612,7 @@ __global__ void __launch_bounds__(64u << (2 * NLDS), NLDS == 2 ? 4 : 3) ntt_wave
     if (p.mode == 1) {  // inter-pass twiddle w_N^(column * frequency)
         wave_for8([&](auto J) {
             constexpr unsigned j = decltype(J)::value;
-            const unsigned e = sub * (k | (j << shift));  // < N
+            const unsigned e = (sub + p.sub_base) * (k | (j << shift));  // < N
             if (e) {
                 Fr tw = fp_load(p.tw_lo + (e & ((1u << NTT_TW_LO_LOG) - 1)));
                 if (p.log_n > NTT_TW_LO_LOG) tw = fp_mul(tw, fp_load(p.tw_hi + (e >> NTT_TW_LO_LOG)));
@@ -822,6 +829,79 @@ static int ntt_run_wave(plonk_ctx* ctx, const Fr* in, Fr* out, unsigned log_n, b
     PLONK_TRY(ntt_get_roots(ctx, log_r2, inverse, &c.roots));
     PLONK_TRY(prof_begin(ctx, "ntt_pass", 32.0 * (double)N * (double)batch));
     PLONK_TRY(ntt_wave_launch(ctx, c, log_r2, 1u << log_r1, (unsigned)batch));
+    PLONK_TRY(prof_end(ctx));
+    PLONK_CHECK_HIP(hipGetLastError());
+    return PLONK_OK;
+}
+
+// ---- distributed four-step transform: the two local steps (the all-to-all between them is comm.hip's) ------------------
+// N = R1 R2 over W = 2^log_w ranks.  Rank g holds the columns c = g R2/W .. of the R1 x R2 matrix x[i1 R2 + c] as
+// [R1][R2/W]; ntt_dist_columns leaves (k1, c) * w_N^(c k1) in the same layout, whose block of rows k1 = h R1/W .. is what
+// rank h needs; ntt_dist_rows takes the W received blocks [source rank][R1/W][R2/W] and leaves the frequencies
+// k1 + R1 k2 of its rows as [R2][R1/W] (times 1/N for the inverse).
+int ntt_dist_plan(unsigned log_n, unsigned log_w, unsigned* log_r1, unsigned* log_r2) {
+    unsigned r1 = 0, r2 = 0;
+    PLONK_REQUIRE(ntt_wave_plan(log_n, &r1, &r2) && r2, PLONK_ERR_ARG,
+                  "distributed NTT supports sizes 2^18, 2^20, 2^22, 2^24, 2^26 (got 2^%u)", log_n);
+    PLONK_REQUIRE(log_w + 5 <= r2 && log_w + 5 <= r1, PLONK_ERR_ARG, "2^%u ranks are too many for a 2^%u-point transform", log_w, log_n);
+    *log_r1 = r1;
+    *log_r2 = r2;
+    return PLONK_OK;
+}
+
+static void ntt_wave_consts(NttWave* p, unsigned log_n, bool inverse) {
+    memset(p, 0, sizeof *p);
+    p->log_n = log_n;
+    const Fr w8 = host_root_of_unity(3, inverse);
+    p->w8_1 = w8;
+    p->w8_2 = fp_sqr(w8);
+    p->w8_3 = fp_mul(p->w8_2, w8);
+}
+
+int ntt_dist_columns(plonk_ctx* ctx, const Fr* in, Fr* out, unsigned log_n, unsigned log_w, unsigned rank, bool inverse) {
+    unsigned log_r1, log_r2;
+    PLONK_TRY(ntt_dist_plan(log_n, log_w, &log_r1, &log_r2));
+    const unsigned log_cl = log_r2 - log_w;
+    NttWave a;
+    ntt_wave_consts(&a, log_n, inverse);
+    PLONK_TRY(get_lo_hi(ctx, log_n, inverse, &a.tw_lo, &a.tw_hi));
+    PLONK_TRY(ntt_get_roots(ctx, log_r1, inverse, &a.roots));
+    a.mode = 1;
+    a.log_other = log_cl;
+    a.sub_base = rank << log_cl;
+    a.in = in;
+    a.out = out;
+    a.in_len = 1u << (log_n - log_w);
+    PLONK_TRY(prof_begin(ctx, "ntt_pass", 32.0 * (double)((size_t)1 << (log_n - log_w))));
+    PLONK_TRY(ntt_wave_launch(ctx, a, log_r1, 1u << log_cl, 1));
+    PLONK_TRY(prof_end(ctx));
+    PLONK_CHECK_HIP(hipGetLastError());
+    return PLONK_OK;
+}
+
+int ntt_dist_rows(plonk_ctx* ctx, const Fr* in, Fr* out, unsigned log_n, unsigned log_w, unsigned rank, bool inverse) {
+    (void)rank;
+    unsigned log_r1, log_r2;
+    PLONK_TRY(ntt_dist_plan(log_n, log_w, &log_r1, &log_r2));
+    const unsigned log_cl = log_r2 - log_w, log_kl = log_r1 - log_w;
+    NttWave c;
+    ntt_wave_consts(&c, log_n, inverse);
+    PLONK_TRY(ntt_get_roots(ctx, log_r2, inverse, &c.roots));
+    c.mode = 2;
+    c.log_other = log_kl;  // output stride: frequency k2 of local row kl at out[k2 * R1/W + kl]
+    if (log_w) {           // W chunks [source rank][R1/W][R2/W]; one rank: plain contiguous rows
+        c.chunk_log = log_cl;
+        c.chunk_stride = 1u << (log_kl + log_cl);
+    }
+    c.in = in;
+    c.out = out;
+    c.in_len = 1u << (log_n - log_w);
+    if (inverse) {
+        c.out_scalar = fp_inv(host_fr_from_u64((uint64_t)1 << log_n));
+        c.has_out_scalar = 1;
+    }
+    PLONK_TRY(prof_begin(ctx, "ntt_pass", 32.0 * (double)((size_t)1 << (log_n - log_w))));
+    PLONK_TRY(ntt_wave_launch(ctx, c, log_r2, 1u << log_kl, 1));
     PLONK_TRY(prof_end(ctx));
     PLONK_CHECK_HIP(hipGetLastError());
     return PLONK_OK;

@@ -133,6 +133,9 @@ Fr host_root_of_unity(unsigned log_n, bool inverse);
 int ntt_run(plonk_ctx*, const Fr* in, Fr* out, unsigned log_n, bool inverse, size_t batch, size_t in_len,
             size_t in_bstride, size_t out_bstride, const Fr* in_scale, const Fr* out_scale, bool scale_by_n_inv);
 int ntt_get_roots(plonk_ctx*, unsigned log_n, bool inverse, const Fr** table_full);
+int ntt_dist_plan(unsigned log_n, unsigned log_w, unsigned* log_r1, unsigned* log_r2);
+int ntt_dist_columns(plonk_ctx*, const Fr* in, Fr* out, unsigned log_n, unsigned log_w, unsigned rank, bool inverse);
+int ntt_dist_rows(plonk_ctx*, const Fr* in, Fr* out, unsigned log_n, unsigned log_w, unsigned rank, bool inverse);
 // msm.hip
 int msm_build_table(plonk_ctx*, plonk_srs*, unsigned c);
 int msm_lagrange_srs(plonk_ctx*, plonk_srs*, unsigned log_n, plonk_srs** out);  // owned by (and freed with) the parent

@@ -1,4 +1,5 @@
-"""Proof-level data parallelism over the GPUs of one node.
+"""Multi-GPU support: proof-level data parallelism over the GPUs of one node, and one transform
+split across GPUs (`ntt_distributed`).
 
 Proofs are independent (the reference's `Prover.prove`, /root/reference/prover.py:51-84, keeps no
 cross-proof state), so the path shards by proof index with NO data-path collective: rank r of W proves
@@ -145,6 +146,13 @@ class SocketComm:
     def max(self, value: float) -> float:
         return max(struct.unpack("<d", p)[0] for p in self._star.all_gather(struct.pack("<d", value)))
 
+    def all_to_all(self, blocks):
+        """blocks[r] goes to rank r; returns the W blocks addressed to this rank, by source rank."""
+        n = len(blocks[0])
+        assert len(blocks) == self.world and all(len(b) == n for b in blocks)
+        everything = self._star.all_gather(b"".join(blocks))
+        return [everything[r][n * self.rank : n * (self.rank + 1)] for r in range(self.world)]
+
     def barrier(self):
         self._star.all_gather(b"")
 
@@ -209,6 +217,32 @@ def init_from_env(ctx=None, backend="rccl"):
     if backend == "sockets":
         return SocketComm(rank, world)
     raise ValueError("unknown distributed backend %r (rccl | sockets)" % (backend,))
+
+
+def ntt_distributed(comm, ctx, d_in, d_out, log_n, inverse=False):
+    """One transform of 2^log_n points across the ranks of `comm` (four-step; include/plonk_hip.h describes the column /
+    frequency-strided layouts).  `d_in`, `d_out`: DeviceBuffers of N / W elements.  RcclComm: one C call
+    (plonk_fr_ntt_distributed: column pass, grouped ncclSend/ncclRecv, row pass, all on the device).  Other transports
+    (SocketComm; tests): the same two local passes with the exchange staged through the host."""
+    from ._lib import check
+
+    world, rank = (1, 0) if comm is None else (comm.world, comm.rank)
+    log_w = world.bit_length() - 1
+    assert 1 << log_w == world, "a power-of-two number of ranks is needed"
+    if isinstance(comm, RcclComm):
+        check(ctx.L.plonk_fr_ntt_distributed(comm._h, d_in.ptr, d_out.ptr, log_n, int(inverse)))
+        return
+    local = (1 << log_n) >> log_w
+    cols = ctx.alloc(local)
+    check(ctx.L.plonk_fr_ntt_dist_columns(ctx.handle, d_in.ptr, cols.ptr, log_n, log_w, rank, int(inverse)))
+    if world > 1:
+        raw = ctypes.create_string_buffer(32 * local)
+        check(ctx.L.plonk_mem_d2h(ctx.handle, raw, cols.ptr, 32 * local))
+        per = 32 * local // world
+        got = comm.all_to_all([raw.raw[per * r : per * (r + 1)] for r in range(world)])
+        check(ctx.L.plonk_mem_h2d(ctx.handle, cols.ptr, b"".join(got), 32 * local))
+    check(ctx.L.plonk_fr_ntt_dist_rows(ctx.handle, cols.ptr, d_out.ptr, log_n, log_w, rank, int(inverse)))
+    ctx.sync()
 
 
 def gather_proofs(local_blob: bytes, total: int, comm=None):

@@ -20,4 +20,9 @@ int plonk_comm_size(const plonk_comm* c, int* r, int* w) { *r = c->rank; *w = c-
 int plonk_gather_results(plonk_comm*, const uint8_t* s, size_t n, uint8_t* r) { memcpy(r, s, n); return PLONK_OK; }
 int plonk_comm_max_f64(plonk_comm*, double*) { return PLONK_OK; }
 int plonk_comm_barrier(plonk_comm*) { return PLONK_OK; }
+int plonk_comm_all_to_all(plonk_comm*, const void* s, void* r, size_t n) { memcpy(r, s, n); return PLONK_OK; }
+int plonk_fr_ntt_distributed(plonk_comm*, const void*, void*, unsigned, int) {
+    plonk_set_error("the emulation build has no RCCL: run plonk_fr_ntt_dist_columns / _rows around another transport");
+    return PLONK_ERR_STATE;
+}
 }

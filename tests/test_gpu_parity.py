@@ -407,3 +407,23 @@ def test_lagrange_srs_paths(setup):
 @pytest.mark.gpu
 def test_product_verifier(setup):
     pc.verifier_cases(setup, full_size=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("log_n", [18, 22])
+def test_distributed_ntt_single_rank_rccl(log_n):
+    """plonk_fr_ntt_distributed through a real (one-rank) RCCL communicator: column pass, all-to-all, row pass; the output
+    layout [R2][R1] holds frequency k1 + R1 k2 at [k2][k1] — for one rank that is the natural order.  Forward and inverse."""
+    from oracle import c_oracle
+    from plonkathon_amd import get_context
+    from plonkathon_amd import distributed as D
+
+    ctx = get_context()
+    comm = D.RcclComm(ctx, 0, 1)
+    v = pc.rand_vec(900 + log_n, 1 << log_n)
+    d_in, d_out = ctx.upload_ints(v), ctx.alloc(len(v))
+    D.ntt_distributed(comm, ctx, d_in, d_out, log_n)
+    assert ctx.download_ints(d_out) == c_oracle.fr_ntt(v)
+    D.ntt_distributed(comm, ctx, d_in, d_out, log_n, inverse=True)
+    assert ctx.download_ints(d_out) == c_oracle.fr_ntt(v, True)
+    comm.close()
