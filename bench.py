@@ -270,7 +270,7 @@ def main():
         blobs = [pr.download_raw() for pr in provers]   # sync + 768 B per proof back to the host
         local = b"".join(b[0] for b in blobs)
         status = b"".join(b[1] for b in blobs)
-        gathered = D.gather_proofs(local, total, comm) if comm is not None else None  # the path's one collective
+        gathered = D.gather_proofs_lazy(local, total, comm) if comm is not None else None  # the path's one collective
         return local, status, gathered
 
     def barrier():
@@ -298,9 +298,9 @@ def main():
         return sum(p[0] for p in parts), sum(p[1] for p in parts), sum(p[2] for p in parts)
 
     assert not any(proofs[1]), "a proof in the batch reported a failure status"
-    gathered = proofs[2] if comm is not None else D.gather_proofs(proofs[0], total, None)
+    gathered = proofs[2] if comm is not None else D.gather_proofs_lazy(proofs[0], total, None)
     n_results = len(gathered)
-    assert n_results == total and all(g is not None for g in gathered)
+    assert n_results == total and gathered.complete() and len(gathered[total - 1]) == 768
 
     # the dominant kernel: the lookup MSM when the table fits in HBM (default), else the bucket method's accumulate
     info = setup.device_bases(ctx).lookup_info()

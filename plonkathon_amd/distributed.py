@@ -264,5 +264,36 @@ def gather_proofs(local_blob: bytes, total: int, comm=None):
     return out
 
 
+class GatheredProofs:
+    """The result of one all-gather without any per-proof work: W per-rank blobs, proofs looked up on demand.
+    `g[i]` = the 768 bytes of global proof i; `len(g)` = number of proofs."""
+
+    def __init__(self, parts, total, world):
+        self.parts, self.total, self.world = parts, total, world
+
+    def __len__(self):
+        return self.total
+
+    def __getitem__(self, idx):
+        if not 0 <= idx < self.total:
+            raise IndexError(idx)
+        r, j = idx % self.world, idx // self.world  # shard_indices is round-robin
+        return self.parts[r][PROOF_BYTES * j : PROOF_BYTES * (j + 1)]
+
+    def complete(self):
+        """every rank delivered its whole shard"""
+        return all(len(self.parts[r]) >= PROOF_BYTES * len(range(r, self.total, self.world)) for r in range(self.world))
+
+
+def gather_proofs_lazy(local_blob: bytes, total: int, comm=None) -> GatheredProofs:
+    """`gather_proofs` for the hot loop: one all-gather, O(1) host work (no per-proof slicing: at 8 GPUs x 10 240 proofs
+    per step the eager form spends tens of milliseconds per step in Python)."""
+    if comm is None:
+        return GatheredProofs([bytes(local_blob)], total, 1)
+    per = (total + comm.world - 1) // comm.world
+    parts = comm.all_gather(bytes(local_blob) + bytes(PROOF_BYTES * per - len(local_blob)))
+    return GatheredProofs(parts, total, comm.world)
+
+
 def max_over_ranks(value: float, comm=None) -> float:
     return value if comm is None else comm.max(value)

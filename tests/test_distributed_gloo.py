@@ -181,3 +181,25 @@ def test_shard_indices_cover_everything():
         for world in (1, 2, 4, 8):
             seen = sorted(i for r in range(world) for i in shard_indices(total, r, world))
             assert seen == list(range(total))
+
+
+def test_lazy_gather_matches_the_eager_one():
+    """GatheredProofs (O(1) per step, used inside bench.py's timed loop) indexes exactly like gather_proofs."""
+    from plonkathon_amd import distributed as D
+
+    for total, world in ((5, 2), (512, 8), (7, 1), (10, 4)):
+        blobs = [b"".join(bytes([i % 251]) * 768 for i in D.shard_indices(total, r, world)) for r in range(world)]
+
+        class Replay:
+            def __init__(self, rank):
+                self.rank, self.world = rank, world
+
+            def all_gather(self, payload):
+                per = (total + world - 1) // world
+                return [b + bytes(768 * per - len(b)) for b in blobs]
+
+        for r in range(world):
+            eager = D.gather_proofs(blobs[r], total, Replay(r) if world > 1 else None) if world > 1 else D.gather_proofs(blobs[0], total, None)
+            lazy = D.gather_proofs_lazy(blobs[r], total, Replay(r) if world > 1 else None)
+            assert len(lazy) == total and lazy.complete()
+            assert [lazy[i] for i in range(total)] == eager

@@ -5,7 +5,7 @@ export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 ( timeout 1200 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> gpurun_out/pytest_gpu.log )
 tail -4 gpurun_out/pytest_gpu.log
-for lib in libplonk_hip_oldmsm.so libplonk_hip.so libplonk_hip_oldmsm.so libplonk_hip.so; do
+for lib in libplonk_hip.so; do
 PLONK_HIP_LIB=$PWD/plonkathon_amd/$lib timeout 600 python bench.py --steps 4 --warmup 1 --batches-per-step 8 --no-cpu-baseline --no-microbench --no-fallbacks 2>>gpurun_out/benchg.err | python -c "
 import sys,json
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$lib', d['value'], d['ms_per_step'], d['host']['host_upload_ms_per_proof'])"
