@@ -723,18 +723,27 @@ static bool msm_lookup_prepare(plonk_ctx* ctx, plonk_srs* srs) {
     }
     if (!srs->fixed) return false;
     if (srs->shared && (!want || want == srs->lookup_bits)) return true;
-    if (MsmLookupTable* t = lut_find(srs, want)) {
-        lut_attach(srs, t);
-        return true;
+    if (want) {
+        if (MsmLookupTable* t = lut_find(srs, want)) {
+            lut_attach(srs, t);
+            return true;
+        }
     }
     if (srs->lookup_failed) return false;
     const size_t budget = ctx->msm_lookup_budget ? ctx->msm_lookup_budget : msm_default_lookup_budget();
-    // more windows bits = fewer additions; below 8 bits the table no longer beats the bucket method — which,
-    // however, cannot index more than 2^15 bases, so larger base sets accept any table that fits
+    // A table another context of this device already built for these bases is taken as it is — unless this context's
+    // budget affords a bigger one (more window bits = fewer additions), which is then built and shared in its turn.
+    MsmLookupTable* have = want ? nullptr : lut_find(srs, 0);
+    // below 8 bits the table no longer beats the bucket method — which, however, cannot index more than 2^15 bases, so
+    // larger base sets accept any table that fits
     const unsigned c_min = want ? want : (srs->n_points > 32768 ? 4 : 8);
-    for (unsigned c = want ? want : 17; c >= c_min; c--) {
+    for (unsigned c = want ? want : 17; c >= c_min && (!have || c > have->bits); c--) {
         if (msm_lookup_bytes(srs->n_points, c) > budget) continue;
         if (msm_lookup_build(ctx, srs, c) == PLONK_OK) return true;
+    }
+    if (have) {
+        lut_attach(srs, have);
+        return true;
     }
     srs->lookup_failed = true;
     return false;

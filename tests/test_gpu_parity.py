@@ -127,7 +127,7 @@ def test_msm_window_configs(setup):
 
 
 def test_msm_lookup_tables():
-    """Lookup MSM at several table sizes (forced), then the automatic choice (c = 16 on an idle MI355X)."""
+    """Lookup MSM at several table sizes (forced), then the automatic choice (the library's 4 GiB default budget: c = 11)."""
     from plonkathon_amd import Setup, get_context
 
     ctx = get_context()
@@ -303,7 +303,9 @@ def test_gpu_proofs_verify_under_the_pairing_check(setup):
     from oracle.poseidon import poseidon_program_lines
 
     pc.proofs_verify(setup, pc.chain_lines(2048), 2048, {"x0": 5}, ["x0"])
+    pc.proofs_verify(setup, pc.chain_lines(2048), 2048, {"x0": 0xDEADBEEF12345}, ["x0"])  # a second witness per circuit
     pc.proofs_verify(setup, poseidon_program_lines(), 2048, {"L0": 1, "M0": 2}, ["L0", "M0", "M64"])
+    pc.proofs_verify(setup, poseidon_program_lines(), 2048, {"L0": 77, "M0": 123456789}, ["L0", "M0", "M64"])
 
 
 @pytest.mark.gpu
@@ -427,3 +429,43 @@ def test_distributed_ntt_single_rank_rccl(log_n):
     D.ntt_distributed(comm, ctx, d_in, d_out, log_n, inverse=True)
     assert ctx.download_ints(d_out) == c_oracle.fr_ntt(v, True)
     comm.close()
+
+
+@pytest.mark.gpu
+def test_full_size_lookup_table_on_an_explicit_budget():
+    """The c = 17 table (128.8 GB: what bench.py opts into with a 150 GB budget) — the default budget never builds it.
+    MSMs against the oracle, both methods byte-identical on 64 full-size commitments, the 2^11 chain proofs against the
+    fixtures, and the table really is the one attached (bits, bytes, shared by a second context)."""
+    import json
+
+    import bench
+    from plonkathon_amd import BatchProver, Context, Program, Setup
+
+    a, b = Context(0), Context(0)
+    a.msm_lookup(0, 0, int(150e9))
+    b.msm_lookup(0, 0, int(150e9))
+    sa = Setup.from_file(pc.PTAU)
+    bench.GROUP_ORDER = 2048
+    program = Program(pc.chain_lines(2048), 2048)
+    proofs = BatchProver(sa, program, a).prove_batch([bench.witness_for(0), bench.witness_for(1)])
+    info = sa.device_bases(a).lookup_info()
+    assert info["bits"] == 17 and info["bytes"] == 2048 * 15 * 65536 * 64, info
+    fx = {c["name"]: c for c in json.load(open(os.path.join(pc.GOLDEN, "oracle_proofs.json")))["cases"]}
+    for i, name in ((0, "chain_2048_x0_3"), (1, "chain_2048_x0_4")):
+        got = pc.flat(proofs[i])
+        for k, v in fx[name]["proof"].items():
+            assert got[k] == (pc.pt(v) if isinstance(v, list) else int(v)), (name, k)
+    # a second context on the same device attaches to the same table; the bucket method agrees byte for byte
+    pb = BatchProver(sa, program, b)
+    wits = [bench.witness_for(10 + i) for i in range(8)]
+    pb.upload(wits)
+    pb.run()
+    blob_lookup = pb.download_raw()[0]
+    assert sa.device_bases(b).lookup_info()["bits"] == 17 and sa.device_bases(b).lookup_info()["sharers"] == 2
+    c = Context(0)
+    c.msm_lookup(1)
+    pcx = BatchProver(sa, program, c)
+    pcx.upload(wits)
+    pcx.run()
+    assert pcx.download_raw()[0] == blob_lookup
+    del pb, pcx, proofs
