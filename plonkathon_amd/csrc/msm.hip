@@ -6,9 +6,10 @@
 // with one Fq inversion per addition (~109k additions for N = 2^11); the result is a group element,
 // so any correct schedule yields the same affine point.  Two schedules:
 //
-// A. LOOKUP MSM — the default for a reusable SRS (plonk_srs_load_ptau).  Every multiple
-//    L[w][i][d] = d * 2^(c w) * P_i a signed c-bit digit can select is precomputed into HBM (128.8 GB
-//    at c = 17 for 2^11 points); an MSM is N * ceil(255 / c) mixed additions of looked-up points:
+// A. LOOKUP MSM — for a reusable SRS (plonk_srs_load_ptau), within the HBM budget the caller grants (4 GiB by
+//    default: c = 11; bench.py opts into 150 GB: c = 17).  Every multiple L[w][i][d] = d * 2^(c w) * P_i a signed
+//    c-bit digit can select is precomputed into HBM (128.8 GB at c = 17 for 2^11 points), ONE table per (device,
+//    base set, c) shared by every context; an MSM is N * ceil(255 / c) mixed additions of looked-up points:
 //      msm_lookup_kernel           lanes walk flat ranges of (scalar, window) items, 64 random bytes per item
 //      msm_lookup_finalize_kernel  sum of the workgroup partials + deferred additions -> canonical affine
 //    See the section "Lookup MSM" below.
@@ -28,13 +29,16 @@
 //                             its lanes cross at different steps.  >= 80 % of this method's time.
 //   3. msm_bucket_reduce_kernel (two waves per MSM) lane l owns K/128 consecutive buckets: walking them top-down,
 //                             run += pieces of bucket k, tot += run; its share is tot + (first bucket - 1) * run;
-//                             shares are tree-reduced through LDS ("wave-reduced bucket sum") and lane 0
-//                             converts the result to the unique affine representative, canonical x||y.
+//                             shares are summed across waves through LDS and then inside wave 0 by a cross-lane
+//                             butterfly (wave.h: DPP / ds_swizzle / v_permlane32_swap — the "wave-reduced bucket
+//                             sum"); lane 0 converts the result to the unique affine representative, canonical x||y.
 //                             Buckets never exist in memory.
 //    Window-table reads hit L2 / Infinity Cache (3.4 MiB at c = 10).
 //
 // Both inner loops keep the accumulator as 9 x 29-bit limbs with lazy reductions (fpl.h, g1l_madd_fast) and run
 // at the rate of a bare mixed-addition loop (13.4 G additions/s chip-wide): the kernels are integer-ALU bound.
+// Steps the fast formulas cannot take are deferred to a 256-slot list per MSM; an MSM that overflows it is redone by
+// msm_slow_kernel.  msm_lagrange_srs builds the Lagrange-basis view of an SRS out of the same kernels.
 #include <stdlib.h>
 #include <string.h>
 

@@ -512,15 +512,26 @@ template <unsigned RB, unsigned MASK> PLONK_DEV void wave_swap_bit(Fr (&x)[8], u
 }
 
 // x[BASE + f] *= roots[(low * f * mult) mod N], f = 1 .. COUNT-1   (compile-time register indices: x stays in VGPRs)
+// The wave kernel keeps its elements as redundant residues in [0, 2m) (fp.h: fp_add2 / fp_sub2 / fp_mul2 — a
+// multiplication without the final conditional subtraction) and canonicalises once, at the last store.
 template <unsigned LOG_N, unsigned BASE, unsigned COUNT> PLONK_DEV void wave_twiddle(Fr (&x)[8], unsigned low, unsigned mult, const Fr* roots) {
     wave_for<COUNT - 1>([&](auto F) {
         constexpr unsigned f = decltype(F)::value + 1;
-        x[BASE + f] = fp_mul(x[BASE + f], fp_load(roots + ((low * f * mult) & ((1u << LOG_N) - 1))));
+        x[BASE + f] = fp_mul2(x[BASE + f], fp_load(roots + ((low * f * mult) & ((1u << LOG_N) - 1))));
     });
 }
 PLONK_DEV void dft4r(Fr& x0, Fr& x1, Fr& x2, Fr& x3, const Fr& w2) {
-    Fr a0 = fp_add(x0, x2), a1 = fp_add(x1, x3), d0 = fp_sub(x0, x2), d1 = fp_mul(fp_sub(x1, x3), w2);
-    x0 = fp_add(a0, a1); x2 = fp_sub(a0, a1); x1 = fp_add(d0, d1); x3 = fp_sub(d0, d1);
+    Fr a0 = fp_add2(x0, x2), a1 = fp_add2(x1, x3), d0 = fp_sub2(x0, x2), d1 = fp_mul2(fp_sub2(x1, x3), w2);
+    x0 = fp_add2(a0, a1); x2 = fp_sub2(a0, a1); x1 = fp_add2(d0, d1); x3 = fp_sub2(d0, d1);
+}
+PLONK_DEV void dft8r(Fr (&x)[8], const Fr& w1, const Fr& w2, const Fr& w3) {
+    Fr a0 = fp_add2(x[0], x[4]), a1 = fp_add2(x[1], x[5]), a2 = fp_add2(x[2], x[6]), a3 = fp_add2(x[3], x[7]);
+    Fr b0 = fp_sub2(x[0], x[4]), b1 = fp_mul2(fp_sub2(x[1], x[5]), w1), b2 = fp_mul2(fp_sub2(x[2], x[6]), w2),
+       b3 = fp_mul2(fp_sub2(x[3], x[7]), w3);
+    Fr c0 = fp_add2(a0, a2), c1 = fp_add2(a1, a3), d0 = fp_sub2(a0, a2), d1 = fp_mul2(fp_sub2(a1, a3), w2);
+    Fr e0 = fp_add2(b0, b2), e1 = fp_add2(b1, b3), f0 = fp_sub2(b0, b2), f1 = fp_mul2(fp_sub2(b1, b3), w2);
+    x[0] = fp_add2(c0, c1); x[4] = fp_sub2(c0, c1); x[2] = fp_add2(d0, d1); x[6] = fp_sub2(d0, d1);
+    x[1] = fp_add2(e0, e1); x[5] = fp_sub2(e0, e1); x[3] = fp_add2(f0, f1); x[7] = fp_sub2(f0, f1);
 }
 
 // register budget: 1024-thread workgroups (L = 2) must fit 128 VGPRs (a few dwords spill); the smaller ones run faster
@@ -556,11 +567,11 @@ __global__ void __launch_bounds__(64u << (2 * NLDS), NLDS == 2 ? 4 : 3) ntt_wave
         wave_for8([&](auto J) {
             constexpr unsigned j = decltype(J)::value;
             const unsigned g = ((j * NT + tid) << in_shift) + in_off;
-            if (g < p.in_len) x[j] = fp_mul(x[j], fp_load(p.in_scale + g));
+            if (g < p.in_len) x[j] = fp_mul2(x[j], fp_load(p.in_scale + g));
         });
     }
     // stage A: digit = index bits LOG_N-1 .. LOG_N-3, low = tid
-    dft8(x, p.w8_1, p.w8_2, p.w8_3);
+    dft8r(x, p.w8_1, p.w8_2, p.w8_3);
     wave_twiddle<LOG_N, 0, 8>(x, tid, 1, p.roots);
     // L radix-4 stages on the wave bits: swap register bits (1, 0) with thread bits (tb + 1, tb)
     wave_for<NLDS>([&](auto S) {
@@ -585,13 +596,13 @@ __global__ void __launch_bounds__(64u << (2 * NLDS), NLDS == 2 ? 4 : 3) ntt_wave
     wave_swap_bit<2, 32>(x, lane);
     wave_swap_bit<1, 16>(x, lane);
     wave_swap_bit<0, 8>(x, lane);
-    dft8(x, p.w8_1, p.w8_2, p.w8_3);
+    dft8r(x, p.w8_1, p.w8_2, p.w8_3);
     wave_twiddle<LOG_N, 0, 8>(x, lane & 7u, 1u << (LOG_N - 6), p.roots);
     // stage on lane bits 2..0
     wave_swap_bit<2, 4>(x, lane);
     wave_swap_bit<1, 2>(x, lane);
     wave_swap_bit<0, 1>(x, lane);
-    dft8(x, p.w8_1, p.w8_2, p.w8_3);
+    dft8r(x, p.w8_1, p.w8_2, p.w8_3);
     // frequency of register j: digits in processing order, first digit least significant
     //   d_A = (lane bit 5) * 4 + thread bits (top pair);  then the remaining wave pairs;  (lane bits 4, 3);  (lane bits 2..0);  j
     //   (without wave stages the first digit is simply lane bits 5..3)
@@ -615,23 +626,24 @@ __global__ void __launch_bounds__(64u << (2 * NLDS), NLDS == 2 ? 4 : 3) ntt_wave
             const unsigned e = (sub + p.sub_base) * (k | (j << shift));  // < N
             if (e) {
                 Fr tw = fp_load(p.tw_lo + (e & ((1u << NTT_TW_LO_LOG) - 1)));
-                if (p.log_n > NTT_TW_LO_LOG) tw = fp_mul(tw, fp_load(p.tw_hi + (e >> NTT_TW_LO_LOG)));
-                x[j] = fp_mul(x[j], tw);
+                if (p.log_n > NTT_TW_LO_LOG) tw = fp_mul2(tw, fp_load(p.tw_hi + (e >> NTT_TW_LO_LOG)));
+                x[j] = fp_mul2(x[j], tw);
             }
         });
     }
     if (p.out_scale) {
         wave_for8([&](auto J) {
             constexpr unsigned j = decltype(J)::value;
-            x[j] = fp_mul(x[j], fp_load(p.out_scale + (((k | (j << shift)) << out_shift) + out_off)));
+            x[j] = fp_mul2(x[j], fp_load(p.out_scale + (((k | (j << shift)) << out_shift) + out_off)));
         });
     }
     if (p.has_out_scalar) {
         const Fr sc = p.out_scalar;
-        wave_for8([&](auto J) { x[decltype(J)::value] = fp_mul(x[decltype(J)::value], sc); });
+        wave_for8([&](auto J) { x[decltype(J)::value] = fp_mul2(x[decltype(J)::value], sc); });
     }
     wave_for8([&](auto J) {
         constexpr unsigned j = decltype(J)::value;
+        if (p.mode != 1) fp_reduce_once<FrParams>(x[j].v);  // canonical results; the column pass hands redundant values on
         fp_store(out + (((k | (j << shift)) << out_shift) + out_off), x[j]);
     });
 }

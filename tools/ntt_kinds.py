@@ -14,9 +14,9 @@ def fill(n):
     for off in range(0, n, per):
         check(L.plonk_mem_d2d(H, buf.at(off), src.ptr, 32 * min(per, n - off)))
     return buf
-shapes = [(12, 1), (14, 1), (16, 1), (16, 8), (17, 1), (18, 1), (19, 1), (20, 1), (21, 1), (22, 1)]
+shapes = [(9, 4096), (11, 512), (11, 2048), (13, 512), (13, 2048), (18, 16), (20, 8), (22, 1)]
 out = {}
-for kind in (0, 1):
+for kind in (3,):
     check(L.plonk_ntt_select_kernel(H, kind))
     for log_n, batch in shapes:
         n = 1 << log_n
