@@ -35,3 +35,19 @@ def test_world_size_must_match_gpus(emu_cdll):
     r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "4", "--log-n", "4"], env=env,
                        capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and "WORLD_SIZE" in r.stderr
+
+
+def test_launched_by_torch_distributed_run(emu_cdll):
+    """The driver's form: `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` — RANK / WORLD_SIZE / MASTER_*
+    come from the launcher (whose own store owns MASTER_PORT: the rendezvous uses MASTER_PORT + 1), no torch in bench.py itself."""
+    env = dict(os.environ, PLONK_HIP_LIB=EMU_LIB, PLONK_MSM_TABLE_GB="0.0001")
+    env.pop("WORLD_SIZE", None)
+    port = 29700 + os.getpid() % 200
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(REPO, "bench.py"), "--gpus", "2", "--dist-backend", "sockets", "--log-n", "4",
+           "--batch", "3", "--batches-per-step", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-microbench",
+           "--no-fallbacks", "--no-lookup"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["ranks_in_communicator"] == 2 and line["config"]["gather_in_timed_region"]
