@@ -469,3 +469,31 @@ def test_full_size_lookup_table_on_an_explicit_budget():
     pcx.run()
     assert pcx.download_raw()[0] == blob_lookup
     del pb, pcx, proofs
+
+
+@pytest.mark.gpu
+def test_wave_kernel_two_pass_splits_and_batches():
+    """The wave kernel forced (kind 3) on the splits the dispatcher does not pick by itself: 2^24 = 2^13 x 2^11 (properties),
+    and a batch of three 2^18 transforms in one call, exact against the C oracle."""
+    import ctypes
+
+    from oracle import c_oracle
+    from plonkathon_amd import get_context
+    from plonkathon_amd._lib import check
+
+    ctx = get_context()
+    try:
+        check(ctx.L.plonk_ntt_select_kernel(ctx.handle, 3))
+        pc.ntt_roundtrip_and_linearity(24, seed=31)
+        n = 1 << 18
+        vecs = [pc.rand_vec(70 + i, n) for i in range(3)]
+        buf = ctx.upload_ints([x for v in vecs for x in v])
+        out = ctx.alloc(3 * n)
+        check(ctx.L.plonk_fr_ntt(ctx.handle, buf.ptr, out.ptr, 18, 0, 3))
+        got = ctx.download_ints(out)
+        for i, v in enumerate(vecs):
+            assert got[i * n : (i + 1) * n] == c_oracle.fr_ntt(v), i
+        check(ctx.L.plonk_fr_ntt(ctx.handle, out.ptr, out.ptr, 18, 1, 3))  # in place, inverse
+        assert ctx.download_ints(out) == [x for v in vecs for x in v]
+    finally:
+        check(ctx.L.plonk_ntt_select_kernel(ctx.handle, 0))
