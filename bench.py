@@ -443,16 +443,19 @@ def main():
         # standalone NTT and MSM rates; with N GPUs every rank runs a replica and the whole-job
         # rate is N x (work of one replica) / (time of the slowest rank)
         ms11 = D.max_over_ranks(ntt_microbench(ctx, 11, 512), comm)
+        ms11b = D.max_over_ranks(ntt_microbench(ctx, 11, 2048), comm)
         ms13 = D.max_over_ranks(ntt_microbench(ctx, 13, 512), comm)
         ms16 = D.max_over_ranks(ntt_microbench(ctx, 16, 1), comm)
         ms20 = D.max_over_ranks(ntt_microbench(ctx, 20, 1), comm)
         ms_msm = D.max_over_ranks(msm_microbench(ctx, setup.device_bases(ctx), 4608), comm)
         line["ntt"] = {
             "gf_elems_per_s_2^11_x512": world * 512 * 2048 / (ms11 * 1e-3),
+            "gf_elems_per_s_2^11_x2048": world * 2048 * 2048 / (ms11b * 1e-3),
             "gf_elems_per_s_2^13_x512": world * 512 * 8192 / (ms13 * 1e-3),
             "gf_elems_per_s_2^16": world * (1 << 16) / (ms16 * 1e-3),
             "gf_elems_per_s_2^20": world * (1 << 20) / (ms20 * 1e-3),
             "ms_2^11_x512": ms11,
+            "ms_2^11_x2048": ms11b,
             "ms_2^13_x512": ms13,
             "ms_2^16": ms16,
             "ms_2^20": ms20,
