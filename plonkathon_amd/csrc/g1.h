@@ -139,8 +139,9 @@ PLONK_HD G1Affine g1_to_affine(const G1Xyzz& p) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Lazy-limb accumulator for the MSM inner loop (fpl.h): same madd-2008-s formulas, no canonical
-// reductions.  Invariants between calls (all limbs normalised): x < 8m, y < 4m, zz < 2m, zzz < 2m.
+// Lazy-limb accumulator for the MSM inner loop (fpl.h): same madd-2008-s formulas on signed limbs, no canonical
+// reductions, one carry sweep per addition.  Invariants between calls (all four normalised): x in (-7m, 5m),
+// y, zz, zzz in (-m, 2m).
 #include "fpl.h"
 
 typedef FpL<FqParams> FqL;
@@ -181,6 +182,11 @@ PLONK_HD G1XyzzL g1l_from_xyzz(const G1Xyzz& p) {
 // exceptional — identity base (0, 0), or P == +-Q (detected by a cheap filter with a 2^-25 false-positive
 // rate) — and the caller resolves it with the general packed formulas (msm.hip defers it to the bucket
 // reduction).  No calls, no packed arithmetic: minimal live registers.
+//
+// Bounds (|value| / m, see fpl.h): U2, S2, PP, Q, PPP, R^2, ZZ3, ZZZ3, Y3 are products, in (-1, 2); P = U2 - X1 in
+// (-6, 9); R = S2 - Y1 in (-3, 3); X3 = R^2 - PPP - 2Q in (-7, 5); D = Q - X3 in (-6, 9).  Products: P^2 <= 81,
+// X1 PP <= 14, P PP <= 18, R^2 <= 9, R D + Y1 PPP <= 27 + 4 — all below the 128 of fpl_mul.  Limbs: every
+// multiplicand is a normalised value or the difference of two, within (-2^29, 2^29).
 PLONK_HD bool g1l_madd_fast(G1XyzzL& p, const Fq& x2p, const Fq& y2p) {
     if (fp_is_zero(x2p) && fp_is_zero(y2p)) return false;
     const FqL x2 = fpl_from_fp(x2p), y2 = fpl_from_fp(y2p);
@@ -192,53 +198,48 @@ PLONK_HD bool g1l_madd_fast(G1XyzzL& p, const Fq& x2p, const Fq& y2p) {
         p.inf = false;
         return true;
     }
-    const FqL u2 = fpl_mul(x2, p.zz);                                  // < 2m
-    const FqL pp_ = fpl_norm(fpl_sub<FqParams, 8>(u2, p.x));           // U2 - X1 + 8m   in (0, 10m)
-    {   // cheap filter for P == 0 (mod m): limb 0 must match limb 0 of some j*m, j < 16
-        bool maybe = false;
-#pragma unroll
-        for (unsigned j = 0; j < 16; j++)
-            maybe |= pp_.l[0] == (uint32_t)(((uint64_t)j * fp29_mod_limb<FqParams>(0)) & FP29_MASK);
-        if (maybe) return false;  // (2^-25 false-positive rate: the general path copes)
-    }
-    const FqL s2 = fpl_mul(y2, p.zzz);                                 // < 2m
-    const FqL rr = fpl_norm(fpl_sub<FqParams, 4>(s2, p.y));            // S2 - Y1 + 4m   in (0, 6m)
-    const FqL pp = fpl_sqr(pp_);                                       // < 2m
-    const FqL q = fpl_mul(p.x, pp);                                    // < 2m   (X1 dead after this)
+    const FqL u2 = fpl_mul(x2, p.zz);
+    const FqL pp_ = fpl_sub(u2, p.x);                                  // P = U2 - X1
+    if (fpl_maybe_zero_mod<FqParams, -5, 8>(pp_)) return false;        // (2^-25 false-positive rate: the general path copes)
+    const FqL s2 = fpl_mul(y2, p.zzz);
+    const FqL rr = fpl_sub(s2, p.y);                                   // R = S2 - Y1
+    const FqL pp = fpl_sqr(pp_);
+    const FqL q = fpl_mul(p.x, pp);                                    // (X1 dead after this)
     p.zz = fpl_mul(p.zz, pp);
-    const FqL ppp = fpl_mul(pp_, pp);                                  // < 2m   (P, PP dead after this)
+    const FqL ppp = fpl_mul(pp_, pp);                                  // (P, PP dead after this)
     p.zzz = fpl_mul(p.zzz, ppp);
-    const FqL r2 = fpl_sqr(rr);                                        // < 2m
-    // X3 = R^2 - PPP - 2Q  ->  R^2 + (2m - PPP) + (4m - 2Q)  in (0, 8m)
-    p.x = fpl_norm(fpl_sub<FqParams, 4>(fpl_sub<FqParams, 2>(r2, ppp), fpl_add(q, q)));
-    const FqL d = fpl_norm(fpl_sub<FqParams, 8>(q, p.x));              // Q - X3 + 8m    in (0, 10m)
-    FqL zero;
-#pragma unroll
-    for (int i = 0; i < 9; i++) zero.l[i] = 0;
-    const FqL ny1 = fpl_norm(fpl_sub<FqParams, 4>(zero, p.y));         // 4m - Y1        in (0, 4m]
-    // Y3 = R (Q - X3) - Y1 PPP as one sum of products with a single reduction: 6*10 + 4*2 <= 128
-    p.y = fpl_mul_add(rr, d, ny1, ppp);                                // < 2m
+    const FqL r2 = fpl_sqr(rr);
+    p.x = fpl_norm(fpl_sub(fpl_sub(r2, ppp), fpl_add(q, q)));          // X3 = R^2 - PPP - 2Q: the one carry sweep
+    const FqL d = fpl_sub(q, p.x);                                     // Q - X3
+    // Y3 = R (Q - X3) - Y1 PPP as one sum of products with a single reduction
+    p.y = fpl_mul_add(rr, d, fpl_neg(p.y), ppp);
     return true;
 }
 
-// Piece form of a lazy accumulator for msm_accumulate_kernel: four 256-bit words, x and y < 4m, zz and zzz
-// < 2m (not canonical; g1_piece_load canonicalises), identity = all zero.  Costs ~100 instructions, no
-// multiplication, so flushing at a bucket boundary stays cheap.
-PLONK_HD void fpl_pack_lt4m(const FqL& a, bool sub4m, uint32_t out[8]) {
-    uint32_t w[9];
-    fp29_pack(a.l, w);                      // limbs 0..8 -> words 0..7 (bits < 256) ...
-    w[8] = a.l[8] >> 24;                    // ... bit 256 and up (limb 8 starts at bit 232)
-    if (sub4m) {                            // value < 8m: subtract 4m when that does not go negative
-        uint32_t t[9], borrow = 0;
+// Piece form of a lazy accumulator for msm_accumulate_kernel: four 256-bit words in [0, 4m) (not canonical;
+// g1_piece_load canonicalises), identity = all zero.  Costs ~150 instructions, no multiplication, so flushing at a
+// bucket boundary stays cheap.
+//   K = the multiple of m added first to make the value positive; value + K m must stay below 13 m < 2^258.
+template <unsigned K> PLONK_HD void fpl_pack_lt4m(const FqL& a, uint32_t out[8]) {
+    const FqL t = fpl_add_km_norm<FqParams, K>(a);
+    uint32_t u[9], w[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) u[i] = (uint32_t)t.l[i];
+    fp29_pack(u, w);                        // limbs 0..8 -> words 0..7 (bits < 256) ...
+    w[8] = u[8] >> 24;                      // ... bit 256 and up (limb 8 starts at bit 232)
+#pragma unroll
+    for (int sh = 3; sh >= 2; sh--) {       // subtract 8m, then 4m, when that does not go negative
+        if ((K + 2) <= (1u << sh)) continue;   // value < (K + 2) m: nothing to take off
+        uint32_t s[9], borrow = 0;
 #pragma unroll
         for (int i = 0; i < 9; i++) {
-            // 4m as 9 words
-            const uint32_t mi = i < 8 ? ((FqParams::mod(i) << 2) | (i ? FqParams::mod(i - 1) >> 30 : 0)) : (FqParams::mod(7) >> 30);
-            t[i] = fp_sbb(w[i], mi, borrow);
+            const uint32_t mi = i < 8 ? ((FqParams::mod(i) << sh) | (i ? FqParams::mod(i - 1) >> (32 - sh) : 0))
+                                      : (FqParams::mod(7) >> (32 - sh));
+            s[i] = fp_sbb(w[i], mi, borrow);
         }
         if (!borrow) {
 #pragma unroll
-            for (int i = 0; i < 9; i++) w[i] = t[i];
+            for (int i = 0; i < 9; i++) w[i] = s[i];
         }
     }
 #pragma unroll
@@ -248,10 +249,10 @@ PLONK_HD void fpl_pack_lt4m(const FqL& a, bool sub4m, uint32_t out[8]) {
 PLONK_HD G1Xyzz g1l_to_piece(const G1XyzzL& p) {
     if (p.inf) return g1_xyzz_identity();
     G1Xyzz r;
-    fpl_pack_lt4m(p.x, true, r.x.v);
-    fpl_pack_lt4m(p.y, false, r.y.v);
-    fpl_pack_lt4m(p.zz, false, r.zz.v);
-    fpl_pack_lt4m(p.zzz, false, r.zzz.v);
+    fpl_pack_lt4m<8>(p.x, r.x.v);           // (-7m, 5m) + 8m -> (m, 13m) -> [0, 4m)
+    fpl_pack_lt4m<1>(p.y, r.y.v);           // (-m, 2m) + m -> (0, 3m)
+    fpl_pack_lt4m<1>(p.zz, r.zz.v);
+    fpl_pack_lt4m<1>(p.zzz, r.zzz.v);
     return r;
 }
 
@@ -266,8 +267,8 @@ PLONK_HD G1Xyzz g1_piece_load(const G1Xyzz* src) {
     for (int k = 0; k < 3; k++) {
         fp_reduce_once<FqParams>(r.x.v);
         fp_reduce_once<FqParams>(r.y.v);
+        fp_reduce_once<FqParams>(r.zz.v);
+        fp_reduce_once<FqParams>(r.zzz.v);
     }
-    fp_reduce_once<FqParams>(r.zz.v);
-    fp_reduce_once<FqParams>(r.zzz.v);
     return r;
 }

@@ -83,3 +83,24 @@ extern "C" void probe_g1l_chain(const uint32_t* pts, const int* neg, int n, uint
     if (memcmp(&r, &direct, 64) != 0) memset(&r, 0xff, 64);  // the two routes must agree
     memcpy(out, &r, 64);
 }
+
+// raw signed-limb probe of fpl.h: op 0 = mul(a, b), 1 = sqr(a), 2 = mul_add(a, b, c, d), 3 = norm(a), 4 = to_fp(a)
+// (8 packed words in out[0..7]), 5 = pack_lt4m<8>(a) (8 words), 6 = pack_lt4m<1>(a) (8 words); limbs as int32[9]
+extern "C" void probe_fpl(int op, const int32_t* a, const int32_t* b, const int32_t* c, const int32_t* d, int32_t* out) {
+    FqL x, y, z, w, r = fpl_zero<FqParams>();
+    memcpy(x.l, a, 36);
+    memcpy(y.l, b, 36);
+    memcpy(z.l, c, 36);
+    memcpy(w.l, d, 36);
+    switch (op) {
+        case 0: r = fpl_mul(x, y); break;
+        case 1: r = fpl_sqr(x); break;
+        case 2: r = fpl_mul_add(x, y, z, w); break;
+        case 3: r = fpl_norm(x); break;
+        case 4: { Fq f = fpl_to_fp(x); memcpy(r.l, f.v, 32); break; }
+        case 5: fpl_pack_lt4m<8>(x, (uint32_t*)r.l); break;
+        case 6: fpl_pack_lt4m<1>(x, (uint32_t*)r.l); break;
+        default: break;
+    }
+    memcpy(out, r.l, 36);
+}

@@ -112,3 +112,85 @@ def test_lazy_accumulator_chain(probe):
     for pts, negs in (([G, G], [0, 0]), ([G, G], [0, 1]), ([G, G, P[1]], [0, 1, 0]), ([G] * 5, [0] * 5),
                       ([P[3], P[4], P[3], P[4]], [0, 0, 1, 1]), ([P[5]] * 9, [0] * 9), ([None, G, None], [0, 0, 0])):
         assert run(pts, negs) == ref(pts, negs)
+
+
+def test_signed_limb_arithmetic_at_the_bounds(probe):
+    """fpl.h on raw signed limbs at the edges of its documented operand ranges (differences of normalised values with
+    every limb at +-(2^29 - 1), values up to the 128 m^2 product bound): congruence, output range and normalisation."""
+    m = field.Q_MOD
+    Ri = pow(R261 % m, -1, m)
+    L = (1 << 29) - 1
+    rng = random.Random(9)
+    I9 = ctypes.c_int32 * 9
+
+    def val(l):
+        return sum(int(v) << (29 * i) for i, v in enumerate(l))
+
+    def limbs_of(v):  # normalised limbs of a (possibly negative) value
+        out = []
+        for i in range(8):
+            out.append(v & L)
+            v >>= 29
+        return out + [v]
+
+    def diff_operand(kind, top):
+        """difference of two normalised values: limbs 0..7 within [-L, L]; limb 8 sets the size (|value| ~ top * m)"""
+        if kind == 0:
+            lo = [L] * 8
+        elif kind == 1:
+            lo = [-L] * 8
+        elif kind == 2:
+            lo = [L if i % 2 else -L for i in range(8)]
+        else:
+            lo = [rng.randrange(-L, L + 1) for _ in range(8)]
+        return lo + [(top * m) >> 232]
+
+    def call(op, a, b=None, c=None, d=None):
+        z = [0] * 9
+        out = I9()
+        probe.probe_fpl(op, I9(*a), I9(*(b or z)), I9(*(c or z)), I9(*(d or z)), out)
+        return list(out)
+
+    def check_product(r, want):
+        assert all(0 <= v <= L for v in r[:8]), r
+        assert -m < val(r) < 2 * m
+        assert val(r) % m == want % m
+
+    tops = [-9, -6, -3, -1, 0, 1, 2, 5, 9]
+    for ka in range(4):
+        for kb in range(4):
+            for ta in tops:
+                for tb in tops:
+                    a, b = diff_operand(ka, ta), diff_operand(kb, tb)
+                    if abs(val(a)) * abs(val(b)) > 128 * m * m:
+                        continue
+                    check_product(call(0, a, b), val(a) * val(b) * Ri)
+                    if ta == tb and ka == kb:
+                        check_product(call(1, a), val(a) * val(a) * Ri)
+                    c, d = diff_operand(kb, -tb), diff_operand(ka, ta)
+                    if abs(val(a) * val(b)) + abs(val(c) * val(d)) <= 128 * m * m:
+                        check_product(call(2, a, b, c, d), (val(a) * val(b) + val(c) * val(d)) * Ri)
+    # one operand a SUM of two normalised values (limbs to 2^30), the other normalised
+    a = [2 * L] * 8 + [(3 * m) >> 232]
+    b = [L] * 8 + [(2 * m) >> 232]
+    check_product(call(0, a, b), val(a) * val(b) * Ri)
+    # carry sweep of the X3 shape: r2 - ppp - 2q
+    for _ in range(200):
+        x = [rng.randrange(-3 * L, L + 1) for _ in range(8)] + [rng.randrange(-(1 << 26), 1 << 26)]
+        r = call(3, x)
+        assert all(0 <= v <= L for v in r[:8]) and val(r) == val(x)
+    # canonical conversion and the piece form, over the accumulator's ranges
+    for lo, hi, op in ((-127, 127, 4), (-7, 5, 5), (-1, 2, 6)):
+        for _ in range(200):
+            v = rng.randrange(lo * m + 1, hi * m)
+            out = call(op, limbs_of(v))
+            got = sum((out[i] & 0xFFFFFFFF) << (32 * i) for i in range(8))
+            if op == 4:
+                assert got == v % m
+            else:
+                assert got % m == v % m and 0 <= got < 4 * m
+        for v in (lo * m + 1, hi * m - 1, 0, -1, 1, m, -m):
+            if lo * m < v < hi * m:
+                out = call(op, limbs_of(v))
+                got = sum((out[i] & 0xFFFFFFFF) << (32 * i) for i in range(8))
+                assert got % m == v % m
