@@ -29,8 +29,10 @@ Rank 0 prints ONE JSON line: the contract fields, plus
 import argparse
 import json
 import os
+import glob
 import subprocess
 import sys
+import threading
 import time
 
 REPO = os.path.dirname(os.path.abspath(__file__))
@@ -38,8 +40,11 @@ sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s measured copy)
 # chip-wide rate of the MSM loop's unit of work — the lazy mixed addition on register-resident operands —
-# measured by tools/ubench (profiles/r01_k_ubench.json: g1_lazy_madd_Gops; fq_lazy_mul_Gops = 167)
-G1_MADD_CEILING_G = 13.5
+# measured by tools/ubench in a burst of a few milliseconds, i.e. at the nominal 2.4 GHz shader clock
+# (profiles/r02_q_ubench.json: g1_lazy_madd_Gops; fq_lazy_mul_Gops = 174).  Under the sustained prover load the
+# chip holds ~2.07 GHz (`clocks` below), so `ceiling_at_sustained_clock` scales it by the measured clock.
+G1_MADD_CEILING_G = 18.8
+NOMINAL_SCLK_MHZ = 2400.0
 MSM_WINDOW_BITS = 10      # bucket-method default (csrc/msm.hip); 26 windows of signed 10-bit digits
 GROUP_ORDER = 2048
 R_MOD = 21888242871839275222246405745257275088548364400416034343698204186575808495617
@@ -156,6 +161,53 @@ def msm_microbench(ctx, bases, batch, reps=3):
         ms = ctx.timer_stop_ms()
         best = ms if best is None or ms < best else best
     return best
+
+
+class ClockSampler(threading.Thread):
+    """Shader clock and socket power of one GPU, read from amdgpu's hwmon files every 0.25 s while the timed region runs
+    (a few file reads per sample; the prover's host thread spends its time inside ctypes calls, which release the GIL).
+    Reports medians; None when the files are not there."""
+
+    def __init__(self, index):
+        super().__init__(daemon=True)
+        self.freq = self.power = None
+        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/hwmon/hwmon*/freq1_input"))
+        if cards:
+            d = os.path.dirname(cards[min(index, len(cards) - 1)])
+            self.freq = os.path.join(d, "freq1_input")
+            for name in ("power1_average", "power1_input"):
+                if os.path.exists(os.path.join(d, name)):
+                    self.power = os.path.join(d, name)
+                    break
+        self.samples, self.stop_flag = [], threading.Event()
+
+    @staticmethod
+    def _read(path):
+        try:
+            with open(path) as f:
+                return float(f.read().strip())
+        except (OSError, ValueError, TypeError):
+            return None
+
+    def run(self):
+        while self.freq and not self.stop_flag.wait(0.25):
+            self.samples.append((self._read(self.freq), self._read(self.power) if self.power else None))
+
+    def summary(self):
+        self.stop_flag.set()
+
+        def med(xs):
+            xs = sorted(x for x in xs if x is not None)
+            return xs[len(xs) // 2] if xs else None
+
+        f, p = med([a for a, _ in self.samples]), med([b for _, b in self.samples])
+        if f is None:
+            return None
+        fs = [a for a, _ in self.samples if a is not None]
+        return {"sclk_mhz_median": f / 1e6, "sclk_mhz_min": min(fs) / 1e6, "sclk_mhz_max": max(fs) / 1e6,
+                "socket_power_w_median": p / 1e6 if p is not None else None, "samples": len(fs),
+                "source": "amdgpu hwmon freq1_input / power1_*, sampled every 0.25 s over the timed region",
+                "nominal_sclk_mhz": NOMINAL_SCLK_MHZ}
 
 
 def spawn_ranks(args):
@@ -285,11 +337,14 @@ def main():
         c.profile_reset()
         c.profile(True)
     barrier()
+    sampler = ClockSampler(local_rank)
+    sampler.start()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         proofs = step()
     barrier()
     elapsed = D.max_over_ranks(time.perf_counter() - t0, comm)
+    clocks = sampler.summary()
     for c in ctxs:
         c.profile(False)
 
@@ -351,6 +406,7 @@ def main():
         },
     }
     line["host"]["end_to_end_proofs_per_s_from_dicts_per_gpu"] = per_gpu / (t_up + per_gpu * elapsed / total_proofs * world)
+    line["clocks"] = clocks  # rank 0's GPU; None when amdgpu's hwmon files are not visible
 
     def pmc_traffic(kernel, run):
         """HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside this process)."""
@@ -403,12 +459,16 @@ def main():
         # whole-step view: every mixed addition of the timed region over its wall time — with several streams the per-launch
         # durations above include the time a launch shares the chip with another stream's kernels, this figure does not care
         step_gmadd = n_msm * windows * GROUP_ORDER / elapsed / 1e9
+        sustained = G1_MADD_CEILING_G * clocks["sclk_mhz_median"] / NOMINAL_SCLK_MHZ if clocks else None
         line["roofline"]["alu"] = {"achieved_g1_gmadd_per_s": gmadd, "ceiling_g1_gmadd_per_s": G1_MADD_CEILING_G,
                                    "frac": gmadd / G1_MADD_CEILING_G,
                                    "whole_step_g1_gmadd_per_s": step_gmadd, "whole_step_frac": step_gmadd / G1_MADD_CEILING_G,
+                                   "ceiling_at_sustained_clock": sustained,
+                                   "whole_step_frac_at_sustained_clock": step_gmadd / sustained if sustained else None,
                                    "note": "%d mixed additions per MSM (8 Fq mul + 2 sqr + 8 add/sub each); ceiling = the same "
-                                           "addition in a register-only loop (tools/ubench), i.e. the kernel adds no overhead "
-                                           "beyond the arithmetic itself" % (windows * GROUP_ORDER)}
+                                           "addition in a register-only loop (tools/ubench) timed in a millisecond burst at the "
+                                           "nominal clock; the sustained prover load runs at the lower clock in `clocks`, and "
+                                           "its additions also fetch 64 table bytes each" % (windows * GROUP_ORDER)}
     ntt_ms, ntt_launches, ntt_bytes = profile_sum("ntt_pass")
     if ntt_launches:
         line["prover_ntt"] = {"kernel": "ntt passes inside the timed prover steps", "launches": ntt_launches, "total_ms": ntt_ms,

@@ -143,12 +143,19 @@ template <class P> PLONK_FP_CALL Fp<P> fp_mul(const Fp<P> a, const Fp<P> b) {
     const uint32_t ninv = P::NINV & FP29_MASK;
     uint32_t q[9];
     uint64_t acc = 0;
+    PLONK_CHAIN_BEGIN();
 #pragma unroll
     for (int k = 0; k < 9; k++) {
 #pragma unroll
-        for (int i = 0; i <= k; i++) acc += (uint64_t)x[i] * y[k - i];
+        for (int i = 0; i <= k; i++) {
+            acc += (uint64_t)x[i] * y[k - i];
+            PLONK_CHAIN(acc);
+        }
 #pragma unroll
-        for (int i = 0; i < k; i++) acc += (uint64_t)q[i] * fp29_mod_limb<P>(k - i);
+        for (int i = 0; i < k; i++) {
+            acc += (uint64_t)q[i] * fp29_mod_limb<P>(k - i);
+            PLONK_CHAIN(acc);
+        }
         q[k] = ((uint32_t)acc * ninv) & FP29_MASK;
         acc += (uint64_t)q[k] * fp29_mod_limb<P>(0);
         acc >>= 29;
@@ -156,13 +163,20 @@ template <class P> PLONK_FP_CALL Fp<P> fp_mul(const Fp<P> a, const Fp<P> b) {
 #pragma unroll
     for (int k = 9; k < 17; k++) {
 #pragma unroll
-        for (int i = k - 8; i < 9; i++) acc += (uint64_t)x[i] * y[k - i];
+        for (int i = k - 8; i < 9; i++) {
+            acc += (uint64_t)x[i] * y[k - i];
+            PLONK_CHAIN(acc);
+        }
 #pragma unroll
-        for (int i = k - 8; i < 9; i++) acc += (uint64_t)q[i] * fp29_mod_limb<P>(k - i);
+        for (int i = k - 8; i < 9; i++) {
+            acc += (uint64_t)q[i] * fp29_mod_limb<P>(k - i);
+            PLONK_CHAIN(acc);
+        }
         r[k - 9] = (uint32_t)acc & FP29_MASK;
         acc >>= 29;
     }
     r[8] = (uint32_t)acc;
+    PLONK_CHAIN_END(r[8]);
     Fp<P> out;
     fp29_pack(r, out.v);
     fp_reduce_once<P>(out.v);
@@ -206,12 +220,19 @@ template <class P> PLONK_FP_CALL Fp<P> fp_mul2(const Fp<P> a, const Fp<P> b) {
     const uint32_t ninv = P::NINV & FP29_MASK;
     uint32_t q[9];
     uint64_t acc = 0;
+    PLONK_CHAIN_BEGIN();
 #pragma unroll
     for (int k = 0; k < 9; k++) {
 #pragma unroll
-        for (int i = 0; i <= k; i++) acc += (uint64_t)x[i] * y[k - i];
+        for (int i = 0; i <= k; i++) {
+            acc += (uint64_t)x[i] * y[k - i];
+            PLONK_CHAIN(acc);
+        }
 #pragma unroll
-        for (int i = 0; i < k; i++) acc += (uint64_t)q[i] * fp29_mod_limb<P>(k - i);
+        for (int i = 0; i < k; i++) {
+            acc += (uint64_t)q[i] * fp29_mod_limb<P>(k - i);
+            PLONK_CHAIN(acc);
+        }
         q[k] = ((uint32_t)acc * ninv) & FP29_MASK;
         acc += (uint64_t)q[k] * fp29_mod_limb<P>(0);
         acc >>= 29;
@@ -219,13 +240,20 @@ template <class P> PLONK_FP_CALL Fp<P> fp_mul2(const Fp<P> a, const Fp<P> b) {
 #pragma unroll
     for (int k = 9; k < 17; k++) {
 #pragma unroll
-        for (int i = k - 8; i < 9; i++) acc += (uint64_t)x[i] * y[k - i];
+        for (int i = k - 8; i < 9; i++) {
+            acc += (uint64_t)x[i] * y[k - i];
+            PLONK_CHAIN(acc);
+        }
 #pragma unroll
-        for (int i = k - 8; i < 9; i++) acc += (uint64_t)q[i] * fp29_mod_limb<P>(k - i);
+        for (int i = k - 8; i < 9; i++) {
+            acc += (uint64_t)q[i] * fp29_mod_limb<P>(k - i);
+            PLONK_CHAIN(acc);
+        }
         r[k - 9] = (uint32_t)acc & FP29_MASK;
         acc >>= 29;
     }
     r[8] = (uint32_t)acc;
+    PLONK_CHAIN_END(r[8]);
     Fp<P> out;
     fp29_pack(r, out.v);
     return out;
@@ -240,6 +268,7 @@ template <class P> PLONK_FP_CALL Fp<P> fp_sqr(const Fp<P> a) {
     const uint32_t ninv = P::NINV & FP29_MASK;
     uint32_t q[9];
     uint64_t acc = 0;
+    PLONK_CHAIN_BEGIN();
 #pragma unroll
     for (int k = 0; k < 17; k++) {
 #pragma unroll
@@ -247,20 +276,28 @@ template <class P> PLONK_FP_CALL Fp<P> fp_sqr(const Fp<P> a) {
             const int j = k - i;
             if (i > 8 || j > 8 || i > j) continue;
             acc += (i == j) ? (uint64_t)x[i] * x[i] : (uint64_t)x2[i] * x[j];
+            PLONK_CHAIN(acc);
         }
         if (k < 9) {
 #pragma unroll
-            for (int i = 0; i < k; i++) acc += (uint64_t)q[i] * fp29_mod_limb<P>(k - i);
+            for (int i = 0; i < k; i++) {
+            acc += (uint64_t)q[i] * fp29_mod_limb<P>(k - i);
+            PLONK_CHAIN(acc);
+        }
             q[k] = ((uint32_t)acc * ninv) & FP29_MASK;
             acc += (uint64_t)q[k] * fp29_mod_limb<P>(0);
         } else {
 #pragma unroll
-            for (int i = k - 8; i < 9; i++) acc += (uint64_t)q[i] * fp29_mod_limb<P>(k - i);
+            for (int i = k - 8; i < 9; i++) {
+            acc += (uint64_t)q[i] * fp29_mod_limb<P>(k - i);
+            PLONK_CHAIN(acc);
+        }
             r[k - 9] = (uint32_t)acc & FP29_MASK;
         }
         acc >>= 29;
     }
     r[8] = (uint32_t)acc;
+    PLONK_CHAIN_END(r[8]);
     Fp<P> out;
     fp29_pack(r, out.v);
     fp_reduce_once<P>(out.v);

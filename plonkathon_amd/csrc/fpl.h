@@ -27,6 +27,7 @@ struct FpL {
 // Hides from the compiler that a limb is known to be non-negative.  Without it LLVM multiplies a signed limb by a
 // masked one as sext x zext — a v_mad_u64_u32 plus a correction v_mad_u64_u32 with the sign mask — instead of one
 // v_mad_i64_i32 (24 extra multiplier instructions and 48 moves per mixed addition when measured).  No instruction.
+// PLONK_CHAIN_ORDERED (hip_compat.h) keeps each column sum a chain that starts from the carry.
 #if defined(__HIP_DEVICE_COMPILE__)
 #define FPL_ANY_SIGN(x) asm("" : "+v"(x))
 #else
@@ -73,6 +74,15 @@ template <class P> PLONK_HD FpL<P> fpl_neg(const FpL<P>& a) {
     return r;
 }
 
+// neg ? -a : a without a branch: (x ^ s) - s with s = 0 or -1
+template <class P> PLONK_HD FpL<P> fpl_cneg(const FpL<P>& a, bool neg) {
+    const int32_t s = neg ? -1 : 0;
+    FpL<P> r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.l[i] = (a.l[i] ^ s) - s;
+    return r;
+}
+
 // carry sweep: limbs 0..7 back into [0, 2^29), the sign moves to limb 8 (input limbs: any int32)
 template <class P> PLONK_HD FpL<P> fpl_norm(const FpL<P>& a) {
     FpL<P> r;
@@ -96,9 +106,15 @@ template <class P> PLONK_HD FpL<P> fpl_mul(const FpL<P>& a, const FpL<P>& b) {
 #pragma unroll
     for (int k = 0; k < 9; k++) {
 #pragma unroll
-        for (int i = 0; i <= k; i++) acc += (int64_t)a.l[i] * b.l[k - i];
+        for (int i = 0; i <= k; i++) {
+            acc += (int64_t)a.l[i] * b.l[k - i];
+            PLONK_CHAIN_ORDERED(acc);
+        }
 #pragma unroll
-        for (int i = 0; i < k; i++) acc += (int64_t)((uint64_t)q[i] * fp29_mod_limb<P>(k - i));
+        for (int i = 0; i < k; i++) {
+            acc += (int64_t)((uint64_t)q[i] * fp29_mod_limb<P>(k - i));
+            PLONK_CHAIN_ORDERED(acc);
+        }
         q[k] = ((uint32_t)acc * ninv) & FP29_MASK;
         acc += (int64_t)((uint64_t)q[k] * fp29_mod_limb<P>(0));
         acc >>= 29;  // exact: the low 29 bits are zero
@@ -106,9 +122,15 @@ template <class P> PLONK_HD FpL<P> fpl_mul(const FpL<P>& a, const FpL<P>& b) {
 #pragma unroll
     for (int k = 9; k < 17; k++) {
 #pragma unroll
-        for (int i = k - 8; i < 9; i++) acc += (int64_t)a.l[i] * b.l[k - i];
+        for (int i = k - 8; i < 9; i++) {
+            acc += (int64_t)a.l[i] * b.l[k - i];
+            PLONK_CHAIN_ORDERED(acc);
+        }
 #pragma unroll
-        for (int i = k - 8; i < 9; i++) acc += (int64_t)((uint64_t)q[i] * fp29_mod_limb<P>(k - i));
+        for (int i = k - 8; i < 9; i++) {
+            acc += (int64_t)((uint64_t)q[i] * fp29_mod_limb<P>(k - i));
+            PLONK_CHAIN_ORDERED(acc);
+        }
         r.l[k - 9] = (int32_t)((uint32_t)acc & FP29_MASK);
         FPL_ANY_SIGN(r.l[k - 9]);
         acc >>= 29;
@@ -128,11 +150,20 @@ template <class P> PLONK_HD FpL<P> fpl_mul_add(const FpL<P>& a, const FpL<P>& b,
 #pragma unroll
     for (int k = 0; k < 9; k++) {
 #pragma unroll
-        for (int i = 0; i <= k; i++) acc += (int64_t)a.l[i] * b.l[k - i];
+        for (int i = 0; i <= k; i++) {
+            acc += (int64_t)a.l[i] * b.l[k - i];
+            PLONK_CHAIN_ORDERED(acc);
+        }
 #pragma unroll
-        for (int i = 0; i <= k; i++) acc += (int64_t)c.l[i] * d.l[k - i];
+        for (int i = 0; i <= k; i++) {
+            acc += (int64_t)c.l[i] * d.l[k - i];
+            PLONK_CHAIN_ORDERED(acc);
+        }
 #pragma unroll
-        for (int i = 0; i < k; i++) acc += (int64_t)((uint64_t)q[i] * fp29_mod_limb<P>(k - i));
+        for (int i = 0; i < k; i++) {
+            acc += (int64_t)((uint64_t)q[i] * fp29_mod_limb<P>(k - i));
+            PLONK_CHAIN_ORDERED(acc);
+        }
         q[k] = ((uint32_t)acc * ninv) & FP29_MASK;
         acc += (int64_t)((uint64_t)q[k] * fp29_mod_limb<P>(0));
         acc >>= 29;
@@ -140,11 +171,20 @@ template <class P> PLONK_HD FpL<P> fpl_mul_add(const FpL<P>& a, const FpL<P>& b,
 #pragma unroll
     for (int k = 9; k < 17; k++) {
 #pragma unroll
-        for (int i = k - 8; i < 9; i++) acc += (int64_t)a.l[i] * b.l[k - i];
+        for (int i = k - 8; i < 9; i++) {
+            acc += (int64_t)a.l[i] * b.l[k - i];
+            PLONK_CHAIN_ORDERED(acc);
+        }
 #pragma unroll
-        for (int i = k - 8; i < 9; i++) acc += (int64_t)c.l[i] * d.l[k - i];
+        for (int i = k - 8; i < 9; i++) {
+            acc += (int64_t)c.l[i] * d.l[k - i];
+            PLONK_CHAIN_ORDERED(acc);
+        }
 #pragma unroll
-        for (int i = k - 8; i < 9; i++) acc += (int64_t)((uint64_t)q[i] * fp29_mod_limb<P>(k - i));
+        for (int i = k - 8; i < 9; i++) {
+            acc += (int64_t)((uint64_t)q[i] * fp29_mod_limb<P>(k - i));
+            PLONK_CHAIN_ORDERED(acc);
+        }
         r.l[k - 9] = (int32_t)((uint32_t)acc & FP29_MASK);
         FPL_ANY_SIGN(r.l[k - 9]);
         acc >>= 29;
@@ -169,15 +209,22 @@ template <class P> PLONK_HD FpL<P> fpl_sqr(const FpL<P>& a) {
             const int j = k - i;
             if (i > 8 || j > 8 || i > j) continue;
             acc += (i == j) ? (int64_t)a.l[i] * a.l[i] : (int64_t)a2[i] * a.l[j];
+            PLONK_CHAIN_ORDERED(acc);
         }
         if (k < 9) {
 #pragma unroll
-            for (int i = 0; i < k; i++) acc += (int64_t)((uint64_t)q[i] * fp29_mod_limb<P>(k - i));
+            for (int i = 0; i < k; i++) {
+            acc += (int64_t)((uint64_t)q[i] * fp29_mod_limb<P>(k - i));
+            PLONK_CHAIN_ORDERED(acc);
+        }
             q[k] = ((uint32_t)acc * ninv) & FP29_MASK;
             acc += (int64_t)((uint64_t)q[k] * fp29_mod_limb<P>(0));
         } else {
 #pragma unroll
-            for (int i = k - 8; i < 9; i++) acc += (int64_t)((uint64_t)q[i] * fp29_mod_limb<P>(k - i));
+            for (int i = k - 8; i < 9; i++) {
+            acc += (int64_t)((uint64_t)q[i] * fp29_mod_limb<P>(k - i));
+            PLONK_CHAIN_ORDERED(acc);
+        }
             r.l[k - 9] = (int32_t)((uint32_t)acc & FP29_MASK);
             FPL_ANY_SIGN(r.l[k - 9]);
         FPL_ANY_SIGN(r.l[k - 9]);
@@ -234,16 +281,11 @@ template <class P> PLONK_HD Fp<P> fpl_to_fp(const FpL<P>& a) {
 template <class P> PLONK_HD_NOINLINE bool fpl_is_zero_mod_slow(const FpL<P>& a) { return fp_is_zero(fpl_to_fp(a)); }
 
 // cheap filter for "a == 0 (mod m)" when a is known to lie within [JLO m, JHI m] (limb 0: any int32): a = j*m forces
-// (limb 0 mod 2^29) == (j*m mod 2^29).  True with probability ~(JHI - JLO + 1) 2^-29 for a random a.
+// limb0 * (-1/m) == -j (mod 2^29), so one multiplication by the Montgomery constant recovers the candidate j and a range
+// check replaces a comparison per j.  True with probability (JHI - JLO + 1) 2^-29 for a random a.
 template <class P, int JLO, int JHI> PLONK_HD bool fpl_maybe_zero_mod(const FpL<P>& a) {
-    const uint32_t low = (uint32_t)a.l[0] & FP29_MASK;
-    bool maybe = false;
-#pragma unroll
-    for (int j = JLO; j <= JHI; j++) {
-        const uint32_t l0 = (uint32_t)((int64_t)j * (int64_t)fp29_mod_limb<P>(0)) & FP29_MASK;
-        maybe |= low == l0;
-    }
-    return maybe;
+    const uint32_t minus_j = ((uint32_t)a.l[0] * (P::NINV & FP29_MASK)) & FP29_MASK;
+    return ((minus_j + (uint32_t)JHI) & FP29_MASK) <= (uint32_t)(JHI - JLO);
 }
 
 // exact test, a within (-16 m, 16 m)

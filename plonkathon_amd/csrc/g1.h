@@ -181,15 +181,16 @@ PLONK_HD G1XyzzL g1l_from_xyzz(const G1Xyzz& p) {
 // acc += (x2, y2), canonical Montgomery coordinates.  Returns false WITHOUT touching acc when the step is
 // exceptional — identity base (0, 0), or P == +-Q (detected by a cheap filter with a 2^-25 false-positive
 // rate) — and the caller resolves it with the general packed formulas (msm.hip defers it to the bucket
-// reduction).  No calls, no packed arithmetic: minimal live registers.
+// reduction).  No calls, no packed arithmetic: minimal live registers.  neg_y adds (x2, -y2) instead: on signed limbs
+// the negation is 18 bit operations on y2, against ~40 instructions for a packed m - y and its select.
 //
 // Bounds (|value| / m, see fpl.h): U2, S2, PP, Q, PPP, R^2, ZZ3, ZZZ3, Y3 are products, in (-1, 2); P = U2 - X1 in
 // (-6, 9); R = S2 - Y1 in (-3, 3); X3 = R^2 - PPP - 2Q in (-7, 5); D = Q - X3 in (-6, 9).  Products: P^2 <= 81,
 // X1 PP <= 14, P PP <= 18, R^2 <= 9, R D + Y1 PPP <= 27 + 4 — all below the 128 of fpl_mul.  Limbs: every
 // multiplicand is a normalised value or the difference of two, within (-2^29, 2^29).
-PLONK_HD bool g1l_madd_fast(G1XyzzL& p, const Fq& x2p, const Fq& y2p) {
+PLONK_HD bool g1l_madd_fast(G1XyzzL& p, const Fq& x2p, const Fq& y2p, bool neg_y = false) {
     if (fp_is_zero(x2p) && fp_is_zero(y2p)) return false;
-    const FqL x2 = fpl_from_fp(x2p), y2 = fpl_from_fp(y2p);
+    const FqL x2 = fpl_from_fp(x2p), y2 = fpl_cneg(fpl_from_fp(y2p), neg_y);   // y2 in (-m, m)
     if (p.inf) {
         p.x = x2;
         p.y = y2;

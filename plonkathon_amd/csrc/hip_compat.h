@@ -32,3 +32,24 @@
 #endif
 #define PLONK_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
 #endif
+
+// PLONK_CHAIN(acc): an empty statement that merely USES the running 64-bit column sum of a product-scanning
+// multiplication.  The second use makes every partial sum a leaf for LLVM's reassociation, which otherwise sums a
+// column's products from zero and adds the carry of the previous column last — one v_lshl_add_u64 per column, 16 per
+// multiplication (5-7 % of the instructions of every ALU-bound kernel here).  With the chain kept as written the carry is
+// the addend of the column's first v_mad_u64_u32.  Emits no instruction.  The statements of one multiplication are
+// threaded through a scalar token (BEGIN ... END ties it to a result word) instead of being `volatile`, so that the
+// scheduler may still interleave independent multiplications: volatile statements keep program order, which cost the
+// 3-waves-per-SIMD NTT kernel 4 % at saturation (profiles/r02_p_chain_ab.txt).  PLONK_CHAIN_ORDERED is that volatile
+// form: the MSM loop (fpl.h), whose ten multiplications are one dependent sequence anyway, runs 2.5 % faster with it.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define PLONK_CHAIN_BEGIN() uint32_t plonk_chain_tok = 0
+#define PLONK_CHAIN(acc) asm("" : "=s"(plonk_chain_tok) : "v"(acc), "0"(plonk_chain_tok))
+#define PLONK_CHAIN_END(word) asm("" : "+v"(word) : "s"(plonk_chain_tok))
+#define PLONK_CHAIN_ORDERED(acc) asm volatile("" ::"v"(acc))
+#else
+#define PLONK_CHAIN_BEGIN() ((void)0)
+#define PLONK_CHAIN(acc) ((void)0)
+#define PLONK_CHAIN_END(word) ((void)0)
+#define PLONK_CHAIN_ORDERED(acc) ((void)0)
+#endif

@@ -269,7 +269,7 @@ __global__ void __launch_bounds__(MSM_BLOCK, MSM_ACC_WAVES) msm_accumulate_kerne
         run.inf = true;
     };
     auto accumulate = [&](const Fq& x, const Fq& y, uint32_t en) {
-        if (!g1l_madd_fast(run, x, y) && !(fp_is_zero(x) && fp_is_zero(y))) {
+        if (!g1l_madd_fast(run, x, y, (en & 0x8000u) != 0) && !(fp_is_zero(x) && fp_is_zero(y))) {
             const uint32_t slot = atomicAdd(n_deferred + m, 1u);
             if (slot < MSM_DEFER_CAP) deferred[(size_t)m * MSM_DEFER_CAP + slot] = MsmDeferred{k, en};
         }
@@ -282,8 +282,7 @@ __global__ void __launch_bounds__(MSM_BLOCK, MSM_ACC_WAVES) msm_accumulate_kerne
             while (e < st[k]);
         }
         const G1Affine* src = table + (size_t)(en >> 16) * table_n + (en & 0x7fffu);
-        Fq x = fp_load(&src->x), y = fp_load(&src->y);
-        if (en & 0x8000u) y = fp_neg(y);
+        const Fq x = fp_load(&src->x), y = fp_load(&src->y);
         accumulate(x, y, en);
     };
     for (uint32_t base = (hi - 1) & ~3u;; base -= 4) {
@@ -434,10 +433,13 @@ __global__ void __launch_bounds__(MSM_BLOCK, MSM_ACC_WAVES) msm_lookup_kernel(
         const int d = (int)((uint32_t)(two >> sh) & mask) - (int)half;
         if (d) {
             const uint32_t ad = d < 0 ? (uint32_t)-d : (uint32_t)d;
+#ifdef MSM_PROBE_REGION_MASK  // timing probe only (wrong results): the gathers stay random but span fewer 4 MB regions
+            const G1Affine* src = lookup + (((((size_t)w * table_n + i) & MSM_PROBE_REGION_MASK) << (c - 1)) + (ad - 1));
+#else
             const G1Affine* src = lookup + ((((size_t)w * table_n + i) << (c - 1)) + (ad - 1));
-            Fq x = fp_load(&src->x), y = fp_load(&src->y);
-            if (d < 0) y = fp_neg(y);
-            if (!g1l_madd_fast(run, x, y) && !(fp_is_zero(x) && fp_is_zero(y))) {  // see msm_accumulate_kernel
+#endif
+            const Fq x = fp_load(&src->x), y = fp_load(&src->y);
+            if (!g1l_madd_fast(run, x, y, d < 0) && !(fp_is_zero(x) && fp_is_zero(y))) {  // see msm_accumulate_kernel
                 const uint32_t slot = atomicAdd(n_deferred + m, 1u);
                 if (slot < MSM_DEFER_CAP) deferred[(size_t)m * deferred_stride + slot] = MsmDeferred{item, (uint32_t)d};
             }

@@ -69,8 +69,8 @@ extern "C" void probe_g1l_chain(const uint32_t* pts, const int* neg, int n, uint
     for (int i = 0; i < n; i++) {
         G1Affine a;
         memcpy(&a, pts + 16 * i, 64);
-        if (neg[i]) a.y = fp_neg(a.y);
-        if (!g1l_madd_fast(acc, a.x, a.y)) {  // exceptional step: the general packed formulas
+        if (!g1l_madd_fast(acc, a.x, a.y, neg[i] != 0)) {  // exceptional step: the general packed formulas
+            if (neg[i]) a.y = fp_neg(a.y);
             G1Xyzz t = g1l_to_xyzz(acc);
             g1_madd(t, a);
             acc = g1l_from_xyzz(t);
