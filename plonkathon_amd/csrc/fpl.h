@@ -27,7 +27,7 @@ struct FpL {
 // Hides from the compiler that a limb is known to be non-negative.  Without it LLVM multiplies a signed limb by a
 // masked one as sext x zext — a v_mad_u64_u32 plus a correction v_mad_u64_u32 with the sign mask — instead of one
 // v_mad_i64_i32 (24 extra multiplier instructions and 48 moves per mixed addition when measured).  No instruction.
-// PLONK_CHAIN_ORDERED (hip_compat.h) keeps each column sum a chain that starts from the carry.
+// PLONK_CHAIN (hip_compat.h) keeps each column sum a chain that starts from the carry.
 #if defined(__HIP_DEVICE_COMPILE__)
 #define FPL_ANY_SIGN(x) asm("" : "+v"(x))
 #else
@@ -103,17 +103,18 @@ template <class P> PLONK_HD FpL<P> fpl_mul(const FpL<P>& a, const FpL<P>& b) {
     uint32_t q[9];
     FpL<P> r;
     int64_t acc = 0;
+    PLONK_CHAIN_BEGIN();
 #pragma unroll
     for (int k = 0; k < 9; k++) {
 #pragma unroll
         for (int i = 0; i <= k; i++) {
             acc += (int64_t)a.l[i] * b.l[k - i];
-            PLONK_CHAIN_ORDERED(acc);
+            PLONK_CHAIN(acc);
         }
 #pragma unroll
         for (int i = 0; i < k; i++) {
             acc += (int64_t)((uint64_t)q[i] * fp29_mod_limb<P>(k - i));
-            PLONK_CHAIN_ORDERED(acc);
+            PLONK_CHAIN(acc);
         }
         q[k] = ((uint32_t)acc * ninv) & FP29_MASK;
         acc += (int64_t)((uint64_t)q[k] * fp29_mod_limb<P>(0));
@@ -124,18 +125,19 @@ template <class P> PLONK_HD FpL<P> fpl_mul(const FpL<P>& a, const FpL<P>& b) {
 #pragma unroll
         for (int i = k - 8; i < 9; i++) {
             acc += (int64_t)a.l[i] * b.l[k - i];
-            PLONK_CHAIN_ORDERED(acc);
+            PLONK_CHAIN(acc);
         }
 #pragma unroll
         for (int i = k - 8; i < 9; i++) {
             acc += (int64_t)((uint64_t)q[i] * fp29_mod_limb<P>(k - i));
-            PLONK_CHAIN_ORDERED(acc);
+            PLONK_CHAIN(acc);
         }
         r.l[k - 9] = (int32_t)((uint32_t)acc & FP29_MASK);
         FPL_ANY_SIGN(r.l[k - 9]);
         acc >>= 29;
     }
     r.l[8] = (int32_t)acc;
+    PLONK_CHAIN_END(r.l[8]);
     return r;
 }
 
@@ -147,22 +149,23 @@ template <class P> PLONK_HD FpL<P> fpl_mul_add(const FpL<P>& a, const FpL<P>& b,
     uint32_t q[9];
     FpL<P> r;
     int64_t acc = 0;
+    PLONK_CHAIN_BEGIN();
 #pragma unroll
     for (int k = 0; k < 9; k++) {
 #pragma unroll
         for (int i = 0; i <= k; i++) {
             acc += (int64_t)a.l[i] * b.l[k - i];
-            PLONK_CHAIN_ORDERED(acc);
+            PLONK_CHAIN(acc);
         }
 #pragma unroll
         for (int i = 0; i <= k; i++) {
             acc += (int64_t)c.l[i] * d.l[k - i];
-            PLONK_CHAIN_ORDERED(acc);
+            PLONK_CHAIN(acc);
         }
 #pragma unroll
         for (int i = 0; i < k; i++) {
             acc += (int64_t)((uint64_t)q[i] * fp29_mod_limb<P>(k - i));
-            PLONK_CHAIN_ORDERED(acc);
+            PLONK_CHAIN(acc);
         }
         q[k] = ((uint32_t)acc * ninv) & FP29_MASK;
         acc += (int64_t)((uint64_t)q[k] * fp29_mod_limb<P>(0));
@@ -173,23 +176,24 @@ template <class P> PLONK_HD FpL<P> fpl_mul_add(const FpL<P>& a, const FpL<P>& b,
 #pragma unroll
         for (int i = k - 8; i < 9; i++) {
             acc += (int64_t)a.l[i] * b.l[k - i];
-            PLONK_CHAIN_ORDERED(acc);
+            PLONK_CHAIN(acc);
         }
 #pragma unroll
         for (int i = k - 8; i < 9; i++) {
             acc += (int64_t)c.l[i] * d.l[k - i];
-            PLONK_CHAIN_ORDERED(acc);
+            PLONK_CHAIN(acc);
         }
 #pragma unroll
         for (int i = k - 8; i < 9; i++) {
             acc += (int64_t)((uint64_t)q[i] * fp29_mod_limb<P>(k - i));
-            PLONK_CHAIN_ORDERED(acc);
+            PLONK_CHAIN(acc);
         }
         r.l[k - 9] = (int32_t)((uint32_t)acc & FP29_MASK);
         FPL_ANY_SIGN(r.l[k - 9]);
         acc >>= 29;
     }
     r.l[8] = (int32_t)acc;
+    PLONK_CHAIN_END(r.l[8]);
     return r;
 }
 
@@ -202,6 +206,7 @@ template <class P> PLONK_HD FpL<P> fpl_sqr(const FpL<P>& a) {
     for (int i = 0; i < 9; i++) a2[i] = a.l[i] * 2;
     FpL<P> r;
     int64_t acc = 0;
+    PLONK_CHAIN_BEGIN();
 #pragma unroll
     for (int k = 0; k < 17; k++) {
 #pragma unroll
@@ -209,13 +214,13 @@ template <class P> PLONK_HD FpL<P> fpl_sqr(const FpL<P>& a) {
             const int j = k - i;
             if (i > 8 || j > 8 || i > j) continue;
             acc += (i == j) ? (int64_t)a.l[i] * a.l[i] : (int64_t)a2[i] * a.l[j];
-            PLONK_CHAIN_ORDERED(acc);
+            PLONK_CHAIN(acc);
         }
         if (k < 9) {
 #pragma unroll
             for (int i = 0; i < k; i++) {
             acc += (int64_t)((uint64_t)q[i] * fp29_mod_limb<P>(k - i));
-            PLONK_CHAIN_ORDERED(acc);
+            PLONK_CHAIN(acc);
         }
             q[k] = ((uint32_t)acc * ninv) & FP29_MASK;
             acc += (int64_t)((uint64_t)q[k] * fp29_mod_limb<P>(0));
@@ -223,7 +228,7 @@ template <class P> PLONK_HD FpL<P> fpl_sqr(const FpL<P>& a) {
 #pragma unroll
             for (int i = k - 8; i < 9; i++) {
             acc += (int64_t)((uint64_t)q[i] * fp29_mod_limb<P>(k - i));
-            PLONK_CHAIN_ORDERED(acc);
+            PLONK_CHAIN(acc);
         }
             r.l[k - 9] = (int32_t)((uint32_t)acc & FP29_MASK);
             FPL_ANY_SIGN(r.l[k - 9]);
@@ -232,6 +237,7 @@ template <class P> PLONK_HD FpL<P> fpl_sqr(const FpL<P>& a) {
         acc >>= 29;
     }
     r.l[8] = (int32_t)acc;
+    PLONK_CHAIN_END(r.l[8]);
     return r;
 }
 

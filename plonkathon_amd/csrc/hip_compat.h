@@ -40,16 +40,13 @@
 // the addend of the column's first v_mad_u64_u32.  Emits no instruction.  The statements of one multiplication are
 // threaded through a scalar token (BEGIN ... END ties it to a result word) instead of being `volatile`, so that the
 // scheduler may still interleave independent multiplications: volatile statements keep program order, which cost the
-// 3-waves-per-SIMD NTT kernel 4 % at saturation (profiles/r02_p_chain_ab.txt).  PLONK_CHAIN_ORDERED is that volatile
-// form: the MSM loop (fpl.h), whose ten multiplications are one dependent sequence anyway, runs 2.5 % faster with it.
+// 3-waves-per-SIMD NTT kernel 4 % at saturation, and were no faster for the MSM loop (profiles/r02_p_chain_ab.txt, r02_q).
 #if defined(__HIP_DEVICE_COMPILE__)
 #define PLONK_CHAIN_BEGIN() uint32_t plonk_chain_tok = 0
 #define PLONK_CHAIN(acc) asm("" : "=s"(plonk_chain_tok) : "v"(acc), "0"(plonk_chain_tok))
 #define PLONK_CHAIN_END(word) asm("" : "+v"(word) : "s"(plonk_chain_tok))
-#define PLONK_CHAIN_ORDERED(acc) asm volatile("" ::"v"(acc))
 #else
 #define PLONK_CHAIN_BEGIN() ((void)0)
 #define PLONK_CHAIN(acc) ((void)0)
 #define PLONK_CHAIN_END(word) ((void)0)
-#define PLONK_CHAIN_ORDERED(acc) ((void)0)
 #endif

@@ -47,7 +47,9 @@
 #include "plonk_internal.h"
 #include "wave.h"
 
+#ifndef MSM_BLOCK
 #define MSM_BLOCK 256
+#endif
 #define MSM_DEFAULT_WINDOW_BITS 10
 #define MSM_MAX_WINDOW_BITS 13
 #ifndef MSM_ACC_WAVES
@@ -761,9 +763,9 @@ static int msm_run_lookup(plonk_ctx* ctx, plonk_srs* srs, const Fr* d_scalars, s
     const size_t items = n * W;
     PLONK_REQUIRE(items < ((size_t)1 << 32), PLONK_ERR_ARG, "MSM size %zu too large for the lookup path", n);
     unsigned G = ctx->msm_groups;
-    if (!G) {
+    if (!G) {  // enough waves to occupy 1024 SIMDs three to four deep, in as few workgroups per MSM as that takes
         G = 1;
-        while (G < 64 && M * G < 1024) G *= 2;
+        while (G < 64 && M * G * (MSM_BLOCK / 64) < 3072) G *= 2;
     }
     while (G > 1 && (size_t)G * MSM_BLOCK * 2 > items) G /= 2;  // at least two additions per lane
     const size_t part_bytes = (M * G * sizeof(G1Xyzz) + 255) & ~(size_t)255;
