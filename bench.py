@@ -357,6 +357,24 @@ def main():
     lookup_bits = info["bits"]
     msm_kernel = "msm_lookup" if lookup_bits else "msm_accumulate"
     msm_ms, msm_launches, msm_bytes = profile_sum(msm_kernel)
+    # The same kernel with the chip to itself: with several streams a launch's event-to-event duration includes the time
+    # it shares the CUs with the other streams' kernels, so the per-launch figures of the timed region understate the
+    # kernel.  A short untimed phase runs the batches of stream 0 alone (the other streams idle) and reads its events.
+    iso = None
+    if NS > 1 and msm_launches:
+        barrier()
+        ctx.profile_reset()
+        ctx.profile(True)
+        for _ in range(3):
+            for pr in provers[0::NS]:
+                pr.run()
+                pr.download_raw()
+        ctx.sync()
+        ctx.profile(False)
+        i_ms, i_n, i_bytes = ctx.profile_read(msm_kernel)
+        if i_n:
+            iso = (i_ms * 1e-3 / i_n, i_bytes / i_n, i_n)
+        barrier()
     total_proofs = args.steps * total
     line = {
         "metric": "proofs/sec at group_order=2^%d (PLONK prover hot path: NTT + quotient + KZG MSM)" % args.log_n,
@@ -434,8 +452,23 @@ def main():
             "concurrent_streams": NS,
             "note": "algorithmic bytes = 96*N+64 per MSM (SURVEY.md 8(d)); the kernel is integer-ALU bound (DESIGN.md 3/4.2), "
                     "see `alu`; with the lookup table every addition also reads 64 table bytes, i.e. `traffic` is the real demand; "
-                    "with concurrent_streams > 1 a launch shares the chip with the other stream's kernels for part of its duration",
+                    "with concurrent_streams > 1 a launch shares the chip with the other streams' kernels, so avg_launch_us / achieved / "
+                    "frac of the timed region are diluted by the concurrency: `isolated` is the same kernel with one stream active",
         }
+        if iso:
+            i_avg, i_bytes, i_n = iso
+            msms_per_launch = i_bytes / (96.0 * GROUP_ORDER + 64.0)
+            wb = lookup_bits or MSM_WINDOW_BITS
+            i_gmadd = msms_per_launch * ((255 + wb - 1) // wb) * GROUP_ORDER / i_avg / 1e9
+            line["roofline"]["isolated"] = {
+                "avg_launch_us": i_avg * 1e6, "launches": i_n, "achieved": i_bytes / i_avg / 1e9,
+                "frac": i_bytes / i_avg / 1e9 / HBM_PEAK_GBS, "g1_gmadd_per_s": i_gmadd,
+                "alu_frac": i_gmadd / G1_MADD_CEILING_G,
+                "alu_frac_at_sustained_clock": (i_gmadd / (G1_MADD_CEILING_G * clocks["sclk_mhz_median"] / NOMINAL_SCLK_MHZ)
+                                                if clocks else None),
+                "note": "the same kernel on the same inputs with one stream active (untimed phase right after the timed region): "
+                        "its duration when it does not share the chip; profiles/ holds the rocprofv3 trace of a one-stream run"}
+            line["roofline"]["frac_isolated"] = line["roofline"]["isolated"]["frac"]
         if lookup_bits:  # the lookup method's own algorithmic bytes: one 64-byte table entry per addition + the scalars
             windows_l = (255 + lookup_bits - 1) // lookup_bits
             per_msm = GROUP_ORDER * windows_l * 64.0 + 32.0 * GROUP_ORDER + 64.0
