@@ -79,7 +79,9 @@ int plonk_ntt_configure(plonk_ctx* ctx, unsigned tile_log, unsigned single_pass_
 /* kernel family: 0 = auto (what measures fastest on MI355X: the in-register "wave" kernel — digits exchanged inside a
  * wave by DPP / ds_swizzle / v_permlane32_swap, LDS only across waves — for 2^9, 2^11, 2^13 and the two-pass sizes
  * built from them; Stockham radix-8 for other single-pass sizes; radix-2 stages otherwise), 1 = radix-2 stages,
- * 2 = Stockham radix-8, 3 = wave kernel where it applies, 4 = auto without the wave kernel (A/B measurements) */
+ * 2 = Stockham radix-8, 3 = the wave kernel on packed [0, 2m) residues where it applies (round 2's first form, kept for
+ * A/B measurements), 4 = auto without the wave kernels, 5 = the wave kernel on signed 29-bit limbs where it applies
+ * (what auto uses) */
 int plonk_ntt_select_kernel(plonk_ctx* ctx, unsigned kind);
 /* Lower-level pieces used by the batched prover: coefficient form in, fixed offset table. */
 int plonk_fr_coset_ntt_from_coeffs(plonk_ctx* ctx, const void* d_coeffs, void* d_out, unsigned log_n,

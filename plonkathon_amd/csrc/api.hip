@@ -266,7 +266,7 @@ int plonk_ntt_configure(plonk_ctx* ctx, unsigned tile_log, unsigned single_pass_
 int plonk_ntt_select_kernel(plonk_ctx* ctx, unsigned kind) {
     PLONK_REQUIRE(ctx, PLONK_ERR_ARG, "ctx is NULL");
     PLONK_ENTER(ctx);
-    PLONK_REQUIRE(kind <= 4, PLONK_ERR_ARG, "kernel kind must be 0 (auto), 1 (radix-2 stages), 2 (Stockham radix-8), 3 (in-register wave kernel) or 4 (auto without the wave kernel)");
+    PLONK_REQUIRE(kind <= 5, PLONK_ERR_ARG, "kernel kind must be 0 (auto), 1 (radix-2 stages), 2 (Stockham radix-8), 3 (in-register wave kernel, packed residues), 4 (auto without the wave kernels) or 5 (in-register wave kernel, signed limbs)");
     ctx->ntt_kind = kind;
     return PLONK_OK;
 }

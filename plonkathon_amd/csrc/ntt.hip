@@ -19,6 +19,9 @@
 
 #include "plonk_internal.h"
 #include "wave.h"
+#include "fpl.h"
+
+typedef FpL<FrParams> FrL;
 
 // defaults live in plonk_ctx (ntt_tile_log = 12: 4096 elements = 128 KiB of LDS; ntt_single_log = 11;
 // ntt_radix_log = 10) and can be changed with plonk_ntt_configure for tuning / small-size tests.
@@ -481,6 +484,7 @@ struct NttWave {
     Fr out_scalar;
     unsigned has_out_scalar;
     Fr w8_1, w8_2, w8_3;
+    const int32_t* jm;    // fpl_reduce_small's table of j * m (the limb-form kernel)
 };
 
 // f(0) .. f(7) with compile-time arguments: the element array must never be indexed by a run-time value, or it moves
@@ -649,6 +653,196 @@ __global__ void __launch_bounds__(64u << (2 * NLDS), NLDS == 2 ? 4 : 3) ntt_wave
 }
 
 // ------------------------------------------------------------------------------------------------
+// Variant C on signed limbs ("wave-limb" kernel; plonk_ntt_select_kernel(kind = 5), and the default where the wave kernel
+// applies).  Same dataflow as ntt_wave_kernel, but an element is 9 signed 29-bit limbs (fpl.h) from the first load to the
+// last store: additions and subtractions are 9 independent 32-bit operations instead of two 8-word carry chains and a
+// select, multiplications skip the unpack / pack / conditional subtraction of the packed form, and the cross-lane and LDS
+// exchanges move 9 words instead of 8.
+//
+// Range discipline (m = the modulus; "N-form" = limbs 0..7 in [0, 2^29), limb 8 signed and small).  Every stage receives
+// N-form elements with |value| < 2 m: loads are canonical, multiplications return N-form in (-m, 2m), and the one output of
+// each butterfly group that carries no twiddle factor (index 0) goes through fpl_reduce_small (N-form, |value| < 0.51 m).
+// Inside a radix-8 butterfly five carry sweeps keep every limb inside int32 and every multiplicand inside fpl_mul's
+// operand bound (|limb| < 1.27 * 2^30): the bounds are written on each line of dft8l / dft4l.  |value| never exceeds 16 m
+// (a sum of eight inputs), fpl_mul tolerates 128 m.
+template <unsigned RB, unsigned MASK> PLONK_DEV void wavel_swap_bit(FrL (&x)[8], unsigned lane) {
+    const bool hi = (lane & MASK) != 0;
+    wave_for<4>([&](auto I) {
+        constexpr unsigned i4 = decltype(I)::value;
+        constexpr unsigned r = ((i4 >> RB) << (RB + 1)) | (i4 & ((1u << RB) - 1)), r1 = r | (1u << RB);
+        wave_for<9>([&](auto W) {
+            constexpr unsigned i = decltype(W)::value;
+            const uint32_t send = (uint32_t)(hi ? x[r].l[i] : x[r1].l[i]);
+            const uint32_t recv = wave_lane_xor<MASK>(send, lane);
+            if (hi) x[r].l[i] = (int32_t)recv;
+            else x[r1].l[i] = (int32_t)recv;
+        });
+    });
+}
+
+// x[BASE + f] *= roots[(low * f * mult) mod N], f = 1 .. COUNT-1;  x[BASE] (no factor) is range-reduced instead
+template <unsigned LOG_N, unsigned BASE, unsigned COUNT> PLONK_DEV void wavel_twiddle(FrL (&x)[8], unsigned low, unsigned mult, const Fr* roots, const int32_t* jm) {
+    x[BASE] = fpl_reduce_small(x[BASE], jm);
+    wave_for<COUNT - 1>([&](auto F) {
+        constexpr unsigned f = decltype(F)::value + 1;
+        x[BASE + f] = fpl_mul(x[BASE + f], fpl_from_fp(fp_load(roots + ((low * f * mult) & ((1u << LOG_N) - 1)))));
+    });
+}
+// inputs N-form, |value| < 2.  Outputs: x0 in [0, 2^31) (for fpl_reduce_small), x1..x3 multiplicands; |value| < 8
+PLONK_DEV void dft4l(FrL& x0, FrL& x1, FrL& x2, FrL& x3, const FrL& w2) {
+    const FrL a0 = fpl_add(x0, x2), a1 = fpl_add(x1, x3);                 // [0, 2^30)
+    const FrL d0 = fpl_sub(x0, x2);                                       // (-2^29, 2^29)
+    const FrL d1 = fpl_mul(fpl_sub(x1, x3), w2);                          // N-form, (-m, 2m)
+    x0 = fpl_add(a0, a1);                                                 // [0, 2^31)
+    x2 = fpl_sub(a0, a1);                                                 // (-2^30, 2^30)
+    x1 = fpl_add(d0, d1);                                                 // (-2^29, 2^30)
+    x3 = fpl_sub(d0, d1);                                                 // (-2^30, 2^29)
+}
+// inputs N-form, |value| < 2.  Outputs: every limb within (-2^30, 2^30] (multiplicands, and fit for fpl_reduce_small);
+// |value| <= 16
+PLONK_DEV void dft8l(FrL (&x)[8], const FrL& w1, const FrL& w2, const FrL& w3) {
+    const FrL a0 = fpl_add(x[0], x[4]), a1 = fpl_add(x[1], x[5]), a2 = fpl_add(x[2], x[6]), a3 = fpl_add(x[3], x[7]);  // [0, 2^30)
+    const FrL b0 = fpl_norm(fpl_sub(x[0], x[4]));                         // N-form (sweep 1)
+    const FrL b1 = fpl_mul(fpl_sub(x[1], x[5]), w1), b2 = fpl_mul(fpl_sub(x[2], x[6]), w2), b3 = fpl_mul(fpl_sub(x[3], x[7]), w3);  // operands (-2^29, 2^29)
+    const FrL c0 = fpl_norm(fpl_add(a0, a2)), c1 = fpl_norm(fpl_add(a1, a3));  // sums [0, 2^31) -> N-form (sweeps 2, 3)
+    const FrL d0 = fpl_norm(fpl_sub(a0, a2));                             // (-2^30, 2^30) -> N-form (sweep 4)
+    const FrL d1 = fpl_mul(fpl_sub(a1, a3), w2);                          // operand (-2^30, 2^30)
+    const FrL e0 = fpl_add(b0, b2), e1 = fpl_add(b1, b3);                 // [0, 2^30)
+    const FrL f0 = fpl_sub(b0, b2);                                       // (-2^29, 2^29)
+    const FrL f1 = fpl_mul(fpl_sub(b1, b3), w2);                          // operand (-2^29, 2^29)
+    x[0] = fpl_add(c0, c1);                                               // [0, 2^30)
+    x[4] = fpl_sub(c0, c1);                                               // (-2^29, 2^29)
+    x[2] = fpl_add(d0, d1);                                               // [0, 2^30)
+    x[6] = fpl_sub(d0, d1);                                               // (-2^29, 2^29)
+    x[1] = fpl_norm(fpl_add(e0, e1));                                     // [0, 2^31) -> N-form (sweep 5)
+    x[5] = fpl_sub(e0, e1);                                               // (-2^30, 2^30)
+    x[3] = fpl_add(f0, f1);                                               // (-2^29, 2^30)
+    x[7] = fpl_sub(f0, f1);                                               // (-2^30, 2^29)
+}
+PLONK_DEV void wavel_lds_st(u32x4* lo, u32x4* hi, uint32_t* top, unsigned i, const FrL& a) {
+    lo[i] = u32x4{(uint32_t)a.l[0], (uint32_t)a.l[1], (uint32_t)a.l[2], (uint32_t)a.l[3]};
+    hi[i] = u32x4{(uint32_t)a.l[4], (uint32_t)a.l[5], (uint32_t)a.l[6], (uint32_t)a.l[7]};
+    top[i] = (uint32_t)a.l[8];
+}
+PLONK_DEV FrL wavel_lds_ld(const u32x4* lo, const u32x4* hi, const uint32_t* top, unsigned i) {
+    const u32x4 a = lo[i], b = hi[i];
+    FrL r;
+    r.l[0] = (int32_t)a.x; r.l[1] = (int32_t)a.y; r.l[2] = (int32_t)a.z; r.l[3] = (int32_t)a.w;
+    r.l[4] = (int32_t)b.x; r.l[5] = (int32_t)b.y; r.l[6] = (int32_t)b.z; r.l[7] = (int32_t)b.w;
+    r.l[8] = (int32_t)top[i];
+    return r;
+}
+
+template <unsigned NLDS>
+__global__ void __launch_bounds__(64u << (2 * NLDS), NLDS == 2 ? 4 : 3) ntt_wavel_kernel(NttWave p) {
+    constexpr unsigned LOG_N = 9 + 2 * NLDS, NT = 64u << (2 * NLDS);
+    PLONK_DYN_SMEM(smem);
+    u32x4* l_lo = reinterpret_cast<u32x4*>(smem);  // 4 * NT elements as two 16-byte planes and one 4-byte plane
+    u32x4* l_hi = l_lo + 4 * NT;
+    uint32_t* l_top = reinterpret_cast<uint32_t*>(l_hi + 4 * NT);
+    const unsigned tid = threadIdx.x, lane = tid & 63;
+    const unsigned bidx = p.mode ? blockIdx.y : blockIdx.x;
+    const Fr* in = p.in + (size_t)bidx * p.in_bstride;
+    Fr* out = p.out + (size_t)bidx * p.out_bstride;
+    const unsigned b = blockIdx.x;  // XCD-aware column / row order: see ntt_wave_kernel
+    const unsigned sub = !p.mode ? 0 : ((gridDim.x & 31u) ? b : ((b & ~31u) | ((b & 7u) << 2) | ((b >> 3) & 3u)));
+    const unsigned in_shift = p.mode == 1 ? p.log_other : 0, out_shift = p.mode ? p.log_other : 0;
+    const unsigned in_off = p.mode == 1 ? sub : (p.mode == 2 ? (p.chunk_log ? sub << p.chunk_log : sub << LOG_N) : 0);
+    const unsigned out_off = p.mode ? sub : 0;
+    const unsigned chunk_mask = (1u << p.chunk_log) - 1;
+    const int32_t* jm = p.jm;
+    const FrL w8_1 = fpl_from_fp_uniform(p.w8_1), w8_2 = fpl_from_fp_uniform(p.w8_2), w8_3 = fpl_from_fp_uniform(p.w8_3);  // 27 SGPRs
+
+    FrL x[8];
+    wave_for8([&](auto J) {  // position j * NT + tid: consecutive lanes read consecutive positions
+        constexpr unsigned j = decltype(J)::value;
+        const unsigned pos = j * NT + tid;
+        const unsigned g = p.chunk_log ? (pos >> p.chunk_log) * p.chunk_stride + (pos & chunk_mask) + in_off : (pos << in_shift) + in_off;
+        x[j] = g < p.in_len ? fpl_from_fp(fp_load(in + g)) : fpl_zero<FrParams>();  // [0, 2m): the column pass hands on canonical values
+    });
+    if (p.in_scale) {
+        wave_for8([&](auto J) {
+            constexpr unsigned j = decltype(J)::value;
+            const unsigned g = ((j * NT + tid) << in_shift) + in_off;
+            if (g < p.in_len) x[j] = fpl_mul(x[j], fpl_from_fp(fp_load(p.in_scale + g)));
+        });
+    }
+    // stage A: digit = index bits LOG_N-1 .. LOG_N-3, low = tid
+    dft8l(x, w8_1, w8_2, w8_3);
+    wavel_twiddle<LOG_N, 0, 8>(x, tid, 1, p.roots, jm);
+    // L radix-4 stages on the wave bits: swap register bits (1, 0) with thread bits (tb + 1, tb)
+    wave_for<NLDS>([&](auto S) {
+        constexpr unsigned s = decltype(S)::value;
+        constexpr unsigned tb = 6 + 2 * (NLDS - 1 - s);
+        const unsigned mine = (tid >> tb) & 3u, rest = tid & ~(3u << tb);
+        wave_for<2>([&](auto R2) {
+            constexpr unsigned r2 = decltype(R2)::value;
+            wave_for<4>([&](auto Q) { wavel_lds_st(l_lo, l_hi, l_top, decltype(Q)::value * NT + tid, x[4 * r2 + decltype(Q)::value]); });
+            __syncthreads();
+            wave_for<4>([&](auto Q) { x[4 * r2 + decltype(Q)::value] = wavel_lds_ld(l_lo, l_hi, l_top, mine * NT + (rest | (decltype(Q)::value << tb))); });
+            __syncthreads();
+        });
+        const unsigned low = tid & ((1u << tb) - 1);
+        const unsigned mult = 1u << (LOG_N - (tb + 2));  // N / S, S = 2^(tb + 2)
+        dft4l(x[0], x[1], x[2], x[3], w8_2);
+        dft4l(x[4], x[5], x[6], x[7], w8_2);
+        wavel_twiddle<LOG_N, 0, 4>(x, low, mult, p.roots, jm);
+        wavel_twiddle<LOG_N, 4, 4>(x, low, mult, p.roots, jm);
+    });
+    // stage on lane bits 5..3
+    wavel_swap_bit<2, 32>(x, lane);
+    wavel_swap_bit<1, 16>(x, lane);
+    wavel_swap_bit<0, 8>(x, lane);
+    dft8l(x, w8_1, w8_2, w8_3);
+    wavel_twiddle<LOG_N, 0, 8>(x, lane & 7u, 1u << (LOG_N - 6), p.roots, jm);
+    // stage on lane bits 2..0
+    wavel_swap_bit<2, 4>(x, lane);
+    wavel_swap_bit<1, 2>(x, lane);
+    wavel_swap_bit<0, 1>(x, lane);
+    dft8l(x, w8_1, w8_2, w8_3);
+    // frequency of register j: see ntt_wave_kernel
+    unsigned k, shift = 3;
+    if (NLDS) {
+        k = (((lane >> 5) & 1u) << 2) | ((tid >> (6 + 2 * (NLDS > 0 ? NLDS - 1 : 0))) & 3u);
+        for (unsigned s = 1; s < NLDS; s++) {
+            k |= ((tid >> (6 + 2 * (NLDS - 1 - s))) & 3u) << shift;
+            shift += 2;
+        }
+        k |= ((lane >> 3) & 3u) << shift;
+        shift += 2;
+    } else {
+        k = (lane >> 3) & 7u;
+    }
+    k |= (lane & 7u) << shift;
+    shift += 3;
+    if (p.mode == 1) {  // inter-pass twiddle w_N^(column * frequency)
+        wave_for8([&](auto J) {
+            constexpr unsigned j = decltype(J)::value;
+            const unsigned e = (sub + p.sub_base) * (k | (j << shift));  // < N
+            if (e) {
+                FrL tw = fpl_from_fp(fp_load(p.tw_lo + (e & ((1u << NTT_TW_LO_LOG) - 1))));
+                if (p.log_n > NTT_TW_LO_LOG) tw = fpl_mul(tw, fpl_from_fp(fp_load(p.tw_hi + (e >> NTT_TW_LO_LOG))));
+                x[j] = fpl_mul(x[j], tw);
+            }
+        });
+    }
+    if (p.out_scale) {
+        wave_for8([&](auto J) {
+            constexpr unsigned j = decltype(J)::value;
+            x[j] = fpl_mul(x[j], fpl_from_fp(fp_load(p.out_scale + (((k | (j << shift)) << out_shift) + out_off))));
+        });
+    }
+    if (p.has_out_scalar) {
+        const FrL sc = fpl_from_fp_uniform(p.out_scalar);
+        wave_for8([&](auto J) { x[decltype(J)::value] = fpl_mul(x[decltype(J)::value], sc); });
+    }
+    wave_for8([&](auto J) {  // |value| <= 16 m whatever happened above -> (-0.51 m, 0.51 m) -> canonical
+        constexpr unsigned j = decltype(J)::value;
+        fp_store(out + (((k | (j << shift)) << out_shift) + out_off), fpl_pack_canonical(fpl_reduce_small(x[j], jm)));
+    });
+}
+
+// ------------------------------------------------------------------------------------------------
 // host side: roots of unity, cached tables, pass planning
 
 static Fr host_fr_from_u64(uint64_t x) {
@@ -754,17 +948,49 @@ static bool ntt_wave_plan(unsigned log_n, unsigned* log_r1, unsigned* log_r2) {
     }
 }
 
+// fpl_reduce_small's table of j * m for the limb-form kernel: 49 entries of 12 words, built on the host once per context
+static int ntt_get_jm(plonk_ctx* ctx, const int32_t** out) {
+    if (!ctx->ntt_jm) {
+        int32_t host[(2 * FPL_RS_J + 1) * 12];
+        for (int j = -FPL_RS_J; j <= FPL_RS_J; j++) fpl_jm_entry<FrParams>(j, host + (j + FPL_RS_J) * 12);
+        void* d = nullptr;
+        if (hipMalloc(&d, sizeof host) != hipSuccess) {
+            plonk_set_error("hipMalloc of the NTT range-reduction table failed");
+            return PLONK_ERR_NOMEM;
+        }
+        ctx->owned.push_back(d);
+        PLONK_CHECK_HIP(hipMemcpy(d, host, sizeof host, hipMemcpyHostToDevice));
+        ctx->ntt_jm = (const int32_t*)d;
+    }
+    *out = ctx->ntt_jm;
+    return PLONK_OK;
+}
+
 static int ntt_wave_launch(plonk_ctx* ctx, const NttWave& p, unsigned log_r, unsigned grid_x, unsigned grid_y) {
     const unsigned nlds = (log_r - 9) / 2, nt = 64u << (2 * nlds);
-    const size_t shmem = (size_t)4 * nt * 32;
-    if (!ctx->ntt_wave_attr_set) {  // a per-device attribute: tracked per context
-        PLONK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ntt_wave_kernel<2>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)(128 * 1024)));
-        ctx->ntt_wave_attr_set = true;
+    if (ctx->ntt_kind == 3) {  // the packed-residue form of round 2's first half, kept selectable for A/B runs
+        const size_t shmem = (size_t)4 * nt * 32;
+        if (!ctx->ntt_wave_attr_set) {  // a per-device attribute: tracked per context
+            PLONK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ntt_wave_kernel<2>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(128 * 1024)));
+            ctx->ntt_wave_attr_set = true;
+        }
+        if (nlds == 0) PLONK_LAUNCH(ntt_wave_kernel<0>, dim3(grid_x, grid_y), dim3(nt), shmem, ctx->stream, p);
+        else if (nlds == 1) PLONK_LAUNCH(ntt_wave_kernel<1>, dim3(grid_x, grid_y), dim3(nt), shmem, ctx->stream, p);
+        else PLONK_LAUNCH(ntt_wave_kernel<2>, dim3(grid_x, grid_y), dim3(nt), shmem, ctx->stream, p);
+        return PLONK_OK;
     }
-    if (nlds == 0) PLONK_LAUNCH(ntt_wave_kernel<0>, dim3(grid_x, grid_y), dim3(nt), shmem, ctx->stream, p);
-    else if (nlds == 1) PLONK_LAUNCH(ntt_wave_kernel<1>, dim3(grid_x, grid_y), dim3(nt), shmem, ctx->stream, p);
-    else PLONK_LAUNCH(ntt_wave_kernel<2>, dim3(grid_x, grid_y), dim3(nt), shmem, ctx->stream, p);
+    NttWave q = p;
+    PLONK_TRY(ntt_get_jm(ctx, &q.jm));
+    const size_t shmem = (size_t)4 * nt * 36;  // 9 words per element
+    if (!ctx->ntt_wavel_attr_set) {
+        PLONK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ntt_wavel_kernel<2>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)(144 * 1024)));
+        ctx->ntt_wavel_attr_set = true;
+    }
+    if (nlds == 0) PLONK_LAUNCH(ntt_wavel_kernel<0>, dim3(grid_x, grid_y), dim3(nt), shmem, ctx->stream, q);
+    else if (nlds == 1) PLONK_LAUNCH(ntt_wavel_kernel<1>, dim3(grid_x, grid_y), dim3(nt), shmem, ctx->stream, q);
+    else PLONK_LAUNCH(ntt_wavel_kernel<2>, dim3(grid_x, grid_y), dim3(nt), shmem, ctx->stream, q);
     return PLONK_OK;
 }
 
@@ -925,12 +1151,12 @@ int ntt_run(plonk_ctx* ctx, const Fr* in, Fr* out, unsigned log_n, bool inverse,
     if (!batch) return PLONK_OK;
     const size_t N = (size_t)1 << log_n;
     unsigned wr1, wr2;
-    if ((ctx->ntt_kind == 0 || ctx->ntt_kind == 3) && ntt_wave_plan(log_n, &wr1, &wr2) && ctx->ntt_single_log >= 11 && ctx->ntt_radix_log >= 10) {
-        // measured on MI355X (profiles/r02_e_ntt_kinds.json): the one-pass sizes always win (+22 % at 2^11 / 2^13); the
-        // two-pass form wins when there is enough work to fill the chip several times over (2^18 x 16, 2^20 x 8, 2^22), but a
-        // lone 2^18 / 2^20 is faster on the radix-2 passes (smaller per-thread chains) and 2^24 on three of those
-        const bool two_pass_ok = (log_n == 18 || log_n == 20 || log_n == 22) && ((size_t)batch << log_n) >= ((size_t)1 << 22);
-        if (!wr2 || two_pass_ok || ctx->ntt_kind == 3)
+    if ((ctx->ntt_kind == 0 || ctx->ntt_kind == 3 || ctx->ntt_kind == 5) && ntt_wave_plan(log_n, &wr1, &wr2) && ctx->ntt_single_log >= 11 && ctx->ntt_radix_log >= 10) {
+        // measured on MI355X (profiles/r02_e_ntt_kinds.json, r02_v_ntt_kinds.json): the one-pass sizes always win; the
+        // two-pass form on signed limbs wins at 2^18, 2^20 and 2^22 for any batch (a lone 2^20: 0.132 ms against 0.134 on the
+        // radix-2 LDS passes, 0.146 for the packed-residue wave kernel); 2^24 stays on three LDS passes
+        const bool two_pass_ok = log_n == 18 || log_n == 20 || log_n == 22;
+        if (!wr2 || two_pass_ok || ctx->ntt_kind == 3 || ctx->ntt_kind == 5)
             return ntt_run_wave(ctx, in, out, log_n, inverse, batch, in_len, in_bstride, out_bstride, in_scale, out_scale, scale_by_n_inv);
     }
     PLONK_REQUIRE(batch <= 65535, PLONK_ERR_ARG, "NTT batch %zu exceeds 65535", batch);

@@ -99,7 +99,7 @@ struct plonk_ctx {
     int msm_lookup_mode = 0;         // 0 auto (fixed SRS only), 1 off, 2 force msm_lookup_bits for every base set
     unsigned msm_lookup_bits = 0;    // 0 = largest window whose table fits the budget
     size_t msm_lookup_budget = 0;    // bytes; 0 = default (PLONK_MSM_TABLE_GB if set, else 4 GiB)
-    bool ntt_attr_set = false, msm_attr_set = false, ntt_wave_attr_set = false;  // hipFuncSetAttribute is per device: tracked per context
+    bool ntt_attr_set = false, msm_attr_set = false, ntt_wave_attr_set = false, ntt_wavel_attr_set = false;  // hipFuncSetAttribute is per device: tracked per context
     // per-kernel HIP-event profiling (bench.py roofline): one record per instrumented launch
     struct ProfRec { const char* name; hipEvent_t a, b; double algo_bytes; };
     bool profiling = false;
@@ -107,6 +107,7 @@ struct plonk_ctx {
     std::vector<hipEvent_t> event_pool;
     unsigned ntt_tile_log = 12, ntt_single_log = 11, ntt_radix_log = 10;
     bool ntt_adaptive_tiles = true;
+    const int32_t* ntt_jm = nullptr;  // fpl_reduce_small's table (device), built on first use by the limb-form NTT kernel
     unsigned ntt_kind = 0;  // 0 = auto (Stockham radix-8 for single-pass sizes, radix-2 stages otherwise), 1 / 2 = force
 };
 

@@ -44,6 +44,19 @@ def ntt_vs_oracle(log_ns, seed0=0):
         assert ints(P(v, Basis.LAGRANGE).ifft()) == fft_ints(v, True), ("ifft", log_n)
 
 
+def ntt_extreme_inputs(log_ns):
+    """Inputs that drive the limb-form kernel's range bounds: every element at r - 1 (all partial sums at their maximum),
+    alternating 0 / r - 1 (differences at their extremes), a lone r - 1, and vectors whose transform is constant."""
+    m = R_MOD
+    for log_n in log_ns:
+        n = 1 << log_n
+        for name, v in (("max", [m - 1] * n), ("alt", [(m - 1) * (i & 1) for i in range(n)]),
+                        ("alt8", [(m - 1) * ((i >> 3) & 1) for i in range(n)]), ("one", [m - 1] + [0] * (n - 1)),
+                        ("half", [(m - 1) // 2 + (i % 3) for i in range(n)])):
+            assert ints(P(v, Basis.MONOMIAL).fft()) == fft_ints(v), ("fft", name, log_n)
+            assert ints(P(v, Basis.LAGRANGE).ifft()) == fft_ints(v, True), ("ifft", name, log_n)
+
+
 def ntt_roundtrip_and_linearity(log_n, seed=5):
     """Size-independent properties for sizes the oracle does not reach in seconds."""
     n = 1 << log_n

@@ -32,7 +32,7 @@ def test_ntt_forced_variants(emu):
 
     ctx = get_context()
     try:
-        for kind in (1, 2, 3):
+        for kind in (1, 2, 3, 5):
             check(ctx.L.plonk_ntt_select_kernel(ctx.handle, kind))
             check(ctx.L.plonk_ntt_configure(ctx.handle, 0, 0, 0))
             pc.ntt_vs_oracle([0, 1, 2, 3, 4, 5, 6, 7, 9, 11, 12, 13], seed0=10 * kind)
@@ -45,6 +45,10 @@ def test_ntt_forced_variants(emu):
 
 def test_ntt_properties(emu):
     pc.ntt_roundtrip_and_linearity(12)
+
+
+def test_ntt_extreme_inputs(emu):
+    pc.ntt_extreme_inputs((9, 11, 13))
 
 
 def test_poly_golden(emu):

@@ -50,7 +50,7 @@ def test_ntt_forced_variants():
 
     ctx = get_context()
     try:
-        for kind in (1, 2, 3):
+        for kind in (1, 2, 3, 5):
             check(ctx.L.plonk_ntt_select_kernel(ctx.handle, kind))
             check(ctx.L.plonk_ntt_configure(ctx.handle, 0, 0, 0))
             pc.ntt_vs_oracle([0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 16], seed0=10 * kind)
@@ -60,6 +60,10 @@ def test_ntt_forced_variants():
     finally:
         check(ctx.L.plonk_ntt_configure(ctx.handle, 0, 0, 0))
         check(ctx.L.plonk_ntt_select_kernel(ctx.handle, 0))
+
+
+def test_ntt_extreme_inputs():
+    pc.ntt_extreme_inputs((9, 11, 13, 16))
 
 
 @pytest.mark.parametrize("log_n", [18, 20, 22, 24])
@@ -472,8 +476,9 @@ def test_full_size_lookup_table_on_an_explicit_budget():
 
 
 @pytest.mark.gpu
-def test_wave_kernel_two_pass_splits_and_batches():
-    """The wave kernel forced (kind 3) on the splits the dispatcher does not pick by itself: 2^24 = 2^13 x 2^11 (properties),
+@pytest.mark.parametrize("wave_kind", [3, 5])
+def test_wave_kernel_two_pass_splits_and_batches(wave_kind):
+    """The wave kernels forced (kind 3: packed residues, kind 5: signed limbs) on the splits the dispatcher does not pick by itself: 2^24 = 2^13 x 2^11 (properties),
     and a batch of three 2^18 transforms in one call, exact against the C oracle."""
     import ctypes
 
@@ -483,7 +488,7 @@ def test_wave_kernel_two_pass_splits_and_batches():
 
     ctx = get_context()
     try:
-        check(ctx.L.plonk_ntt_select_kernel(ctx.handle, 3))
+        check(ctx.L.plonk_ntt_select_kernel(ctx.handle, wave_kind))
         pc.ntt_roundtrip_and_linearity(24, seed=31)
         n = 1 << 18
         vecs = [pc.rand_vec(70 + i, n) for i in range(3)]

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""NTT microbench per kernel kind (0 auto, 1 radix-2 stages, 2 Stockham, 3 wave): ms and G elem/s at several shapes."""
+"""NTT microbench per kernel kind (0 auto, 1 radix-2 stages, 2 Stockham, 3 wave on packed residues, 5 wave on signed
+limbs): ms and G elem/s at several shapes.  NTT_KINDS=3,5 selects the kinds."""
 import json, os, random, sys
 REPO = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 sys.path.insert(0, REPO)
@@ -14,9 +15,9 @@ def fill(n):
     for off in range(0, n, per):
         check(L.plonk_mem_d2d(H, buf.at(off), src.ptr, 32 * min(per, n - off)))
     return buf
-shapes = [(9, 4096), (11, 512), (11, 2048), (13, 512), (13, 2048), (18, 16), (20, 8), (22, 1)]
+shapes = [(9, 4096), (11, 512), (11, 2048), (13, 512), (13, 2048), (18, 1), (18, 16), (20, 1), (20, 8), (22, 1)]
 out = {}
-for kind in (3,):
+for kind in [int(k) for k in os.environ.get('NTT_KINDS', '3,5').split(',')]:
     check(L.plonk_ntt_select_kernel(H, kind))
     for log_n, batch in shapes:
         n = 1 << log_n
