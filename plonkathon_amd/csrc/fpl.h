@@ -25,6 +25,54 @@ struct FpL {
     int32_t l[9];
 };
 
+// Range checks of the emulator build (tests/emu, -DPLONK_EMU: the same sources compiled for the host by the CPU test-suite):
+// every operation below asserts the operand bounds its header documents — no int32 limb overflow, column sums inside 64
+// bits, |a||b| <= 128 m^2 — on the data the emulated kernels actually see (random, golden and adversarial inputs of the NTT,
+// MSM and prover tests).  They compile to nothing in the product.
+#ifdef PLONK_EMU
+#include <stdio.h>
+#include <stdlib.h>
+#define FPL_CHECK(cond, what)                                                       \
+    do {                                                                            \
+        if (!(cond)) {                                                              \
+            fprintf(stderr, "fpl.h range check failed: %s (%s:%d)\n", what, __FILE__, __LINE__); \
+            abort();                                                                \
+        }                                                                           \
+    } while (0)
+template <class L> inline long double fpl_dbg_value(const L& a) {  // ~ value / 2^232 (good to 64 bits: enough for bounds)
+    long double v = 0;
+    for (int i = 8; i >= 0; i--) v = v * 536870912.0L + (long double)a.l[i];
+    return v;
+}
+template <class L> inline long long fpl_dbg_maxlimb(const L& a) {
+    long long m = 0;
+    for (int i = 0; i < 9; i++) {
+        long long v = a.l[i] < 0 ? -(long long)a.l[i] : (long long)a.l[i];
+        if (v > m) m = v;
+    }
+    return m;
+}
+template <class P, class L> inline void fpl_dbg_check_product(const L& a, const L& b, const L* c, const L* d) {
+    // column sums: 9 products per pair of operands + 9 reduction products < 2^58 + carries, inside (-2^63, 2^63)
+    long double col = 9.0L * (long double)fpl_dbg_maxlimb(a) * (long double)fpl_dbg_maxlimb(b) + 9.0L * 288230376151711744.0L + 1099511627776.0L;
+    long double mm = 0;
+    for (int i = 8; i >= 0; i--) mm = mm * 536870912.0L + (long double)fp29_mod_limb<P>(i);
+    long double val = fabsl(fpl_dbg_value(a)) * fabsl(fpl_dbg_value(b));
+    if (c) {
+        col += 9.0L * (long double)fpl_dbg_maxlimb(*c) * (long double)fpl_dbg_maxlimb(*d);
+        val += fabsl(fpl_dbg_value(*c)) * fabsl(fpl_dbg_value(*d));
+    }
+    if (!(col < 9223372036854775808.0L))
+        fprintf(stderr, "fpl.h: max |limb| a %lld b %lld c %lld d %lld\n", fpl_dbg_maxlimb(a), fpl_dbg_maxlimb(b), c ? fpl_dbg_maxlimb(*c) : 0LL, d ? fpl_dbg_maxlimb(*d) : 0LL);
+    FPL_CHECK(col < 9223372036854775808.0L, "column sum of a product exceeds 64 bits");
+    FPL_CHECK(val <= 128.0L * mm * mm, "|a||b| exceeds 128 m^2");
+}
+#define FPL_CHECK_I32(expr64, what) FPL_CHECK((expr64) >= -2147483648LL && (expr64) <= 2147483647LL, what)
+#else
+#define FPL_CHECK(cond, what) ((void)0)
+#define FPL_CHECK_I32(expr64, what) ((void)0)
+#endif
+
 // Hides from the compiler that a limb is known to be non-negative.  Without it LLVM multiplies a signed limb by a
 // masked one as sext x zext — a v_mad_u64_u32 plus a correction v_mad_u64_u32 with the sign mask — instead of one
 // v_mad_i64_i32 (24 extra multiplier instructions and 48 moves per mixed addition when measured).  No instruction.
@@ -77,14 +125,20 @@ template <class P> PLONK_HD FpL<P> fpl_zero() {
 template <class P> PLONK_HD FpL<P> fpl_add(const FpL<P>& a, const FpL<P>& b) {
     FpL<P> r;
 #pragma unroll
-    for (int i = 0; i < 9; i++) r.l[i] = a.l[i] + b.l[i];
+    for (int i = 0; i < 9; i++) {
+        FPL_CHECK_I32((long long)a.l[i] + b.l[i], "fpl_add overflows a limb");
+        r.l[i] = a.l[i] + b.l[i];
+    }
     return r;
 }
 
 template <class P> PLONK_HD FpL<P> fpl_sub(const FpL<P>& a, const FpL<P>& b) {
     FpL<P> r;
 #pragma unroll
-    for (int i = 0; i < 9; i++) r.l[i] = a.l[i] - b.l[i];
+    for (int i = 0; i < 9; i++) {
+        FPL_CHECK_I32((long long)a.l[i] - b.l[i], "fpl_sub overflows a limb");
+        r.l[i] = a.l[i] - b.l[i];
+    }
     return r;
 }
 
@@ -110,16 +164,21 @@ template <class P> PLONK_HD FpL<P> fpl_norm(const FpL<P>& a) {
     int32_t carry = 0;
 #pragma unroll
     for (int i = 0; i < 8; i++) {
+        FPL_CHECK_I32((long long)a.l[i] + carry, "fpl_norm overflows a limb");
         const int32_t v = a.l[i] + carry;
         r.l[i] = v & (int32_t)FP29_MASK;
         FPL_ANY_SIGN(r.l[i]);
         carry = v >> 29;  // arithmetic: floor division
     }
+    FPL_CHECK_I32((long long)a.l[8] + carry, "fpl_norm overflows the top limb");
     r.l[8] = a.l[8] + carry;
     return r;
 }
 
 template <class P> PLONK_HD FpL<P> fpl_mul(const FpL<P>& a, const FpL<P>& b) {
+#ifdef PLONK_EMU
+    fpl_dbg_check_product<P>(a, b, (const FpL<P>*)nullptr, (const FpL<P>*)nullptr);
+#endif
     const uint32_t ninv = P::NINV & FP29_MASK;
     uint32_t q[9];
     FpL<P> r;
@@ -166,6 +225,9 @@ template <class P> PLONK_HD FpL<P> fpl_mul(const FpL<P>& a, const FpL<P>& b) {
 // 2 x 171.  All four operands with limbs within (-2^29, 2^29): a column holds at most 18 products below 2^58 plus 9
 // reduction products, inside 64 bits.  Returns a normalised value in (-m, 2m).
 template <class P> PLONK_HD FpL<P> fpl_mul_add(const FpL<P>& a, const FpL<P>& b, const FpL<P>& c, const FpL<P>& d) {
+#ifdef PLONK_EMU
+    fpl_dbg_check_product<P>(a, b, &c, &d);
+#endif
     const uint32_t ninv = P::NINV & FP29_MASK;
     uint32_t q[9];
     FpL<P> r;
@@ -220,6 +282,9 @@ template <class P> PLONK_HD FpL<P> fpl_mul_add(const FpL<P>& a, const FpL<P>& b,
 
 // limbs within (-2^29, 2^29)
 template <class P> PLONK_HD FpL<P> fpl_sqr(const FpL<P>& a) {
+#ifdef PLONK_EMU
+    fpl_dbg_check_product<P>(a, a, (const FpL<P>*)nullptr, (const FpL<P>*)nullptr);
+#endif
     const uint32_t ninv = P::NINV & FP29_MASK;
     uint32_t q[9];
     int32_t a2[9];
@@ -288,8 +353,13 @@ template <class P> PLONK_HD constexpr int32_t fpl_km_limb(unsigned k, int i) {
 template <class P, unsigned K> PLONK_HD FpL<P> fpl_add_km_norm(const FpL<P>& a) {
     FpL<P> t;
 #pragma unroll
-    for (int i = 0; i < 9; i++) t.l[i] = a.l[i] + fpl_km_limb<P>(K, i);
-    return fpl_norm(t);
+    for (int i = 0; i < 9; i++) {
+        FPL_CHECK_I32((long long)a.l[i] + fpl_km_limb<P>(K, i), "fpl_add_km_norm overflows a limb");
+        t.l[i] = a.l[i] + fpl_km_limb<P>(K, i);
+    }
+    const FpL<P> r = fpl_norm(t);
+    FPL_CHECK(r.l[8] >= 0, "fpl_add_km_norm: the value was below -K m");
+    return r;
 }
 
 // any value within (-128 m, 128 m) (limbs within (-2^30, 2^30)) -> canonical packed element
@@ -331,6 +401,7 @@ template <class P> PLONK_HD bool fpl_is_zero_mod(const FpL<P>& a) {
 template <class P> PLONK_HD FpL<P> fpl_reduce_small(const FpL<P>& x, const int32_t* jm) {
     constexpr float inv_top = 1.0f / (float)(P::mod(7) >> 8);  // m >> 232
     int j = (int)rintf((float)x.l[8] * inv_top);
+    FPL_CHECK(j > -FPL_RS_J && j < FPL_RS_J, "fpl_reduce_small: |value| beyond the table");
     j = j < -FPL_RS_J ? -FPL_RS_J : (j > FPL_RS_J ? FPL_RS_J : j);  // (memory safety only: the bound above keeps |j| <= FPL_RS_J - 1)
     const int32_t* t = jm + (j + FPL_RS_J) * 12;
     const u32x4 t0 = *reinterpret_cast<const u32x4*>(t), t1 = *reinterpret_cast<const u32x4*>(t + 4);
@@ -339,6 +410,15 @@ template <class P> PLONK_HD FpL<P> fpl_reduce_small(const FpL<P>& x, const int32
     r.l[0] = x.l[0] - (int32_t)t0.x; r.l[1] = x.l[1] - (int32_t)t0.y; r.l[2] = x.l[2] - (int32_t)t0.z; r.l[3] = x.l[3] - (int32_t)t0.w;
     r.l[4] = x.l[4] - (int32_t)t1.x; r.l[5] = x.l[5] - (int32_t)t1.y; r.l[6] = x.l[6] - (int32_t)t1.z; r.l[7] = x.l[7] - (int32_t)t1.w;
     r.l[8] = x.l[8] - t8;
+#ifdef PLONK_EMU
+    {
+        const int32_t tt[9] = {(int32_t)t0.x, (int32_t)t0.y, (int32_t)t0.z, (int32_t)t0.w, (int32_t)t1.x, (int32_t)t1.y, (int32_t)t1.z, (int32_t)t1.w, t8};
+        for (int i = 0; i < 9; i++) FPL_CHECK_I32((long long)x.l[i] - tt[i], "fpl_reduce_small overflows a limb");
+        long double mm = 0;
+        for (int i = 8; i >= 0; i--) mm = mm * 536870912.0L + (long double)fp29_mod_limb<P>(i);
+        FPL_CHECK(fabsl(fpl_dbg_value(r)) < 0.51L * mm, "fpl_reduce_small: result outside (-0.51 m, 0.51 m)");
+    }
+#endif
     return fpl_norm(r);
 }
 

@@ -193,7 +193,7 @@ PLONK_HD bool g1l_madd_fast(G1XyzzL& p, const Fq& x2p, const Fq& y2p, bool neg_y
     const FqL x2 = fpl_from_fp(x2p), y2 = fpl_cneg(fpl_from_fp(y2p), neg_y);   // y2 in (-m, m)
     if (p.inf) {
         p.x = x2;
-        p.y = y2;
+        p.y = fpl_norm(y2);  // a negated y2 has limbs in (-2^29, 0]: the invariant wants them normalised (R = S2 - Y1 is squared)
         p.zz = fpl_one<FqParams>();
         p.zzz = p.zz;
         p.inf = false;
@@ -243,6 +243,7 @@ template <unsigned K> PLONK_HD void fpl_pack_lt4m(const FqL& a, uint32_t out[8])
             for (int i = 0; i < 9; i++) w[i] = s[i];
         }
     }
+    FPL_CHECK(w[8] == 0, "fpl_pack_lt4m: the piece does not fit 256 bits");
 #pragma unroll
     for (int i = 0; i < 8; i++) out[i] = w[i];
 }

@@ -110,7 +110,10 @@ def test_lazy_accumulator_chain(probe):
         assert run(pts, negs) == ref(pts, negs)
     G = P[0]
     for pts, negs in (([G, G], [0, 0]), ([G, G], [0, 1]), ([G, G, P[1]], [0, 1, 0]), ([G] * 5, [0] * 5),
-                      ([P[3], P[4], P[3], P[4]], [0, 0, 1, 1]), ([P[5]] * 9, [0] * 9), ([None, G, None], [0, 0, 0])):
+                      ([P[3], P[4], P[3], P[4]], [0, 0, 1, 1]), ([P[5]] * 9, [0] * 9), ([None, G, None], [0, 0, 0]),
+                      # a negated point into the empty accumulator, then additions: R = S2 - Y1 with Y1 = -y (the emulator
+                      # build's range checks in fpl.h abort if Y1 is left un-normalised)
+                      ([G, P[1], P[2]], [1, 0, 1]), ([P[7], P[8], P[9], P[10]], [1, 1, 0, 0]), ([None, P[6], P[5]], [0, 1, 0])):
         assert run(pts, negs) == ref(pts, negs)
 
 
