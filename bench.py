@@ -332,14 +332,15 @@ def main():
         c.profile_reset()
         c.profile(True)
     barrier()
-    sampler = ClockSampler(local_rank)
-    sampler.start()
+    sampler = ClockSampler(local_rank) if rank == 0 else None  # one sampler per job: rank 0's GPU
+    if sampler:
+        sampler.start()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         proofs = step()
     barrier()
     elapsed = D.max_over_ranks(time.perf_counter() - t0, comm)
-    clocks = sampler.summary()
+    clocks = sampler.summary() if sampler else None
     for c in ctxs:
         c.profile(False)
 
