@@ -51,3 +51,30 @@ def test_launched_by_torch_distributed_run(emu_cdll):
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["config"]["ranks_in_communicator"] == 2 and line["config"]["gather_in_timed_region"]
+
+
+def test_clock_sampler_parses_rocm_smi_text():
+    """The sampler's regular expressions on rocm-smi's own layout (two GPUs listed; only the asked index is read)."""
+    sys.path.insert(0, REPO)
+    import bench
+
+    text = """
+============================ ROCm System Management Interface ============================
+====================================== Current clock frequencies ======================================
+GPU[0]		: fclk clock level: 0: (1250Mhz)
+GPU[0]		: mclk clock level: 3: (2000Mhz)
+GPU[0]		: sclk clock level: 1: (2077Mhz)
+GPU[0]		: socclk clock level: 0: (28Mhz)
+GPU[1]		: sclk clock level: S: (95Mhz)
+=================================== Power Consumption ====================================
+GPU[0]		: Current Socket Graphics Package Power (W): 1141.0
+GPU[1]		: Current Socket Graphics Package Power (W): 234.0
+"""
+    f = [(int(m.group(1)), int(m.group(2))) for m in bench.ClockSampler.SCLK.finditer(text)]
+    w = [(int(m.group(1)), float(m.group(2))) for m in bench.ClockSampler.POWER.finditer(text)]
+    assert f == [(0, 2077), (1, 95)] and w == [(0, 1141.0), (1, 234.0)]
+    s = bench.ClockSampler(0)
+    s.samples = [(2077, 1141.0), (2050, 1200.0), (2404, None)]
+    out = s.summary()
+    assert out["sclk_mhz_median"] == 2077 and out["sclk_mhz_min"] == 2050 and out["socket_power_w_median"] == 1200.0
+    assert bench.ClockSampler(0).summary() is None  # nothing sampled (no rocm-smi): the bench line carries null
