@@ -259,8 +259,8 @@ __global__ void __launch_bounds__(MSM_BLOCK, MSM_ACC_WAVES) msm_accumulate_kerne
     }
     unsigned k = a;
     G1Xyzz* out = pieces + (size_t)m * piece_stride + t - 1;  // out[k] = slot t + k - 1
-    // Accumulator kept as 9 x 29-bit limbs with lazy reductions (fpl.h / g1l_madd_fast): the same 1548
-    // multiplier instructions per mixed addition as the packed canonical form but ~2x fewer of everything
+    // Accumulator kept as 9 signed 29-bit limbs with lazy reductions (fpl.h / g1l_madd_fast): the same ~1550
+    // multiplier instructions per mixed addition as the packed canonical form but ~3x fewer of everything
     // else.  The rare steps the fast formulas cannot take (the accumulator equals +-the table point, i.e.
     // duplicate bases) are not resolved here — a call or an inlined general addition in this loop costs
     // 25 % of its speed — they are appended to the MSM's deferred list with their bucket, and
@@ -377,7 +377,7 @@ __global__ void __launch_bounds__(256) msm_bucket_reduce_kernel(const uint32_t* 
 //     L[w][i][d] = d * 2^(c w) * P_i,   d = 1 .. 2^(c-1)      (128.8 GB at c = 17, 68.7 GB at c = 16)
 // so that an MSM is just N * ceil(255 / c) mixed additions of looked-up points (30 720 at c = 17 against
 // 53 248 sorted bucket additions plus the bucket reduction): 64 random bytes from HBM per addition — the chip
-// sustains 20 G such reads/s (tools/ubench/gather.hip) against the 13.5 G additions/s its ALUs can do.
+// sustains 20 G such reads/s (tools/ubench/gather.hip) against the 16-19 G additions/s its ALUs can do.
 // Signed digits as in the bucket method; a lane walks a flat range of (scalar, window) items.
 
 // tmp[i * half + d - 1] = d * wbase[w * n + i] for one window w, XYZZ (converted by g1_batch_to_affine_kernel)
