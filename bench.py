@@ -109,6 +109,30 @@ def cpu_baseline():
     prim["ec_lincomb_2^11_s"] = best_of(lambda: ec_lincomb(list(zip(pts, scal))))[0]
     prim["samples"] = 3
     prim["note"] = "best of 3; oracle/fr_poly.py (poly.py:113-148 restated) and oracle/g1.py (curve.py:38-111 restated), 1 core"
+    # the same primitives by the oracle's C restatement (oracle/c/bn254_oracle.c: 4 x 64-bit Montgomery limbs, one core,
+    # gcc -O2): what a compiled single-threaded CPU implementation of the reference's algorithms does — a fairer
+    # yardstick for the kernels than pure Python.  Only the C call is timed, not the marshalling of Python ints.
+    try:
+        import ctypes
+
+        from oracle import c_oracle
+
+        L = c_oracle.lib()
+        cprim = {}
+        for log_n in (11, 13, 16, 20):
+            n = 1 << log_n
+            raw = b"".join(rng.randrange(R_MOD).to_bytes(32, "little") for _ in range(min(n, 4096))) * (n // min(n, 4096))
+            buf = (ctypes.c_uint64 * (4 * n)).from_buffer_copy(raw)
+            cprim["ntt_2^%d_ms" % log_n] = 1e3 * best_of(lambda: L.oracle_fr_ntt(buf, ctypes.c_uint(log_n), ctypes.c_int(0)))[0]
+        pb = (ctypes.c_uint64 * (8 * GROUP_ORDER)).from_buffer_copy(
+            b"".join(int(p[0]).to_bytes(32, "little") + int(p[1]).to_bytes(32, "little") for p in pts))
+        sb = (ctypes.c_uint64 * (4 * GROUP_ORDER)).from_buffer_copy(b"".join(int(x).to_bytes(32, "little") for x in scal))
+        out, ident = (ctypes.c_uint64 * 8)(), ctypes.c_int(0)
+        cprim["g1_lincomb_2^11_ms"] = 1e3 * best_of(lambda: L.oracle_g1_lincomb(pb, sb, ctypes.c_size_t(GROUP_ORDER), out, ctypes.byref(ident)))[0]
+        cprim["note"] = "oracle/c (C restatement of poly.py:113-148 and curve.py:38-111), 1 core, best of 3, C call only"
+        prim["c"] = cprim
+    except Exception as exc:  # the C oracle is optional test infrastructure: the Python figures above stand on their own
+        prim["c"] = {"error": repr(exc)}
     return dt, proof, prim
 
 
@@ -580,6 +604,11 @@ def main():
         if "ntt" in line:
             line["cpu_baseline"]["gpu_speedup_fft_2^11"] = prim["fft_2^11_ms"] / (line["ntt"]["ms_2^11_x512"] / 512)
             line["cpu_baseline"]["gpu_speedup_ec_lincomb_2^11"] = prim["ec_lincomb_2^11_s"] * 1e3 / (line["msm"]["ms_4608"] / 4608)
+            cp = prim.get("c", {})
+            if "ntt_2^11_ms" in cp:  # against the compiled single-core restatement
+                line["cpu_baseline"]["gpu_speedup_vs_c_ntt_2^11"] = cp["ntt_2^11_ms"] / (line["ntt"]["ms_2^11_x512"] / 512)
+                line["cpu_baseline"]["gpu_speedup_vs_c_ntt_2^20"] = cp["ntt_2^20_ms"] / line["ntt"]["ms_2^20"]
+                line["cpu_baseline"]["gpu_speedup_vs_c_g1_lincomb_2^11"] = cp["g1_lincomb_2^11_ms"] / (line["msm"]["ms_4608"] / 4608)
     if rank == 0:
         print(json.dumps(line), flush=True)
     if comm is not None:
