@@ -57,6 +57,25 @@ def ntt_extreme_inputs(log_ns):
             assert ints(P(v, Basis.LAGRANGE).ifft()) == fft_ints(v, True), ("ifft", name, log_n)
 
 
+def ntt_extreme_limbs(log_ns):
+    """Inputs whose MONTGOMERY representation (what the kernels hold: x * 2^261 mod r, as 29-bit limbs) has every limb at
+    its maximum 2^29 - 1, laid out over the eight register slots of the wave kernels' first butterfly in the patterns
+    that maximise its sums and differences.  With the emulator build the range checks of fpl.h run on exactly these."""
+    m = R_MOD
+    r_inv = pow(1 << 261, -1, m)
+    top = (m >> 232) - 1
+    max_mont = (top << 232) | ((1 << 232) - 1)          # < m, limbs 0..7 all 2^29 - 1
+    hi, lo = max_mont * r_inv % m, 0                    # the canonical values that upload to those representations
+    for log_n in log_ns:
+        n = 1 << log_n
+        nt = n // 8                                     # element j * nt + tid sits in register slot j of thread tid
+        for name, slots in (("all", 0xFF), ("low_half", 0x0F), ("high_half", 0xF0), ("even", 0x55), ("odd", 0xAA),
+                            ("pairs", 0x33), ("one", 0x01), ("seven", 0xFE)):
+            v = [hi if (slots >> (i // nt)) & 1 else lo for i in range(n)]
+            assert ints(P(v, Basis.MONOMIAL).fft()) == fft_ints(v), ("fft", name, log_n)
+            assert ints(P(v, Basis.LAGRANGE).ifft()) == fft_ints(v, True), ("ifft", name, log_n)
+
+
 def ntt_roundtrip_and_linearity(log_n, seed=5):
     """Size-independent properties for sizes the oracle does not reach in seconds."""
     n = 1 << log_n

@@ -49,6 +49,7 @@ def test_ntt_properties(emu):
 
 def test_ntt_extreme_inputs(emu):
     pc.ntt_extreme_inputs((9, 11, 13))
+    pc.ntt_extreme_limbs((9, 11))
 
 
 def test_poly_golden(emu):

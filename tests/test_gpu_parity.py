@@ -64,6 +64,7 @@ def test_ntt_forced_variants():
 
 def test_ntt_extreme_inputs():
     pc.ntt_extreme_inputs((9, 11, 13, 16))
+    pc.ntt_extreme_limbs((9, 11, 13))
 
 
 @pytest.mark.parametrize("log_n", [18, 20, 22, 24])
