@@ -109,9 +109,9 @@ def cpu_baseline():
     prim["ec_lincomb_2^11_s"] = best_of(lambda: ec_lincomb(list(zip(pts, scal))))[0]
     prim["samples"] = 3
     prim["note"] = "best of 3; oracle/fr_poly.py (poly.py:113-148 restated) and oracle/g1.py (curve.py:38-111 restated), 1 core"
-    # the same primitives by the oracle's C restatement (oracle/c/bn254_oracle.c: 4 x 64-bit Montgomery limbs, one core,
-    # gcc -O2): what a compiled single-threaded CPU implementation of the reference's algorithms does — a fairer
-    # yardstick for the kernels than pure Python.  Only the C call is timed, not the marshalling of Python ints.
+    # the same primitives by the oracle's C half (oracle/c/bn254_oracle.c: iterative in-place NTT, Jacobian double-and-add,
+    # 4 x 64-bit Montgomery limbs, one core, gcc -O2): what a plain compiled single-threaded CPU implementation does — a
+    # fairer yardstick for the kernels than pure Python.  Only the C call is timed, not the marshalling of Python ints.
     try:
         import ctypes
 
@@ -129,7 +129,7 @@ def cpu_baseline():
         sb = (ctypes.c_uint64 * (4 * GROUP_ORDER)).from_buffer_copy(b"".join(int(x).to_bytes(32, "little") for x in scal))
         out, ident = (ctypes.c_uint64 * 8)(), ctypes.c_int(0)
         cprim["g1_lincomb_2^11_ms"] = 1e3 * best_of(lambda: L.oracle_g1_lincomb(pb, sb, ctypes.c_size_t(GROUP_ORDER), out, ctypes.byref(ident)))[0]
-        cprim["note"] = "oracle/c (C restatement of poly.py:113-148 and curve.py:38-111), 1 core, best of 3, C call only"
+        cprim["note"] = "oracle/c (iterative in-place NTT, Jacobian double-and-add; same results as poly.py:113-148 / curve.py:38-111), 1 core, best of 3, C call only"
         prim["c"] = cprim
     except Exception as exc:  # the C oracle is optional test infrastructure: the Python figures above stand on their own
         prim["c"] = {"error": repr(exc)}
