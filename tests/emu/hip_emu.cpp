@@ -78,9 +78,11 @@ void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& bo
             g_fibers[t].stack = mmap(nullptr, kStack, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
             if (g_fibers[t].stack == MAP_FAILED) { perror("hipemu mmap"); abort(); }
         }
-    static std::vector<unsigned char> smem;
-    if (smem.size() < shmem + 64) smem.resize(shmem + 64);
-    g_dyn_smem = (unsigned char*)(((uintptr_t)smem.data() + 63) & ~(uintptr_t)63);
+    // dynamic LDS: a fresh allocation of EXACTLY the launch's size, so that the AddressSanitizer build (make asan) sees a
+    // kernel that indexes past the LDS it asked for
+    void* smem = nullptr;
+    if (posix_memalign(&smem, 64, shmem ? shmem : 1) != 0) { perror("hipemu posix_memalign"); abort(); }
+    g_dyn_smem = (unsigned char*)smem;
     g_blockDim = block;
     g_gridDim = grid;
     g_nthreads = nthreads;
@@ -117,6 +119,8 @@ void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& bo
             }
     g_cur = -1;
     g_body = nullptr;
+    g_dyn_smem = nullptr;
+    free(smem);
 }
 }  // namespace hipemu
 
