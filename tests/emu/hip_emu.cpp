@@ -103,9 +103,27 @@ void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& bo
                     makecontext(&f.ctx, fiber_entry, 0);
                 }
                 int alive = nthreads;
+                // Scheduling order of the fibres between synchronisation points.  Any order is a legal GPU schedule for
+                // code that only communicates through barriers, wave-level primitives and atomics, so a result that
+                // changes under PLONK_EMU_SCHED=reverse (or random:<seed>) means a missing barrier / a race.
+                static const char* sched_env = getenv("PLONK_EMU_SCHED");
+                static unsigned sched_rng = sched_env && !strncmp(sched_env, "random", 6) ? (unsigned)atoi(sched_env + (sched_env[6] ? 7 : 6)) * 2654435761u + 12345u : 0u;
+                static bool sched_said = false;
+                if (sched_env && !sched_said) {
+                    fprintf(stderr, "hipemu: fibre schedule = %s\n", sched_env);
+                    sched_said = true;
+                }
+                std::vector<int> order(nthreads);
+                for (int t = 0; t < nthreads; t++) order[t] = sched_env && !strcmp(sched_env, "reverse") ? nthreads - 1 - t : t;
                 while (alive > 0) {
                     int progressed = 0;
-                    for (int t = 0; t < nthreads; t++) {
+                    if (sched_rng)
+                        for (int t = nthreads - 1; t > 0; t--) {
+                            sched_rng = sched_rng * 1664525u + 1013904223u;
+                            std::swap(order[t], order[(sched_rng >> 8) % (unsigned)(t + 1)]);
+                        }
+                    for (int ti = 0; ti < nthreads; ti++) {
+                        const int t = order[ti];
                         Fiber& f = g_fibers[t];
                         if (f.done) continue;
                         g_cur = t;
