@@ -43,3 +43,35 @@ def test_pack_dicts_le32_orders_by_key_and_reports_missing_keys():
     with pytest.raises(KeyError):
         _pypack.pack_dicts_le32([{"a": 1}], ["a", "zz"], R_MOD)
     assert _pypack.pack_dicts_le32([], keys, R_MOD) == b""
+
+
+def test_pack_dicts_le32_walk_shortcut_never_changes_the_result():
+    """Dictionaries that share keys and order take the walking shortcut; every deviation must fall back to look-ups."""
+    rng = random.Random(8)
+    keys = ["v%d" % i for i in range(40)]
+
+    def ref(ws):
+        return b"".join(want(w[k]) for w in ws for k in keys)
+
+    same = [{k: rng.randrange(R_MOD) for k in keys} for _ in range(5)]
+    assert _pypack.pack_dicts_le32(same, keys, R_MOD) == ref(same)
+    # the dictionaries list the keys in another order than `keys`, with keys the circuit does not use in between
+    order = keys[::-1]
+    extra = [dict([("unused", 1)] + [(k, rng.randrange(R_MOD)) for k in order] + [("tail", 2)]) for _ in range(4)]
+    assert _pypack.pack_dicts_le32(extra, keys, R_MOD) == ref(extra)
+    # deviations inside the batch: other order, other size, equal-but-distinct key objects, values off the fast path
+    odd = [dict(same[0]),
+           {k: rng.randrange(R_MOD) for k in order},                       # same keys, other order
+           dict({k: rng.randrange(R_MOD) for k in keys}, more=3),           # one key more
+           {"".join(list(k)): rng.randrange(R_MOD) for k in keys},          # equal strings, new objects
+           {k: (-5 if i == 7 else R_MOD + 9 if i == 8 else Wrapped(11) if i == 9 else rng.randrange(R_MOD)) for i, k in enumerate(keys)},
+           {k: 2**300 + i for i, k in enumerate(keys)}]
+    assert _pypack.pack_dicts_le32(odd, keys, R_MOD) == ref(odd)
+    # a later dictionary that lacks a key raises KeyError(key) whatever the first one looked like
+    broken = [dict(same[0]), {k: 1 for k in keys[:-1]}]
+    with pytest.raises(KeyError):
+        _pypack.pack_dicts_le32(broken, keys, R_MOD)
+    with pytest.raises(KeyError):
+        _pypack.pack_dicts_le32([{k: 1 for k in keys[1:]}, dict(same[0])], keys, R_MOD)
+    # a key listed twice is served by the general path
+    assert _pypack.pack_dicts_le32(same, keys + keys[:3], R_MOD) == b"".join(want(w[k]) for w in same for k in keys + keys[:3])
