@@ -76,13 +76,16 @@ int plonk_fr_coset_to_coeffs(plonk_ctx* ctx, const void* d_in, void* d_out, unsi
 /* tuning / test knob (0 = default): LDS tile = 2^tile_log elements (<= 12), sizes <= 2^single_pass_log
  * (<= 11) run as one pass, larger sizes split into passes of radix <= 2^radix_log (<= 10). */
 int plonk_ntt_configure(plonk_ctx* ctx, unsigned tile_log, unsigned single_pass_log, unsigned radix_log);
-/* kernel family: 0 = auto (what measures fastest on MI355X: the in-register "wave" kernel — digits exchanged inside a
- * wave by DPP / ds_swizzle / v_permlane32_swap, LDS only across waves — for 2^9, 2^11, 2^13 and the two-pass sizes
- * built from them; Stockham radix-8 for other single-pass sizes; radix-2 stages otherwise), 1 = radix-2 stages,
- * 2 = Stockham radix-8, 3 = the wave kernel on packed [0, 2m) residues where it applies (round 2's first form, kept for
- * A/B measurements), 4 = auto without the wave kernels, 5 = the wave kernel on signed 29-bit limbs where it applies
- * (what auto uses) */
+/* kernel family: 0 = auto (what measures fastest on MI355X: the in-register "wave" kernels — 4 or 8 elements per
+ * thread as signed 29-bit limbs, digits exchanged inside a wave by DPP / v_permlane16_swap / v_permlane32_swap, LDS only
+ * across waves — for 2^8 .. 2^13 in one launch and 2^16 .. 2^26 as two passes of those; the LDS kernels elsewhere:
+ * Stockham radix-8 for single-pass sizes, radix-2 stages otherwise), 1 = radix-2 stages, 2 = Stockham radix-8,
+ * 4 = auto among the LDS kernels only (A/B runs), 5 = the wave kernels wherever they apply, whatever
+ * plonk_ntt_configure says.  (3, round 2's packed-residue wave kernel, is gone.) */
 int plonk_ntt_select_kernel(plonk_ctx* ctx, unsigned kind);
+/* two-pass wave transforms N = R1 R2 (R1-point column transforms, then R2-point row transforms): log2 R1 for one
+ * log2 N in [16, 26]; 0 = the default (as square as possible).  Both factors must lie in 2^8 .. 2^13.  A/B runs, tests. */
+int plonk_ntt_set_split(plonk_ctx* ctx, unsigned log_n, unsigned log_r1);
 /* Lower-level pieces used by the batched prover: coefficient form in, fixed offset table. */
 int plonk_fr_coset_ntt_from_coeffs(plonk_ctx* ctx, const void* d_coeffs, void* d_out, unsigned log_n,
                                    unsigned log_expand, const uint8_t offset_le32[32], size_t batch);
@@ -106,6 +109,30 @@ int plonk_fr_rotate(plonk_ctx* ctx, const void* d_in, void* d_out, size_t count,
 int plonk_fr_batch_inverse(plonk_ctx* ctx, const void* d_in, void* d_out, size_t count);
 int plonk_fr_barycentric(plonk_ctx* ctx, const void* d_vals, unsigned log_n, const uint8_t x_le32[32],
                          uint8_t out_le32[32]);
+
+/* plonk_fr_powers       out[k] = first * base^k, k < count: Scalar.roots_of_unity (curve.py:19-24), and the coset points
+ *                       X_big[k] = fft_cofactor * mu^k the prover divides by (prover.py:160-161, 271-283)
+ * plonk_fr_equal        the reference's `==` on two Polynomials (poly.py:20-21) and its `values[k:] == [0] * m` sanity
+ *                       checks (prover.py:205-208, 288, 299) on the device: *out_equal = (a == b elementwise), d_b NULL
+ *                       compares with zero; only the verdict crosses PCIe                                             */
+int plonk_fr_powers(plonk_ctx* ctx, const uint8_t first_le32[32], const uint8_t base_le32[32], size_t count, void* d_out);
+int plonk_fr_equal(plonk_ctx* ctx, const void* d_a, const void* d_b, size_t count, int* out_equal);
+
+/* ---- the fused round kernels on their own (what Prover.round_2 / round_3 of the reference-shaped API call) -----------
+ * plonk_fr_grand_product  prover.py:121-146: the permutation accumulator from the wire values A, B, C and the
+ *                       permutation polynomials S1, S2, S3 (Lagrange, 2^log_n each): Z_0 = 1, Z_{i+1} = Z_i num_i / den_i
+ *                       with num_i = (A_i + beta w^i + gamma)(B_i + 2 beta w^i + gamma)(C_i + 3 beta w^i + gamma),
+ *                       den_i = (A_i + beta S1_i + gamma)(..S2..)(..S3..); x / 0 == 0 as py_ecc.  Two block scans and
+ *                       one inversion instead of n.  *out_closes = 1 iff the product closes to 1 (prover.py:132).
+ * plonk_fr_quotient     prover.py:188-203: QUOT_big = (gate + alpha * permutation + alpha^2 (Z - 1) L0) / Z_H on the
+ *                       4n-point coset offset * mu^k, one fused pass.  d_evals = the coset extensions (fft_expand,
+ *                       4 * 2^log_n values each) of A, B, C, PI, Z, QL, QR, QM, QO, QC, S1, S2, S3, L0, in that order;
+ *                       Z(w x) is Z_big read 4 places ahead (prover.py:173), X_big and 1 / Z_H come from `offset`.      */
+int plonk_fr_grand_product(plonk_ctx* ctx, const void* d_a, const void* d_b, const void* d_c, const void* d_s1, const void* d_s2,
+                           const void* d_s3, unsigned log_n, const uint8_t beta_le32[32], const uint8_t gamma_le32[32],
+                           void* d_z_out, int* out_closes);
+int plonk_fr_quotient(plonk_ctx* ctx, unsigned log_n, const void* const d_evals[14], const uint8_t offset_le32[32],
+                      const uint8_t alpha_le32[32], const uint8_t beta_le32[32], const uint8_t gamma_le32[32], void* d_out);
 
 /* ---- G1 multi-scalar multiplication ------------------------------------------------------------
  * plonk_srs_load_ptau   Setup.from_file's G1 section, setup.py:29-41: `n_points` affine points, each

@@ -31,6 +31,17 @@ def fr_ntt(values, inverse=False):
     return [int.from_bytes(out[32 * i : 32 * i + 32], "little") for i in range(n)]
 
 
+def fr_ntt_bytes(raw, inverse=False):
+    """The same transform on canonical 32-byte little-endian elements back to back (sizes where Python ints are too slow)."""
+    n = len(raw) // 32
+    log_n = n.bit_length() - 1
+    assert 1 << log_n == n and len(raw) == 32 * n
+    buf = (ctypes.c_uint64 * (4 * n)).from_buffer_copy(raw)
+    rc = lib().oracle_fr_ntt(buf, ctypes.c_uint(log_n), ctypes.c_int(1 if inverse else 0))
+    assert rc == 0
+    return bytes(buf)
+
+
 def g1_lincomb(points, scalars):
     """curve.py:38-49 on affine int tuples (None = identity) and canonical scalars."""
     n = len(points)

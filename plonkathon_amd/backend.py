@@ -41,6 +41,21 @@ class Context:
             check(self.L.plonk_fr_upload(self.handle, buf.ptr, b"".join(int(v).to_bytes(32, "little") for v in ints), len(ints)))
         return buf
 
+    def upload_bytes(self, raw):
+        """`raw` = canonical 32-byte little-endian elements back to back (the C-ABI's host format)."""
+        assert len(raw) % 32 == 0
+        buf = DeviceBuffer(self, len(raw) // 32)
+        if raw:
+            check(self.L.plonk_fr_upload(self.handle, buf.ptr, bytes(raw), len(raw) // 32))
+        return buf
+
+    def download_bytes(self, buf, n=None, offset=0):
+        n = buf.n if n is None else n
+        out = ctypes.create_string_buffer(32 * max(n, 1))
+        if n:
+            check(self.L.plonk_fr_download(self.handle, out, ctypes.c_void_p(buf.ptr.value + 32 * offset), n))
+        return out.raw[: 32 * n]
+
     def download_ints(self, buf, n=None, offset=0):
         n = buf.n if n is None else n
         if n == 0:

@@ -14,11 +14,12 @@ void plonk_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+// No cache of our own: the integrator (or another library on this thread) may call hipSetDevice between two entry
+// points, so HIP's own per-thread record is the only one that can be trusted.  hipGetDevice is a thread-local read.
 int plonk_use_device(int device) {
-    static thread_local int current = -1;
-    if (current == device) return PLONK_OK;
+    int current = -1;
+    if (hipGetDevice(&current) == hipSuccess && current == device) return PLONK_OK;
     PLONK_CHECK_HIP(hipSetDevice(device));
-    current = device;
     return PLONK_OK;
 }
 
@@ -79,13 +80,13 @@ uint64_t plonk_fnv1a64(const void* data, size_t n) {
     return h;
 }
 
-static Fr fr_from_le32(const uint8_t* b) {
+Fr fr_from_le32(const uint8_t* b) {
     Fr a;
     memcpy(a.v, b, 32);
     return fp_to_mont(a);
 }
 
-static bool le32_below_modulus(const uint8_t* b, bool fq) {
+bool le32_below_modulus(const uint8_t* b, bool fq) {
     uint32_t v[8];
     memcpy(v, b, 32);
     for (int i = 7; i >= 0; i--) {
@@ -266,8 +267,18 @@ int plonk_ntt_configure(plonk_ctx* ctx, unsigned tile_log, unsigned single_pass_
 int plonk_ntt_select_kernel(plonk_ctx* ctx, unsigned kind) {
     PLONK_REQUIRE(ctx, PLONK_ERR_ARG, "ctx is NULL");
     PLONK_ENTER(ctx);
-    PLONK_REQUIRE(kind <= 5, PLONK_ERR_ARG, "kernel kind must be 0 (auto), 1 (radix-2 stages), 2 (Stockham radix-8), 3 (in-register wave kernel, packed residues), 4 (auto without the wave kernels) or 5 (in-register wave kernel, signed limbs)");
+    PLONK_REQUIRE(kind <= 5 && kind != 3, PLONK_ERR_ARG, "kernel kind must be 0 (auto), 1 (radix-2 stages), 2 (Stockham radix-8), 4 (auto among the LDS kernels) or 5 (in-register wave kernels wherever they apply)");
     ctx->ntt_kind = kind;
+    return PLONK_OK;
+}
+
+int plonk_ntt_set_split(plonk_ctx* ctx, unsigned log_n, unsigned log_r1) {
+    PLONK_REQUIRE(ctx, PLONK_ERR_ARG, "ctx is NULL");
+    PLONK_ENTER(ctx);
+    PLONK_REQUIRE(log_n >= 16 && log_n <= 26, PLONK_ERR_ARG, "two-pass wave transforms cover 2^16 .. 2^26 (got 2^%u)", log_n);
+    PLONK_REQUIRE(log_r1 == 0 || (log_r1 >= 8 && log_r1 <= 13 && log_n - log_r1 >= 8 && log_n - log_r1 <= 13), PLONK_ERR_ARG,
+                  "2^%u = 2^%u x 2^%u: both factors must lie in 2^8 .. 2^13", log_n, log_r1, log_n - log_r1);
+    ctx->ntt_split[log_n] = (unsigned char)log_r1;
     return PLONK_OK;
 }
 
@@ -291,7 +302,7 @@ int plonk_fr_ntt_dist_rows(plonk_ctx* ctx, const void* d_in, void* d_out, unsign
 }
 
 // power table first * base^i, i < n, cached per (base, first, n)
-static int get_power_table(plonk_ctx* ctx, const Fr& base, const Fr& first, size_t n, const Fr** out) {
+extern "C++" int get_power_table(plonk_ctx* ctx, const Fr& base, const Fr& first, size_t n, const Fr** out) {
     std::string key((const char*)base.v, 32);
     key.append((const char*)first.v, 32);
     key.append((const char*)&n, sizeof n);
@@ -394,6 +405,29 @@ int plonk_fr_batch_inverse(plonk_ctx* ctx, const void* d_in, void* d_out, size_t
     PLONK_REQUIRE(ctx && (count == 0 || (d_in && d_out)), PLONK_ERR_ARG, "bad argument");
     PLONK_ENTER(ctx);
     return k_fr_batch_inverse(ctx, (const Fr*)d_in, (Fr*)d_out, count);
+}
+
+int plonk_fr_powers(plonk_ctx* ctx, const uint8_t first_le32[32], const uint8_t base_le32[32], size_t count, void* d_out) {
+    PLONK_REQUIRE(ctx && first_le32 && base_le32 && (count == 0 || d_out), PLONK_ERR_ARG, "bad argument");
+    PLONK_ENTER(ctx);
+    PLONK_REQUIRE(le32_below_modulus(first_le32, false) && le32_below_modulus(base_le32, false), PLONK_ERR_ARG,
+                  "first / base is not a canonical Fr value");
+    return k_fr_powers(ctx, fr_from_le32(base_le32), fr_from_le32(first_le32), (Fr*)d_out, count);
+}
+
+int plonk_fr_equal(plonk_ctx* ctx, const void* d_a, const void* d_b, size_t count, int* out_equal) {
+    PLONK_REQUIRE(ctx && out_equal && (count == 0 || d_a), PLONK_ERR_ARG, "bad argument");
+    PLONK_ENTER(ctx);
+    *out_equal = 1;
+    if (!count) return PLONK_OK;
+    void* flag;
+    PLONK_TRY(ctx_scratch(ctx, 3, 64, &flag));
+    PLONK_TRY(k_fr_count_diff(ctx, (const Fr*)d_a, (const Fr*)d_b, count, (unsigned long long*)flag));
+    unsigned long long diff = 0;
+    PLONK_CHECK_HIP(hipMemcpyAsync(&diff, flag, sizeof diff, hipMemcpyDeviceToHost, ctx->stream));
+    PLONK_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    *out_equal = diff == 0;
+    return PLONK_OK;
 }
 
 int plonk_fr_barycentric(plonk_ctx* ctx, const void* d_vals, unsigned log_n, const uint8_t x_le32[32],

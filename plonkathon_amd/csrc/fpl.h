@@ -398,12 +398,14 @@ template <class P> PLONK_HD bool fpl_is_zero_mod(const FpL<P>& a) {
 // by limb; one carry sweep.  Result: normalised, value within (-0.51 m, 0.51 m).  ~41 instructions against ~235 for a
 // multiplication by one — what the butterfly outputs that carry no twiddle factor get in the limb-form NTT kernel.
 #define FPL_RS_J 24
-template <class P> PLONK_HD FpL<P> fpl_reduce_small(const FpL<P>& x, const int32_t* jm) {
+// BIAS = 1 subtracts (j - 1) m instead: the result lies within (0.49 m, 1.51 m) — what the last store wants, one
+// conditional subtraction away from canonical (fpl_pack_positive).
+template <class P, int BIAS = 0> PLONK_HD FpL<P> fpl_reduce_small(const FpL<P>& x, const int32_t* jm) {
     constexpr float inv_top = 1.0f / (float)(P::mod(7) >> 8);  // m >> 232
     int j = (int)rintf((float)x.l[8] * inv_top);
     FPL_CHECK(j > -FPL_RS_J && j < FPL_RS_J, "fpl_reduce_small: |value| beyond the table");
-    j = j < -FPL_RS_J ? -FPL_RS_J : (j > FPL_RS_J ? FPL_RS_J : j);  // (memory safety only: the bound above keeps |j| <= FPL_RS_J - 1)
-    const int32_t* t = jm + (j + FPL_RS_J) * 12;
+    j = j < -FPL_RS_J + BIAS ? -FPL_RS_J + BIAS : (j > FPL_RS_J ? FPL_RS_J : j);  // (memory safety only: the bound above keeps |j| <= FPL_RS_J - 1)
+    const int32_t* t = jm + (j + FPL_RS_J - BIAS) * 12;
     const u32x4 t0 = *reinterpret_cast<const u32x4*>(t), t1 = *reinterpret_cast<const u32x4*>(t + 4);
     const int32_t t8 = t[8];
     FpL<P> r;
@@ -416,7 +418,7 @@ template <class P> PLONK_HD FpL<P> fpl_reduce_small(const FpL<P>& x, const int32
         for (int i = 0; i < 9; i++) FPL_CHECK_I32((long long)x.l[i] - tt[i], "fpl_reduce_small overflows a limb");
         long double mm = 0;
         for (int i = 8; i >= 0; i--) mm = mm * 536870912.0L + (long double)fp29_mod_limb<P>(i);
-        FPL_CHECK(fabsl(fpl_dbg_value(r)) < 0.51L * mm, "fpl_reduce_small: result outside (-0.51 m, 0.51 m)");
+        FPL_CHECK(fabsl(fpl_dbg_value(r) - (long double)BIAS * mm) < 0.51L * mm, "fpl_reduce_small: result outside (-0.51 m, 0.51 m) (+ BIAS m)");
     }
 #endif
     return fpl_norm(r);
@@ -446,6 +448,18 @@ template <class P> PLONK_HD Fp<P> fpl_pack_canonical(const FpL<P>& a) {
     Fp<P> out;
     fp29_pack(u, out.v);
     fp_reduce_once<P>(out.v);
+    fp_reduce_once<P>(out.v);
+    return out;
+}
+
+// normalised value within (0, 2m), limbs non-negative (fpl_reduce_small<P, 1>'s result) -> canonical packed element
+template <class P> PLONK_HD Fp<P> fpl_pack_positive(const FpL<P>& a) {
+    FPL_CHECK(a.l[8] >= 0, "fpl_pack_positive: negative value");
+    uint32_t u[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) u[i] = (uint32_t)a.l[i];
+    Fp<P> out;
+    fp29_pack(u, out.v);
     fp_reduce_once<P>(out.v);
     return out;
 }

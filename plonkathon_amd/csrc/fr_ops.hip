@@ -169,6 +169,24 @@ __global__ void fr_powers_kernel(Fr base, Fr first, Fr* out, size_t n) {
     }
 }
 
+// number of positions where a and b differ (b null: where a is non-zero) — the reference's `==` on two Polynomials /
+// its `values[k:] == [0] * m` checks (poly.py:20-21, prover.py:205-208, 288, 299) without moving the vectors to the host
+__global__ void fr_count_diff_kernel(const Fr* a, const Fr* b, size_t n, unsigned long long* count) {
+    unsigned long long mine = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const Fr x = fp_load(a + i);
+        mine += b ? !fp_eq(x, fp_load(b + i)) : !fp_is_zero(x);
+    }
+    if (mine) atomicAdd(count, mine);
+}
+
+int k_fr_count_diff(plonk_ctx* ctx, const Fr* a, const Fr* b, size_t n, unsigned long long* d_count) {
+    PLONK_CHECK_HIP(hipMemsetAsync(d_count, 0, sizeof *d_count, ctx->stream));
+    PLONK_LAUNCH(fr_count_diff_kernel, grid_for(n, 256), dim3(256), 0, ctx->stream, a, b, n, d_count);
+    PLONK_CHECK_HIP(hipGetLastError());
+    return PLONK_OK;
+}
+
 int k_fr_powers(plonk_ctx* ctx, const Fr& base_mont, const Fr& first_mont, Fr* out, size_t n) {
     if (!n) return PLONK_OK;
     size_t nchunks = (n + POW_CHUNK - 1) / POW_CHUNK;

@@ -21,6 +21,8 @@
 #define PLONK_FP_CALL __host__ __device__ __forceinline__
 #endif
 #define PLONK_DEV __device__ __forceinline__
+// a lambda whose body must be inlined at every call (large bodies otherwise become calls, and the arrays they touch move to scratch)
+#define PLONK_LAMBDA_INLINE __attribute__((always_inline))
 #define PLONK_KERNEL(...) HIP_KERNEL_NAME(__VA_ARGS__)
 #define PLONK_LAUNCH(kern, grid, block, shmem, stream, ...) \
     hipLaunchKernelGGL(kern, grid, block, shmem, stream, __VA_ARGS__)

@@ -27,6 +27,16 @@ typedef FpL<FrParams> FrL;
 // ntt_radix_log = 10) and can be changed with plonk_ntt_configure for tuning / small-size tests.
 #define NTT_TW_LO_LOG 10
 
+// f(0) .. f(N-1) with compile-time arguments: the element array must never be indexed by a run-time value, or it moves
+// from VGPRs to scratch memory (clang gives up unrolling loops whose bodies hold two field multiplications)
+template <unsigned J> struct WaveIdx { static constexpr unsigned value = J; };
+template <unsigned N, class F> PLONK_DEV void wave_for(F f) {
+    if constexpr (N > 0) {
+        wave_for<N - 1>(f);
+        f(WaveIdx<N - 1>{});
+    }
+}
+
 struct NttPass {
     const Fr* in;
     Fr* out;
@@ -140,19 +150,19 @@ __global__ void __launch_bounds__(512) ntt_pass_stockham_kernel(NttPass p) {
     }
 
     // global element index of tile position (i, c) on the input side
-    auto in_index = [&](unsigned i, unsigned c) -> size_t {
+    auto in_index = [&](unsigned i, unsigned c) PLONK_LAMBDA_INLINE -> size_t {
         if (!p.last) return base + ((size_t)i << p.log_s) + c;
         size_t row = p.nprev ? ((((size_t)(kb << p.log_c) + c) << (p.log_h - log_r1)) + rest) : 0;
         return (row << p.log_r) + i;
     };
-    auto load_in = [&](unsigned i, unsigned c) -> Fr {
+    auto load_in = [&](unsigned i, unsigned c) PLONK_LAMBDA_INLINE -> Fr {
         const size_t g = in_index(i, c);
         if (p.first && g >= p.in_len) return fp_zero<FrParams>();
         Fr v = fp_load(in + g);
         if (p.first && p.in_scale) v = fp_mul(v, fp_load(p.in_scale + g));
         return v;
     };
-    auto store_out = [&](unsigned k, unsigned c, Fr v) {
+    auto store_out = [&](unsigned k, unsigned c, Fr v) PLONK_LAMBDA_INLINE {
         if (!p.last) {
             const size_t jrest = ((size_t)cb << p.log_c) + c;
             const size_t ex = (jrest * k) << p.log_h;  // < N
@@ -170,7 +180,7 @@ __global__ void __launch_bounds__(512) ntt_pass_stockham_kernel(NttPass p) {
         }
     };
     // w_R^e for any e (table holds e < R/2; w^(e + R/2) = -w^e)
-    auto twiddle = [&](unsigned e) -> Fr {
+    auto twiddle = [&](unsigned e) PLONK_LAMBDA_INLINE -> Fr {
         e &= R - 1;
         const unsigned idx = e & (R / 2 - 1);
         Fr t = p.tw_in_lds ? lds_ld(w_lo, w_hi, idx) : fp_load(p.small_tw + idx);
@@ -207,12 +217,13 @@ __global__ void __launch_bounds__(512) ntt_pass_stockham_kernel(NttPass p) {
             if (active) {
                 if (c_fastest) { c = gid & (C - 1); g = gid >> p.log_c; }
                 else { g = gid & (groups_per_col - 1); c = gid >> (p.log_r - lr); }
-#pragma unroll
-                for (unsigned j = 0; j < 8; j++)
+                wave_for<8>([&](auto J) {  // compile-time expansion: `#pragma unroll` gives up on bodies this large and x[] would move to scratch
+                    constexpr unsigned j = decltype(J)::value;
                     if (j < rho) {
                         const unsigned i = g + j * groups_per_col;
                         x[j] = from_global ? load_in(i, c) : lds_ld(d_lo, d_hi, LIDX(i, c));
                     }
+                });
             }
             if (!from_global) __syncthreads();  // every lane has its inputs in registers
             if (active) {
@@ -221,8 +232,8 @@ __global__ void __launch_bounds__(512) ntt_pass_stockham_kernel(NttPass p) {
                 else dft2(x);
                 const unsigned pp = g >> log_ss, q = g & ((1u << log_ss) - 1);
                 const unsigned tw_scale = p.log_r - log_nn;  // w_n^(p j') = w_R^((p j') << tw_scale)
-#pragma unroll
-                for (unsigned j = 0; j < 8; j++)
+                wave_for<8>([&](auto J) {
+                    constexpr unsigned j = decltype(J)::value;
                     if (j < rho) {
                         Fr v = x[j];
                         if (j && pp) v = fp_mul(v, twiddle((pp * j) << tw_scale));
@@ -230,6 +241,7 @@ __global__ void __launch_bounds__(512) ntt_pass_stockham_kernel(NttPass p) {
                         if (to_global) store_out(o, c, v);
                         else lds_st(d_lo, d_hi, LIDX(o, c), v);
                     }
+                });
             }
             if (!to_global) __syncthreads();  // outputs visible before the next sweep / level reads
         }
@@ -444,23 +456,35 @@ __global__ void __launch_bounds__(1024) ntt_pass_radix2_kernel(NttPass p) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Variant C ("wave" kernel): the whole transform in registers, exchanges INSIDE a wave by cross-lane moves.
-// plonk_ntt_select_kernel(kind = 3); the default for the single-pass sizes it covers (2^9, 2^11, 2^13).
+// Variant C ("wave" kernels): the whole transform in registers, exchanges INSIDE a wave by cross-lane moves.
+// The default wherever it applies: every size 2^8 .. 2^13 in one launch, 2^16 .. 2^26 as two passes of those.
 //
-// N = 2^(9 + 2 L) points, L = 0, 1, 2; N / 8 threads (64, 256, 1024), each holding 8 elements in registers.
-// Decimation in frequency by digits: a radix-8 stage, L radix-4 stages, two radix-8 stages.  The bits of the element
-// index live in three places — the register index (3 bits), the lane (6 bits) and, for L > 0, the wave (2 L bits).  A
-// stage works on the digit currently held in the register index; between stages that digit is swapped with
-//   * two WAVE bits: the only exchange that needs LDS, run in two rounds of 4 elements per thread (16 KiB per 64
-//     lanes, so LDS no longer limits occupancy: the Stockham kernel's 64 KiB tile held it to 2 waves per SIMD);
-//   * three LANE bits: an 8 x 8 transpose inside groups of 8 lanes as three single-bit swaps, each a cross-lane move
-//     (DPP quad_perm / row_ror for lane ^ 1, 2, 8; ds_swizzle for lane ^ 4, 16; v_permlane32_swap for lane ^ 32)
-//     plus two selects per dword — no LDS, no barrier for the last six levels of every transform.
-// After a stage on digit q of a sub-transform of size S (S / 8 or S / 4 remaining points indexed by `low`), output f is
-// multiplied by w_S^(low f) = roots[(N / S) low f]  (the Cooley-Tukey twiddle between the digit DFT and the remaining
-// sub-transforms).  Outputs appear at frequency k = d_A + 8 d_B + ... (first digit least significant), which the
-// final store turns into a natural-order write.  Coset scaling, zero padding n -> 4n, 1/N and the inverse-coset
-// scaling are fused into the first load / last store as in the other kernels.
+// N = 2^(LOG_E + 6 + 2 L) points, L = 0, 1, 2; N / E threads (64, 256, 1024), each holding E = 2^LOG_E elements in
+// registers as 9 signed 29-bit limbs (fpl.h) from the first load to the last store:
+//   E = 8: N = 2^9, 2^11, 2^13   radix 8, L x radix 4, radix 8, radix 8     (3 waves per SIMD; 4 at 1024 threads)
+//   E = 4: N = 2^8, 2^10, 2^12   radix 4, L x radix 4, 3 x radix 4          (half the registers: 4+ waves per SIMD, and
+//                                 twice the workgroups for a lone transform — round 3)
+// Decimation in frequency by digits.  The bits of the element index live in three places — the register index (LOG_E
+// bits), the lane (6 bits) and, for L > 0, the wave (2 L bits).  A stage works on the digit currently held in the
+// register index; between stages that digit is swapped with
+//   * two WAVE bits: the only exchange that needs LDS, in rounds of 4 elements per thread (36 B x 4 x threads);
+//   * LANE bits: single-bit swaps of a register-index bit with a lane bit.  lane ^ 32 and lane ^ 16 are ONE instruction
+//     per pair of words (v_permlane32_swap / v_permlane16_swap exchange exactly the halves / rows a bit swap trades);
+//     lane ^ 1, 2, 8 are two selects whose moved operand comes through DPP (quad_perm / row_ror); lane ^ 4 goes
+//     through ds_swizzle — no LDS memory, no barrier for the last six levels of every transform.
+// After a stage on a digit of a sub-transform of size S (remaining points indexed by `low`), output f is multiplied by
+// w_S^(low f) = roots[(N / S) low f]  (the Cooley-Tukey twiddle between the digit DFT and the remaining sub-transforms);
+// the root table is stored AS LIMBS (12 words per entry: no unpacking in the loop).  Outputs appear at frequency
+// k = d_A + r_A d_B + ... (first digit least significant), which the final store turns into a natural-order write.
+// Coset scaling, zero padding n -> 4n, 1/N and the inverse-coset scaling are fused into the first load / last store.
+//
+// Range discipline (m = the modulus; "N-form" = limbs 0..7 in [0, 2^29), limb 8 signed and small).  Every stage receives
+// N-form elements with |value| < 2 m: loads are canonical, multiplications return N-form in (-m, 2m), and the one output of
+// each butterfly group that carries no twiddle factor (index 0) goes through fpl_reduce_small (N-form, |value| < 0.51 m).
+// Inside a radix-8 butterfly five carry sweeps keep every limb inside int32 and every multiplicand inside fpl_mul's
+// operand bound (|limb| < 1.27 * 2^30): the bounds are written on each line of dft8l / dft4l.  |value| never exceeds 16 m
+// (a sum of eight inputs), fpl_mul tolerates 128 m.
+#define NTT_LIMB_STRIDE 12  // int32 words per entry of a limb-form table (9 used)
 struct NttWave {
     const Fr* in;
     Fr* out;
@@ -476,216 +500,54 @@ struct NttWave {
     // all-to-all as W chunks [source rank][local row][source's columns]: position c of a row sits at
     // (c >> chunk_log) * chunk_stride + row * 2^chunk_log + (c & (2^chunk_log - 1)).  chunk_log = 0 means contiguous rows.
     unsigned sub_base, chunk_log, chunk_stride;
-    const Fr* tw_lo;      // inter-pass twiddles w_N^e = tw_lo[e & 1023] * tw_hi[e >> 10]   (mode 1)
-    const Fr* tw_hi;
-    const Fr* roots;      // w_R^k, k < R, R = this kernel's transform size (direction of the transform)
-    const Fr* in_scale;   // per-element factor at load (coset offset powers) or null
-    const Fr* out_scale;  // per-element factor at store or null
+    const int32_t* tw_lo;  // inter-pass twiddles w_N^e = tw_lo[e & 1023] * tw_hi[e >> 10], limb form   (mode 1)
+    const int32_t* tw_hi;
+    const int32_t* roots;  // w_R^k, k < R, R = this kernel's transform size (direction of the transform), limb form
+    const Fr* in_scale;    // per-element factor at load (coset offset powers) or null
+    const Fr* out_scale;   // per-element factor at store or null
     Fr out_scalar;
     unsigned has_out_scalar;
     Fr w8_1, w8_2, w8_3;
-    const int32_t* jm;    // fpl_reduce_small's table of j * m (the limb-form kernel)
+    const int32_t* jm;     // fpl_reduce_small's table of j * m
 };
 
-// f(0) .. f(7) with compile-time arguments: the element array must never be indexed by a run-time value, or it moves
-// from VGPRs to scratch memory (clang gives up unrolling loops whose bodies hold two field multiplications)
-template <unsigned J> struct WaveIdx { static constexpr unsigned value = J; };
-template <unsigned N, class F> PLONK_DEV void wave_for(F f) {
-    if constexpr (N > 0) {
-        wave_for<N - 1>(f);
-        f(WaveIdx<N - 1>{});
-    }
+// entry idx of a limb-form table
+PLONK_DEV FrL wavel_ld_tw(const int32_t* tab, unsigned idx) {
+    const int32_t* t = tab + (size_t)idx * NTT_LIMB_STRIDE;
+    const u32x4 a = *reinterpret_cast<const u32x4*>(t), b = *reinterpret_cast<const u32x4*>(t + 4);
+    FrL r;
+    r.l[0] = (int32_t)a.x; r.l[1] = (int32_t)a.y; r.l[2] = (int32_t)a.z; r.l[3] = (int32_t)a.w;
+    r.l[4] = (int32_t)b.x; r.l[5] = (int32_t)b.y; r.l[6] = (int32_t)b.z; r.l[7] = (int32_t)b.w;
+    r.l[8] = t[8];
+#pragma unroll
+    for (int i = 0; i < 9; i++) FPL_ANY_SIGN(r.l[i]);
+    return r;
 }
-template <class F> PLONK_DEV void wave_for8(F f) { wave_for<8>(f); }
 
 // swap register-index bit RB with the lane bit of MASK: lanes with the bit clear keep x[r] and trade x[r | 1 << RB],
 // lanes with the bit set keep x[r | 1 << RB] and trade x[r]
-template <unsigned RB, unsigned MASK> PLONK_DEV void wave_swap_bit(Fr (&x)[8], unsigned lane) {
+template <unsigned E, unsigned RB, unsigned MASK> PLONK_DEV void wavel_swap_bit(FrL (&x)[E], unsigned lane) {
     const bool hi = (lane & MASK) != 0;
-    wave_for<4>([&](auto I) {
-        constexpr unsigned i4 = decltype(I)::value;
-        constexpr unsigned r = ((i4 >> RB) << (RB + 1)) | (i4 & ((1u << RB) - 1)), r1 = r | (1u << RB);  // the 4 indices with bit RB clear
-        wave_for<8>([&](auto W) {
-            constexpr unsigned i = decltype(W)::value;
-            const uint32_t send = hi ? x[r].v[i] : x[r1].v[i];
-            const uint32_t recv = wave_lane_xor<MASK>(send, lane);
-            if (hi) x[r].v[i] = recv;
-            else x[r1].v[i] = recv;
-        });
-    });
-}
-
-// x[BASE + f] *= roots[(low * f * mult) mod N], f = 1 .. COUNT-1   (compile-time register indices: x stays in VGPRs)
-// The wave kernel keeps its elements as redundant residues in [0, 2m) (fp.h: fp_add2 / fp_sub2 / fp_mul2 — a
-// multiplication without the final conditional subtraction) and canonicalises once, at the last store.
-template <unsigned LOG_N, unsigned BASE, unsigned COUNT> PLONK_DEV void wave_twiddle(Fr (&x)[8], unsigned low, unsigned mult, const Fr* roots) {
-    wave_for<COUNT - 1>([&](auto F) {
-        constexpr unsigned f = decltype(F)::value + 1;
-        x[BASE + f] = fp_mul2(x[BASE + f], fp_load(roots + ((low * f * mult) & ((1u << LOG_N) - 1))));
-    });
-}
-PLONK_DEV void dft4r(Fr& x0, Fr& x1, Fr& x2, Fr& x3, const Fr& w2) {
-    Fr a0 = fp_add2(x0, x2), a1 = fp_add2(x1, x3), d0 = fp_sub2(x0, x2), d1 = fp_mul2(fp_sub2(x1, x3), w2);
-    x0 = fp_add2(a0, a1); x2 = fp_sub2(a0, a1); x1 = fp_add2(d0, d1); x3 = fp_sub2(d0, d1);
-}
-PLONK_DEV void dft8r(Fr (&x)[8], const Fr& w1, const Fr& w2, const Fr& w3) {
-    Fr a0 = fp_add2(x[0], x[4]), a1 = fp_add2(x[1], x[5]), a2 = fp_add2(x[2], x[6]), a3 = fp_add2(x[3], x[7]);
-    Fr b0 = fp_sub2(x[0], x[4]), b1 = fp_mul2(fp_sub2(x[1], x[5]), w1), b2 = fp_mul2(fp_sub2(x[2], x[6]), w2),
-       b3 = fp_mul2(fp_sub2(x[3], x[7]), w3);
-    Fr c0 = fp_add2(a0, a2), c1 = fp_add2(a1, a3), d0 = fp_sub2(a0, a2), d1 = fp_mul2(fp_sub2(a1, a3), w2);
-    Fr e0 = fp_add2(b0, b2), e1 = fp_add2(b1, b3), f0 = fp_sub2(b0, b2), f1 = fp_mul2(fp_sub2(b1, b3), w2);
-    x[0] = fp_add2(c0, c1); x[4] = fp_sub2(c0, c1); x[2] = fp_add2(d0, d1); x[6] = fp_sub2(d0, d1);
-    x[1] = fp_add2(e0, e1); x[5] = fp_sub2(e0, e1); x[3] = fp_add2(f0, f1); x[7] = fp_sub2(f0, f1);
-}
-
-// register budget: 1024-thread workgroups (L = 2) must fit 128 VGPRs (a few dwords spill); the smaller ones run faster
-// without spills at 3 waves per SIMD (measured: 18.1 vs 16.8 G elements/s at 2^11 x 2048)
-template <unsigned NLDS>
-__global__ void __launch_bounds__(64u << (2 * NLDS), NLDS == 2 ? 4 : 3) ntt_wave_kernel(NttWave p) {
-    constexpr unsigned LOG_N = 9 + 2 * NLDS, NT = 64u << (2 * NLDS);
-    PLONK_DYN_SMEM(smem);
-    u32x4* l_lo = reinterpret_cast<u32x4*>(smem);  // 4 * NT elements as two 16-byte planes
-    u32x4* l_hi = l_lo + 4 * NT;
-    const unsigned tid = threadIdx.x, lane = tid & 63;
-    const unsigned bidx = p.mode ? blockIdx.y : blockIdx.x;
-    const Fr* in = p.in + (size_t)bidx * p.in_bstride;
-    Fr* out = p.out + (size_t)bidx * p.out_bstride;
-    // column / row of a two-pass transform.  Workgroup b runs on XCD b % 8 (each XCD has its own L2): the remap gives
-    // every XCD four ADJACENT columns (rows) per group of 32, so the 32-byte elements it touches share 128-byte lines.
-    const unsigned b = blockIdx.x;
-    const unsigned sub = !p.mode ? 0 : ((gridDim.x & 31u) ? b : ((b & ~31u) | ((b & 7u) << 2) | ((b >> 3) & 3u)));
-    // global index of sub-transform position pos on the input side, of frequency o on the output side
-    const unsigned in_shift = p.mode == 1 ? p.log_other : 0, out_shift = p.mode ? p.log_other : 0;
-    const unsigned in_off = p.mode == 1 ? sub : (p.mode == 2 ? (p.chunk_log ? sub << p.chunk_log : sub << LOG_N) : 0);
-    const unsigned out_off = p.mode ? sub : 0;
-    const unsigned chunk_mask = (1u << p.chunk_log) - 1;
-
-    Fr x[8];
-    wave_for8([&](auto J) {  // position j * NT + tid: consecutive lanes read consecutive positions
-        constexpr unsigned j = decltype(J)::value;
-        const unsigned pos = j * NT + tid;
-        const unsigned g = p.chunk_log ? (pos >> p.chunk_log) * p.chunk_stride + (pos & chunk_mask) + in_off : (pos << in_shift) + in_off;
-        x[j] = g < p.in_len ? fp_load(in + g) : fp_zero<FrParams>();
-    });
-    if (p.in_scale) {
-        wave_for8([&](auto J) {
-            constexpr unsigned j = decltype(J)::value;
-            const unsigned g = ((j * NT + tid) << in_shift) + in_off;
-            if (g < p.in_len) x[j] = fp_mul2(x[j], fp_load(p.in_scale + g));
-        });
-    }
-    // stage A: digit = index bits LOG_N-1 .. LOG_N-3, low = tid
-    dft8r(x, p.w8_1, p.w8_2, p.w8_3);
-    wave_twiddle<LOG_N, 0, 8>(x, tid, 1, p.roots);
-    // L radix-4 stages on the wave bits: swap register bits (1, 0) with thread bits (tb + 1, tb)
-    wave_for<NLDS>([&](auto S) {
-        constexpr unsigned s = decltype(S)::value;
-        constexpr unsigned tb = 6 + 2 * (NLDS - 1 - s);
-        const unsigned mine = (tid >> tb) & 3u, rest = tid & ~(3u << tb);
-        wave_for<2>([&](auto R2) {
-            constexpr unsigned r2 = decltype(R2)::value;
-            wave_for<4>([&](auto Q) { lds_st(l_lo, l_hi, decltype(Q)::value * NT + tid, x[4 * r2 + decltype(Q)::value]); });
-            __syncthreads();
-            wave_for<4>([&](auto Q) { x[4 * r2 + decltype(Q)::value] = lds_ld(l_lo, l_hi, mine * NT + (rest | (decltype(Q)::value << tb))); });
-            __syncthreads();
-        });
-        const unsigned low = tid & ((1u << tb) - 1);
-        const unsigned mult = 1u << (LOG_N - (tb + 2));  // N / S, S = 2^(tb + 2)
-        dft4r(x[0], x[1], x[2], x[3], p.w8_2);
-        dft4r(x[4], x[5], x[6], x[7], p.w8_2);
-        wave_twiddle<LOG_N, 0, 4>(x, low, mult, p.roots);
-        wave_twiddle<LOG_N, 4, 4>(x, low, mult, p.roots);
-    });
-    // stage on lane bits 5..3
-    wave_swap_bit<2, 32>(x, lane);
-    wave_swap_bit<1, 16>(x, lane);
-    wave_swap_bit<0, 8>(x, lane);
-    dft8r(x, p.w8_1, p.w8_2, p.w8_3);
-    wave_twiddle<LOG_N, 0, 8>(x, lane & 7u, 1u << (LOG_N - 6), p.roots);
-    // stage on lane bits 2..0
-    wave_swap_bit<2, 4>(x, lane);
-    wave_swap_bit<1, 2>(x, lane);
-    wave_swap_bit<0, 1>(x, lane);
-    dft8r(x, p.w8_1, p.w8_2, p.w8_3);
-    // frequency of register j: digits in processing order, first digit least significant
-    //   d_A = (lane bit 5) * 4 + thread bits (top pair);  then the remaining wave pairs;  (lane bits 4, 3);  (lane bits 2..0);  j
-    //   (without wave stages the first digit is simply lane bits 5..3)
-    unsigned k, shift = 3;
-    if (NLDS) {
-        k = (((lane >> 5) & 1u) << 2) | ((tid >> (6 + 2 * (NLDS > 0 ? NLDS - 1 : 0))) & 3u);
-        for (unsigned s = 1; s < NLDS; s++) {
-            k |= ((tid >> (6 + 2 * (NLDS - 1 - s))) & 3u) << shift;
-            shift += 2;
-        }
-        k |= ((lane >> 3) & 3u) << shift;
-        shift += 2;
-    } else {
-        k = (lane >> 3) & 7u;
-    }
-    k |= (lane & 7u) << shift;
-    shift += 3;
-    if (p.mode == 1) {  // inter-pass twiddle w_N^(column * frequency)
-        wave_for8([&](auto J) {
-            constexpr unsigned j = decltype(J)::value;
-            const unsigned e = (sub + p.sub_base) * (k | (j << shift));  // < N
-            if (e) {
-                Fr tw = fp_load(p.tw_lo + (e & ((1u << NTT_TW_LO_LOG) - 1)));
-                if (p.log_n > NTT_TW_LO_LOG) tw = fp_mul2(tw, fp_load(p.tw_hi + (e >> NTT_TW_LO_LOG)));
-                x[j] = fp_mul2(x[j], tw);
-            }
-        });
-    }
-    if (p.out_scale) {
-        wave_for8([&](auto J) {
-            constexpr unsigned j = decltype(J)::value;
-            x[j] = fp_mul2(x[j], fp_load(p.out_scale + (((k | (j << shift)) << out_shift) + out_off)));
-        });
-    }
-    if (p.has_out_scalar) {
-        const Fr sc = p.out_scalar;
-        wave_for8([&](auto J) { x[decltype(J)::value] = fp_mul2(x[decltype(J)::value], sc); });
-    }
-    wave_for8([&](auto J) {
-        constexpr unsigned j = decltype(J)::value;
-        if (p.mode != 1) fp_reduce_once<FrParams>(x[j].v);  // canonical results; the column pass hands redundant values on
-        fp_store(out + (((k | (j << shift)) << out_shift) + out_off), x[j]);
-    });
-}
-
-// ------------------------------------------------------------------------------------------------
-// Variant C on signed limbs ("wave-limb" kernel; plonk_ntt_select_kernel(kind = 5), and the default where the wave kernel
-// applies).  Same dataflow as ntt_wave_kernel, but an element is 9 signed 29-bit limbs (fpl.h) from the first load to the
-// last store: additions and subtractions are 9 independent 32-bit operations instead of two 8-word carry chains and a
-// select, multiplications skip the unpack / pack / conditional subtraction of the packed form, and the cross-lane and LDS
-// exchanges move 9 words instead of 8.
-//
-// Range discipline (m = the modulus; "N-form" = limbs 0..7 in [0, 2^29), limb 8 signed and small).  Every stage receives
-// N-form elements with |value| < 2 m: loads are canonical, multiplications return N-form in (-m, 2m), and the one output of
-// each butterfly group that carries no twiddle factor (index 0) goes through fpl_reduce_small (N-form, |value| < 0.51 m).
-// Inside a radix-8 butterfly five carry sweeps keep every limb inside int32 and every multiplicand inside fpl_mul's
-// operand bound (|limb| < 1.27 * 2^30): the bounds are written on each line of dft8l / dft4l.  |value| never exceeds 16 m
-// (a sum of eight inputs), fpl_mul tolerates 128 m.
-template <unsigned RB, unsigned MASK> PLONK_DEV void wavel_swap_bit(FrL (&x)[8], unsigned lane) {
-    const bool hi = (lane & MASK) != 0;
-    wave_for<4>([&](auto I) {
-        constexpr unsigned i4 = decltype(I)::value;
-        constexpr unsigned r = ((i4 >> RB) << (RB + 1)) | (i4 & ((1u << RB) - 1)), r1 = r | (1u << RB);
+    wave_for<E / 2>([&](auto I) {
+        constexpr unsigned ih = decltype(I)::value;
+        constexpr unsigned r = ((ih >> RB) << (RB + 1)) | (ih & ((1u << RB) - 1)), r1 = r | (1u << RB);  // the indices with bit RB clear
         wave_for<9>([&](auto W) {
             constexpr unsigned i = decltype(W)::value;
-            const uint32_t send = (uint32_t)(hi ? x[r].l[i] : x[r1].l[i]);
-            const uint32_t recv = wave_lane_xor<MASK>(send, lane);
-            if (hi) x[r].l[i] = (int32_t)recv;
-            else x[r1].l[i] = (int32_t)recv;
+            wave_swap_words<MASK>(x[r].l[i], x[r1].l[i], hi, lane);
         });
     });
 }
 
 // x[BASE + f] *= roots[(low * f * mult) mod N], f = 1 .. COUNT-1;  x[BASE] (no factor) is range-reduced instead
-template <unsigned LOG_N, unsigned BASE, unsigned COUNT> PLONK_DEV void wavel_twiddle(FrL (&x)[8], unsigned low, unsigned mult, const Fr* roots, const int32_t* jm) {
+template <unsigned LOG_N, unsigned BASE, unsigned COUNT, unsigned E>
+PLONK_DEV void wavel_twiddle(FrL (&x)[E], unsigned low, unsigned mult, const int32_t* roots, const int32_t* jm) {
     x[BASE] = fpl_reduce_small(x[BASE], jm);
     wave_for<COUNT - 1>([&](auto F) {
         constexpr unsigned f = decltype(F)::value + 1;
-        x[BASE + f] = fpl_mul(x[BASE + f], fpl_from_fp(fp_load(roots + ((low * f * mult) & ((1u << LOG_N) - 1)))));
+        x[BASE + f] = fpl_mul(x[BASE + f], wavel_ld_tw(roots, (low * f * mult) & ((1u << LOG_N) - 1)));
+#ifndef PLONK_NTT_NO_FENCE13
+        if constexpr (LOG_N == 13) PLONK_SCHED_FENCE();  // 1024 threads: 128 VGPRs; keeps the scheduler from holding several twiddles in flight
+#endif
     });
 }
 // inputs N-form, |value| < 2.  Outputs: x0 in [0, 2^31) (for fpl_reduce_small), x1..x3 multiplicands; |value| < 8
@@ -719,6 +581,11 @@ PLONK_DEV void dft8l(FrL (&x)[8], const FrL& w1, const FrL& w2, const FrL& w3) {
     x[3] = fpl_add(f0, f1);                                               // (-2^29, 2^30)
     x[7] = fpl_sub(f0, f1);                                               // (-2^30, 2^29)
 }
+// the digit DFT on the register index: radix 8 (E = 8) or radix 4 (E = 4)
+template <unsigned E> PLONK_DEV void wavel_dft(FrL (&x)[E], const FrL& w1, const FrL& w2, const FrL& w3) {
+    if constexpr (E == 8) dft8l(x, w1, w2, w3);
+    else dft4l(x[0], x[1], x[2], x[3], w2);
+}
 PLONK_DEV void wavel_lds_st(u32x4* lo, u32x4* hi, uint32_t* top, unsigned i, const FrL& a) {
     lo[i] = u32x4{(uint32_t)a.l[0], (uint32_t)a.l[1], (uint32_t)a.l[2], (uint32_t)a.l[3]};
     hi[i] = u32x4{(uint32_t)a.l[4], (uint32_t)a.l[5], (uint32_t)a.l[6], (uint32_t)a.l[7]};
@@ -733,9 +600,16 @@ PLONK_DEV FrL wavel_lds_ld(const u32x4* lo, const u32x4* hi, const uint32_t* top
     return r;
 }
 
-template <unsigned NLDS>
-__global__ void __launch_bounds__(64u << (2 * NLDS), NLDS == 2 ? 4 : 3) ntt_wavel_kernel(NttWave p) {
-    constexpr unsigned LOG_N = 9 + 2 * NLDS, NT = 64u << (2 * NLDS);
+// waves per SIMD the register allocation aims at: 1024-thread workgroups must fit 128 VGPRs (4); the E = 8 forms run
+// faster without spills at 3 (measured in round 2: 18.1 vs 16.8 G elements/s at 2^11 x 2048); E = 4 fits 4 without spills
+template <unsigned LOG_E, unsigned NLDS> struct WavelCfg {
+    static constexpr unsigned E = 1u << LOG_E, LOG_N = LOG_E + 6 + 2 * NLDS, NT = 64u << (2 * NLDS);
+    static constexpr unsigned WAVES = (NLDS == 2 || LOG_E == 2) ? 4 : 3;
+};
+
+template <unsigned LOG_E, unsigned NLDS>
+__global__ void __launch_bounds__(64u << (2 * NLDS), (WavelCfg<LOG_E, NLDS>::WAVES)) ntt_wavel_kernel(NttWave p) {
+    constexpr unsigned E = 1u << LOG_E, LOG_N = LOG_E + 6 + 2 * NLDS, NT = 64u << (2 * NLDS), LOG_T = 6 + 2 * NLDS;
     PLONK_DYN_SMEM(smem);
     u32x4* l_lo = reinterpret_cast<u32x4*>(smem);  // 4 * NT elements as two 16-byte planes and one 4-byte plane
     u32x4* l_hi = l_lo + 4 * NT;
@@ -744,38 +618,41 @@ __global__ void __launch_bounds__(64u << (2 * NLDS), NLDS == 2 ? 4 : 3) ntt_wave
     const unsigned bidx = p.mode ? blockIdx.y : blockIdx.x;
     const Fr* in = p.in + (size_t)bidx * p.in_bstride;
     Fr* out = p.out + (size_t)bidx * p.out_bstride;
-    const unsigned b = blockIdx.x;  // XCD-aware column / row order: see ntt_wave_kernel
+    // column / row of a two-pass transform.  Workgroup b runs on XCD b % 8 (each XCD has its own L2): the remap gives
+    // every XCD four ADJACENT columns (rows) per group of 32, so the 32-byte elements it touches share 128-byte lines.
+    const unsigned b = blockIdx.x;
     const unsigned sub = !p.mode ? 0 : ((gridDim.x & 31u) ? b : ((b & ~31u) | ((b & 7u) << 2) | ((b >> 3) & 3u)));
+    // global index of sub-transform position pos on the input side, of frequency o on the output side
     const unsigned in_shift = p.mode == 1 ? p.log_other : 0, out_shift = p.mode ? p.log_other : 0;
     const unsigned in_off = p.mode == 1 ? sub : (p.mode == 2 ? (p.chunk_log ? sub << p.chunk_log : sub << LOG_N) : 0);
     const unsigned out_off = p.mode ? sub : 0;
     const unsigned chunk_mask = (1u << p.chunk_log) - 1;
     const int32_t* jm = p.jm;
-    const FrL w8_1 = fpl_from_fp_uniform(p.w8_1), w8_2 = fpl_from_fp_uniform(p.w8_2), w8_3 = fpl_from_fp_uniform(p.w8_3);  // 27 SGPRs
+    const FrL w8_1 = fpl_from_fp_uniform(p.w8_1), w8_2 = fpl_from_fp_uniform(p.w8_2), w8_3 = fpl_from_fp_uniform(p.w8_3);  // SGPRs
 
-    FrL x[8];
-    wave_for8([&](auto J) {  // position j * NT + tid: consecutive lanes read consecutive positions
+    FrL x[E];
+    wave_for<E>([&](auto J) {  // position j * NT + tid: consecutive lanes read consecutive positions
         constexpr unsigned j = decltype(J)::value;
         const unsigned pos = j * NT + tid;
         const unsigned g = p.chunk_log ? (pos >> p.chunk_log) * p.chunk_stride + (pos & chunk_mask) + in_off : (pos << in_shift) + in_off;
         x[j] = g < p.in_len ? fpl_from_fp(fp_load(in + g)) : fpl_zero<FrParams>();  // [0, 2m): the column pass hands on canonical values
     });
     if (p.in_scale) {
-        wave_for8([&](auto J) {
+        wave_for<E>([&](auto J) {
             constexpr unsigned j = decltype(J)::value;
             const unsigned g = ((j * NT + tid) << in_shift) + in_off;
             if (g < p.in_len) x[j] = fpl_mul(x[j], fpl_from_fp(fp_load(p.in_scale + g)));
         });
     }
-    // stage A: digit = index bits LOG_N-1 .. LOG_N-3, low = tid
-    dft8l(x, w8_1, w8_2, w8_3);
-    wavel_twiddle<LOG_N, 0, 8>(x, tid, 1, p.roots, jm);
+    // stage A: digit = the top LOG_E index bits, low = tid
+    wavel_dft<E>(x, w8_1, w8_2, w8_3);
+    wavel_twiddle<LOG_N, 0, E>(x, tid, 1, p.roots, jm);
     // L radix-4 stages on the wave bits: swap register bits (1, 0) with thread bits (tb + 1, tb)
     wave_for<NLDS>([&](auto S) {
         constexpr unsigned s = decltype(S)::value;
         constexpr unsigned tb = 6 + 2 * (NLDS - 1 - s);
         const unsigned mine = (tid >> tb) & 3u, rest = tid & ~(3u << tb);
-        wave_for<2>([&](auto R2) {
+        wave_for<E / 4>([&](auto R2) {
             constexpr unsigned r2 = decltype(R2)::value;
             wave_for<4>([&](auto Q) { wavel_lds_st(l_lo, l_hi, l_top, decltype(Q)::value * NT + tid, x[4 * r2 + decltype(Q)::value]); });
             __syncthreads();
@@ -784,61 +661,91 @@ __global__ void __launch_bounds__(64u << (2 * NLDS), NLDS == 2 ? 4 : 3) ntt_wave
         });
         const unsigned low = tid & ((1u << tb) - 1);
         const unsigned mult = 1u << (LOG_N - (tb + 2));  // N / S, S = 2^(tb + 2)
-        dft4l(x[0], x[1], x[2], x[3], w8_2);
-        dft4l(x[4], x[5], x[6], x[7], w8_2);
-        wavel_twiddle<LOG_N, 0, 4>(x, low, mult, p.roots, jm);
-        wavel_twiddle<LOG_N, 4, 4>(x, low, mult, p.roots, jm);
+        wave_for<E / 4>([&](auto R2) {
+            constexpr unsigned r2 = decltype(R2)::value;
+            dft4l(x[4 * r2], x[4 * r2 + 1], x[4 * r2 + 2], x[4 * r2 + 3], w8_2);
+            wavel_twiddle<LOG_N, 4 * r2, 4>(x, low, mult, p.roots, jm);
+        });
     });
-    // stage on lane bits 5..3
-    wavel_swap_bit<2, 32>(x, lane);
-    wavel_swap_bit<1, 16>(x, lane);
-    wavel_swap_bit<0, 8>(x, lane);
-    dft8l(x, w8_1, w8_2, w8_3);
-    wavel_twiddle<LOG_N, 0, 8>(x, lane & 7u, 1u << (LOG_N - 6), p.roots, jm);
-    // stage on lane bits 2..0
-    wavel_swap_bit<2, 4>(x, lane);
-    wavel_swap_bit<1, 2>(x, lane);
-    wavel_swap_bit<0, 1>(x, lane);
-    dft8l(x, w8_1, w8_2, w8_3);
-    // frequency of register j: see ntt_wave_kernel
-    unsigned k, shift = 3;
-    if (NLDS) {
-        k = (((lane >> 5) & 1u) << 2) | ((tid >> (6 + 2 * (NLDS > 0 ? NLDS - 1 : 0))) & 3u);
-        for (unsigned s = 1; s < NLDS; s++) {
-            k |= ((tid >> (6 + 2 * (NLDS - 1 - s))) & 3u) << shift;
-            shift += 2;
-        }
-        k |= ((lane >> 3) & 3u) << shift;
-        shift += 2;
+    if constexpr (E == 8) {
+        // stage on lane bits 5..3
+        wavel_swap_bit<E, 2, 32>(x, lane);
+        wavel_swap_bit<E, 1, 16>(x, lane);
+        wavel_swap_bit<E, 0, 8>(x, lane);
+        dft8l(x, w8_1, w8_2, w8_3);
+        wavel_twiddle<LOG_N, 0, 8>(x, lane & 7u, 1u << (LOG_N - 6), p.roots, jm);
+        // stage on lane bits 2..0
+        wavel_swap_bit<E, 2, 4>(x, lane);
+        wavel_swap_bit<E, 1, 2>(x, lane);
+        wavel_swap_bit<E, 0, 1>(x, lane);
+        dft8l(x, w8_1, w8_2, w8_3);
     } else {
-        k = (lane >> 3) & 7u;
+        // stages on lane bits (5, 4), (3, 2), (1, 0)
+        wavel_swap_bit<E, 1, 32>(x, lane);
+        wavel_swap_bit<E, 0, 16>(x, lane);
+        dft4l(x[0], x[1], x[2], x[3], w8_2);
+        wavel_twiddle<LOG_N, 0, 4>(x, lane & 15u, 1u << (LOG_N - 6), p.roots, jm);
+        wavel_swap_bit<E, 1, 8>(x, lane);
+        wavel_swap_bit<E, 0, 4>(x, lane);
+        dft4l(x[0], x[1], x[2], x[3], w8_2);
+        wavel_twiddle<LOG_N, 0, 4>(x, lane & 3u, 1u << (LOG_N - 4), p.roots, jm);
+        wavel_swap_bit<E, 1, 2>(x, lane);
+        wavel_swap_bit<E, 0, 1>(x, lane);
+        dft4l(x[0], x[1], x[2], x[3], w8_2);
+        x[0] = fpl_norm(x[0]);  // [0, 2^31) -> N-form: the optional multiplications below take limbs within (-2^30, 2^30]
     }
-    k |= (lane & 7u) << shift;
-    shift += 3;
+    // frequency of register j: digits in processing order, first digit least significant
+    unsigned k, shift;
+    if constexpr (E == 8) {
+        //   d_A = (lane bit 5) * 4 + thread bits (top pair);  then the remaining wave pairs;  (lane bits 4, 3);  (lane bits 2..0);  j
+        //   (without wave stages the first digit is simply lane bits 5..3)
+        shift = 3;
+        if (NLDS) {
+            k = (((lane >> 5) & 1u) << 2) | ((tid >> (6 + 2 * (NLDS > 0 ? NLDS - 1 : 0))) & 3u);
+            for (unsigned s = 1; s < NLDS; s++) {
+                k |= ((tid >> (6 + 2 * (NLDS - 1 - s))) & 3u) << shift;
+                shift += 2;
+            }
+            k |= ((lane >> 3) & 3u) << shift;
+            shift += 2;
+        } else {
+            k = (lane >> 3) & 7u;
+        }
+        k |= (lane & 7u) << shift;
+        shift += 3;
+    } else {
+        //   every digit has two bits: the thread-index pairs from the top down hold d_A, d_B, ..; j is the last digit
+        k = 0;
+        wave_for<LOG_T / 2>([&](auto I) {
+            constexpr unsigned i = decltype(I)::value;
+            k |= ((tid >> (LOG_T - 2 - 2 * i)) & 3u) << (2 * i);
+        });
+        shift = LOG_T;
+    }
     if (p.mode == 1) {  // inter-pass twiddle w_N^(column * frequency)
-        wave_for8([&](auto J) {
+        wave_for<E>([&](auto J) {
             constexpr unsigned j = decltype(J)::value;
             const unsigned e = (sub + p.sub_base) * (k | (j << shift));  // < N
             if (e) {
-                FrL tw = fpl_from_fp(fp_load(p.tw_lo + (e & ((1u << NTT_TW_LO_LOG) - 1))));
-                if (p.log_n > NTT_TW_LO_LOG) tw = fpl_mul(tw, fpl_from_fp(fp_load(p.tw_hi + (e >> NTT_TW_LO_LOG))));
+                FrL tw = wavel_ld_tw(p.tw_lo, e & ((1u << NTT_TW_LO_LOG) - 1));
+                if (p.log_n > NTT_TW_LO_LOG) tw = fpl_mul(tw, wavel_ld_tw(p.tw_hi, e >> NTT_TW_LO_LOG));
                 x[j] = fpl_mul(x[j], tw);
             }
         });
     }
     if (p.out_scale) {
-        wave_for8([&](auto J) {
+        wave_for<E>([&](auto J) {
             constexpr unsigned j = decltype(J)::value;
             x[j] = fpl_mul(x[j], fpl_from_fp(fp_load(p.out_scale + (((k | (j << shift)) << out_shift) + out_off))));
         });
     }
     if (p.has_out_scalar) {
         const FrL sc = fpl_from_fp_uniform(p.out_scalar);
-        wave_for8([&](auto J) { x[decltype(J)::value] = fpl_mul(x[decltype(J)::value], sc); });
+        wave_for<E>([&](auto J) { x[decltype(J)::value] = fpl_mul(x[decltype(J)::value], sc); });
     }
-    wave_for8([&](auto J) {  // |value| <= 16 m whatever happened above -> (-0.51 m, 0.51 m) -> canonical
+    wave_for<E>([&](auto J) {  // |value| <= 16 m whatever happened above -> (-0.51 m, 0.51 m) -> canonical
         constexpr unsigned j = decltype(J)::value;
-        fp_store(out + (((k | (j << shift)) << out_shift) + out_off), fpl_pack_canonical(fpl_reduce_small(x[j], jm)));
+        fp_store(out + (((k | (j << shift)) << out_shift) + out_off), fpl_pack_positive(fpl_reduce_small<FrParams, 1>(x[j], jm)));
     });
 }
 
@@ -934,18 +841,64 @@ static unsigned plan_passes(const plonk_ctx* ctx, unsigned log_n, unsigned radic
     return P;
 }
 
-// the wave kernel (variant C): N = 2^9, 2^11, 2^13 in one pass (one workgroup of N / 8 threads per transform), and
-// N = R1 R2 with R1, R2 from that set in two passes (columns, then rows)
-static bool ntt_wave_plan(unsigned log_n, unsigned* log_r1, unsigned* log_r2) {
-    switch (log_n) {
-        case 9: case 11: case 13: *log_r1 = log_n; *log_r2 = 0; return true;
-        case 18: *log_r1 = 9; *log_r2 = 9; return true;
-        case 20: *log_r1 = 11; *log_r2 = 9; return true;
-        case 22: *log_r1 = 11; *log_r2 = 11; return true;
-        case 24: *log_r1 = 13; *log_r2 = 11; return true;
-        case 26: *log_r1 = 13; *log_r2 = 13; return true;
-        default: return false;
+// the wave kernels (variant C): N = 2^8 .. 2^13 in one pass (one workgroup of N / 4 or N / 8 threads per transform), and
+// N = R1 R2 with R1, R2 from that set in two passes (columns, then rows).  Default splits: as square as possible
+// (measured on MI355X, profiles/r03_*ntt_splits*); plonk_ntt_set_split overrides one size (A/B runs, tests).
+static bool ntt_wave_plan(const plonk_ctx* ctx, unsigned log_n, unsigned* log_r1, unsigned* log_r2) {
+    if (log_n >= 8 && log_n <= 13) {
+        *log_r1 = log_n;
+        *log_r2 = 0;
+        return true;
     }
+    if (log_n < 16 || log_n > 26) return false;
+    unsigned r1 = (log_n + 1) / 2;
+    if (ctx && log_n < sizeof ctx->ntt_split / sizeof ctx->ntt_split[0] && ctx->ntt_split[log_n]) r1 = ctx->ntt_split[log_n];
+    if (r1 < 8 || r1 > 13 || log_n - r1 < 8 || log_n - r1 > 13) return false;
+    *log_r1 = r1;
+    *log_r2 = log_n - r1;
+    return true;
+}
+
+// limb form of a packed table: NTT_LIMB_STRIDE words per entry (what wavel_ld_tw reads)
+__global__ void ntt_limb_table_kernel(const Fr* in, int32_t* out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const FrL a = fpl_from_fp(fp_load(in + i));
+    int32_t* o = out + i * NTT_LIMB_STRIDE;
+    for (int w = 0; w < 9; w++) o[w] = a.l[w];
+    o[9] = o[10] = o[11] = 0;
+}
+
+static int ntt_limb_table(plonk_ctx* ctx, std::map<unsigned, int32_t*>& cache, unsigned key, const Fr* packed, size_t n, const int32_t** out) {
+    auto it = cache.find(key);
+    if (it == cache.end()) {
+        void* d = nullptr;
+        if (hipMalloc(&d, n * NTT_LIMB_STRIDE * sizeof(int32_t)) != hipSuccess) {
+            plonk_set_error("hipMalloc of a %zu-entry limb-form twiddle table failed", n);
+            return PLONK_ERR_NOMEM;
+        }
+        ctx->owned.push_back(d);
+        PLONK_LAUNCH(ntt_limb_table_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, packed, (int32_t*)d, n);
+        PLONK_CHECK_HIP(hipGetLastError());
+        it = cache.emplace(key, (int32_t*)d).first;
+    }
+    *out = it->second;
+    return PLONK_OK;
+}
+
+static int ntt_get_roots_limbs(plonk_ctx* ctx, unsigned log_n, bool inverse, const int32_t** out) {
+    const Fr* packed;
+    PLONK_TRY(ntt_get_roots(ctx, log_n, inverse, &packed));
+    return ntt_limb_table(ctx, ctx->tw.full_l, log_n | (inverse ? 256u : 0u), packed, (size_t)1 << log_n, out);
+}
+
+static int get_lo_hi_limbs(plonk_ctx* ctx, unsigned log_n, bool inverse, const int32_t** lo, const int32_t** hi) {
+    const Fr *plo, *phi;
+    PLONK_TRY(get_lo_hi(ctx, log_n, inverse, &plo, &phi));
+    const unsigned key = log_n | (inverse ? 256u : 0u);
+    const unsigned log_lo = log_n < NTT_TW_LO_LOG ? log_n : NTT_TW_LO_LOG;
+    PLONK_TRY(ntt_limb_table(ctx, ctx->tw.lo_l, key, plo, (size_t)1 << log_lo, lo));
+    return ntt_limb_table(ctx, ctx->tw.hi_l, key, phi, log_n > NTT_TW_LO_LOG ? ((size_t)1 << (log_n - NTT_TW_LO_LOG)) : 1, hi);
 }
 
 // fpl_reduce_small's table of j * m for the limb-form kernel: 49 entries of 12 words, built on the host once per context
@@ -966,39 +919,40 @@ static int ntt_get_jm(plonk_ctx* ctx, const int32_t** out) {
     return PLONK_OK;
 }
 
-static int ntt_wave_launch(plonk_ctx* ctx, const NttWave& p, unsigned log_r, unsigned grid_x, unsigned grid_y) {
-    const unsigned nlds = (log_r - 9) / 2, nt = 64u << (2 * nlds);
-    if (ctx->ntt_kind == 3) {  // the packed-residue form of round 2's first half, kept selectable for A/B runs
-        const size_t shmem = (size_t)4 * nt * 32;
-        if (!ctx->ntt_wave_attr_set) {  // a per-device attribute: tracked per context
-            PLONK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ntt_wave_kernel<2>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(128 * 1024)));
-            ctx->ntt_wave_attr_set = true;
-        }
-        if (nlds == 0) PLONK_LAUNCH(ntt_wave_kernel<0>, dim3(grid_x, grid_y), dim3(nt), shmem, ctx->stream, p);
-        else if (nlds == 1) PLONK_LAUNCH(ntt_wave_kernel<1>, dim3(grid_x, grid_y), dim3(nt), shmem, ctx->stream, p);
-        else PLONK_LAUNCH(ntt_wave_kernel<2>, dim3(grid_x, grid_y), dim3(nt), shmem, ctx->stream, p);
-        return PLONK_OK;
+template <unsigned LOG_E, unsigned NLDS> static int ntt_wavel_launch_as(plonk_ctx* ctx, const NttWave& q, unsigned grid_x, unsigned grid_y) {
+    constexpr unsigned nt = 64u << (2 * NLDS);
+    const size_t shmem = NLDS ? (size_t)4 * nt * 36 : 0;  // one round of the wave-bit exchange: 4 elements of 9 words per thread
+    if (NLDS == 2 && !ctx->ntt_wavel_attr_set[LOG_E - 2]) {  // 144 KiB: above the default limit; a per-device attribute, tracked per context
+        PLONK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ntt_wavel_kernel<LOG_E, NLDS>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)(144 * 1024)));
+        ctx->ntt_wavel_attr_set[LOG_E - 2] = true;
     }
+    void (*const kern)(NttWave) = ntt_wavel_kernel<LOG_E, NLDS>;  // (a template-id's comma would split the macro's arguments)
+    PLONK_LAUNCH(kern, dim3(grid_x, grid_y), dim3(nt), shmem, ctx->stream, q);
+    return PLONK_OK;
+}
+
+// log_r = 8, 10, 12: 4 elements per thread; 9, 11, 13: 8 elements per thread
+static int ntt_wave_launch(plonk_ctx* ctx, const NttWave& p, unsigned log_r, unsigned grid_x, unsigned grid_y) {
     NttWave q = p;
     PLONK_TRY(ntt_get_jm(ctx, &q.jm));
-    const size_t shmem = (size_t)4 * nt * 36;  // 9 words per element
-    if (!ctx->ntt_wavel_attr_set) {
-        PLONK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ntt_wavel_kernel<2>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)(144 * 1024)));
-        ctx->ntt_wavel_attr_set = true;
+    switch (log_r) {
+        case 8: return ntt_wavel_launch_as<2, 0>(ctx, q, grid_x, grid_y);
+        case 10: return ntt_wavel_launch_as<2, 1>(ctx, q, grid_x, grid_y);
+        case 12: return ntt_wavel_launch_as<2, 2>(ctx, q, grid_x, grid_y);
+        case 9: return ntt_wavel_launch_as<3, 0>(ctx, q, grid_x, grid_y);
+        case 11: return ntt_wavel_launch_as<3, 1>(ctx, q, grid_x, grid_y);
+        case 13: return ntt_wavel_launch_as<3, 2>(ctx, q, grid_x, grid_y);
     }
-    if (nlds == 0) PLONK_LAUNCH(ntt_wavel_kernel<0>, dim3(grid_x, grid_y), dim3(nt), shmem, ctx->stream, q);
-    else if (nlds == 1) PLONK_LAUNCH(ntt_wavel_kernel<1>, dim3(grid_x, grid_y), dim3(nt), shmem, ctx->stream, q);
-    else PLONK_LAUNCH(ntt_wavel_kernel<2>, dim3(grid_x, grid_y), dim3(nt), shmem, ctx->stream, q);
-    return PLONK_OK;
+    plonk_set_error("no wave kernel for a 2^%u-point transform", log_r);
+    return PLONK_ERR_ARG;
 }
 
 static int ntt_run_wave(plonk_ctx* ctx, const Fr* in, Fr* out, unsigned log_n, bool inverse, size_t batch, size_t in_len,
                         size_t in_bstride, size_t out_bstride, const Fr* in_scale, const Fr* out_scale, bool scale_by_n_inv) {
     const size_t N = (size_t)1 << log_n;
     unsigned log_r1 = 0, log_r2 = 0;
-    ntt_wave_plan(log_n, &log_r1, &log_r2);
+    ntt_wave_plan(ctx, log_n, &log_r1, &log_r2);
     NttWave p;
     memset(&p, 0, sizeof p);
     p.log_n = log_n;
@@ -1015,7 +969,7 @@ static int ntt_run_wave(plonk_ctx* ctx, const Fr* in, Fr* out, unsigned log_n, b
         p.in_bstride = in_bstride;
         p.out_bstride = out_bstride;
         p.in_len = in_len32;
-        PLONK_TRY(ntt_get_roots(ctx, log_n, inverse, &p.roots));
+        PLONK_TRY(ntt_get_roots_limbs(ctx, log_n, inverse, &p.roots));
         p.in_scale = in_scale;
         p.out_scale = out_scale;
         p.out_scalar = n_inv;
@@ -1039,7 +993,7 @@ static int ntt_run_wave(plonk_ctx* ctx, const Fr* in, Fr* out, unsigned log_n, b
     void* sc;
     PLONK_TRY(ctx_scratch(ctx, 0, batch * N * sizeof(Fr), &sc));
     Fr* tmp = (Fr*)sc;
-    PLONK_TRY(get_lo_hi(ctx, log_n, inverse, &p.tw_lo, &p.tw_hi));
+    PLONK_TRY(get_lo_hi_limbs(ctx, log_n, inverse, &p.tw_lo, &p.tw_hi));
     NttWave a = p;
     a.mode = 1;
     a.log_other = log_r2;
@@ -1049,7 +1003,7 @@ static int ntt_run_wave(plonk_ctx* ctx, const Fr* in, Fr* out, unsigned log_n, b
     a.out_bstride = N;
     a.in_len = in_len32;
     a.in_scale = in_scale;
-    PLONK_TRY(ntt_get_roots(ctx, log_r1, inverse, &a.roots));
+    PLONK_TRY(ntt_get_roots_limbs(ctx, log_r1, inverse, &a.roots));
     PLONK_TRY(prof_begin(ctx, "ntt_pass", 32.0 * (double)N * (double)batch));
     PLONK_TRY(ntt_wave_launch(ctx, a, log_r1, 1u << log_r2, (unsigned)batch));
     PLONK_TRY(prof_end(ctx));
@@ -1064,7 +1018,7 @@ static int ntt_run_wave(plonk_ctx* ctx, const Fr* in, Fr* out, unsigned log_n, b
     c.out_scale = out_scale;
     c.out_scalar = n_inv;
     c.has_out_scalar = scale_by_n_inv;
-    PLONK_TRY(ntt_get_roots(ctx, log_r2, inverse, &c.roots));
+    PLONK_TRY(ntt_get_roots_limbs(ctx, log_r2, inverse, &c.roots));
     PLONK_TRY(prof_begin(ctx, "ntt_pass", 32.0 * (double)N * (double)batch));
     PLONK_TRY(ntt_wave_launch(ctx, c, log_r2, 1u << log_r1, (unsigned)batch));
     PLONK_TRY(prof_end(ctx));
@@ -1079,8 +1033,9 @@ static int ntt_run_wave(plonk_ctx* ctx, const Fr* in, Fr* out, unsigned log_n, b
 // k1 + R1 k2 of its rows as [R2][R1/W] (times 1/N for the inverse).
 int ntt_dist_plan(unsigned log_n, unsigned log_w, unsigned* log_r1, unsigned* log_r2) {
     unsigned r1 = 0, r2 = 0;
-    PLONK_REQUIRE(ntt_wave_plan(log_n, &r1, &r2) && r2, PLONK_ERR_ARG,
-                  "distributed NTT supports sizes 2^18, 2^20, 2^22, 2^24, 2^26 (got 2^%u)", log_n);
+    // the default split (no per-context override: every rank must pick the same one)
+    PLONK_REQUIRE(ntt_wave_plan(nullptr, log_n, &r1, &r2) && r2, PLONK_ERR_ARG,
+                  "distributed NTT supports sizes 2^16 .. 2^26 (got 2^%u)", log_n);
     PLONK_REQUIRE(log_w + 5 <= r2 && log_w + 5 <= r1, PLONK_ERR_ARG, "2^%u ranks are too many for a 2^%u-point transform", log_w, log_n);
     *log_r1 = r1;
     *log_r2 = r2;
@@ -1102,8 +1057,8 @@ int ntt_dist_columns(plonk_ctx* ctx, const Fr* in, Fr* out, unsigned log_n, unsi
     const unsigned log_cl = log_r2 - log_w;
     NttWave a;
     ntt_wave_consts(&a, log_n, inverse);
-    PLONK_TRY(get_lo_hi(ctx, log_n, inverse, &a.tw_lo, &a.tw_hi));
-    PLONK_TRY(ntt_get_roots(ctx, log_r1, inverse, &a.roots));
+    PLONK_TRY(get_lo_hi_limbs(ctx, log_n, inverse, &a.tw_lo, &a.tw_hi));
+    PLONK_TRY(ntt_get_roots_limbs(ctx, log_r1, inverse, &a.roots));
     a.mode = 1;
     a.log_other = log_cl;
     a.sub_base = rank << log_cl;
@@ -1124,7 +1079,7 @@ int ntt_dist_rows(plonk_ctx* ctx, const Fr* in, Fr* out, unsigned log_n, unsigne
     const unsigned log_cl = log_r2 - log_w, log_kl = log_r1 - log_w;
     NttWave c;
     ntt_wave_consts(&c, log_n, inverse);
-    PLONK_TRY(ntt_get_roots(ctx, log_r2, inverse, &c.roots));
+    PLONK_TRY(ntt_get_roots_limbs(ctx, log_r2, inverse, &c.roots));
     c.mode = 2;
     c.log_other = log_kl;  // output stride: frequency k2 of local row kl at out[k2 * R1/W + kl]
     if (log_w) {           // W chunks [source rank][R1/W][R2/W]; one rank: plain contiguous rows
@@ -1151,14 +1106,12 @@ int ntt_run(plonk_ctx* ctx, const Fr* in, Fr* out, unsigned log_n, bool inverse,
     if (!batch) return PLONK_OK;
     const size_t N = (size_t)1 << log_n;
     unsigned wr1, wr2;
-    if ((ctx->ntt_kind == 0 || ctx->ntt_kind == 3 || ctx->ntt_kind == 5) && ntt_wave_plan(log_n, &wr1, &wr2) && ctx->ntt_single_log >= 11 && ctx->ntt_radix_log >= 10) {
-        // measured on MI355X (profiles/r02_e_ntt_kinds.json, r02_v_ntt_kinds.json): the one-pass sizes always win; the
-        // two-pass form on signed limbs wins at 2^18, 2^20 and 2^22 for any batch (a lone 2^20: 0.132 ms against 0.134 on the
-        // radix-2 LDS passes, 0.146 for the packed-residue wave kernel); 2^24 stays on three LDS passes
-        const bool two_pass_ok = log_n == 18 || log_n == 20 || log_n == 22;
-        if (!wr2 || two_pass_ok || ctx->ntt_kind == 3 || ctx->ntt_kind == 5)
-            return ntt_run_wave(ctx, in, out, log_n, inverse, batch, in_len, in_bstride, out_bstride, in_scale, out_scale, scale_by_n_inv);
-    }
+    // The wave kernels serve every size they cover (2^8 .. 2^13 in one launch, 2^16 .. 2^26 in two): measured on MI355X
+    // they beat the LDS kernels at every such size and batch (profiles/r02_e_ntt_kinds.json, r02_v_ntt_kinds.json,
+    // r03_*).  kind 4 = automatic choice among the LDS kernels only (A/B runs); a plonk_ntt_configure with small tiles
+    // (the multi-pass tests) also keeps a transform on the LDS kernels.
+    if ((ctx->ntt_kind == 0 || ctx->ntt_kind == 5) && ntt_wave_plan(ctx, log_n, &wr1, &wr2) && ((ctx->ntt_single_log >= 11 && ctx->ntt_radix_log >= 10) || ctx->ntt_kind == 5))
+        return ntt_run_wave(ctx, in, out, log_n, inverse, batch, in_len, in_bstride, out_bstride, in_scale, out_scale, scale_by_n_inv);
     PLONK_REQUIRE(batch <= 65535, PLONK_ERR_ARG, "NTT batch %zu exceeds 65535", batch);
     unsigned radices[4];
     const unsigned P = plan_passes(ctx, log_n, radices);

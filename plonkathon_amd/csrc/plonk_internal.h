@@ -50,6 +50,7 @@ struct NttTables {
     std::map<unsigned, Fr*> small;   // w_R^k, k < R/2              (per-pass LDS twiddles)
     std::map<unsigned, Fr*> lo, hi;  // w_N^e = lo[e & 1023] * hi[e >> 10]   (inter-pass twiddles)
     std::map<unsigned, Fr*> full;    // w_N^k, k < N                 (barycentric / permutation argument)
+    std::map<unsigned, int32_t*> full_l, lo_l, hi_l;  // the same tables as 29-bit limbs, 12 words per entry (wave NTT kernels)
 };
 
 // One lookup table per (process, device, base set), shared by every plonk_srs / context / stream that
@@ -99,7 +100,7 @@ struct plonk_ctx {
     int msm_lookup_mode = 0;         // 0 auto (fixed SRS only), 1 off, 2 force msm_lookup_bits for every base set
     unsigned msm_lookup_bits = 0;    // 0 = largest window whose table fits the budget
     size_t msm_lookup_budget = 0;    // bytes; 0 = default (PLONK_MSM_TABLE_GB if set, else 4 GiB)
-    bool ntt_attr_set = false, msm_attr_set = false, ntt_wave_attr_set = false, ntt_wavel_attr_set = false;  // hipFuncSetAttribute is per device: tracked per context
+    bool ntt_attr_set = false, msm_attr_set = false, ntt_wavel_attr_set[2] = {false, false};  // hipFuncSetAttribute is per device: tracked per context
     // per-kernel HIP-event profiling (bench.py roofline): one record per instrumented launch
     struct ProfRec { const char* name; hipEvent_t a, b; double algo_bytes; };
     bool profiling = false;
@@ -108,7 +109,8 @@ struct plonk_ctx {
     unsigned ntt_tile_log = 12, ntt_single_log = 11, ntt_radix_log = 10;
     bool ntt_adaptive_tiles = true;
     const int32_t* ntt_jm = nullptr;  // fpl_reduce_small's table (device), built on first use by the limb-form NTT kernel
-    unsigned ntt_kind = 0;  // 0 = auto (Stockham radix-8 for single-pass sizes, radix-2 stages otherwise), 1 / 2 = force
+    unsigned char ntt_split[32] = {0};  // plonk_ntt_set_split: log2 R1 of the two-pass wave plan per log2 N (0 = default)
+    unsigned ntt_kind = 0;  // 0 = auto (wave kernels where they apply, else LDS kernels), 1 / 2 = force an LDS kernel, 4 = auto among the LDS kernels, 5 = force wave
 };
 
 // scratch slot use: 0 = NTT inter-pass buffer, 1 = MSM digits/partials, 2-3 = API-level temporaries
@@ -129,6 +131,11 @@ int k_fr_powers(plonk_ctx*, const Fr& base_mont, const Fr& first_mont, Fr* out, 
 int k_fr_rotate(plonk_ctx*, const Fr* in, Fr* out, size_t n, size_t shift, size_t batch);
 int k_fr_barycentric(plonk_ctx*, const Fr* vals, const Fr* roots, unsigned log_n, const Fr* xs_dev, size_t x_stride,
                      const Fr& n_inv_mont, Fr* out_dev, size_t n_polys);
+int k_fr_count_diff(plonk_ctx*, const Fr* a, const Fr* b_or_null, size_t n, unsigned long long* d_count);
+// api.hip
+Fr fr_from_le32(const uint8_t* b);                 // canonical little-endian bytes -> Montgomery form (host)
+bool le32_below_modulus(const uint8_t* b, bool fq);
+int get_power_table(plonk_ctx*, const Fr& base, const Fr& first, size_t n, const Fr** out);  // first * base^i, cached per context
 // ntt.hip
 Fr host_root_of_unity(unsigned log_n, bool inverse);
 int ntt_run(plonk_ctx*, const Fr* in, Fr* out, unsigned log_n, bool inverse, size_t batch, size_t in_len,

@@ -399,16 +399,20 @@ __global__ void __launch_bounds__(2 * TC_LANES) transcript_kernel(int round, Pro
 // whole column costs two block scans and ONE field inversion.  A zero denominator factor is skipped
 // in the scans and zeroes the ratio it belongs to (py_ecc: x / 0 == 0).
 #define GP_THREADS 256
-__global__ void __launch_bounds__(GP_THREADS) grand_product_kernel(const Fr* wit, const Fr* s_lag, const Fr* roots,
-                                                                   const ProofState* st, size_t n, size_t B, Fr* z_out,
+// Inputs by pointer: proof b's columns at abc[k] + b n, the permutation polynomials sig[k] shared.  The challenges come
+// from the proofs' transcript states (st, the lock-step prover) or, st == null, from `direct` (plonk_fr_grand_product).
+struct RoundChallenges { Fr beta, gamma, alpha; };
+struct GrandProductIn { const Fr* abc[3]; const Fr* sig[3]; };
+__global__ void __launch_bounds__(GP_THREADS) grand_product_kernel(GrandProductIn in, const Fr* roots, const ProofState* st,
+                                                                   RoundChallenges direct, size_t n, Fr* z_out,
                                                                    uint32_t* closes, Fr* num_buf, Fr* den_buf) {
     __shared__ Fr sc_n[GP_THREADS], sc_d[GP_THREADS];
     __shared__ Fr tot_inv;
     const size_t b = blockIdx.x;
     const unsigned tid = threadIdx.x;
-    const Fr beta = st[b].beta, gamma = st[b].gamma;
-    const Fr *A = wit + b * n, *Bv = wit + (B + b) * n, *C = wit + (2 * B + b) * n;
-    const Fr *S1 = s_lag, *S2 = s_lag + n, *S3 = s_lag + 2 * n;
+    const Fr beta = st ? st[b].beta : direct.beta, gamma = st ? st[b].gamma : direct.gamma;
+    const Fr *A = in.abc[0] + b * n, *Bv = in.abc[1] + b * n, *C = in.abc[2] + b * n;
+    const Fr *S1 = in.sig[0], *S2 = in.sig[1], *S3 = in.sig[2];
     Fr *NUM = num_buf + b * n, *DEN = den_buf + b * n;  // this proof's factors; a lane only ever touches its own chunk
     const size_t per = (n + GP_THREADS - 1) / GP_THREADS;
     const size_t lo = tid * per, hi = (lo + per < n) ? lo + per : n;
@@ -466,22 +470,21 @@ __global__ void __launch_bounds__(GP_THREADS) grand_product_kernel(const Fr* wit
 
 // ------------------------------------------------------------------------------------------------
 // Round 3 (prover.py:188-203): quotient evaluations on the 4n-point coset, fully fused.
-//   big = [A, B, C, PI, Z][B][4n]; fixed = [QM, QL, QR, QO, QC, S1, S2, S3][4n]
+//   wit = A, B, C, PI, Z on the coset, proof b at + b 4n; fixed = QM, QL, QR, QO, QC, S1, S2, S3 (FX_* order), l0, xs: [4n].
+//   Challenges from the transcript states (st) or, st == null, from `direct` (plonk_fr_quotient).
 struct ZhInv { Fr v[4]; };
-__global__ void quotient_kernel(const Fr* big, const Fr* fixed, const Fr* l0, const Fr* xs, ZhInv zh,
-                                const ProofState* st, size_t n4, size_t B, Fr* quot) {
+struct QuotientIn { const Fr* wit[5]; const Fr* fixed[FX_COUNT]; const Fr* l0; const Fr* xs; };
+__global__ void quotient_kernel(QuotientIn in, ZhInv zh, const ProofState* st, RoundChallenges direct, size_t n4, size_t B, Fr* quot) {
     const size_t total = B * n4;
     for (size_t gI = (size_t)blockIdx.x * blockDim.x + threadIdx.x; gI < total; gI += (size_t)gridDim.x * blockDim.x) {
         const size_t b = gI / n4, k = gI - b * n4;
-        const Fr beta = st[b].beta, gamma = st[b].gamma, alpha = st[b].alpha;
-        const Fr a = fp_load(big + (0 * B + b) * n4 + k), bb = fp_load(big + (1 * B + b) * n4 + k),
-                 c = fp_load(big + (2 * B + b) * n4 + k), pi = fp_load(big + (3 * B + b) * n4 + k),
-                 z = fp_load(big + (4 * B + b) * n4 + k);
+        const Fr beta = st ? st[b].beta : direct.beta, gamma = st ? st[b].gamma : direct.gamma, alpha = st ? st[b].alpha : direct.alpha;
+        const Fr a = fp_load(in.wit[0] + b * n4 + k), bb = fp_load(in.wit[1] + b * n4 + k), c = fp_load(in.wit[2] + b * n4 + k),
+                 pi = fp_load(in.wit[3] + b * n4 + k), z = fp_load(in.wit[4] + b * n4 + k);
         const size_t kw = (k + 4 < n4) ? k + 4 : k + 4 - n4;  // Z(w x) = Z_big.shift(4), prover.py:173
-        const Fr zw = fp_load(big + (4 * B + b) * n4 + kw);
-        const Fr qm = fp_load(fixed + FX_QM * n4 + k), ql = fp_load(fixed + FX_QL * n4 + k),
-                 qr = fp_load(fixed + FX_QR * n4 + k), qo = fp_load(fixed + FX_QO * n4 + k),
-                 qc = fp_load(fixed + FX_QC * n4 + k);
+        const Fr zw = fp_load(in.wit[4] + b * n4 + kw);
+        const Fr qm = fp_load(in.fixed[FX_QM] + k), ql = fp_load(in.fixed[FX_QL] + k), qr = fp_load(in.fixed[FX_QR] + k),
+                 qo = fp_load(in.fixed[FX_QO] + k), qc = fp_load(in.fixed[FX_QC] + k);
         // gate: A QL + B QR + A B QM + C QO + PI + QC
         Fr gate = fp_add(fp_mul(a, ql), fp_mul(bb, qr));
         gate = fp_add(gate, fp_mul(fp_mul(a, bb), qm));
@@ -489,12 +492,12 @@ __global__ void quotient_kernel(const Fr* big, const Fr* fixed, const Fr* l0, co
         gate = fp_add(gate, fp_add(pi, qc));
         // permutation
         const Fr ag = fp_add(a, gamma), bg = fp_add(bb, gamma), cg = fp_add(c, gamma);
-        const Fr bx = fp_mul(beta, fp_load(xs + k));
+        const Fr bx = fp_mul(beta, fp_load(in.xs + k));
         Fr p1 = fp_mul(fp_mul(fp_add(ag, bx), fp_add(bg, fp_dbl(bx))), fp_mul(fp_add(cg, fp_mul3(bx)), z));
-        Fr p2 = fp_mul(fp_mul(fp_add(ag, fp_mul(beta, fp_load(fixed + FX_S1 * n4 + k))),
-                              fp_add(bg, fp_mul(beta, fp_load(fixed + FX_S2 * n4 + k)))),
-                       fp_mul(fp_add(cg, fp_mul(beta, fp_load(fixed + FX_S3 * n4 + k))), zw));
-        Fr first = fp_mul(fp_sub(z, fp_one<FrParams>()), fp_load(l0 + k));
+        Fr p2 = fp_mul(fp_mul(fp_add(ag, fp_mul(beta, fp_load(in.fixed[FX_S1] + k))),
+                              fp_add(bg, fp_mul(beta, fp_load(in.fixed[FX_S2] + k)))),
+                       fp_mul(fp_add(cg, fp_mul(beta, fp_load(in.fixed[FX_S3] + k))), zw));
+        Fr first = fp_mul(fp_sub(z, fp_one<FrParams>()), fp_load(in.l0 + k));
         Fr acc = fp_add(gate, fp_mul(alpha, fp_add(fp_sub(p1, p2), fp_mul(alpha, first))));
         fp_store(quot + gI, fp_mul(acc, zh.v[k & 3]));
     }
@@ -943,9 +946,13 @@ int plonk_prover_run(plonk_prover* p, size_t B) {
     else PLONK_TRY(msm_run_device(ctx, p->srs, p->coef, n, 3 * B, n, cxy, cfl));
     PLONK_LAUNCH(transcript_kernel, dim3(tg), dim3(2 * TC_LANES), 0, s, 1, p->state, B, (const Fq*)cxy, (const uint8_t*)cfl, p->chal);
     // ---- round 2: grand product Z, commit                                      prover.py:121-152
-    PLONK_LAUNCH(grand_product_kernel, dim3((unsigned)B), dim3(GP_THREADS), 0, s, (const Fr*)p->wit_lag,
-                 (const Fr*)(p->fixed_lag + FX_S1 * n), p->roots, (const ProofState*)p->state, n, B, p->z_lag, closes, p->num,
-                 p->wz);  // num / wz: scratch until round 5
+    GrandProductIn gp;
+    for (int k = 0; k < 3; k++) {
+        gp.abc[k] = p->wit_lag + (size_t)k * B * n;
+        gp.sig[k] = p->fixed_lag + (FX_S1 + k) * n;
+    }
+    PLONK_LAUNCH(grand_product_kernel, dim3((unsigned)B), dim3(GP_THREADS), 0, s, gp, p->roots, (const ProofState*)p->state,
+                 RoundChallenges{}, n, p->z_lag, closes, p->num, p->wz);  // num / wz: scratch until round 5
     PLONK_TRY(ntt_run(ctx, p->z_lag, p->coef + 4 * B * n, log_n, true, B, n, n, n, nullptr, nullptr, true));
     if (p->lag_srs) PLONK_TRY(msm_run_device(ctx, p->lag_srs, p->z_lag, n, B, n, cxy + 2 * 3 * B, cfl + 3 * B));
     else PLONK_TRY(msm_run_device(ctx, p->srs, p->coef + 4 * B * n, n, B, n, cxy + 2 * 3 * B, cfl + 3 * B));
@@ -964,8 +971,12 @@ int plonk_prover_run(plonk_prover* p, size_t B) {
     }
     ZhInv zh;
     for (int k = 0; k < 4; k++) zh.v[k] = p->zh_inv[k];
-    PLONK_LAUNCH(quotient_kernel, grid1(B * n4), dim3(256), 0, s, (const Fr*)p->big, (const Fr*)p->fixed_big,
-                 (const Fr*)p->l0_big, (const Fr*)p->x_big, zh, (const ProofState*)p->state, n4, B, p->quot);
+    QuotientIn qi;
+    for (int k = 0; k < 5; k++) qi.wit[k] = p->big + (size_t)k * B * n4;
+    for (int k = 0; k < FX_COUNT; k++) qi.fixed[k] = p->fixed_big + (size_t)k * n4;
+    qi.l0 = p->l0_big;
+    qi.xs = p->x_big;
+    PLONK_LAUNCH(quotient_kernel, grid1(B * n4), dim3(256), 0, s, qi, zh, (const ProofState*)p->state, RoundChallenges{}, n4, B, p->quot);
     PLONK_TRY(ntt_run(ctx, p->quot, p->quot, log_n + 2, true, B, n4, n4, n4, nullptr, p->ginv_pow, false));
     PLONK_CHECK_HIP(hipMemsetAsync(closes + B, 0, B * sizeof(uint32_t), s));
     PLONK_LAUNCH(quotient_degree_check_kernel, grid1(B * n), dim3(256), 0, s, (const Fr*)p->quot, n, B, closes + B);
@@ -1037,6 +1048,85 @@ int plonk_prover_challenges(plonk_prover* p, size_t b, uint8_t out_le32[6 * 32])
         Fr c = fp_from_mont(*ch[i]);
         memcpy(out_le32 + 32 * i, c.v, 32);
     }
+    return PLONK_OK;
+}
+
+}  // extern "C"
+
+// ---- the fused round kernels on their own: what Prover.round_2 / round_3 of the reference-shaped API call
+extern "C" {
+
+// prover.py:121-146: Z_0 = 1, Z_{i+1} = Z_i * num_i / den_i from the wire values and the permutation polynomials
+int plonk_fr_grand_product(plonk_ctx* ctx, const void* d_a, const void* d_b, const void* d_c, const void* d_s1, const void* d_s2,
+                           const void* d_s3, unsigned log_n, const uint8_t beta_le32[32], const uint8_t gamma_le32[32], void* d_z_out,
+                           int* out_closes) {
+    PLONK_REQUIRE(ctx && d_a && d_b && d_c && d_s1 && d_s2 && d_s3 && beta_le32 && gamma_le32 && d_z_out && out_closes, PLONK_ERR_ARG, "bad argument");
+    PLONK_ENTER(ctx);
+    PLONK_REQUIRE(log_n <= PLONK_FR_TWO_ADICITY, PLONK_ERR_ARG, "size 2^%u exceeds the 2-adicity of Fr", log_n);
+    PLONK_REQUIRE(le32_below_modulus(beta_le32, false) && le32_below_modulus(gamma_le32, false), PLONK_ERR_ARG, "challenge is not a canonical Fr value");
+    const size_t n = (size_t)1 << log_n;
+    const Fr* roots;
+    PLONK_TRY(ntt_get_roots(ctx, log_n, false, &roots));
+    void* scratch;
+    PLONK_TRY(ctx_scratch(ctx, 2, (2 * n + 2) * sizeof(Fr), &scratch));  // num, den, and the closes flag
+    Fr* num = (Fr*)scratch;
+    uint32_t* closes = reinterpret_cast<uint32_t*>(num + 2 * n);
+    GrandProductIn gp = {{(const Fr*)d_a, (const Fr*)d_b, (const Fr*)d_c}, {(const Fr*)d_s1, (const Fr*)d_s2, (const Fr*)d_s3}};
+    RoundChallenges ch;
+    ch.beta = fr_from_le32(beta_le32);
+    ch.gamma = fr_from_le32(gamma_le32);
+    ch.alpha = fp_zero<FrParams>();
+    PLONK_LAUNCH(grand_product_kernel, dim3(1), dim3(GP_THREADS), 0, ctx->stream, gp, roots, (const ProofState*)nullptr, ch, n,
+                 (Fr*)d_z_out, closes, num, num + n);
+    PLONK_CHECK_HIP(hipGetLastError());
+    uint32_t c = 0;
+    PLONK_CHECK_HIP(hipMemcpyAsync(&c, closes, sizeof c, hipMemcpyDeviceToHost, ctx->stream));
+    PLONK_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    *out_closes = (int)c;
+    return PLONK_OK;
+}
+
+// prover.py:188-203: QUOT_big = (gate + alpha * permutation + alpha^2 * (Z - 1) L0) / Z_H on the 4n-point coset
+// offset * mu^k.  d_evals = the coset extensions (fft_expand, 4n values each) of A, B, C, PI, Z, QL, QR, QM, QO, QC, S1,
+// S2, S3, L0 in that order; X_big and 1 / Z_H (four distinct values) are derived from the offset here.
+int plonk_fr_quotient(plonk_ctx* ctx, unsigned log_n, const void* const d_evals[14], const uint8_t offset_le32[32],
+                      const uint8_t alpha_le32[32], const uint8_t beta_le32[32], const uint8_t gamma_le32[32], void* d_out) {
+    PLONK_REQUIRE(ctx && d_evals && offset_le32 && alpha_le32 && beta_le32 && gamma_le32 && d_out, PLONK_ERR_ARG, "bad argument");
+    for (int k = 0; k < 14; k++) PLONK_REQUIRE(d_evals[k], PLONK_ERR_ARG, "d_evals[%d] is NULL", k);
+    PLONK_ENTER(ctx);
+    PLONK_REQUIRE(log_n + 2 <= PLONK_FR_TWO_ADICITY, PLONK_ERR_ARG, "size 2^%u exceeds the 2-adicity of Fr", log_n + 2);
+    PLONK_REQUIRE(le32_below_modulus(offset_le32, false) && le32_below_modulus(alpha_le32, false) && le32_below_modulus(beta_le32, false) &&
+                      le32_below_modulus(gamma_le32, false), PLONK_ERR_ARG, "offset / challenge is not a canonical Fr value");
+    const size_t n4 = (size_t)4 << log_n;
+    const Fr off = fr_from_le32(offset_le32), one = fp_one<FrParams>();
+    QuotientIn qi;
+    for (int k = 0; k < 5; k++) qi.wit[k] = (const Fr*)d_evals[k];
+    qi.fixed[FX_QL] = (const Fr*)d_evals[5];
+    qi.fixed[FX_QR] = (const Fr*)d_evals[6];
+    qi.fixed[FX_QM] = (const Fr*)d_evals[7];
+    qi.fixed[FX_QO] = (const Fr*)d_evals[8];
+    qi.fixed[FX_QC] = (const Fr*)d_evals[9];
+    qi.fixed[FX_S1] = (const Fr*)d_evals[10];
+    qi.fixed[FX_S2] = (const Fr*)d_evals[11];
+    qi.fixed[FX_S3] = (const Fr*)d_evals[12];
+    qi.l0 = (const Fr*)d_evals[13];
+    PLONK_TRY(get_power_table(ctx, host_root_of_unity(log_n + 2, false), off, n4, &qi.xs));  // X_big[k] = offset * mu^k
+    // Z_H(x_k) = (offset mu^k)^n - 1 = offset^n i^k - 1, i = mu^n: four values (prover.py:178); 1 / 0 == 0 as py_ecc
+    Fr on = off;
+    for (unsigned i = 0; i < log_n; i++) on = fp_sqr(on);
+    const Fr i4 = host_root_of_unity(2, false);
+    ZhInv zh;
+    Fr cur = on;
+    for (int k = 0; k < 4; k++) {
+        zh.v[k] = fp_inv(fp_sub(cur, one));
+        cur = fp_mul(cur, i4);
+    }
+    RoundChallenges ch;
+    ch.alpha = fr_from_le32(alpha_le32);
+    ch.beta = fr_from_le32(beta_le32);
+    ch.gamma = fr_from_le32(gamma_le32);
+    PLONK_LAUNCH(quotient_kernel, grid1(n4), dim3(256), 0, ctx->stream, qi, zh, (const ProofState*)nullptr, ch, n4, (size_t)1, (Fr*)d_out);
+    PLONK_CHECK_HIP(hipGetLastError());
     return PLONK_OK;
 }
 

@@ -5,6 +5,7 @@
 //       MASK 8      DPP row_ror:8          (same rate)
 //       MASK 4, 16  ds_swizzle, bit mode   (the LDS crossbar without memory: 17 T/s)
 //       MASK 32     v_permlane32_swap      (the gfx950 half-wave exchange: 8.7 T/s; ds_bpermute manages 6.5 T/s)
+//   wave_swap_words<MASK>(a, b)   swap a register-index bit with a lane bit (the NTT wave kernels' transposes)
 //   g1_wave_reduce(p, lane)       butterfly sum of one G1 point per lane: afterwards every lane holds the total
 //                                 ("wave-reduced bucket sum": the last six levels of the MSM reductions)
 // Used by the NTT wave kernels (ntt.hip) for their in-register digit exchanges and by the MSM kernels (msm.hip).
@@ -20,6 +21,54 @@ template <unsigned MASK> PLONK_DEV uint32_t wave_lane_xor(uint32_t v, unsigned l
     // lane ^ 32: v_permlane32_swap exchanges the upper half of its first operand with the lower half of the second
     auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
     return lane < 32 ? r[1] : r[0];
+}
+
+// Swap one register-index bit with the lane bit of MASK, for one word of the two registers involved: lanes with the bit
+// clear keep a and give b to their partner lane ^ MASK (receiving its a into b), lanes with the bit set keep b and give a.
+//   MASK 32, 16  v_permlane32_swap / v_permlane16_swap: the instruction exchanges exactly the halves (rows) this trade
+//                moves — one instruction, no select
+//   MASK 8, 4    two DPP moves whose bank_mask writes only the receiving lanes (row_ror:8; row_shr:4 / row_shl:4): the
+//                select is part of the move
+//   MASK 2, 1    a quad_perm DPP move and a select per direction (bank_mask cannot split a quad)
+// PLONK_SWAP_VIA_SELECT (A/B switch): the round-2 form for every mask — select the word to send, one cross-lane move,
+// two selects.
+template <unsigned MASK> PLONK_DEV void wave_swap_words(int32_t& a, int32_t& b, bool hi, unsigned lane) {
+#if !defined(PLONK_SWAP_VIA_SELECT)
+    if constexpr (MASK == 32) {
+        auto r = __builtin_amdgcn_permlane32_swap((uint32_t)a, (uint32_t)b, false, false);
+        a = (int32_t)r[0];
+        b = (int32_t)r[1];
+        return;
+    } else if constexpr (MASK == 16) {
+        auto r = __builtin_amdgcn_permlane16_swap((uint32_t)a, (uint32_t)b, false, false);
+        a = (int32_t)r[0];
+        b = (int32_t)r[1];
+        return;
+    } else if constexpr (MASK == 8) {
+        const int na = __builtin_amdgcn_update_dpp(a, b, 0x128, 0xf, 0xC, false);  // lanes 8..15 of a row: a <- b of lane - 8
+        const int nb = __builtin_amdgcn_update_dpp(b, a, 0x128, 0xf, 0x3, false);  // lanes 0..7 of a row:  b <- a of lane + 8
+        a = na;
+        b = nb;
+        return;
+    } else if constexpr (MASK == 4) {
+        const int na = __builtin_amdgcn_update_dpp(a, b, 0x114, 0xf, 0xA, false);  // row_shr:4, banks 1 and 3: a <- b of lane - 4
+        const int nb = __builtin_amdgcn_update_dpp(b, a, 0x104, 0xf, 0x5, false);  // row_shl:4, banks 0 and 2: b <- a of lane + 4
+        a = na;
+        b = nb;
+        return;
+    } else {
+        const int32_t pa = (int32_t)wave_lane_xor<MASK>((uint32_t)a, lane), pb = (int32_t)wave_lane_xor<MASK>((uint32_t)b, lane);
+        const int32_t na = hi ? pb : a, nb = hi ? b : pa;
+        a = na;
+        b = nb;
+        return;
+    }
+#else
+    const uint32_t send = (uint32_t)(hi ? a : b);
+    const uint32_t recv = wave_lane_xor<MASK>(send, lane);
+    if (hi) a = (int32_t)recv;
+    else b = (int32_t)recv;
+#endif
 }
 
 template <unsigned MASK> PLONK_DEV Fq fq_wave_xor(const Fq& a, unsigned lane) {

@@ -222,6 +222,9 @@ def _g1_neg(pt):
 G2 = (Fq2(_G2_COORDS[0]), Fq2(_G2_COORDS[1]))
 
 
+LAGRANGE_SRS_MAX_LOG = 12  # largest 2^k for which Setup.commit builds the Lagrange-basis SRS on first use
+
+
 class Setup:
     def __init__(self, powers_of_x=None, X2=None, _g1_mont_bytes: Optional[bytes] = None):
         self._powers = powers_of_x
@@ -282,7 +285,12 @@ class Setup:
         assert values.basis == Basis.LAGRANGE
         n = len(values)
         assert n <= self._n  # setup.py:70
-        lag = self.device_bases().lagrange(_log2_exact(n))
+        bases, log_n = self.device_bases(), _log2_exact(n)
+        # Building the view is n MSMs of size n (and an n x n scalar matrix): worth it once per circuit size at the
+        # prover's sizes, quadratic beyond them — larger polynomials take the reference's route, ifft then one MSM.
+        if log_n > LAGRANGE_SRS_MAX_LOG and log_n not in bases._views:
+            return self.commit_coeffs(values.ifft())
+        lag = bases.lagrange(log_n)
         return _msm(lag, values.device().ptr, n, 1, n)[0]
 
     def commit_coeffs(self, coeffs: Polynomial):

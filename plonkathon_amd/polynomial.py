@@ -68,8 +68,39 @@ class Polynomial:
             self._dev = get_context().upload_ints([x.n for x in self._values])
         return self._dev
 
+    @classmethod
+    def from_bytes(cls, raw, basis):
+        """From canonical 32-byte little-endian elements back to back (no per-element Python objects)."""
+        return cls._from_device(get_context().upload_bytes(raw), basis)
+
+    @classmethod
+    def powers(cls, first, base, n, basis=Basis.LAGRANGE):
+        """[first * base^k for k < n] built on the device: Scalar.roots_of_unity (curve.py:19-24), the coset points
+        fft_cofactor * mu^k of prover.py:160-161."""
+        ctx = get_context()
+        out = ctx.alloc(n)
+        check(ctx.L.plonk_fr_powers(ctx.handle, le32(Scalar(first).n), le32(Scalar(base).n), n, out.ptr))
+        return cls._from_device(out, basis, n)
+
+    def is_zero(self, start=0, stop=None):
+        """values[start:stop] == [0] * (stop - start), decided on the device (prover.py:205-208, 288, 299)."""
+        stop = self._n if stop is None else stop
+        ctx = get_context()
+        eq = ctypes.c_int(0)
+        check(ctx.L.plonk_fr_equal(ctx.handle, self.device().at(start), None, stop - start, ctypes.byref(eq)))
+        return bool(eq.value)
+
     def __eq__(self, other):  # poly.py:20-21
-        return (self.basis == other.basis) and (self.values == other.values)
+        if self.basis != other.basis:
+            return False
+        if self._values is None or other._values is None:  # at least one side lives in HBM: compare there
+            if self._n != other._n:
+                return False
+            ctx = get_context()
+            eq = ctypes.c_int(0)
+            check(ctx.L.plonk_fr_equal(ctx.handle, self.device().ptr, other.device().ptr, self._n, ctypes.byref(eq)))
+            return bool(eq.value)
+        return self.values == other.values
 
     # ---- pointwise operators ------------------------------------------------------------------
     def _binary(self, other, op):

@@ -145,7 +145,9 @@ void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& bo
 struct hipemuEvent { timespec ts; };
 
 hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
-hipError_t hipSetDevice(int) { return hipSuccess; }
+static thread_local int g_emu_device = 0;
+hipError_t hipSetDevice(int d) { g_emu_device = d; return hipSuccess; }
+hipError_t hipGetDevice(int* d) { *d = g_emu_device; return hipSuccess; }
 hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
     memset(p, 0, sizeof *p);
     snprintf(p->name, sizeof p->name, "hipemu (CPU fibers; tests only)");

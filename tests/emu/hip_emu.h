@@ -25,6 +25,7 @@
 #define PLONK_HD_NOINLINE inline
 #define PLONK_SCHED_FENCE() ((void)0)
 #define PLONK_DEV inline
+#define PLONK_LAMBDA_INLINE
 #define PLONK_KERNEL(...) __VA_ARGS__
 #define PLONK_DYN_SMEM(name) unsigned char* name = ::hipemu::g_dyn_smem
 
@@ -66,13 +67,20 @@ template <class T> inline T __shfl_up(T v, unsigned d, int = 64) {
 }
 // cross-lane builtins of the NTT wave kernels (csrc/ntt_wave.hip), emulated on top of the wave shuffle: the three DPP
 // controls in use (quad_perm, row_ror), ds_swizzle in bit mode, and the v_permlane32_swap half exchange
-inline int __builtin_amdgcn_update_dpp(int, int src, int ctrl, int, int, bool) {
-    const int lane = (int)(threadIdx.x & 63);
+inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
+    const int lane = (int)(threadIdx.x & 63), in_row = lane & 15;
     int from = lane;
+    bool valid = true;
     if (ctrl < 0x100) from = (lane & ~3) | ((ctrl >> (2 * (lane & 3))) & 3);        // quad_perm
+    else if (ctrl >= 0x101 && ctrl <= 0x10f) { from = lane + (ctrl - 0x100); valid = in_row + (ctrl - 0x100) <= 15; }  // row_shl:n reads lane + n
+    else if (ctrl >= 0x111 && ctrl <= 0x11f) { from = lane - (ctrl - 0x110); valid = in_row >= (ctrl - 0x110); }       // row_shr:n reads lane - n
     else if (ctrl >= 0x121 && ctrl <= 0x12f) from = (lane & ~15) | ((lane + (ctrl - 0x120)) & 15);  // row_ror:n (n = 8: lane ^ 8)
     else abort();
-    return __shfl(src, from);
+    const int v = __shfl(src, valid ? from : lane);  // every lane takes part in the exchange
+    const bool enabled = ((row_mask >> (lane >> 4)) & 1) && ((bank_mask >> ((lane >> 2) & 3)) & 1);
+    if (!enabled) return old;
+    if (!valid) return bound_ctrl ? 0 : old;
+    return v;
 }
 inline int __builtin_amdgcn_ds_swizzle(int src, int pattern) {
     const int lane = (int)(threadIdx.x & 63);
@@ -87,6 +95,14 @@ inline hipemu_u2 __builtin_amdgcn_permlane32_swap(unsigned vdst, unsigned src, b
     hipemu_u2 r;
     r.v[0] = lane < 32 ? vdst : src_lo;   // new vdst: lanes 32-63 take src[0..31]
     r.v[1] = lane < 32 ? dst_hi : src;    // new src:  lanes 0-31 take vdst[32..63]
+    return r;
+}
+inline hipemu_u2 __builtin_amdgcn_permlane16_swap(unsigned vdst, unsigned src, bool, bool) {
+    const int lane = (int)(threadIdx.x & 63);
+    const unsigned src_even = __shfl(src, lane & ~16), dst_odd = __shfl(vdst, lane | 16);
+    hipemu_u2 r;
+    r.v[0] = (lane & 16) ? src_even : vdst;  // new vdst: odd rows take the even row below them of src
+    r.v[1] = (lane & 16) ? src : dst_odd;    // new src:  even rows take the odd row above them of vdst
     return r;
 }
 inline unsigned long long __ballot(int pred) { return ::hipemu::ballot(pred); }
@@ -119,6 +135,7 @@ enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
 struct hipDeviceProp_t { char name[256]; int multiProcessorCount; size_t totalGlobalMem; char gcnArchName[256]; };
 hipError_t hipGetDeviceCount(int* n);
 hipError_t hipSetDevice(int d);
+hipError_t hipGetDevice(int* d);
 hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int d);
 hipError_t hipMalloc(void** p, size_t n);
 hipError_t hipFree(void* p);

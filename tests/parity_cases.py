@@ -68,9 +68,10 @@ def ntt_extreme_limbs(log_ns):
     hi, lo = max_mont * r_inv % m, 0                    # the canonical values that upload to those representations
     for log_n in log_ns:
         n = 1 << log_n
-        nt = n // 8                                     # element j * nt + tid sits in register slot j of thread tid
-        for name, slots in (("all", 0xFF), ("low_half", 0x0F), ("high_half", 0xF0), ("even", 0x55), ("odd", 0xAA),
-                            ("pairs", 0x33), ("one", 0x01), ("seven", 0xFE)):
+        slots_n = 8 if log_n & 1 else 4                 # elements per thread of the wave kernel serving this size
+        nt = n // slots_n                               # element j * nt + tid sits in register slot j of thread tid
+        for name, slots in (("all", 0xFF), ("low_half", 0x0F if slots_n == 8 else 0x3), ("high_half", 0xF0 if slots_n == 8 else 0xC),
+                            ("even", 0x55), ("odd", 0xAA), ("pairs", 0x33 if slots_n == 8 else 0x9), ("one", 0x01), ("seven", 0xFE)):
             v = [hi if (slots >> (i // nt)) & 1 else lo for i in range(n)]
             assert ints(P(v, Basis.MONOMIAL).fft()) == fft_ints(v), ("fft", name, log_n)
             assert ints(P(v, Basis.LAGRANGE).ifft()) == fft_ints(v, True), ("ifft", name, log_n)

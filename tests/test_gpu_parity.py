@@ -50,7 +50,7 @@ def test_ntt_forced_variants():
 
     ctx = get_context()
     try:
-        for kind in (1, 2, 3, 5):
+        for kind in (1, 2, 4, 5):
             check(ctx.L.plonk_ntt_select_kernel(ctx.handle, kind))
             check(ctx.L.plonk_ntt_configure(ctx.handle, 0, 0, 0))
             pc.ntt_vs_oracle([0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 16], seed0=10 * kind)
@@ -63,8 +63,8 @@ def test_ntt_forced_variants():
 
 
 def test_ntt_extreme_inputs():
-    pc.ntt_extreme_inputs((9, 11, 13, 16))
-    pc.ntt_extreme_limbs((9, 11, 13))
+    pc.ntt_extreme_inputs((8, 9, 10, 11, 12, 13, 16))
+    pc.ntt_extreme_limbs((8, 9, 10, 11, 12, 13))
 
 
 @pytest.mark.parametrize("log_n", [18, 20, 22, 24])
@@ -246,7 +246,7 @@ def test_api_prover_matches_batch_prover_2_11(setup):
     assert pc.flat(p1.prove(dict(wit))) == pc.flat(BatchProver(setup, program).prove(dict(wit)))
 
 
-@pytest.mark.parametrize("log_n", [17, 18, 20, 22])
+@pytest.mark.parametrize("log_n", [16, 17, 18, 19, 20, 21, 22])
 def test_ntt_exact_vs_c_oracle(log_n):
     """Bit-exact forward and inverse transforms at microbench sizes against the C half of the oracle."""
     from oracle import c_oracle
@@ -255,6 +255,42 @@ def test_ntt_exact_vs_c_oracle(log_n):
     v = pc.rand_vec(4000 + log_n, 1 << log_n)
     assert pc.ints(pc.P(v, Basis.MONOMIAL).fft()) == c_oracle.fr_ntt(v)
     assert pc.ints(pc.P(v, Basis.LAGRANGE).ifft()) == c_oracle.fr_ntt(v, True)
+
+
+def _random_canonical_bytes(seed, n):
+    """n canonical elements (< 2^253 < r) as 32-byte little-endian words, from a seeded numpy generator."""
+    import numpy as np
+
+    a = np.random.default_rng(seed).integers(0, 256, size=(n, 32), dtype=np.uint8)
+    a[:, 31] &= 0x1F
+    return a.tobytes()
+
+
+@pytest.mark.parametrize("log_n,split", [(24, 0), (24, 13), (23, 0)])
+def test_ntt_exact_vs_c_oracle_at_full_size(log_n, split):
+    """BASELINE configs[3]'s largest size (and its neighbours), bit-exact in both directions against the C oracle, on bytes
+    (16 M Python ints would take minutes); 2^24 on both of its splits (2^12 x 2^12, the default, and 2^13 x 2^11)."""
+    import ctypes
+
+    from oracle import c_oracle
+    from plonkathon_amd import get_context
+    from plonkathon_amd._lib import check
+
+    ctx = get_context()
+    n = 1 << log_n
+    raw = _random_canonical_bytes(9000 + log_n, n)
+    try:
+        if split:
+            check(ctx.L.plonk_ntt_set_split(ctx.handle, log_n, split))
+        buf = ctx.upload_bytes(raw)
+        out = ctx.alloc(n)
+        check(ctx.L.plonk_fr_ntt(ctx.handle, buf.ptr, out.ptr, log_n, 0, 1))
+        fwd = ctx.download_bytes(out)
+        assert fwd == c_oracle.fr_ntt_bytes(raw), "forward"
+        check(ctx.L.plonk_fr_ntt(ctx.handle, buf.ptr, buf.ptr, log_n, 1, 1))  # inverse, in place
+        assert ctx.download_bytes(buf) == c_oracle.fr_ntt_bytes(raw, True), "inverse"
+    finally:
+        check(ctx.L.plonk_ntt_set_split(ctx.handle, log_n, 0))
 
 
 def test_batched_msm_vs_c_oracle(setup):
@@ -477,10 +513,11 @@ def test_full_size_lookup_table_on_an_explicit_budget():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("wave_kind", [3, 5])
-def test_wave_kernel_two_pass_splits_and_batches(wave_kind):
-    """The wave kernels forced (kind 3: packed residues, kind 5: signed limbs) on the splits the dispatcher does not pick by itself: 2^24 = 2^13 x 2^11 (properties),
-    and a batch of three 2^18 transforms in one call, exact against the C oracle."""
+@pytest.mark.parametrize("log_n,split", [(18, 9), (18, 10), (20, 11), (20, 12), (22, 13), (22, 9), (19, 11), (21, 8)])
+def test_wave_kernel_two_pass_splits_and_batches(log_n, split):
+    """Two-pass wave transforms on splits the dispatcher does not pick by itself (every pairing of the 4- and
+    8-element-per-thread kernels, and of small with large factors): a batch of three transforms in one call, exact
+    against the C oracle, and back in place."""
     import ctypes
 
     from oracle import c_oracle
@@ -489,17 +526,16 @@ def test_wave_kernel_two_pass_splits_and_batches(wave_kind):
 
     ctx = get_context()
     try:
-        check(ctx.L.plonk_ntt_select_kernel(ctx.handle, wave_kind))
-        pc.ntt_roundtrip_and_linearity(24, seed=31)
-        n = 1 << 18
-        vecs = [pc.rand_vec(70 + i, n) for i in range(3)]
-        buf = ctx.upload_ints([x for v in vecs for x in v])
+        check(ctx.L.plonk_ntt_set_split(ctx.handle, log_n, split))
+        n = 1 << log_n
+        raws = [_random_canonical_bytes(70 + 10 * log_n + i, n) for i in range(3)]
+        buf = ctx.upload_bytes(b"".join(raws))
         out = ctx.alloc(3 * n)
-        check(ctx.L.plonk_fr_ntt(ctx.handle, buf.ptr, out.ptr, 18, 0, 3))
-        got = ctx.download_ints(out)
-        for i, v in enumerate(vecs):
-            assert got[i * n : (i + 1) * n] == c_oracle.fr_ntt(v), i
-        check(ctx.L.plonk_fr_ntt(ctx.handle, out.ptr, out.ptr, 18, 1, 3))  # in place, inverse
-        assert ctx.download_ints(out) == [x for v in vecs for x in v]
+        check(ctx.L.plonk_fr_ntt(ctx.handle, buf.ptr, out.ptr, log_n, 0, 3))
+        got = ctx.download_bytes(out)
+        for i, raw in enumerate(raws):
+            assert got[32 * n * i : 32 * n * (i + 1)] == c_oracle.fr_ntt_bytes(raw), i
+        check(ctx.L.plonk_fr_ntt(ctx.handle, out.ptr, out.ptr, log_n, 1, 3))  # in place, inverse
+        assert ctx.download_bytes(out) == b"".join(raws)
     finally:
-        check(ctx.L.plonk_ntt_select_kernel(ctx.handle, 0))
+        check(ctx.L.plonk_ntt_set_split(ctx.handle, log_n, 0))

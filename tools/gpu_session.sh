@@ -1,0 +1,33 @@
+#!/bin/bash
+# One GPU session = a list of named steps, run in order on the gpurun box; every step writes under gpurun_out/<tag>/.
+#   /usr/local/graft/bin/gpurun --timeout 1500 -- 'bash tools/gpu_session.sh r03a tests ntt_sweep bench'
+# Steps: tests[:<pytest -k expr>]  ntt_sweep[:<args>]  ntt_ab  bench[:<args>]  rocprof  pmc  ubench  smoke
+tag=$1; shift
+out=gpurun_out/$tag
+mkdir -p "$out"
+export TMPDIR=/tmp
+for step in "$@"; do
+  name=${step%%:*}; arg=""; [[ "$step" == *:* ]] && arg=${step#*:}
+  echo "=== $name $arg"
+  case $name in
+    tests)
+      if [ -n "$arg" ]; then timeout 1200 python -m pytest tests -m gpu -x -q -k "$arg" > "$out/pytest_gpu.log" 2>&1
+      else timeout 1500 python -m pytest tests -m gpu -x -q > "$out/pytest_gpu.log" 2>&1; fi
+      echo "pytest rc=$?" >> "$out/pytest_gpu.log"; tail -4 "$out/pytest_gpu.log" ;;
+    smoke) timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > "$out/smoke.log" 2>&1; echo "smoke rc=$?"; tail -2 "$out/smoke.log" ;;
+    ntt_sweep) timeout 600 python tools/ntt_sweep.py $arg > "$out/ntt_sweep.jsonl" 2> "$out/ntt_sweep.err"; echo "rc=$?"; tail -3 "$out/ntt_sweep.jsonl" ;;
+    ntt_ab)   # every alternative build present as plonkathon_amd/libplonk_hip_<name>.so, same shapes
+      for so in plonkathon_amd/libplonk_hip_*.so; do
+        t=$(basename "$so" .so); t=${t#libplonk_hip_}
+        PLONK_HIP_LIB=$so timeout 300 python tools/ntt_sweep.py --tag "$t" $arg >> "$out/ntt_ab.jsonl" 2>> "$out/ntt_ab.err"
+      done
+      timeout 300 python tools/ntt_sweep.py --tag default $arg >> "$out/ntt_ab.jsonl" 2>> "$out/ntt_ab.err"; echo "rc=$?" ;;
+    bench) timeout 900 python bench.py $arg > "$out/bench.json" 2> "$out/bench.err"; echo "bench rc=$?"; cut -c1-400 "$out/bench.json"; echo ;;
+    rocprof)
+      ( cd /tmp && rocprofv3 --kernel-trace --stats -d "$OLDPWD/$out/rocprof" -o trace -- python "$OLDPWD/bench.py" $arg > "$OLDPWD/$out/bench_under_rocprof.json" 2> "$OLDPWD/$out/rocprof.err" ); echo "rocprof rc=$?"
+      find "$out/rocprof" -name "*kernel_stats.csv" | head -1 | xargs -r head -12 ;;
+    pmc) bash tools/pmc_collect.sh "$out" $arg ;;
+    ubench) for b in tools/ubench/*.bin; do timeout 120 "$b" > "$out/$(basename $b .bin).json" 2>&1; done ;;
+    *) echo "unknown step $name" ;;
+  esac
+done
