@@ -217,6 +217,22 @@ int plonk_prover_upload_variables(plonk_prover* p, const uint8_t* vars_le32, siz
 int plonk_prover_run(plonk_prover* p, size_t batch);
 int plonk_prover_download(plonk_prover* p, size_t batch, uint8_t* out_proofs, uint8_t* out_status);
 int plonk_prover_challenges(plonk_prover* p, size_t b, uint8_t out_le32[6 * 32]);
+/* the same download as 480-byte records: the nine commitments compressed (plonk_g1_compress's encoding), then the six
+ * evaluations as 32-byte BIG-endian scalars — north_star's "compressed G1 bytes" form of a proof */
+int plonk_prover_download_compressed(plonk_prover* p, size_t batch, uint8_t* out_proofs480, uint8_t* out_status);
+
+/* ---- compressed G1 encoding ---------------------------------------------------------------------------------
+ * The reference's one G1 byte encoding is x then y as 32-byte big-endian integers (append_point, transcript.py:62-67); it
+ * has no compressed form, so one is defined here, derived from those bytes: the 32 big-endian bytes of x with the two
+ * spare top bits of byte 0 = 10 (y is the smaller root of x^3 + 3, y <= (p-1)/2), 11 (the larger root) or 01 (the point
+ * at infinity, x = 0; py_ecc's None) — gnark-crypto's flag layout for BN254.
+ *   plonk_g1_compress    count affine points x||y (canonical little-endian, (0,0) = infinity, the layout plonk_g1_msm
+ *                        returns) -> count x 32 bytes.  PLONK_ERR_ARG if a coordinate is not below p.
+ *   plonk_g1_decompress  count x 32 bytes -> x||y canonical little-endian + status[i]: 0 ok, 1 malformed (flag bits 00,
+ *                        x >= p, infinity with x != 0), 2 x^3 + 3 is not a square (not a curve point); y by one
+ *                        exponentiation per point, (p + 1) / 4, on the device.                                        */
+int plonk_g1_compress(plonk_ctx* ctx, const uint8_t* h_xy_le, size_t count, uint8_t* h_out32);
+int plonk_g1_decompress(plonk_ctx* ctx, const uint8_t* h_in32, size_t count, uint8_t* h_out_xy_le, uint8_t* h_status);
 
 /* ---- multi-GPU: gather of finished proofs, RCCL over xGMI ---------------------------------------------
  * Proofs are independent (prover.py:51-84 has no cross-proof state), so N GPUs prove disjoint index sets with no

@@ -127,3 +127,40 @@ def ec_lincomb_naive(pairs):
     for pt, coeff in pairs:
         o = add(o, ec_mul(pt, coeff))
     return o
+
+
+# ---- compressed encoding (build-defined; derived from append_point's bytes, /root/reference/transcript.py:62-67) --------
+# 32 bytes: x big-endian, top two bits of byte 0 = 10 (y the smaller root, y <= (p-1)/2), 11 (the larger root), 01 (infinity).
+def compress(pt):
+    if pt is None:
+        return bytes([0x40]) + bytes(31)
+    x, y = int(pt[0]) % Q_MOD, int(pt[1]) % Q_MOD
+    b = bytearray(x.to_bytes(32, "big"))
+    b[0] |= 0xC0 if y > (Q_MOD - 1) // 2 else 0x80
+    return bytes(b)
+
+
+def decompress(b):
+    assert len(b) == 32
+    flag = b[0] & 0xC0
+    x = int.from_bytes(bytes([b[0] & 0x3F]) + b[1:], "big")
+    if flag == 0 or x >= Q_MOD:
+        raise ValueError("malformed encoding")
+    if flag == 0x40:
+        if x:
+            raise ValueError("malformed encoding")
+        return None
+    rhs = (x * x * x + 3) % Q_MOD
+    y = pow(rhs, (Q_MOD + 1) // 4, Q_MOD)  # p = 3 (mod 4)
+    if y * y % Q_MOD != rhs:
+        raise ValueError("not on the curve")
+    if (y > (Q_MOD - 1) // 2) != (flag == 0xC0):
+        y = Q_MOD - y
+    return (x, y)
+
+
+def proof_to_bytes(flat):
+    """`flat` = Proof.flatten() with int / (int, int) / None values -> the 480-byte form of plonkathon_amd.Proof.to_bytes."""
+    pts = ("a_1", "b_1", "c_1", "z_1", "t_lo_1", "t_mid_1", "t_hi_1", "W_z_1", "W_zw_1")
+    scs = ("a_eval", "b_eval", "c_eval", "s1_eval", "s2_eval", "z_shifted_eval")
+    return b"".join(compress(flat[k]) for k in pts) + b"".join(int(flat[k]).to_bytes(32, "big") for k in scs)

@@ -37,6 +37,9 @@ SIGNATURES = {
     "plonk_fr_equal": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_int)]),
     "plonk_fr_grand_product": (ctypes.c_int, [ctypes.c_void_p] + [ctypes.c_void_p] * 6 + [ctypes.c_uint, _u8p, _u8p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]),
     "plonk_fr_quotient": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint, ctypes.POINTER(ctypes.c_void_p), _u8p, _u8p, _u8p, _u8p, ctypes.c_void_p]),
+    "plonk_g1_compress": (ctypes.c_int, [ctypes.c_void_p, _u8p, ctypes.c_size_t, ctypes.c_char_p]),
+    "plonk_g1_decompress": (ctypes.c_int, [ctypes.c_void_p, _u8p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_char_p]),
+    "plonk_prover_download_compressed": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_char_p]),
     "plonk_ntt_select_kernel": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint]),
     "plonk_ntt_set_split": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint, ctypes.c_uint]),
     "plonk_fr_coset_extend": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint, _u8p, ctypes.c_size_t]),

@@ -49,14 +49,9 @@ class BatchProver:
         self._wires = [w.as_list() for w in program.wires()]
         n = self.group_order
         # wire cell -> variable index; one extra all-zero slot serves the empty cells and the padding rows
-        self._vars = sorted({v for row in self._wires for v in row if v is not None}, key=str)
+        variables, self._cell_index = program.wiring_table()
+        self._vars = list(variables)
         pos = {v: i for i, v in enumerate(self._vars)}
-        zero = len(self._vars)
-        self._cell_index = np.full((3, n), zero, dtype=np.int64)
-        for i, row in enumerate(self._wires):
-            for j, v in enumerate(row):
-                if v is not None:
-                    self._cell_index[j, i] = pos[v]
         L, R, M, O, C = program.gate_columns()
         sigma = program.permutation_columns()
         sel = _le(M) + _le(L) + _le(R) + _le(O) + _le(C) + _le(sigma[1]) + _le(sigma[2]) + _le(sigma[3])
@@ -156,6 +151,15 @@ class BatchProver:
         out = ctypes.create_string_buffer(768 * B)
         status = ctypes.create_string_buffer(B)
         check(self.ctx.L.plonk_prover_download(self._h, B, out, status))
+        return out.raw, status.raw[:B]
+
+    def download_compressed(self, B=None):
+        """The resident batch's proofs as 480-byte records (Proof.to_bytes' form: nine compressed commitments, six
+        big-endian evaluations), packed on the device, + the status bytes of download_raw."""
+        B = self._resident if B is None else B
+        out = ctypes.create_string_buffer(480 * B)
+        status = ctypes.create_string_buffer(B)
+        check(self.ctx.L.plonk_prover_download_compressed(self._h, B, out, status))
         return out.raw, status.raw[:B]
 
     def download(self, B=None):

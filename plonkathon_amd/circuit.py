@@ -186,6 +186,25 @@ class Program:
     def wires(self):
         return [c.wires for c in self.constraints]
 
+    def wiring_table(self):
+        """(variables, cell_index): the circuit's variables in a fixed order and, per wire column L / R / O and row, the
+        index of the variable that cell carries — len(variables) for an empty cell or a padding row (witness[None] = 0,
+        prover.py:94-95).  What round 1 needs to build A, B, C from one encoding of each variable's value
+        (prover.py:97-103) without a Python loop over the rows.  Cached."""
+        if getattr(self, "_wiring", None) is None:
+            import numpy as np
+
+            rows = [w.as_list() for w in self.wires()]
+            variables = sorted({v for row in rows for v in row if v is not None}, key=str)
+            pos = {v: i for i, v in enumerate(variables)}
+            cell_index = np.full((3, self.group_order), len(variables), dtype=np.int64)
+            for i, row in enumerate(rows):
+                for j, v in enumerate(row):
+                    if v is not None:
+                        cell_index[j, i] = pos[v]
+            self._wiring = (tuple(variables), cell_index)
+        return self._wiring
+
     def common_preprocessed_input(self) -> CommonPreprocessedInput:  # compiler/program.py:44-57
         L, R, M, O, C = self.make_gate_polynomials()
         S = self.make_s_polynomials()

@@ -452,6 +452,139 @@ template <class P> PLONK_HD Fp<P> fpl_pack_canonical(const FpL<P>& a) {
     return out;
 }
 
+// ---- multiplication by a constant known in advance (the NTT's twiddle factors): Shoup / Barrett form ---------------------
+// For a constant w < m with wp = floor(w 2^261 / m) precomputed, a * w mod m needs no reduction pass over a full product:
+//   q = floor(a wp / 2^261)   the TOP half of one product (columns 7..16 of 17: two guard columns bound the error to 1)
+//   r = a w - q m             the BOTTOM halves of two products (mod 2^261)
+// 53 + 45 + 45 = 143 multiply-adds and 19 column steps against fpl_mul's 171 and 17, and no serial q_k = acc * (-1/m)
+// chain.  The data stays in Montgomery form (a = x R): a w = (x w) R, so w is the PLAIN value of the constant.
+//   a: limbs within fpl_mul's operand range (|limb| < 1.27 * 2^30), |value| < 128 m.
+//   result: normalised, value within (-1.8 m, 2.8 m)   [exact r in (-0.76 m, 1.76 m); q off by at most one either way]
+// wp from the Montgomery form wt = w R mod m of the constant (what the root tables hold): w R = wp m + wt, hence
+// wp = wt * (-1/m) mod 2^261 — one bottom-half product with the 261-bit constant fpl_ninv261.
+template <class P> struct FpLS {
+    int32_t w[9];   // w, 29-bit limbs
+    int32_t wp[9];  // floor(w 2^261 / m), 29-bit limbs
+};
+
+// bottom half of a product of two 9-limb non-negative numbers (host / table construction)
+PLONK_HD void fpl_limbs_mul_low(const uint32_t a[9], const uint32_t b[9], uint32_t out[9]) {
+    uint64_t acc = 0;
+    for (int k = 0; k < 9; k++) {
+        for (int i = 0; i <= k; i++) {
+            const uint64_t t = (uint64_t)a[i] * b[k - i];  // < 2^58: nine of them and a carry stay inside 64 bits
+            acc += t;
+        }
+        out[k] = (uint32_t)acc & FP29_MASK;
+        acc >>= 29;
+    }
+}
+
+// -1/m mod 2^261 as nine 29-bit limbs: Newton / Hensel lifting from 1/m = 1 (mod 2), ten doublings
+template <class P> PLONK_HD void fpl_ninv261(uint32_t out[9]) {
+    uint32_t m[9], inv[9] = {1, 0, 0, 0, 0, 0, 0, 0, 0}, t[9], u[9];
+    for (int i = 0; i < 9; i++) m[i] = fp29_mod_limb<P>(i);
+    for (int it = 0; it < 10; it++) {
+        fpl_limbs_mul_low(m, inv, t);  // m * inv = 1 (mod 2^bits)
+        uint32_t borrow = 0;           // u = 2 - t (mod 2^261)
+        for (int i = 0; i < 9; i++) {
+            const int64_t v = (int64_t)(i == 0 ? 2 : 0) - (int64_t)t[i] - (int64_t)borrow;
+            u[i] = (uint32_t)((uint64_t)v & FP29_MASK);
+            borrow = v < 0 ? 1u : 0u;
+        }
+        fpl_limbs_mul_low(inv, u, t);
+        for (int i = 0; i < 9; i++) inv[i] = t[i];
+    }
+    uint32_t borrow = 0;  // out = -inv (mod 2^261)
+    for (int i = 0; i < 9; i++) {
+        const int64_t v = -(int64_t)inv[i] - (int64_t)borrow;
+        out[i] = (uint32_t)((uint64_t)v & FP29_MASK);
+        borrow = v < 0 ? 1u : 0u;
+    }
+}
+
+// the Shoup pair of a constant given in canonical Montgomery form
+template <class P> PLONK_HD FpLS<P> fpl_shoup_from_mont(const Fp<P>& wt, const uint32_t ninv261[9]) {
+    FpLS<P> r;
+    uint32_t t[9], wp[9];
+    fp29_unpack(wt.v, t);
+    fpl_limbs_mul_low(t, ninv261, wp);
+    FpL<P> one_plain = fpl_zero<P>();
+    one_plain.l[0] = 1;
+    const Fp<P> plain = fpl_pack_canonical(fpl_mul(fpl_from_fp(wt), one_plain));  // w = wt / R mod m, canonical
+    fp29_unpack(plain.v, t);
+    for (int i = 0; i < 9; i++) {
+        r.w[i] = (int32_t)t[i];
+        r.wp[i] = (int32_t)wp[i];
+    }
+    return r;
+}
+
+// FENCE: keep the scheduler from starting the second half (and its loads of w) before the first is done — for kernels at
+// their register limit
+template <class P, bool FENCE = false> PLONK_HD FpL<P> fpl_mul_shoup(const FpL<P>& a, const FpLS<P>& c) {
+#ifdef PLONK_EMU
+    {
+        long double mm = 0;
+        for (int i = 8; i >= 0; i--) mm = mm * 536870912.0L + (long double)fp29_mod_limb<P>(i);
+        FPL_CHECK(fabsl(fpl_dbg_value(a)) < 128.0L * mm, "fpl_mul_shoup: |a| exceeds 128 m");
+        FPL_CHECK(9.0L * (long double)fpl_dbg_maxlimb(a) * 536870912.0L + 9.0L * 288230376151711744.0L + 1099511627776.0L < 9223372036854775808.0L,
+                  "fpl_mul_shoup: column sum exceeds 64 bits");
+    }
+#endif
+    int32_t q[9];
+    int64_t acc = 0;
+    PLONK_CHAIN_BEGIN();
+    // q = floor(a * wp / 2^261): columns 7 and 8 only feed the carry
+#pragma unroll
+    for (int k = 7; k < 17; k++) {
+#pragma unroll
+        for (int i = (k > 8 ? k - 8 : 0); i <= (k < 8 ? k : 8); i++) {
+            acc += (int64_t)a.l[i] * c.wp[k - i];
+            PLONK_CHAIN(acc);
+        }
+        if (k >= 9) {
+            q[k - 9] = (int32_t)((uint32_t)acc & FP29_MASK);
+            FPL_ANY_SIGN(q[k - 9]);
+        }
+        acc >>= 29;  // arithmetic: floor
+    }
+    q[8] = (int32_t)acc;
+    if (FENCE) PLONK_SCHED_FENCE();
+    // r = a * w - q * m  (mod 2^261)
+    FpL<P> r;
+    acc = 0;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+#pragma unroll
+        for (int i = 0; i <= k; i++) {
+            acc += (int64_t)a.l[i] * c.w[k - i];
+            PLONK_CHAIN(acc);
+        }
+#pragma unroll
+        for (int i = 0; i <= k; i++) {
+            acc += (int64_t)q[i] * (-(int32_t)fp29_mod_limb<P>(k - i));
+            PLONK_CHAIN(acc);
+        }
+        if (k < 8) {
+            r.l[k] = (int32_t)((uint32_t)acc & FP29_MASK);
+            FPL_ANY_SIGN(r.l[k]);
+            acc >>= 29;
+        }
+    }
+    r.l[8] = (int32_t)((uint32_t)acc << 3) >> 3;  // |r| < 2^256: limb 8 is the low 29 bits of the column, sign-extended
+    PLONK_CHAIN_END(r.l[8]);
+#ifdef PLONK_EMU
+    {
+        long double mm = 0;
+        for (int i = 8; i >= 0; i--) mm = mm * 536870912.0L + (long double)fp29_mod_limb<P>(i);
+        const long double v = fpl_dbg_value(r);
+        FPL_CHECK(v > -1.8L * mm && v < 2.8L * mm, "fpl_mul_shoup: result outside (-1.8 m, 2.8 m)");
+    }
+#endif
+    return r;
+}
+
 // normalised value within (0, 2m), limbs non-negative (fpl_reduce_small<P, 1>'s result) -> canonical packed element
 template <class P> PLONK_HD Fp<P> fpl_pack_positive(const FpL<P>& a) {
     FPL_CHECK(a.l[8] >= 0, "fpl_pack_positive: negative value");

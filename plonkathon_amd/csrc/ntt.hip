@@ -22,6 +22,7 @@
 #include "fpl.h"
 
 typedef FpL<FrParams> FrL;
+typedef FpLS<FrParams> FrLS;
 
 // defaults live in plonk_ctx (ntt_tile_log = 12: 4096 elements = 128 KiB of LDS; ntt_single_log = 11;
 // ntt_radix_log = 10) and can be changed with plonk_ntt_configure for tuning / small-size tests.
@@ -479,12 +480,14 @@ __global__ void __launch_bounds__(1024) ntt_pass_radix2_kernel(NttPass p) {
 // Coset scaling, zero padding n -> 4n, 1/N and the inverse-coset scaling are fused into the first load / last store.
 //
 // Range discipline (m = the modulus; "N-form" = limbs 0..7 in [0, 2^29), limb 8 signed and small).  Every stage receives
-// N-form elements with |value| < 2 m: loads are canonical, multiplications return N-form in (-m, 2m), and the one output of
-// each butterfly group that carries no twiddle factor (index 0) goes through fpl_reduce_small (N-form, |value| < 0.51 m).
-// Inside a radix-8 butterfly five carry sweeps keep every limb inside int32 and every multiplicand inside fpl_mul's
-// operand bound (|limb| < 1.27 * 2^30): the bounds are written on each line of dft8l / dft4l.  |value| never exceeds 16 m
-// (a sum of eight inputs), fpl_mul tolerates 128 m.
-#define NTT_LIMB_STRIDE 12  // int32 words per entry of a limb-form table (9 used)
+// N-form elements with |value| < 2.8 m: loads are canonical, twiddle multiplications (fpl_mul_shoup: the factor is a known
+// constant, so the product needs 143 multiply-adds instead of fpl_mul's 171) return N-form in (-1.8 m, 2.8 m), and the one
+// output of each butterfly group that carries no twiddle factor (index 0) goes through fpl_reduce_small (N-form,
+// |value| < 0.51 m).  Inside a radix-8 butterfly five carry sweeps keep every limb inside int32 and every multiplicand
+// inside the multiplications' operand bound (|limb| < 1.27 * 2^30): the bounds are written on each line of dft8l / dft4l.
+// |value| never exceeds 22.4 m (a sum of eight inputs): fpl_reduce_small's table reaches 23 m, the multiplications 128 m.
+#define NTT_LIMB_STRIDE 12   // int32 words per entry of a limb-form table (9 used): Montgomery residues (inter-pass twiddles)
+#define NTT_SHOUP_STRIDE 20  // int32 words per entry of a root table: w (9), floor(w 2^261 / m) (9), 2 unused
 struct NttWave {
     const Fr* in;
     Fr* out;
@@ -502,18 +505,19 @@ struct NttWave {
     unsigned sub_base, chunk_log, chunk_stride;
     const int32_t* tw_lo;  // inter-pass twiddles w_N^e = tw_lo[e & 1023] * tw_hi[e >> 10], limb form   (mode 1)
     const int32_t* tw_hi;
-    const int32_t* roots;  // w_R^k, k < R, R = this kernel's transform size (direction of the transform), limb form
+    const int32_t* roots;  // w_R^k, k < R, R = this kernel's transform size (direction of the transform): Shoup pairs (fpl.h)
     const Fr* in_scale;    // per-element factor at load (coset offset powers) or null
     const Fr* out_scale;   // per-element factor at store or null
     Fr out_scalar;
     unsigned has_out_scalar;
-    Fr w8_1, w8_2, w8_3;
+    FrLS w8[3];            // w_8, w_8^2 (= w_4), w_8^3 for the transform direction, Shoup pairs: kernel arguments live in SGPRs
     const int32_t* jm;     // fpl_reduce_small's table of j * m
 };
 
-// entry idx of a limb-form table
+// entry idx of a limb-form table (Montgomery residue)
 PLONK_DEV FrL wavel_ld_tw(const int32_t* tab, unsigned idx) {
-    const int32_t* t = tab + (size_t)idx * NTT_LIMB_STRIDE;
+    // (a 32-bit byte offset from a uniform base: SGPR-base addressing, one VGPR per address instead of two)
+    const int32_t* t = reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(tab) + idx * (unsigned)(NTT_LIMB_STRIDE * sizeof(int32_t)));
     const u32x4 a = *reinterpret_cast<const u32x4*>(t), b = *reinterpret_cast<const u32x4*>(t + 4);
     FrL r;
     r.l[0] = (int32_t)a.x; r.l[1] = (int32_t)a.y; r.l[2] = (int32_t)a.z; r.l[3] = (int32_t)a.w;
@@ -521,6 +525,18 @@ PLONK_DEV FrL wavel_ld_tw(const int32_t* tab, unsigned idx) {
     r.l[8] = t[8];
 #pragma unroll
     for (int i = 0; i < 9; i++) FPL_ANY_SIGN(r.l[i]);
+    return r;
+}
+// entry idx of a root table: the Shoup pair of w^idx, 80 bytes as five 16-byte loads
+PLONK_DEV FrLS wavel_ld_root(const int32_t* tab, unsigned idx) {
+    const u32x4* t = reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(tab) + idx * (unsigned)(NTT_SHOUP_STRIDE * sizeof(int32_t)));
+    const u32x4 a = t[0], b = t[1], c = t[2], d = t[3], e = t[4];
+    FrLS r;
+    r.w[0] = (int32_t)a.x; r.w[1] = (int32_t)a.y; r.w[2] = (int32_t)a.z; r.w[3] = (int32_t)a.w;
+    r.w[4] = (int32_t)b.x; r.w[5] = (int32_t)b.y; r.w[6] = (int32_t)b.z; r.w[7] = (int32_t)b.w;
+    r.w[8] = (int32_t)c.x; r.wp[0] = (int32_t)c.y; r.wp[1] = (int32_t)c.z; r.wp[2] = (int32_t)c.w;
+    r.wp[3] = (int32_t)d.x; r.wp[4] = (int32_t)d.y; r.wp[5] = (int32_t)d.z; r.wp[6] = (int32_t)d.w;
+    r.wp[7] = (int32_t)e.x; r.wp[8] = (int32_t)e.y;
     return r;
 }
 
@@ -544,34 +560,34 @@ PLONK_DEV void wavel_twiddle(FrL (&x)[E], unsigned low, unsigned mult, const int
     x[BASE] = fpl_reduce_small(x[BASE], jm);
     wave_for<COUNT - 1>([&](auto F) {
         constexpr unsigned f = decltype(F)::value + 1;
-        x[BASE + f] = fpl_mul(x[BASE + f], wavel_ld_tw(roots, (low * f * mult) & ((1u << LOG_N) - 1)));
+        x[BASE + f] = fpl_mul_shoup<FrParams, LOG_N == 13>(x[BASE + f], wavel_ld_root(roots, (low * f * mult) & ((1u << LOG_N) - 1)));
 #ifndef PLONK_NTT_NO_FENCE13
         if constexpr (LOG_N == 13) PLONK_SCHED_FENCE();  // 1024 threads: 128 VGPRs; keeps the scheduler from holding several twiddles in flight
 #endif
     });
 }
-// inputs N-form, |value| < 2.  Outputs: x0 in [0, 2^31) (for fpl_reduce_small), x1..x3 multiplicands; |value| < 8
-PLONK_DEV void dft4l(FrL& x0, FrL& x1, FrL& x2, FrL& x3, const FrL& w2) {
+// inputs N-form, |value| < 2.8.  Outputs: x0 in [0, 2^31) (for fpl_reduce_small), x1..x3 multiplicands; |value| < 11.2
+PLONK_DEV void dft4l(FrL& x0, FrL& x1, FrL& x2, FrL& x3, const FrLS& w2) {
     const FrL a0 = fpl_add(x0, x2), a1 = fpl_add(x1, x3);                 // [0, 2^30)
     const FrL d0 = fpl_sub(x0, x2);                                       // (-2^29, 2^29)
-    const FrL d1 = fpl_mul(fpl_sub(x1, x3), w2);                          // N-form, (-m, 2m)
+    const FrL d1 = fpl_mul_shoup(fpl_sub(x1, x3), w2);                    // N-form, (-1.8 m, 2.8 m)
     x0 = fpl_add(a0, a1);                                                 // [0, 2^31)
     x2 = fpl_sub(a0, a1);                                                 // (-2^30, 2^30)
     x1 = fpl_add(d0, d1);                                                 // (-2^29, 2^30)
     x3 = fpl_sub(d0, d1);                                                 // (-2^30, 2^29)
 }
-// inputs N-form, |value| < 2.  Outputs: every limb within (-2^30, 2^30] (multiplicands, and fit for fpl_reduce_small);
-// |value| <= 16
-PLONK_DEV void dft8l(FrL (&x)[8], const FrL& w1, const FrL& w2, const FrL& w3) {
+// inputs N-form, |value| < 2.8.  Outputs: every limb within (-2^30, 2^30] (multiplicands, and fit for fpl_reduce_small);
+// |value| <= 22.4
+PLONK_DEV void dft8l(FrL (&x)[8], const FrLS& w1, const FrLS& w2, const FrLS& w3) {
     const FrL a0 = fpl_add(x[0], x[4]), a1 = fpl_add(x[1], x[5]), a2 = fpl_add(x[2], x[6]), a3 = fpl_add(x[3], x[7]);  // [0, 2^30)
     const FrL b0 = fpl_norm(fpl_sub(x[0], x[4]));                         // N-form (sweep 1)
-    const FrL b1 = fpl_mul(fpl_sub(x[1], x[5]), w1), b2 = fpl_mul(fpl_sub(x[2], x[6]), w2), b3 = fpl_mul(fpl_sub(x[3], x[7]), w3);  // operands (-2^29, 2^29)
+    const FrL b1 = fpl_mul_shoup(fpl_sub(x[1], x[5]), w1), b2 = fpl_mul_shoup(fpl_sub(x[2], x[6]), w2), b3 = fpl_mul_shoup(fpl_sub(x[3], x[7]), w3);  // operands (-2^29, 2^29)
     const FrL c0 = fpl_norm(fpl_add(a0, a2)), c1 = fpl_norm(fpl_add(a1, a3));  // sums [0, 2^31) -> N-form (sweeps 2, 3)
     const FrL d0 = fpl_norm(fpl_sub(a0, a2));                             // (-2^30, 2^30) -> N-form (sweep 4)
-    const FrL d1 = fpl_mul(fpl_sub(a1, a3), w2);                          // operand (-2^30, 2^30)
+    const FrL d1 = fpl_mul_shoup(fpl_sub(a1, a3), w2);                    // operand (-2^30, 2^30)
     const FrL e0 = fpl_add(b0, b2), e1 = fpl_add(b1, b3);                 // [0, 2^30)
     const FrL f0 = fpl_sub(b0, b2);                                       // (-2^29, 2^29)
-    const FrL f1 = fpl_mul(fpl_sub(b1, b3), w2);                          // operand (-2^29, 2^29)
+    const FrL f1 = fpl_mul_shoup(fpl_sub(b1, b3), w2);                    // operand (-2^29, 2^29)
     x[0] = fpl_add(c0, c1);                                               // [0, 2^30)
     x[4] = fpl_sub(c0, c1);                                               // (-2^29, 2^29)
     x[2] = fpl_add(d0, d1);                                               // [0, 2^30)
@@ -582,7 +598,7 @@ PLONK_DEV void dft8l(FrL (&x)[8], const FrL& w1, const FrL& w2, const FrL& w3) {
     x[7] = fpl_sub(f0, f1);                                               // (-2^30, 2^29)
 }
 // the digit DFT on the register index: radix 8 (E = 8) or radix 4 (E = 4)
-template <unsigned E> PLONK_DEV void wavel_dft(FrL (&x)[E], const FrL& w1, const FrL& w2, const FrL& w3) {
+template <unsigned E> PLONK_DEV void wavel_dft(FrL (&x)[E], const FrLS& w1, const FrLS& w2, const FrLS& w3) {
     if constexpr (E == 8) dft8l(x, w1, w2, w3);
     else dft4l(x[0], x[1], x[2], x[3], w2);
 }
@@ -600,6 +616,22 @@ PLONK_DEV FrL wavel_lds_ld(const u32x4* lo, const u32x4* hi, const uint32_t* top
     return r;
 }
 
+// threadIdx.x again, as a value the compiler cannot connect to earlier reads: in the 1024-thread kernel (128 VGPRs) the
+// per-thread LDS addresses, lane masks and twiddle indices of later stages were otherwise computed at the top of the
+// kernel and carried — spilled — through the first stages
+template <bool OPAQUE> PLONK_DEV unsigned wavel_tid() {
+    unsigned t = threadIdx.x;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (OPAQUE) asm volatile("" : "+v"(t));
+#endif
+    return t;
+}
+
+// element g of a uniform base as a 32-bit byte offset (g < 2^27: the wave kernels' transforms have at most 2^26 points):
+// SGPR-base addressing, one VGPR per address instead of two and no 64-bit address arithmetic
+PLONK_DEV const Fr* wavel_at(const Fr* base, unsigned g) { return reinterpret_cast<const Fr*>(reinterpret_cast<const char*>(base) + (g << 5)); }
+PLONK_DEV Fr* wavel_at(Fr* base, unsigned g) { return reinterpret_cast<Fr*>(reinterpret_cast<char*>(base) + (g << 5)); }
+
 // waves per SIMD the register allocation aims at: 1024-thread workgroups must fit 128 VGPRs (4); the E = 8 forms run
 // faster without spills at 3 (measured in round 2: 18.1 vs 16.8 G elements/s at 2^11 x 2048); E = 4 fits 4 without spills
 template <unsigned LOG_E, unsigned NLDS> struct WavelCfg {
@@ -614,7 +646,7 @@ __global__ void __launch_bounds__(64u << (2 * NLDS), (WavelCfg<LOG_E, NLDS>::WAV
     u32x4* l_lo = reinterpret_cast<u32x4*>(smem);  // 4 * NT elements as two 16-byte planes and one 4-byte plane
     u32x4* l_hi = l_lo + 4 * NT;
     uint32_t* l_top = reinterpret_cast<uint32_t*>(l_hi + 4 * NT);
-    const unsigned tid = threadIdx.x, lane = tid & 63;
+    const unsigned tid0 = threadIdx.x;
     const unsigned bidx = p.mode ? blockIdx.y : blockIdx.x;
     const Fr* in = p.in + (size_t)bidx * p.in_bstride;
     Fr* out = p.out + (size_t)bidx * p.out_bstride;
@@ -628,29 +660,30 @@ __global__ void __launch_bounds__(64u << (2 * NLDS), (WavelCfg<LOG_E, NLDS>::WAV
     const unsigned out_off = p.mode ? sub : 0;
     const unsigned chunk_mask = (1u << p.chunk_log) - 1;
     const int32_t* jm = p.jm;
-    const FrL w8_1 = fpl_from_fp_uniform(p.w8_1), w8_2 = fpl_from_fp_uniform(p.w8_2), w8_3 = fpl_from_fp_uniform(p.w8_3);  // SGPRs
+    const FrLS &w8_1 = p.w8[0], &w8_2 = p.w8[1], &w8_3 = p.w8[2];  // kernel arguments: scalar registers
 
     FrL x[E];
     wave_for<E>([&](auto J) {  // position j * NT + tid: consecutive lanes read consecutive positions
         constexpr unsigned j = decltype(J)::value;
-        const unsigned pos = j * NT + tid;
+        const unsigned pos = j * NT + tid0;
         const unsigned g = p.chunk_log ? (pos >> p.chunk_log) * p.chunk_stride + (pos & chunk_mask) + in_off : (pos << in_shift) + in_off;
-        x[j] = g < p.in_len ? fpl_from_fp(fp_load(in + g)) : fpl_zero<FrParams>();  // [0, 2m): the column pass hands on canonical values
+        x[j] = g < p.in_len ? fpl_from_fp(fp_load(wavel_at(in, g))) : fpl_zero<FrParams>();  // [0, 2m): the column pass hands on canonical values
     });
     if (p.in_scale) {
         wave_for<E>([&](auto J) {
             constexpr unsigned j = decltype(J)::value;
-            const unsigned g = ((j * NT + tid) << in_shift) + in_off;
-            if (g < p.in_len) x[j] = fpl_mul(x[j], fpl_from_fp(fp_load(p.in_scale + g)));
+            const unsigned g = ((j * NT + tid0) << in_shift) + in_off;
+            if (g < p.in_len) x[j] = fpl_mul(x[j], fpl_from_fp(fp_load(wavel_at(p.in_scale, g))));
         });
     }
-    // stage A: digit = the top LOG_E index bits, low = tid
+    // stage A: digit = the top LOG_E index bits, low = tid0
     wavel_dft<E>(x, w8_1, w8_2, w8_3);
-    wavel_twiddle<LOG_N, 0, E>(x, tid, 1, p.roots, jm);
+    wavel_twiddle<LOG_N, 0, E>(x, tid0, 1, p.roots, jm);
     // L radix-4 stages on the wave bits: swap register bits (1, 0) with thread bits (tb + 1, tb)
     wave_for<NLDS>([&](auto S) {
         constexpr unsigned s = decltype(S)::value;
         constexpr unsigned tb = 6 + 2 * (NLDS - 1 - s);
+        const unsigned tid = wavel_tid<NLDS == 2>();
         const unsigned mine = (tid >> tb) & 3u, rest = tid & ~(3u << tb);
         wave_for<E / 4>([&](auto R2) {
             constexpr unsigned r2 = decltype(R2)::value;
@@ -667,6 +700,7 @@ __global__ void __launch_bounds__(64u << (2 * NLDS), (WavelCfg<LOG_E, NLDS>::WAV
             wavel_twiddle<LOG_N, 4 * r2, 4>(x, low, mult, p.roots, jm);
         });
     });
+    const unsigned lane = wavel_tid<NLDS == 2>() & 63u;
     if constexpr (E == 8) {
         // stage on lane bits 5..3
         wavel_swap_bit<E, 2, 32>(x, lane);
@@ -696,6 +730,7 @@ __global__ void __launch_bounds__(64u << (2 * NLDS), (WavelCfg<LOG_E, NLDS>::WAV
     }
     // frequency of register j: digits in processing order, first digit least significant
     unsigned k, shift;
+    const unsigned tid = wavel_tid<NLDS == 2>();
     if constexpr (E == 8) {
         //   d_A = (lane bit 5) * 4 + thread bits (top pair);  then the remaining wave pairs;  (lane bits 4, 3);  (lane bits 2..0);  j
         //   (without wave stages the first digit is simply lane bits 5..3)
@@ -736,7 +771,7 @@ __global__ void __launch_bounds__(64u << (2 * NLDS), (WavelCfg<LOG_E, NLDS>::WAV
     if (p.out_scale) {
         wave_for<E>([&](auto J) {
             constexpr unsigned j = decltype(J)::value;
-            x[j] = fpl_mul(x[j], fpl_from_fp(fp_load(p.out_scale + (((k | (j << shift)) << out_shift) + out_off))));
+            x[j] = fpl_mul(x[j], fpl_from_fp(fp_load(wavel_at(p.out_scale, ((k | (j << shift)) << out_shift) + out_off))));
         });
     }
     if (p.has_out_scalar) {
@@ -745,7 +780,7 @@ __global__ void __launch_bounds__(64u << (2 * NLDS), (WavelCfg<LOG_E, NLDS>::WAV
     }
     wave_for<E>([&](auto J) {  // |value| <= 16 m whatever happened above -> (-0.51 m, 0.51 m) -> canonical
         constexpr unsigned j = decltype(J)::value;
-        fp_store(out + (((k | (j << shift)) << out_shift) + out_off), fpl_pack_positive(fpl_reduce_small<FrParams, 1>(x[j], jm)));
+        fp_store(wavel_at(out, ((k | (j << shift)) << out_shift) + out_off), fpl_pack_positive(fpl_reduce_small<FrParams, 1>(x[j], jm)));
     });
 }
 
@@ -842,8 +877,9 @@ static unsigned plan_passes(const plonk_ctx* ctx, unsigned log_n, unsigned radic
 }
 
 // the wave kernels (variant C): N = 2^8 .. 2^13 in one pass (one workgroup of N / 4 or N / 8 threads per transform), and
-// N = R1 R2 with R1, R2 from that set in two passes (columns, then rows).  Default splits: as square as possible
-// (measured on MI355X, profiles/r03_*ntt_splits*); plonk_ntt_set_split overrides one size (A/B runs, tests).
+// N = R1 R2 with R1, R2 from that set in two passes (columns, then rows).  Default splits: the fastest measured on MI355X
+// for a lone transform (profiles/r03_b_ntt_splits.jsonl: the 4-element-per-thread kernels where a size allows them —
+// twice the waves —, and short column transforms for the largest sizes); plonk_ntt_set_split overrides one size.
 static bool ntt_wave_plan(const plonk_ctx* ctx, unsigned log_n, unsigned* log_r1, unsigned* log_r2) {
     if (log_n >= 8 && log_n <= 13) {
         *log_r1 = log_n;
@@ -851,7 +887,9 @@ static bool ntt_wave_plan(const plonk_ctx* ctx, unsigned log_n, unsigned* log_r1
         return true;
     }
     if (log_n < 16 || log_n > 26) return false;
-    unsigned r1 = (log_n + 1) / 2;
+    //                                   2^16 17  18  19  20  21  22  23  24  25  26
+    static const unsigned char best[] = {8,   9, 10, 10, 10, 11, 13, 13, 11, 12, 13};
+    unsigned r1 = best[log_n - 16];
     if (ctx && log_n < sizeof ctx->ntt_split / sizeof ctx->ntt_split[0] && ctx->ntt_split[log_n]) r1 = ctx->ntt_split[log_n];
     if (r1 < 8 || r1 > 13 || log_n - r1 < 8 || log_n - r1 > 13) return false;
     *log_r1 = r1;
@@ -859,26 +897,41 @@ static bool ntt_wave_plan(const plonk_ctx* ctx, unsigned log_n, unsigned* log_r1
     return true;
 }
 
-// limb form of a packed table: NTT_LIMB_STRIDE words per entry (what wavel_ld_tw reads)
-__global__ void ntt_limb_table_kernel(const Fr* in, int32_t* out, size_t n) {
+// limb form of a packed table: NTT_LIMB_STRIDE words per entry (what wavel_ld_tw reads); with shoup != 0 the Shoup pair of
+// every entry, NTT_SHOUP_STRIDE words (what wavel_ld_root reads)
+struct Ninv261 { uint32_t l[9]; };
+__global__ void ntt_limb_table_kernel(const Fr* in, int32_t* out, size_t n, int shoup, Ninv261 ninv) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const FrL a = fpl_from_fp(fp_load(in + i));
-    int32_t* o = out + i * NTT_LIMB_STRIDE;
-    for (int w = 0; w < 9; w++) o[w] = a.l[w];
-    o[9] = o[10] = o[11] = 0;
+    const Fr v = fp_load(in + i);
+    if (shoup) {
+        const FrLS a = fpl_shoup_from_mont(v, ninv.l);
+        int32_t* o = out + i * NTT_SHOUP_STRIDE;
+        for (int w = 0; w < 9; w++) {
+            o[w] = a.w[w];
+            o[9 + w] = a.wp[w];
+        }
+        o[18] = o[19] = 0;
+    } else {
+        const FrL a = fpl_from_fp(v);
+        int32_t* o = out + i * NTT_LIMB_STRIDE;
+        for (int w = 0; w < 9; w++) o[w] = a.l[w];
+        o[9] = o[10] = o[11] = 0;
+    }
 }
 
-static int ntt_limb_table(plonk_ctx* ctx, std::map<unsigned, int32_t*>& cache, unsigned key, const Fr* packed, size_t n, const int32_t** out) {
+static int ntt_limb_table(plonk_ctx* ctx, std::map<unsigned, int32_t*>& cache, unsigned key, const Fr* packed, size_t n, bool shoup, const int32_t** out) {
     auto it = cache.find(key);
     if (it == cache.end()) {
         void* d = nullptr;
-        if (hipMalloc(&d, n * NTT_LIMB_STRIDE * sizeof(int32_t)) != hipSuccess) {
+        Ninv261 ninv;
+        fpl_ninv261<FrParams>(ninv.l);
+        if (hipMalloc(&d, n * (shoup ? NTT_SHOUP_STRIDE : NTT_LIMB_STRIDE) * sizeof(int32_t)) != hipSuccess) {
             plonk_set_error("hipMalloc of a %zu-entry limb-form twiddle table failed", n);
             return PLONK_ERR_NOMEM;
         }
         ctx->owned.push_back(d);
-        PLONK_LAUNCH(ntt_limb_table_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, packed, (int32_t*)d, n);
+        PLONK_LAUNCH(ntt_limb_table_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, packed, (int32_t*)d, n, shoup ? 1 : 0, ninv);
         PLONK_CHECK_HIP(hipGetLastError());
         it = cache.emplace(key, (int32_t*)d).first;
     }
@@ -889,7 +942,7 @@ static int ntt_limb_table(plonk_ctx* ctx, std::map<unsigned, int32_t*>& cache, u
 static int ntt_get_roots_limbs(plonk_ctx* ctx, unsigned log_n, bool inverse, const int32_t** out) {
     const Fr* packed;
     PLONK_TRY(ntt_get_roots(ctx, log_n, inverse, &packed));
-    return ntt_limb_table(ctx, ctx->tw.full_l, log_n | (inverse ? 256u : 0u), packed, (size_t)1 << log_n, out);
+    return ntt_limb_table(ctx, ctx->tw.full_l, log_n | (inverse ? 256u : 0u), packed, (size_t)1 << log_n, true, out);
 }
 
 static int get_lo_hi_limbs(plonk_ctx* ctx, unsigned log_n, bool inverse, const int32_t** lo, const int32_t** hi) {
@@ -897,8 +950,8 @@ static int get_lo_hi_limbs(plonk_ctx* ctx, unsigned log_n, bool inverse, const i
     PLONK_TRY(get_lo_hi(ctx, log_n, inverse, &plo, &phi));
     const unsigned key = log_n | (inverse ? 256u : 0u);
     const unsigned log_lo = log_n < NTT_TW_LO_LOG ? log_n : NTT_TW_LO_LOG;
-    PLONK_TRY(ntt_limb_table(ctx, ctx->tw.lo_l, key, plo, (size_t)1 << log_lo, lo));
-    return ntt_limb_table(ctx, ctx->tw.hi_l, key, phi, log_n > NTT_TW_LO_LOG ? ((size_t)1 << (log_n - NTT_TW_LO_LOG)) : 1, hi);
+    PLONK_TRY(ntt_limb_table(ctx, ctx->tw.lo_l, key, plo, (size_t)1 << log_lo, false, lo));
+    return ntt_limb_table(ctx, ctx->tw.hi_l, key, phi, log_n > NTT_TW_LO_LOG ? ((size_t)1 << (log_n - NTT_TW_LO_LOG)) : 1, false, hi);
 }
 
 // fpl_reduce_small's table of j * m for the limb-form kernel: 49 entries of 12 words, built on the host once per context
@@ -917,6 +970,16 @@ static int ntt_get_jm(plonk_ctx* ctx, const int32_t** out) {
     }
     *out = ctx->ntt_jm;
     return PLONK_OK;
+}
+
+// the radix-8 / radix-4 roots w_8^k of a transform direction as Shoup pairs (kernel arguments)
+static void ntt_wave_w8(NttWave* p, bool inverse) {
+    uint32_t ninv[9];
+    fpl_ninv261<FrParams>(ninv);
+    const Fr w8 = host_root_of_unity(3, inverse), w4 = fp_sqr(w8);
+    p->w8[0] = fpl_shoup_from_mont(w8, ninv);
+    p->w8[1] = fpl_shoup_from_mont(w4, ninv);
+    p->w8[2] = fpl_shoup_from_mont(fp_mul(w4, w8), ninv);
 }
 
 template <unsigned LOG_E, unsigned NLDS> static int ntt_wavel_launch_as(plonk_ctx* ctx, const NttWave& q, unsigned grid_x, unsigned grid_y) {
@@ -956,10 +1019,7 @@ static int ntt_run_wave(plonk_ctx* ctx, const Fr* in, Fr* out, unsigned log_n, b
     NttWave p;
     memset(&p, 0, sizeof p);
     p.log_n = log_n;
-    const Fr w8 = host_root_of_unity(3, inverse);
-    p.w8_1 = w8;
-    p.w8_2 = fp_sqr(w8);
-    p.w8_3 = fp_mul(p.w8_2, w8);
+    ntt_wave_w8(&p, inverse);
     Fr n_inv = fp_zero<FrParams>();
     if (scale_by_n_inv) n_inv = fp_inv(host_fr_from_u64((uint64_t)N));
     const unsigned in_len32 = (unsigned)(in_len < N ? in_len : N);
@@ -1045,10 +1105,7 @@ int ntt_dist_plan(unsigned log_n, unsigned log_w, unsigned* log_r1, unsigned* lo
 static void ntt_wave_consts(NttWave* p, unsigned log_n, bool inverse) {
     memset(p, 0, sizeof *p);
     p->log_n = log_n;
-    const Fr w8 = host_root_of_unity(3, inverse);
-    p->w8_1 = w8;
-    p->w8_2 = fp_sqr(w8);
-    p->w8_3 = fp_mul(p->w8_2, w8);
+    ntt_wave_w8(p, inverse);
 }
 
 int ntt_dist_columns(plonk_ctx* ctx, const Fr* in, Fr* out, unsigned log_n, unsigned log_w, unsigned rank, bool inverse) {

@@ -20,6 +20,7 @@
 
 #include "plonk_internal.h"
 #include "transcript.h"
+#include "g1_codec.h"
 
 #define NEVAL 7  // a, b, c, s1, s2, z_shifted, PI(zeta)
 #define PI_SPARSE_MAX 8
@@ -652,9 +653,21 @@ __global__ void __launch_bounds__(DV_THREADS) divide_linear_kernel(const Fr* p_i
 
 // ------------------------------------------------------------------------------------------------
 // pack results: [B][768] = 9 x (x||y) canonical LE + 6 evaluations canonical LE
-__global__ void pack_proofs_kernel(const Fq* commit_xy, const ProofState* st, size_t B, uint8_t* out) {
+__global__ void pack_proofs_kernel(const Fq* commit_xy, const ProofState* st, size_t B, uint8_t* out, int compressed) {
     const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
+    if (compressed) {  // 480 bytes: nine compressed points, six big-endian scalars (g1_codec.h)
+        uint8_t* o = out + b * 480;
+        for (int slot = 0; slot < 9; slot++) {
+            const Fq x = fp_load(commit_xy + 2 * ((size_t)slot * B + b)), y = fp_load(commit_xy + 2 * ((size_t)slot * B + b) + 1);
+            g1c_compress<FqParams>(x.v, y.v, o + 32 * slot);
+        }
+        for (int e = 0; e < 6; e++) {
+            const Fr v = fp_from_mont(st[b].evals[e]);
+            g1c_be32(v.v, o + 288 + 32 * e);
+        }
+        return;
+    }
     uint32_t* o = reinterpret_cast<uint32_t*>(out + b * 768);
     for (int slot = 0; slot < 9; slot++)
         for (int h = 0; h < 2; h++) {
@@ -1007,7 +1020,15 @@ int plonk_prover_run(plonk_prover* p, size_t B) {
 // Synchronise and fetch: proofs [B][768], status[B] (0 ok; bit0: identity commitment; bit1: Z does
 // not close to 1, i.e. the witness breaks the copy constraints — prover.py:132; bit2: the quotient has
 // degree >= 3n, i.e. the witness breaks a gate constraint — prover.py:108-116, 205-208).
+static int prover_download(plonk_prover* p, size_t B, uint8_t* out_proofs, uint8_t* out_status, bool compressed);
 int plonk_prover_download(plonk_prover* p, size_t B, uint8_t* out_proofs, uint8_t* out_status) {
+    return prover_download(p, B, out_proofs, out_status, false);
+}
+// the same proofs as 480-byte records: nine compressed G1 points + six big-endian scalars (g1_codec.h)
+int plonk_prover_download_compressed(plonk_prover* p, size_t B, uint8_t* out_proofs, uint8_t* out_status) {
+    return prover_download(p, B, out_proofs, out_status, true);
+}
+static int prover_download(plonk_prover* p, size_t B, uint8_t* out_proofs, uint8_t* out_status, bool compressed) {
     PLONK_REQUIRE(p && B && out_proofs && out_status, PLONK_ERR_ARG, "bad argument");
     PLONK_REQUIRE(B == p->resident_b, PLONK_ERR_STATE, "download: batch %zu, but %zu witnesses are resident", B, p->resident_b);
     PLONK_ENTER(p->ctx);
@@ -1016,8 +1037,8 @@ int plonk_prover_download(plonk_prover* p, size_t B, uint8_t* out_proofs, uint8_
     PLONK_TRY(ctx_scratch(ctx, 2, B * 768, &packed));
     unsigned tb = (unsigned)((B + 63) / 64);
     PLONK_LAUNCH(pack_proofs_kernel, dim3(tb), dim3(64), 0, ctx->stream, (const Fq*)p->commit_xy,
-                 (const ProofState*)p->state, B, (uint8_t*)packed);
-    PLONK_CHECK_HIP(hipMemcpyAsync(out_proofs, packed, B * 768, hipMemcpyDeviceToHost, ctx->stream));
+                 (const ProofState*)p->state, B, (uint8_t*)packed, compressed ? 1 : 0);
+    PLONK_CHECK_HIP(hipMemcpyAsync(out_proofs, packed, B * (compressed ? 480 : 768), hipMemcpyDeviceToHost, ctx->stream));
     std::vector<ProofState> st(B);
     std::vector<uint32_t> closes(2 * B);
     std::vector<uint8_t> flags(9 * B);

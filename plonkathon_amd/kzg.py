@@ -307,6 +307,37 @@ class Setup:
                                Scalar.root_of_unity(pk.group_order))
 
 
+def g1_compress(points):
+    """Affine points (None = identity) -> 32 bytes each: x big-endian as append_point writes it (transcript.py:62-67)
+    with the two spare top bits carrying y's root (10 smaller, 11 larger) or infinity (01).  Batched on the device
+    (plonk_g1_compress)."""
+    points = list(points)
+    ctx = get_context()
+    xy = b"".join((le32(0) + le32(0)) if p is None else (le32(int(p[0])) + le32(int(p[1]))) for p in points)
+    out = ctypes.create_string_buffer(32 * max(len(points), 1))
+    check(ctx.L.plonk_g1_compress(ctx.handle, xy, len(points), out))
+    return out.raw[: 32 * len(points)]
+
+
+def g1_decompress(blob):
+    """The inverse: bytes -> list of affine points (None = identity); ValueError on a malformed or off-curve encoding."""
+    assert len(blob) % 32 == 0
+    n = len(blob) // 32
+    ctx = get_context()
+    xy = ctypes.create_string_buffer(64 * max(n, 1))
+    status = ctypes.create_string_buffer(max(n, 1))
+    check(ctx.L.plonk_g1_decompress(ctx.handle, bytes(blob), n, xy, status))
+    out = []
+    for i in range(n):
+        st = status.raw[i]
+        if st:
+            raise ValueError("compressed point %d: %s" % (i, "malformed encoding" if st == 1 else "not on the curve"))
+        x = int.from_bytes(xy.raw[64 * i : 64 * i + 32], "little")
+        y = int.from_bytes(xy.raw[64 * i + 32 : 64 * i + 64], "little")
+        out.append(None if (blob[32 * i] & 0xC0) == 0x40 else (Fq(x), Fq(y)))
+    return out
+
+
 def ec_mul(pt, coeff):  # curve.py:30-33
     return ec_lincomb([(pt, coeff)])
 

@@ -4,18 +4,30 @@ on the GPU through `Polynomial` and `Setup`.
 The reference tree ships the round bodies blanked (exercise skeleton); they are filled in here as
 its comments, asserts and the complete verifier (TESTING_verifier_DO_NOT_OPEN.py:39-163) prescribe
 (SURVEY.md §3.2).  This class is the API-compatible, one-proof-at-a-time path: every step is a
-`Polynomial` operation, in the same order and with the same intermediate names as the reference, so
-it doubles as an end-to-end exercise of the whole C-ABI.  The throughput path — many proofs in
-lock-step with fused kernels — is `plonkathon_amd.batch.BatchProver`.
+`Polynomial` operation or one of the fused round kernels of the C-ABI (`plonk_fr_grand_product`,
+`plonk_fr_quotient`), in the same order and with the same intermediate names as the reference, and no
+step loops over the rows in Python.  The throughput path — many proofs in lock-step — is
+`plonkathon_amd.batch.BatchProver`.
 """
+import ctypes
 from dataclasses import dataclass
 from typing import Optional
 
+import numpy as np
+
+from ._lib import check
+from .backend import get_context
 from .circuit import CommonPreprocessedInput, Program
-from .field import Scalar
+from .field import R_MOD, Scalar, le32
 from .fiat_shamir import Message1, Message2, Message3, Message4, Message5, Transcript
 from .kzg import Setup
-from .polynomial import Basis, Polynomial
+from .polynomial import Basis, Polynomial, _log2_exact
+
+try:  # host-side marshalling helper (csrc/pyext/pypack.c); same bytes either way
+    from ._pypack import pack_dicts_le32 as _pack_witnesses
+except ImportError:  # pragma: no cover - pure-Python equivalent of the packer (not a compute fallback)
+    def _pack_witnesses(witnesses, keys, modulus):
+        return b"".join([(int(w[k]) % modulus).to_bytes(32, "little") for w in witnesses for k in keys])
 
 
 @dataclass
@@ -45,6 +57,31 @@ class Proof:  # prover.py:10-35
         proof["W_zw_1"] = self.msg_5.W_zw_1
         return proof
 
+    # "compressed G1 bytes" (BASELINE north_star): the reference has no byte form of a proof beyond the transcript's
+    # 32-byte big-endian x, y and scalars (transcript.py:62-67); this one is derived from them (kzg.g1_compress).
+    _POINTS = ("a_1", "b_1", "c_1", "z_1", "t_lo_1", "t_mid_1", "t_hi_1", "W_z_1", "W_zw_1")
+    _SCALARS = ("a_eval", "b_eval", "c_eval", "s1_eval", "s2_eval", "z_shifted_eval")
+
+    def to_bytes(self) -> bytes:
+        """480 bytes: the nine commitments in flatten() order, compressed (32 bytes each), then the six evaluations as
+        32-byte big-endian scalars."""
+        from .kzg import g1_compress
+
+        f = self.flatten()
+        return g1_compress([f[k] for k in self._POINTS]) + b"".join(int(f[k]).to_bytes(32, "big") for k in self._SCALARS)
+
+    @classmethod
+    def from_bytes(cls, blob: bytes) -> "Proof":
+        from .kzg import g1_decompress
+
+        assert len(blob) == 480
+        pts = g1_decompress(blob[:288])
+        sc = [int.from_bytes(blob[288 + 32 * i : 320 + 32 * i], "big") for i in range(6)]
+        if max(sc) >= R_MOD:
+            raise ValueError("evaluation is not a canonical Fr value")
+        sc = [Scalar(v) for v in sc]
+        return cls(Message1(*pts[0:3]), Message2(pts[3]), Message3(*pts[4:7]), Message4(*sc), Message5(*pts[7:9]))
+
 
 class Prover:
     group_order: int
@@ -62,12 +99,12 @@ class Prover:
     def prove(self, witness) -> Proof:  # prover.py:51-84
         transcript = Transcript(b"plonk")
         public_vars = self.program.get_public_assignments()
-        PI = Polynomial(
-            [Scalar(-witness[v]) for v in public_vars]
-            + [Scalar(0) for _ in range(self.group_order - len(public_vars))],
-            Basis.LAGRANGE,
+        n = self.group_order
+        # PI = -public inputs, zero padded (prover.py:57-62); encoded straight to the device format
+        self.PI = PI = Polynomial.from_bytes(
+            b"".join(le32(-witness[v] % R_MOD) for v in public_vars) + bytes(32 * (n - len(public_vars))), Basis.LAGRANGE
         )
-        self.PI = PI
+        self._expanded = {}
         msg_1 = self.round_1(witness)
         self.beta, self.gamma = transcript.round_1(msg_1)
         msg_2 = self.round_2()
@@ -77,6 +114,7 @@ class Prover:
         msg_4 = self.round_4()
         self.v = transcript.round_4(msg_4)
         msg_5 = self.round_5()
+        self._expanded = {}
         return Proof(msg_1, msg_2, msg_3, msg_4, msg_5)
 
     # ---------------------------------------------------------------- round 1  (prover.py:86-119)
@@ -84,36 +122,38 @@ class Prover:
         n = self.group_order
         if None not in witness:
             witness[None] = 0
-        cols = [[0] * n for _ in range(3)]
-        for i, w in enumerate(self.program.wires()):
-            cols[0][i], cols[1][i], cols[2][i] = witness[w.L], witness[w.R], witness[w.O]
-        self.A, self.B, self.C = (Polynomial.from_ints(c, Basis.LAGRANGE) for c in cols)
+        # A, B, C (prover.py:97-103): every variable's value is encoded once (a KeyError names a missing one, as
+        # witness[w.L] would) and the wire cells are gathered by index — no Python loop over the rows
+        variables, cell_index = self.program.wiring_table()
+        table = np.frombuffer(_pack_witnesses([witness], variables, R_MOD) + bytes(32), dtype=np.uint64).reshape(len(variables) + 1, 4)
+        cols = np.take(table, cell_index.ravel(), axis=0).reshape(3, n, 4)
+        self.A, self.B, self.C = (Polynomial.from_bytes(cols[k].tobytes(), Basis.LAGRANGE) for k in range(3))
         a_1, b_1, c_1 = (self.setup.commit(p) for p in (self.A, self.B, self.C))
         if self.check:
             pk = self.pk
             assert (
                 self.A * pk.QL + self.B * pk.QR + self.A * self.B * pk.QM + self.C * pk.QO + self.PI + pk.QC
-                == Polynomial([Scalar(0)] * n, Basis.LAGRANGE)
-            )
+            ).is_zero()
         return Message1(a_1, b_1, c_1)
 
     # ---------------------------------------------------------------- round 2  (prover.py:121-152)
     def round_2(self) -> Message2:
         n = self.group_order
         pk = self.pk
-        roots = Polynomial(Scalar.roots_of_unity(n)[:n], Basis.LAGRANGE)
-        num = self.rlc(self.A, roots) * self.rlc(self.B, roots * Scalar(2)) * self.rlc(self.C, roots * Scalar(3))
-        den = self.rlc(self.A, pk.S1) * self.rlc(self.B, pk.S2) * self.rlc(self.C, pk.S3)
-        ratio = (num / den).values
-        Z_values = [Scalar(1)]
-        for i in range(n):
-            Z_values.append(Z_values[-1] * ratio[i])
-        assert Z_values.pop() == 1  # prover.py:132
-        self.Z = Polynomial(Z_values, Basis.LAGRANGE)
+        ctx = get_context()
+        # Z_0 = 1, Z_{i+1} = Z_i * rlc(A_i, w^i) rlc(B_i, 2 w^i) rlc(C_i, 3 w^i) / (rlc(A_i, S1_i) rlc(B_i, S2_i) rlc(C_i, S3_i)):
+        # one fused kernel (two scans, one inversion) instead of n inversions and a serial product
+        Z, closes = ctx.alloc(n), ctypes.c_int(0)
+        check(ctx.L.plonk_fr_grand_product(ctx.handle, self.A.device().ptr, self.B.device().ptr, self.C.device().ptr,
+                                           pk.S1.device().ptr, pk.S2.device().ptr, pk.S3.device().ptr, _log2_exact(n),
+                                           le32(self.beta.n), le32(self.gamma.n), Z.ptr, ctypes.byref(closes)))
+        assert closes.value == 1  # prover.py:132
+        self.Z = Polynomial._from_device(Z, Basis.LAGRANGE, n)
         if self.check:  # prover.py:135-146
-            lhs = num * self.Z
-            rhs = den * self.Z.shift(1 % n) if n > 1 else den * self.Z
-            assert lhs == rhs
+            roots = Polynomial.powers(1, Scalar.root_of_unity(n), n)
+            num = self.rlc(self.A, roots) * self.rlc(self.B, roots * Scalar(2)) * self.rlc(self.C, roots * Scalar(3))
+            den = self.rlc(self.A, pk.S1) * self.rlc(self.B, pk.S2) * self.rlc(self.C, pk.S3)
+            assert num * self.Z == (den * self.Z.shift(1 % n) if n > 1 else den * self.Z)
         return Message2(self.setup.commit(self.Z))
 
     # ---------------------------------------------------------------- round 3  (prover.py:154-226)
@@ -121,32 +161,23 @@ class Prover:
         n = self.group_order
         pk = self.pk
         alpha, beta, gamma, cof = self.alpha, self.beta, self.gamma, self.fft_cofactor
-        mu = Scalar.root_of_unity(4 * n)
-        xs, cur = [], cof
-        for _ in range(4 * n):
-            xs.append(cur)
-            cur = cur * mu
-        X_big = Polynomial(xs, Basis.LAGRANGE)
-        self._X_big = X_big
+        ctx = get_context()
+        # the coset points fft_cofactor * mu^k (prover.py:160-161), built on the device; round 5 divides by X_big - zeta
+        self._X_big = Polynomial.powers(cof, Scalar.root_of_unity(4 * n), 4 * n)
         ex = self.fft_expand
-        A_big, B_big, C_big, PI_big = ex(self.A), ex(self.B), ex(self.C), ex(self.PI)
-        QL_big, QR_big, QM_big, QO_big, QC_big = ex(pk.QL), ex(pk.QR), ex(pk.QM), ex(pk.QO), ex(pk.QC)
-        Z_big = ex(self.Z)
-        Zw_big = Z_big.shift(4)
-        S1_big, S2_big, S3_big = ex(pk.S1), ex(pk.S2), ex(pk.S3)
-        ZH_big = Polynomial([x**n - 1 for x in xs], Basis.LAGRANGE)
-        L0_big = ex(Polynomial([Scalar(1)] + [Scalar(0)] * (n - 1), Basis.LAGRANGE))
-
-        gate = A_big * QL_big + B_big * QR_big + A_big * B_big * QM_big + C_big * QO_big + PI_big + QC_big
-        perm = (
-            self.rlc(A_big, X_big) * self.rlc(B_big, X_big * Scalar(2)) * self.rlc(C_big, X_big * Scalar(3)) * Z_big
-            - self.rlc(A_big, S1_big) * self.rlc(B_big, S2_big) * self.rlc(C_big, S3_big) * Zw_big
-        )
-        first = (Z_big - Scalar(1)) * L0_big
-        QUOT_big = (gate + perm * alpha + first * (alpha * alpha)) / ZH_big
+        L0 = Polynomial.from_bytes(le32(1) + bytes(32 * (n - 1)), Basis.LAGRANGE)
+        evals = [ex(p) for p in (self.A, self.B, self.C, self.PI, self.Z, pk.QL, pk.QR, pk.QM, pk.QO, pk.QC,
+                                 pk.S1, pk.S2, pk.S3, L0)]
+        # QUOT_big = (gate + alpha * permutation + alpha^2 * (Z - 1) L0) / Z_H on the coset (prover.py:188-203), one fused
+        # pass; Z(w x) is Z_big read four places ahead (prover.py:173) and Z_H takes four values there (prover.py:178)
+        ptrs = (ctypes.c_void_p * 14)(*[e.device().ptr for e in evals])
+        quot = ctx.alloc(4 * n)
+        check(ctx.L.plonk_fr_quotient(ctx.handle, _log2_exact(n), ptrs, le32(cof.n), le32(alpha.n), le32(beta.n),
+                                      le32(gamma.n), quot.ptr))
+        QUOT_big = Polynomial._from_device(quot, Basis.LAGRANGE, 4 * n)
         coeffs = self.expanded_evals_to_coeffs(QUOT_big)
         if self.check:
-            assert coeffs.values[-n:] == [0] * n  # prover.py:205-208
+            assert coeffs.is_zero(3 * n, 4 * n)  # prover.py:205-208
         T1c, T2c, T3c = (coeffs.slice(k * n, (k + 1) * n, Basis.MONOMIAL) for k in range(3))
         self.T1, self.T2, self.T3 = T1c.fft(), T2c.fft(), T3c.fft()
         if self.check:  # prover.py:215-219
@@ -154,7 +185,7 @@ class Prover:
                 self.T1.barycentric_eval(cof)
                 + self.T2.barycentric_eval(cof) * cof**n
                 + self.T3.barycentric_eval(cof) * cof ** (n * 2)
-            ) == QUOT_big.values[0]
+            ) == QUOT_big.value_at(0)
         return Message3(*(self.setup.commit_coeffs(t) for t in (T1c, T2c, T3c)))
 
     # ---------------------------------------------------------------- round 4  (prover.py:228-239)
@@ -192,7 +223,7 @@ class Prover:
         )
         if self.check:
             R_coeffs = self.expanded_evals_to_coeffs(R_big)
-            assert R_coeffs.values[n:] == [0] * (3 * n)
+            assert R_coeffs.is_zero(n, 4 * n)
             assert R_coeffs.slice(0, n, Basis.MONOMIAL).fft().barycentric_eval(zeta) == 0  # prover.py:267
 
         X_big = self._X_big
@@ -208,18 +239,25 @@ class Prover:
         ) / (X_big - zeta)
         W_z_coeffs = self.expanded_evals_to_coeffs(W_z_big)
         if self.check:
-            assert W_z_coeffs.values[n:] == [0] * (3 * n)  # prover.py:288
+            assert W_z_coeffs.is_zero(n, 4 * n)  # prover.py:288
         W_z_1 = self.setup.commit_coeffs(W_z_coeffs.slice(0, n, Basis.MONOMIAL))
 
         W_zw_big = (Z_big - zw) / (X_big - zeta * Scalar.root_of_unity(n))
         W_zw_coeffs = self.expanded_evals_to_coeffs(W_zw_big)
         if self.check:
-            assert W_zw_coeffs.values[n:] == [0] * (3 * n)  # prover.py:299
+            assert W_zw_coeffs.is_zero(n, 4 * n)  # prover.py:299
         W_zw_1 = self.setup.commit_coeffs(W_zw_coeffs.slice(0, n, Basis.MONOMIAL))
         return Message5(W_z_1, W_zw_1)
 
     def fft_expand(self, x: Polynomial):  # prover.py:308-309
-        return x.to_coset_extended_lagrange(self.fft_cofactor)
+        # (the reference extends the same polynomial again in round 5; within one proof the extension is kept)
+        cache = getattr(self, "_expanded", None)
+        if cache is None:
+            return x.to_coset_extended_lagrange(self.fft_cofactor)
+        hit = cache.get(id(x))
+        if hit is None or hit[0] is not x:
+            hit = cache[id(x)] = (x, x.to_coset_extended_lagrange(self.fft_cofactor))
+        return hit[1]
 
     def expanded_evals_to_coeffs(self, x: Polynomial):  # prover.py:311-312
         return x.coset_extended_lagrange_to_coeffs(self.fft_cofactor)

@@ -82,6 +82,12 @@ class Polynomial:
         check(ctx.L.plonk_fr_powers(ctx.handle, le32(Scalar(first).n), le32(Scalar(base).n), n, out.ptr))
         return cls._from_device(out, basis, n)
 
+    def value_at(self, i):
+        """values[i] without materialising the rest."""
+        if self._values is not None:
+            return self._values[i]
+        return Scalar(get_context().download_ints(self._dev, 1, offset=i)[0])
+
     def is_zero(self, start=0, stop=None):
         """values[start:stop] == [0] * (stop - start), decided on the device (prover.py:205-208, 288, 299)."""
         stop = self._n if stop is None else stop

@@ -104,3 +104,19 @@ extern "C" void probe_fpl(int op, const int32_t* a, const int32_t* b, const int3
     }
     memcpy(out, r.l, 36);
 }
+
+// fpl_mul_shoup on Fr: a = 9 signed limbs, wt = a constant in canonical Montgomery form (8 packed words);
+// out[0..8] = a * w (limbs), out[9..17] = w, out[18..26] = wp = floor(w 2^261 / r)
+extern "C" void probe_fpl_shoup(const int32_t* a, const uint32_t* wt, int32_t* out) {
+    FpL<FrParams> x;
+    memcpy(x.l, a, 36);
+    Fp<FrParams> c;
+    memcpy(c.v, wt, 32);
+    uint32_t ninv[9];
+    fpl_ninv261<FrParams>(ninv);
+    const FpLS<FrParams> s = fpl_shoup_from_mont(c, ninv);
+    const FpL<FrParams> r = fpl_mul_shoup(x, s);
+    memcpy(out, r.l, 36);
+    memcpy(out + 9, s.w, 36);
+    memcpy(out + 18, s.wp, 36);
+}

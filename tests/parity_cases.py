@@ -100,6 +100,120 @@ def ntt_roundtrip_and_linearity(log_n, seed=5):
     assert roots[:4] == [1, w, w * w % R_MOD, pow(w, 3, R_MOD)] and roots[n - 1] == pow(w, n - 1, R_MOD)
 
 
+def round_kernels_vs_oracle(log_ns=(3, 4, 6)):
+    """The fused round kernels of the C-ABI on their own against the oracle's Polynomial arithmetic (the reference's
+    formulas of prover.py:121-146 and 188-203 spelled out operator by operator), plus plonk_fr_powers / plonk_fr_equal."""
+    import ctypes
+
+    from plonkathon_amd import get_context
+    from plonkathon_amd._lib import check
+    from plonkathon_amd.field import le32
+
+    ctx = get_context()
+    for log_n in log_ns:
+        n = 1 << log_n
+        A, B, C, S1, S2, S3 = (rand_vec(900 + 10 * log_n + k, n) for k in range(6))
+        beta, gamma, alpha, cof = rand_vec(990 + log_n, 4)
+        # a zero denominator factor at row 1 (py_ecc: x / 0 == 0 zeroes the ratio, poly.py:85-100)
+        A[1] = (-(beta * S1[1] + gamma)) % R_MOD
+        w = ofield.root_of_unity(n)
+        roots = [pow(w, i, R_MOD) for i in range(n)]
+        Z, closes_want = [1], None
+        for i in range(n):
+            num = (A[i] + beta * roots[i] + gamma) * (B[i] + 2 * beta * roots[i] + gamma) * (C[i] + 3 * beta * roots[i] + gamma) % R_MOD
+            den = (A[i] + beta * S1[i] + gamma) * (B[i] + beta * S2[i] + gamma) * (C[i] + beta * S3[i] + gamma) % R_MOD
+            Z.append(Z[-1] * num * ofield.inv(den) % R_MOD)
+        closes_want = Z.pop() == 1
+        dev = [ctx.upload_ints(v) for v in (A, B, C, S1, S2, S3)]
+        out, closes = ctx.alloc(n), ctypes.c_int(-1)
+        check(ctx.L.plonk_fr_grand_product(ctx.handle, *[d.ptr for d in dev], log_n, le32(beta), le32(gamma), out.ptr, ctypes.byref(closes)))
+        assert ctx.download_ints(out) == Z, ("grand product", log_n)
+        assert bool(closes.value) == closes_want
+        # quotient on the coset: 14 arbitrary Lagrange vectors -> their extensions -> the fused pass vs operator arithmetic
+        lag = [OPoly(rand_vec(700 + 20 * log_n + k, n), OBasis.LAGRANGE) for k in range(14)]
+        big = [p.to_coset_extended_lagrange(cof) for p in lag]
+        a_, b_, c_, pi, z, ql, qr, qm, qo, qc, s1, s2, s3, l0 = big
+        mu = ofield.root_of_unity(4 * n)
+        X = OPoly([cof * pow(mu, k, R_MOD) % R_MOD for k in range(4 * n)], OBasis.LAGRANGE)
+        ZH = OPoly([(pow(x, n, R_MOD) - 1) % R_MOD for x in X.values], OBasis.LAGRANGE)
+        rl = lambda t1, t2: t1 + t2 * beta + gamma
+        want = (
+            a_ * ql + b_ * qr + a_ * b_ * qm + c_ * qo + pi + qc
+            + (rl(a_, X) * rl(b_, X * 2) * rl(c_, X * 3) * z - rl(a_, s1) * rl(b_, s2) * rl(c_, s3) * z.shift(4)) * alpha
+            + (z - 1) * l0 * (alpha * alpha % R_MOD)
+        ) / ZH
+        dbig = [ctx.upload_ints(p.values) for p in big]
+        ptrs = (ctypes.c_void_p * 14)(*[d.ptr for d in dbig])
+        q = ctx.alloc(4 * n)
+        check(ctx.L.plonk_fr_quotient(ctx.handle, log_n, ptrs, le32(cof), le32(alpha), le32(beta), le32(gamma), q.ptr))
+        assert ctx.download_ints(q) == want.values, ("quotient", log_n)
+        # powers / equal
+        assert ints(Polynomial.powers(cof, mu, 4 * n)) == X.values
+        same = ctx.upload_ints(want.values)
+        eq = ctypes.c_int(-1)
+        check(ctx.L.plonk_fr_equal(ctx.handle, q.ptr, same.ptr, 4 * n, ctypes.byref(eq)))
+        assert eq.value == 1
+        other = list(want.values)
+        other[-1] = (other[-1] + 1) % R_MOD
+        check(ctx.L.plonk_fr_equal(ctx.handle, q.ptr, ctx.upload_ints(other).ptr, 4 * n, ctypes.byref(eq)))
+        assert eq.value == 0
+        zeros = P([0] * n + [5] + [0] * (n - 1))
+        assert zeros.is_zero(0, n) and not zeros.is_zero(0, n + 1) and zeros.is_zero(n + 1, 2 * n) and zeros.value_at(n).n == 5
+        assert P(other) != P(want.values) and P(other) == P(other) and Polynomial._from_device(q, Basis.LAGRANGE, 4 * n) == P(want.values)
+
+
+def g1_encoding_cases(setup):
+    """The compressed G1 / proof encoding: the K6 golden bytes from Prover.prove().to_bytes() and from the lock-step prover's
+    device-side packing, round trips, random points and both roots against the oracle's codec, malformed inputs."""
+    import random
+
+    from plonkathon_amd import BatchProver, Proof, g1_compress, g1_decompress
+
+    k6 = load("k6_proof.json")
+    want = bytes.fromhex(load("k6_proof_bytes.json")["hex"])
+    program = Program(k6["program"], k6["group_order"])
+    wit = {k: int(v) for k, v in k6["witness"].items()}
+    proof = Prover(setup, program).prove(dict(wit))
+    blob = proof.to_bytes()
+    assert blob == want and len(blob) == 480
+    assert flat(Proof.from_bytes(blob)) == flat(proof)
+    bp = BatchProver(setup, program)
+    bp.upload([dict(wit), dict(wit)])
+    bp.run()
+    raw, status = bp.download_compressed()
+    assert status == b"\0\0" and raw[:480] == want and raw[480:] == want
+    # points: multiples of the generator, their negatives (the other root), the identity
+    rng = random.Random(77)
+    pts = [None, og1.G1, og1.neg(og1.G1)]
+    for _ in range(20):
+        q = og1.multiply(og1.G1, rng.randrange(1, R_MOD))
+        pts += [q, og1.neg(q)]
+    enc = g1_compress([None if q is None else (Fq(q[0]), Fq(q[1])) for q in pts])
+    assert enc == b"".join(og1.compress(q) for q in pts)
+    back = g1_decompress(enc)
+    assert [affine(q) for q in back] == [None if q is None else (q[0], q[1]) for q in pts]
+    assert [og1.decompress(enc[32 * i : 32 * i + 32]) for i in range(len(pts))] == [None if q is None else (q[0], q[1]) for q in pts]
+    # malformed: flag bits 00; x >= p; infinity with x != 0; x with no point on the curve
+    bad = [bytes(32), bytes([0x80 | 0x3F]) + b"\xff" * 31, bytes([0x40]) + bytes(30) + b"\x01"]
+    x = 1
+    while pow((x**3 + 3) % Q_MOD, (Q_MOD - 1) // 2, Q_MOD) == 1:
+        x += 1
+    bad.append(bytes([0x80]) + x.to_bytes(32, "big")[1:])
+    for b in bad:
+        try:
+            g1_decompress(b)
+        except ValueError:
+            pass
+        else:
+            raise AssertionError("decoder accepted %s" % b.hex())
+        try:
+            og1.decompress(b)
+        except ValueError:
+            pass
+        else:
+            raise AssertionError("oracle decoder accepted %s" % b.hex())
+
+
 def poly_golden(max_log_n):
     """Every operator of poly.py on the reference-generated vectors (tests/golden/poly_vectors.json)."""
     for case in load("poly_vectors.json")["cases"]:

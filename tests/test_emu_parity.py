@@ -56,6 +56,10 @@ def test_poly_golden(emu):
     pc.poly_golden(max_log_n=11)
 
 
+def test_round_kernels_vs_oracle(emu):
+    pc.round_kernels_vs_oracle((3, 5))
+
+
 def test_poly_asserts(emu):
     pc.poly_asserts()
 
@@ -205,6 +209,12 @@ def test_ntt_two_pass_wave_kernel(emu):
         assert ctx.L.plonk_ntt_set_split(ctx.handle, 18, 14) != 0 and ctx.L.plonk_ntt_set_split(ctx.handle, 15, 8) != 0
     finally:
         check(ctx.L.plonk_ntt_set_split(ctx.handle, 18, 0))
+
+
+def test_g1_and_proof_encoding(emu):
+    from plonkathon_amd import Setup
+
+    pc.g1_encoding_cases(Setup.from_file(pc.PTAU))
 
 
 def test_product_verifier(emu):

@@ -197,3 +197,39 @@ def test_signed_limb_arithmetic_at_the_bounds(probe):
                 out = call(op, limbs_of(v))
                 got = sum((out[i] & 0xFFFFFFFF) << (32 * i) for i in range(8))
                 assert got % m == v % m
+
+
+def test_shoup_multiplication_by_a_constant(probe):
+    """fpl_mul_shoup (the NTT kernels' twiddle multiplication): the Shoup pair (w, floor(w 2^261 / r)) derived from the
+    Montgomery form of a constant, and a * w for operands across fpl_mul's operand range — congruence mod r, result
+    within (-1.8 r, 2.8 r), limbs normalised."""
+    m = field.R_MOD
+    L = (1 << 29) - 1
+    rng = random.Random(11)
+    I9, U8, I27 = ctypes.c_int32 * 9, ctypes.c_uint32 * 8, ctypes.c_int32 * 27
+
+    def val(l):
+        return sum(int(v) << (29 * i) for i, v in enumerate(l))
+
+    consts = [0, 1, 2, m - 1, m - 2, (m - 1) // 2, 5, pow(5, (m - 1) // 2048, m)] + [rng.randrange(m) for _ in range(24)]
+    for w in consts:
+        wt = w * R261 % m
+        words = U8(*[(wt >> (32 * i)) & 0xFFFFFFFF for i in range(8)])
+        operands = []
+        for top in (-120, -17, -2, -1, 0, 1, 2, 16, 127):  # |value| up to 128 r
+            for kind in range(4):
+                lo = [L] * 8 if kind == 0 else [-L] * 8 if kind == 1 else [2 * L if i % 2 else -L for i in range(8)] if kind == 2 else [rng.randrange(-L, 2 * L) for _ in range(8)]
+                operands.append(lo + [(top * m) >> 232])
+        operands.append([int(1.26 * (1 << 30))] * 8 + [0])   # the largest limbs fpl_mul's callers produce
+        operands.append([-int(1.26 * (1 << 30))] * 8 + [0])
+        for a in operands:
+            if abs(val(a)) >= 128 * m:
+                continue
+            out = I27()
+            probe.probe_fpl_shoup(I9(*a), words, out)
+            out = list(out)
+            r, wl, wp = out[:9], out[9:18], out[18:]
+            assert val(wl) == w and val(wp) == (w << 261) // m
+            assert all(0 <= v <= L for v in r[:8]), r
+            assert val(r) % m == val(a) * w % m
+            assert -1.8 * m < val(r) < 2.8 * m

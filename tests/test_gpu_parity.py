@@ -77,6 +77,10 @@ def test_poly_golden():
     pc.poly_golden(max_log_n=16)
 
 
+def test_round_kernels_vs_oracle():
+    pc.round_kernels_vs_oracle((3, 4, 6, 9))
+
+
 def test_poly_asserts():
     pc.poly_asserts()
 
@@ -448,6 +452,10 @@ def test_lagrange_srs_paths(setup):
 
 
 @pytest.mark.gpu
+def test_g1_and_proof_encoding(setup):
+    pc.g1_encoding_cases(setup)
+
+
 def test_product_verifier(setup):
     pc.verifier_cases(setup, full_size=True)
 

@@ -279,3 +279,18 @@ def test_golden_proof_verifies(setup):
     bad = dict(proof)
     bad["W_z_1"] = g1.double(bad["W_z_1"])
     assert not vk.verify_proof(8, bad, [60])
+
+
+def test_compressed_proof_bytes_of_the_golden_proof():
+    """The oracle's codec on the reference's golden proof (test/proof.pickle) against tests/golden/k6_proof_bytes.json
+    (tools/gen_proof_bytes.py writes the encoding's definition out independently), and back."""
+    from oracle import g1 as og1
+
+    g = load("k6_proof.json")["proof"]
+    flat = {k: (pt(v) if isinstance(v, list) or v is None else int(v)) for k, v in g.items()}
+    want = bytes.fromhex(load("k6_proof_bytes.json")["hex"])
+    assert og1.proof_to_bytes(flat) == want
+    for i, k in enumerate(("a_1", "b_1", "c_1", "z_1", "t_lo_1", "t_mid_1", "t_hi_1", "W_z_1", "W_zw_1")):
+        assert og1.decompress(want[32 * i : 32 * i + 32]) == flat[k]
+    assert og1.compress(None) == bytes([0x40]) + bytes(31) and og1.decompress(og1.compress(None)) is None
+    assert og1.decompress(og1.compress(og1.neg(og1.G1))) == og1.neg(og1.G1)

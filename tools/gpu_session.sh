@@ -15,7 +15,7 @@ for step in "$@"; do
       else timeout 1500 python -m pytest tests -m gpu -x -q > "$out/pytest_gpu.log" 2>&1; fi
       echo "pytest rc=$?" >> "$out/pytest_gpu.log"; tail -4 "$out/pytest_gpu.log" ;;
     smoke) timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > "$out/smoke.log" 2>&1; echo "smoke rc=$?"; tail -2 "$out/smoke.log" ;;
-    ntt_sweep) timeout 600 python tools/ntt_sweep.py $arg > "$out/ntt_sweep.jsonl" 2> "$out/ntt_sweep.err"; echo "rc=$?"; tail -3 "$out/ntt_sweep.jsonl" ;;
+    ntt_sweep) timeout 600 python tools/ntt_sweep.py $arg >> "$out/ntt_sweep.jsonl" 2>> "$out/ntt_sweep.err"; echo "rc=$?"; tail -3 "$out/ntt_sweep.jsonl" ;;
     ntt_ab)   # every alternative build present as plonkathon_amd/libplonk_hip_<name>.so, same shapes
       for so in plonkathon_amd/libplonk_hip_*.so; do
         t=$(basename "$so" .so); t=${t#libplonk_hip_}
@@ -27,6 +27,7 @@ for step in "$@"; do
       ( cd /tmp && rocprofv3 --kernel-trace --stats -d "$OLDPWD/$out/rocprof" -o trace -- python "$OLDPWD/bench.py" $arg > "$OLDPWD/$out/bench_under_rocprof.json" 2> "$OLDPWD/$out/rocprof.err" ); echo "rocprof rc=$?"
       find "$out/rocprof" -name "*kernel_stats.csv" | head -1 | xargs -r head -12 ;;
     pmc) bash tools/pmc_collect.sh "$out" $arg ;;
+    latency) timeout 600 python tools/latency.py $arg > "$out/latency.json" 2> "$out/latency.err"; echo "rc=$?"; cat "$out/latency.json" ;;
     ubench) for b in tools/ubench/*.bin; do timeout 120 "$b" > "$out/$(basename $b .bin).json" 2>&1; done ;;
     *) echo "unknown step $name" ;;
   esac
