@@ -18,10 +18,22 @@ collective of the path, an all-gather of the finished proofs (768 B each) over R
 
 Rank 0 prints ONE JSON line: the contract fields, plus
   "roofline"      the dominant kernel of the timed region (msm_lookup; msm_accumulate if no table fits): durations from
-                  HIP events recorded on the library's stream inside the timed region;
+                  HIP events recorded on the library's stream; `frac` is the kernel with the chip to itself (one stream
+                  active, measured right after the timed region), `frac_concurrent` the same launches inside the
+                  N-stream timed region; `traffic` from the committed PMC passes of this round's build;
   "roofline_ntt"  the standalone Fr NTT at 2^20 (BASELINE configs[3]) against the HBM roofline;
-  "ntt", "msm"    NTT GF-elems/s at 2^11 (batched), 2^16, 2^20; MSMs/s at 2^11; N replicas for N GPUs;
-  "fallbacks"     the same prover on a 40 GB table budget and on the bucket method (no table);
+  "ntt"           BASELINE configs[3]: 2^16 / 18 / 20 / 22 / 24, forward and inverse, out of place and in place, a lone
+                  transform and the constant-work batch [2^24 / N][N], each with GF-elems/s, the HBM-roofline fraction
+                  and the PMC traffic; the prover's own sizes (2^10 .. 2^13, batched); N replicas for N GPUs;
+  "msm"           MSMs/s at 2^11;
+  "configs"       BASELINE configs[2]: the mini-Poseidon circuit (test.py:216-239) at group_order 2^10 (the reference's
+                  own size) and 2^11, a lock-step batch of distinct witnesses: proofs/s, and whether proof 0 — inputs
+                  (1, 2) — is bit-identical to the committed fixture;
+  "latency"       ONE proof of the configs[1] circuit: the reference-shaped `Prover(setup, program).prove(witness)` with
+                  and without its sanity asserts, and `BatchProver.prove` (batch of one); speed-up over the oracle proof;
+  "end_to_end"    the same step with a FRESH pre-packed batch uploaded for every lock-step batch inside the timed
+                  region (page-locked host buffers, copy stream overlapped with the other streams' rounds);
+  "fallbacks"     the same prover on the library's default 4 GiB table budget, on a 40 GB budget and on the bucket method;
   "host"          host-side cost of staging witnesses from Python dictionaries, end-to-end rate including it;
   "cpu_baseline"  the oracle (pure-Python port of the reference path) timed on this box, rank 0, N = 1: one full
                   proof, and per primitive fft/ifft at 2^11, 2^13, 2^16 and ec_lincomb at 2^11 (3 samples each).
@@ -64,6 +76,42 @@ def witness_for(proof_index):
         vals.append(x)
         x = x * x % R_MOD
     return dict(zip(["x%d" % i for i in range(GROUP_ORDER)], vals))
+
+
+def poseidon_program_lines():
+    """BASELINE configs[2]: the mini-Poseidon circuit generator of /root/reference/test.py:216-239 (round constants:
+    test/poseidon_rc.json, kept as tests/golden/poseidon_rc.json; MDS = [1/3 .. 1/7], test/mini_poseidon.py:24):
+    1012 constraints, public inputs L0, M0 and the hash M64."""
+    rc = [[int(x) % R_MOD for x in row] for row in json.load(open(os.path.join(REPO, "tests", "golden", "poseidon_rc.json")))]
+    mds = [pow(i, -1, R_MOD) for i in range(3, 8)]
+    o = ["L0 public", "M0 public", "M64 public", "R0 <== 0"]
+    for i in range(64):
+        for j, pos in enumerate(("L", "M", "R")):
+            if i < 4 or i >= 60 or pos == "L":
+                o.append("%sadj%d <== %s%d + %d" % (pos, i, pos, i, rc[i][j]))
+                o.append("%ssq%d <== %sadj%d * %sadj%d" % (pos, i, pos, i, pos, i))
+                o.append("%sqd%d <== %ssq%d * %ssq%d" % (pos, i, pos, i, pos, i))
+                o.append("%sqn%d <== %sqd%d * %sadj%d" % (pos, i, pos, i, pos, i))
+            else:
+                o.append("%sqn%d <== %s%d + %d" % (pos, i, pos, i, rc[i][j]))
+        for j, pos in enumerate(("L", "M", "R")):
+            o.append("%ssuma%d <== Lqn%d * %d" % (pos, i, i, mds[j]))
+            o.append("%ssumb%d <== %ssuma%d + Mqn%d * %d" % (pos, i, pos, i, i, mds[j + 1]))
+            o.append("%s%d <== %ssumb%d + Rqn%d * %d" % (pos, i + 1, pos, i, i, mds[j + 2]))
+    return o
+
+
+def proof_matches_fixture(proof, name):
+    """Proof.flatten() against the committed fixture tests/golden/oracle_proofs.json (oracle proofs: the reference's
+    rounds are blank upstream, the oracle is pinned by the reference's golden proof at group_order 8)."""
+    case = [c for c in json.load(open(os.path.join(REPO, "tests", "golden", "oracle_proofs.json")))["cases"] if c["name"] == name][0]
+    got = proof.flatten()
+    for k, v in case["proof"].items():
+        g = got[k]
+        g = None if g is None else ([str(g[0].n), str(g[1].n)] if isinstance(g, tuple) else str(g.n))
+        if g != v:
+            return False
+    return True
 
 
 def lookup_table_bytes(n, c):
@@ -136,29 +184,60 @@ def cpu_baseline():
     return dt, proof, prim
 
 
-def ntt_microbench(ctx, log_n, batch, reps=5):
+_NTT_SRC = {}
+
+
+def ntt_microbench(ctx, log_n, batch, reps=5, inverse=False, in_place=False):
+    """ms of one plonk_fr_ntt call (best of `reps`, HIP events on the library's stream) on `batch` transforms of 2^log_n."""
     from plonkathon_amd._lib import check
 
     n = 1 << log_n
     import random
 
-    rng = random.Random(log_n)
-    # device-side fill: upload one random block and replicate it (content does not affect timing)
-    per = min(n * batch, 4096)
-    src = ctx.upload_ints([rng.randrange(1 << 253) for _ in range(per)])
+    if id(ctx) not in _NTT_SRC:  # device-side fill: upload one random block and replicate it (content does not affect timing)
+        rng = random.Random(12)
+        _NTT_SRC[id(ctx)] = ctx.upload_ints([rng.randrange(1 << 253) for _ in range(4096)])
+    src = _NTT_SRC[id(ctx)]
     buf = ctx.alloc(n * batch)
-    for off in range(0, n * batch, per):
-        check(ctx.L.plonk_mem_d2d(ctx.handle, buf.at(off), src.ptr, 32 * min(per, n * batch - off)))
-    out = ctx.alloc(n * batch)
-    check(ctx.L.plonk_fr_ntt(ctx.handle, buf.ptr, out.ptr, log_n, 0, batch))  # warm: tables + scratch
+    for off in range(0, n * batch, 4096):
+        check(ctx.L.plonk_mem_d2d(ctx.handle, buf.at(off), src.ptr, 32 * min(4096, n * batch - off)))
+    out = buf if in_place else ctx.alloc(n * batch)
+    inv = 1 if inverse else 0
+    for _ in range(2):
+        check(ctx.L.plonk_fr_ntt(ctx.handle, buf.ptr, out.ptr, log_n, inv, batch))  # warm: tables + scratch
     ctx.sync()
     best = None
     for _ in range(reps):
         ctx.timer_start()
-        check(ctx.L.plonk_fr_ntt(ctx.handle, buf.ptr, out.ptr, log_n, 0, batch))
+        check(ctx.L.plonk_fr_ntt(ctx.handle, buf.ptr, out.ptr, log_n, inv, batch))
         ms = ctx.timer_stop_ms()
         best = ms if best is None or ms < best else best
     return best
+
+
+def ntt_sweep(ctx, comm, world, pmc):
+    """BASELINE configs[3] / SURVEY.md 8(d): N = 2^16 .. 2^24 on random scalars — forward and inverse, out of place and in
+    place, one transform alone and the constant-work batch [2^24 / N][N] (poly.py:113-148).  Per row: ms (slowest rank),
+    whole-job GF-elems/s, fraction of the HBM roofline on the algorithmic 64 N bytes, PMC traffic where a pass exists."""
+    from plonkathon_amd import distributed as D
+
+    rows = {}
+    for log_n in (16, 18, 20, 22, 24):
+        n = 1 << log_n
+        entry = {}
+        for name, inverse, in_place, batch in (("fwd", False, False, 1), ("inv", True, False, 1), ("fwd_in_place", False, True, 1),
+                                                ("inv_in_place", True, True, 1), ("fwd_batched", False, False, (1 << 24) >> log_n)):
+            if name == "fwd_batched" and batch == 1:
+                continue
+            ms = D.max_over_ranks(ntt_microbench(ctx, log_n, batch, inverse=inverse, in_place=in_place), comm)
+            gbs = 64.0 * n * batch / (ms * 1e-3) / 1e9
+            entry[name] = {"ms": ms, "batch": batch, "gf_elems_per_s": world * n * batch / (ms * 1e-3), "hbm_frac": gbs / HBM_PEAK_GBS}
+        tr = pmc.get("ntt_2^%d" % log_n)
+        if tr:
+            entry["pmc_traffic_bytes"] = tr
+            entry["pmc_traffic_over_algorithmic"] = tr / (64.0 * n)
+        rows["2^%d" % log_n] = entry
+    return rows
 
 
 def msm_microbench(ctx, bases, batch, reps=3):
@@ -273,11 +352,14 @@ def main():
     ap.add_argument("--no-lookup", action="store_true", help="bucket-method MSM only")
     ap.add_argument("--lagrange-commits", action="store_true", help="commit rounds 1-2 from Lagrange values over the Lagrange-basis SRS (a second lookup table)")
     ap.add_argument("--msm-groups", type=int, default=0, help="plonk_msm_configure groups: workgroups per MSM (0 = library default)")
-    ap.add_argument("--ntt-kind", type=int, default=0, help="plonk_ntt_select_kernel: 0 auto, 1 radix-2 stages, 2 Stockham, 3 wave, 4 auto without the wave kernel (A/B)")
+    ap.add_argument("--ntt-kind", type=int, default=0, help="plonk_ntt_select_kernel: 0 auto, 1 radix-2 stages, 2 Stockham, 4 auto among the LDS kernels (A/B), 5 wave kernels wherever they apply")
     ap.add_argument("--log-n", type=int, default=11, help="log2(group_order); 11 = the BASELINE workload, smaller values are for functional tests only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-microbench", action="store_true")
     ap.add_argument("--no-fallbacks", action="store_true")
+    ap.add_argument("--no-end-to-end", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip BASELINE configs[2] (Poseidon)")
+    ap.add_argument("--no-latency", action="store_true")
     args = ap.parse_args()
 
     global GROUP_ORDER
@@ -446,22 +528,18 @@ def main():
     line["host"]["end_to_end_proofs_per_s_from_dicts_per_gpu"] = per_gpu / (t_up + per_gpu * elapsed / total_proofs * world)
     line["clocks"] = clocks  # rank 0's GPU; None when amdgpu's hwmon files are not visible
 
-    def pmc_traffic(kernel, run):
-        """HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside this process)."""
-        for name in ("r02_pmc_summary.json", "r01_pmc_summary.json"):
-            path = os.path.join(REPO, "profiles", name)
-            if not os.path.exists(path):
-                continue
-            ks = [k for k in json.load(open(path))["kernels"] if k["kernel"] == kernel and k["run"] == run]
-            n = sum(k["launches"] for k in ks)
-            if n:
-                return sum(k["traffic_bytes"] * k["launches"] for k in ks) / n, "profiles/" + name
-        return None, None
+    # HBM bytes per launch / per transform from the committed PMC passes of this round's build (rocprofv3 cannot run
+    # inside this process): profiles/r03_pmc_summary.json, written by tools/pmc_summary.py from tools/pmc_collect.sh
+    pmc, pmc_src = {"bench": {}, "ntt": {}, "factors": {}}, None
+    for name in ("r03_pmc_summary.json",):
+        path = os.path.join(REPO, "profiles", name)
+        if os.path.exists(path):
+            pmc, pmc_src = json.load(open(path)), "profiles/" + name
 
     if msm_launches:
         avg_s = msm_ms * 1e-3 / msm_launches
         achieved = (msm_bytes / msm_launches) / avg_s / 1e9
-        traffic, traffic_src = pmc_traffic(msm_kernel + "_kernel", "bench") if B == 512 else (None, None)
+        traffic = pmc["bench"].get(msm_kernel + "_kernel") if B == 512 else None
         line["roofline"] = {
             "kernel": msm_kernel + "_kernel",
             "bound": "hbm",
@@ -470,8 +548,10 @@ def main():
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic,
-            "traffic_source": "%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --batch 512` (tools/pmc_collect.sh), "
-                              "2*FETCH+WRITE, launch-weighted mean" % traffic_src,
+            "traffic_source": "%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --batch 512 --streams 1` on this "
+                              "round's build (tools/pmc_collect.sh); FETCH_SIZE scaled by the factor calibrated for this access "
+                              "pattern (`factors`), launch-weighted mean" % pmc_src,
+            "traffic_factors": pmc.get("factors"),
             "launches": msm_launches,
             "avg_launch_us": avg_s * 1e6,
             "concurrent_streams": NS,
@@ -493,7 +573,10 @@ def main():
                                                 if clocks else None),
                 "note": "the same kernel on the same inputs with one stream active (untimed phase right after the timed region): "
                         "its duration when it does not share the chip; profiles/ holds the rocprofv3 trace of a one-stream run"}
-            line["roofline"]["frac_isolated"] = line["roofline"]["isolated"]["frac"]
+            # the headline figure is the kernel with the chip to itself; the N-stream figure of the timed region stays beside it
+            r = line["roofline"]
+            r["frac_concurrent"], r["achieved_concurrent"], r["avg_launch_us_concurrent"] = r["frac"], r["achieved"], r["avg_launch_us"]
+            r["frac"], r["achieved"], r["avg_launch_us"] = r["isolated"]["frac"], r["isolated"]["achieved"], r["isolated"]["avg_launch_us"]
         if lookup_bits:  # the lookup method's own algorithmic bytes: one 64-byte table entry per addition + the scalars
             windows_l = (255 + lookup_bits - 1) // lookup_bits
             per_msm = GROUP_ORDER * windows_l * 64.0 + 32.0 * GROUP_ORDER + 64.0
@@ -502,7 +585,7 @@ def main():
             line["roofline"]["method_GBps"] = per_msm * n_msm_l / (msm_ms * 1e-3) / 1e9
             line["roofline"]["method_frac_of_peak"] = line["roofline"]["method_GBps"] / HBM_PEAK_GBS
         if traffic:  # what the kernel really asks of HBM (table look-ups), per the PMC passes
-            line["roofline"]["traffic_GBps"] = traffic / avg_s / 1e9
+            line["roofline"]["traffic_GBps"] = traffic / (iso[0] if iso else avg_s) / 1e9
             line["roofline"]["traffic_frac_of_peak"] = line["roofline"]["traffic_GBps"] / HBM_PEAK_GBS
         # the honest ceiling: W*N mixed additions per MSM against the rate of a bare mixed-addition loop
         n_msm = msm_bytes / (96.0 * GROUP_ORDER + 64.0)
@@ -531,7 +614,8 @@ def main():
         # the same prover when the HBM for the big table is not available: a 40 GB budget, and no table at all
         fb = {}
         c40 = max(c for c in range(8, 18) if lookup_table_bytes(GROUP_ORDER, c) <= 40e9)
-        for name, conf in (("table_budget_40GB", (0, c40, int(40e9))), ("bucket_method", (1, 0, 0))):
+        c4 = max(c for c in range(8, 18) if lookup_table_bytes(GROUP_ORDER, c) <= 4 << 30)
+        for name, conf in (("library_default_4GiB", (0, c4, 4 << 30)), ("table_budget_40GB", (0, c40, int(40e9))), ("bucket_method", (1, 0, 0))):
             c2 = Context(local_rank)
             c2.msm_lookup(*conf)
             pr = BatchProver(setup, program, c2)
@@ -552,36 +636,131 @@ def main():
             c2.close()
         line["fallbacks"] = fb
 
+    if not args.no_end_to_end and world == 1 and provers[0].variables:
+        # What a caller who produces witnesses natively gets: every lock-step batch of a step is uploaded afresh inside the
+        # timed region (32 MiB per 512 proofs at 2^11, pre-packed in page-locked memory), the copy on the context's copy
+        # stream overlapping the other streams' rounds.  Same witnesses, same kernels, same downloads as `value`.
+        V = len(provers[0].variables)
+        pinned = []
+        for pr, part in zip(provers, parts):
+            buf = pr.ctx.host_alloc(32 * V * len(part))
+            ctypes_blob = _pack_witnesses([witness_for(idx) for idx in part], pr.variables, R_MOD)
+            buf[: len(ctypes_blob)] = ctypes_blob
+            pinned.append(buf)
+
+        def e2e_step():
+            for pr, buf, part in zip(provers, pinned, parts):
+                pr.upload_values_async(buf, len(part))   # H2D on the copy stream, conversion + gather behind an event
+                pr.run()
+            st = b"".join(pr.download_raw()[1] for pr in provers)
+            assert not any(st)
+
+        for _ in range(2):
+            e2e_step()
+        barrier()
+        t0 = time.perf_counter()
+        e2e_steps = max(3, min(args.steps, 5))
+        for _ in range(e2e_steps):
+            e2e_step()
+        barrier()
+        e2e = time.perf_counter() - t0
+        line["end_to_end"] = {
+            "proofs_per_s": e2e_steps * per_gpu / e2e, "ms_per_step": 1e3 * e2e / e2e_steps, "steps": e2e_steps,
+            "fraction_of_value": (e2e_steps * per_gpu / e2e) / (total_proofs / elapsed),
+            "uploaded_bytes_per_proof": 32 * V,
+            "note": "a fresh pre-packed batch per lock-step batch inside the timed region: plonk_prover_upload_variables_async "
+                    "from page-locked memory on a copy stream, overlapped with the other streams' rounds; witness generation "
+                    "and packing (the caller's side) are outside, `host` has their Python cost"}
+        for pr, buf in zip(provers, pinned):
+            pr.ctx.host_free(buf)
+
+    if not args.no_configs and world == 1:
+        # BASELINE configs[2]: the mini-Poseidon circuit (test.py:216-239; 1012 constraints) at the reference's own
+        # group_order 2^10 (test.py:250) and at 2^11; a lock-step batch of distinct witnesses (inputs (1, 2), (2, 3), ..)
+        lines = poseidon_program_lines()
+        cfg = {}
+        PB = min(B, 512)
+        for n_p in (1024, 2048):
+            prog = Program(lines, n_p)
+            t0 = time.perf_counter()
+            wits = [prog.fill_variable_assignments({"L0": 1 + i, "M0": 2 + i}) for i in range(PB)]
+            t_wit = time.perf_counter() - t0
+            pr = BatchProver(setup, prog, ctx)
+            pr.upload(wits)
+            for _ in range(2):
+                pr.run()
+                pr.download_raw()
+            reps = 5
+            ctx.sync()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                pr.run()
+                raw, st = pr.download_raw()
+            dt = (time.perf_counter() - t0) / reps
+            assert not any(st)
+            cfg["poseidon_group_order_%d" % n_p] = {
+                "proofs_per_s": PB / dt, "ms_per_batch_of_%d" % PB: 1e3 * dt, "constraints": len(lines), "streams": 1,
+                "witness_generation_ms_per_proof": 1e3 * t_wit / PB,
+                "proof_0_bit_identical_to_fixture": proof_matches_fixture(BatchProver.decode(raw[:768]), "poseidon_%d" % n_p)}
+            del pr
+        line["configs"] = {"configs[2]": cfg,
+                           "note": "one stream, one lock-step batch resident (the headline runs 20 batches on 4 streams); fixture = "
+                                   "tests/golden/oracle_proofs.json"}
+
+    if not args.no_latency and world == 1:
+        # ONE proof of the configs[1] circuit (north_star: ">= 1000x reference-CPU proof-generation time"): through the
+        # reference's own entry point Prover(setup, program).prove(witness), with and without its sanity asserts
+        # (prover.py:108-116, 132-146, 205-219, 265-267, 288, 299), and through the lock-step prover with a batch of one
+        from plonkathon_amd import Prover
+
+        def lat(fn, reps=10):
+            fn()
+            ts = []
+            for _ in range(reps):
+                t = time.perf_counter()
+                fn()
+                ctx.sync()
+                ts.append(time.perf_counter() - t)
+            ts.sort()
+            return {"best_ms": 1e3 * ts[0], "median_ms": 1e3 * ts[len(ts) // 2], "reps": reps}
+
+        api = Prover(setup, program)
+        wit0 = witness_for(mine[0])
+        lt = {"api_prover_with_asserts": lat(lambda: api.prove(dict(wit0)))}
+        api.check = False
+        lt["api_prover"] = lat(lambda: api.prove(dict(wit0)))
+        b1 = BatchProver(setup, program, ctx)
+        lt["batch_prover_b1"] = lat(lambda: b1.prove(dict(wit0)))
+        flat_a, flat_b = api.prove(dict(wit0)).flatten(), b1.prove(dict(wit0)).flatten()
+        lt["api_equals_batch"] = all(flat_a[k] == flat_b[k] for k in flat_a)
+        lt["proof_bytes"] = len(api.prove(dict(wit0)).to_bytes())
+        lt["note"] = "wall time of one prove() call incl. witness staging and the download of the proof, warm (tables, Lagrange SRS and kernels loaded)"
+        line["latency"] = lt
+        del b1
+
     if not args.no_microbench:
         # standalone NTT and MSM rates; with N GPUs every rank runs a replica and the whole-job
         # rate is N x (work of one replica) / (time of the slowest rank)
-        ms11 = D.max_over_ranks(ntt_microbench(ctx, 11, 512), comm)
-        ms11b = D.max_over_ranks(ntt_microbench(ctx, 11, 2048), comm)
-        ms13 = D.max_over_ranks(ntt_microbench(ctx, 13, 512), comm)
-        ms16 = D.max_over_ranks(ntt_microbench(ctx, 16, 1), comm)
-        ms20 = D.max_over_ranks(ntt_microbench(ctx, 20, 1), comm)
+        small = {}
+        for log_n, batch in ((10, 512), (10, 4096), (11, 512), (11, 2048), (12, 512), (13, 512)):  # the prover's sizes: n and 4n of configs[1] / configs[2]
+            ms = D.max_over_ranks(ntt_microbench(ctx, log_n, batch), comm)
+            small["2^%d_x%d" % (log_n, batch)] = {"ms": ms, "gf_elems_per_s": world * batch * (1 << log_n) / (ms * 1e-3),
+                                                   "hbm_frac": 64.0 * batch * (1 << log_n) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        sweep = ntt_sweep(ctx, comm, world, pmc.get("ntt", {}))
         ms_msm = D.max_over_ranks(msm_microbench(ctx, setup.device_bases(ctx), 4608), comm)
-        line["ntt"] = {
-            "gf_elems_per_s_2^11_x512": world * 512 * 2048 / (ms11 * 1e-3),
-            "gf_elems_per_s_2^11_x2048": world * 2048 * 2048 / (ms11b * 1e-3),
-            "gf_elems_per_s_2^13_x512": world * 512 * 8192 / (ms13 * 1e-3),
-            "gf_elems_per_s_2^16": world * (1 << 16) / (ms16 * 1e-3),
-            "gf_elems_per_s_2^20": world * (1 << 20) / (ms20 * 1e-3),
-            "ms_2^11_x512": ms11,
-            "ms_2^11_x2048": ms11b,
-            "ms_2^13_x512": ms13,
-            "ms_2^16": ms16,
-            "ms_2^20": ms20,
-            "replicas": world,
-        }
+        line["ntt"] = {"prover_sizes": small, "configs3": sweep, "replicas": world,
+                       "pmc_source": pmc_src,
+                       # the round-2 keys, kept for comparisons across rounds
+                       "ms_2^11_x512": small["2^11_x512"]["ms"], "ms_2^16": sweep["2^16"]["fwd"]["ms"], "ms_2^20": sweep["2^20"]["fwd"]["ms"],
+                       "gf_elems_per_s_2^11_x512": small["2^11_x512"]["gf_elems_per_s"], "gf_elems_per_s_2^20": sweep["2^20"]["fwd"]["gf_elems_per_s"]}
         line["msm"] = {"msms_per_s_2^11_x4608": world * 4608 / (ms_msm * 1e-3), "ms_4608": ms_msm, "replicas": world}
+        ms20 = sweep["2^20"]["fwd"]["ms"]
         ach = 64.0 * (1 << 20) / (ms20 * 1e-3) / 1e9  # per GPU
-        tr20, tr20_src = pmc_traffic("ntt_2^20", "ntt")
-        line["roofline_ntt"] = {"kernel": "ntt pass kernels (N=2^20)", "bound": "hbm", "achieved": ach,
-                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": tr20,
-                                "traffic_source": tr20_src,
-                                "note": "ALU-bound on the 254-bit multiplication: 5 N multiplications at ~140 G/s chip-wide bound the "
-                                        "transform at ~10 % of HBM peak (DESIGN.md 4.1)"}
+        line["roofline_ntt"] = {"kernel": "ntt_wavel_kernel (N = 2^20 = 2^10 x 2^10, two launches)", "bound": "hbm", "achieved": ach,
+                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": pmc.get("ntt", {}).get("ntt_2^20"),
+                                "traffic_source": pmc_src,
+                                "note": "ALU-bound on the 254-bit multiplication: ~10.5 N multiplications (two passes + inter-pass "
+                                        "twiddles) at ~150-170 G/s chip-wide bound the transform near 10 % of HBM peak (DESIGN.md 4.1)"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         dt, oproof, prim = cpu_baseline()
         line["cpu_baseline"] = {
@@ -601,6 +780,9 @@ def main():
             ((got[k][0].n, got[k][1].n) if isinstance(got[k], tuple) else got[k].n) == want[k] for k in want
         )
         line["cpu_baseline"]["gpu_proof_bit_identical"] = bool(same)
+        if "latency" in line:  # north_star's target is a latency ratio: the reference-CPU proof time over one GPU proof
+            for k in ("api_prover_with_asserts", "api_prover", "batch_prover_b1"):
+                line["latency"]["speedup_vs_cpu_proof_" + k] = dt / (line["latency"][k]["median_ms"] * 1e-3)
         if "ntt" in line:
             line["cpu_baseline"]["gpu_speedup_fft_2^11"] = prim["fft_2^11_ms"] / (line["ntt"]["ms_2^11_x512"] / 512)
             line["cpu_baseline"]["gpu_speedup_ec_lincomb_2^11"] = prim["ec_lincomb_2^11_s"] * 1e3 / (line["msm"]["ms_4608"] / 4608)

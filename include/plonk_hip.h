@@ -48,6 +48,9 @@ int plonk_ctx_sync(plonk_ctx* ctx);
 int plonk_ctx_device_name(plonk_ctx* ctx, char* buf, size_t buf_len);
 
 /* ---- raw device memory (Polynomial.values storage; poly.py:10-21) --------------------------- */
+/* page-locked host memory for plonk_prover_upload_variables_async (hipHostMalloc / hipHostFree) */
+int plonk_host_alloc(plonk_ctx* ctx, size_t bytes, void** out_hptr);
+int plonk_host_free(plonk_ctx* ctx, void* hptr);
 int plonk_mem_alloc(plonk_ctx* ctx, size_t bytes, void** out_dptr);
 int plonk_mem_free(plonk_ctx* ctx, void* dptr);
 int plonk_mem_h2d(plonk_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);
@@ -196,7 +199,8 @@ int plonk_srs_lookup_info(const plonk_srs* srs, unsigned* out_bits, size_t* out_
  *                         a_eval, b_eval, c_eval, s1_eval, s2_eval, z_shifted_eval canonical LE;
  *                         status[b]: bit 0 = some commitment is the identity (the reference's
  *                         append_point(None) raises), bit 1 = Z does not close to 1 (prover.py:132),
- *                         bit 2 = quotient degree >= 3n, i.e. a gate constraint fails (prover.py:108-116, 205-208).
+ *                         bit 2 = quotient degree >= 3n, i.e. a gate constraint fails (prover.py:108-116, 205-208),
+ *                         bit 3 = a value uploaded by plonk_prover_upload_variables_async was not a canonical Fr value.
  *   plonk_prover_challenges  beta, gamma, alpha, fft_cofactor, zeta, v of proof b (tests).          */
 typedef struct plonk_prover plonk_prover;
 int plonk_prover_create(plonk_ctx* ctx, plonk_srs* srs, unsigned log_n, const uint8_t* selectors_le32,
@@ -214,6 +218,12 @@ int plonk_prover_upload_witness(plonk_prover* p, const uint8_t* abc_le32, const 
  * (prover.py:97-103) and the public inputs are gathered from them on the device.                                */
 int plonk_prover_set_wiring(plonk_prover* p, const uint32_t* cell_index, const uint32_t* public_index, size_t n_vars);
 int plonk_prover_upload_variables(plonk_prover* p, const uint8_t* vars_le32, size_t batch);
+/* The same upload without a host wait: the copy runs on a copy stream of the context and overlaps the compute stream's
+ * kernels (other provers' rounds on the same GPU, or this prover's previous batch), conversion and gather follow behind
+ * an event.  vars_le32 must stay valid until this batch's plonk_prover_download returns, and should be page-locked
+ * (plonk_host_alloc) — a pageable buffer makes the copy synchronous again.  A value that is not below r cannot be
+ * reported here: it sets status bit 3 of the proof it belongs to at plonk_prover_download.                       */
+int plonk_prover_upload_variables_async(plonk_prover* p, const uint8_t* vars_le32, size_t batch);
 int plonk_prover_run(plonk_prover* p, size_t batch);
 int plonk_prover_download(plonk_prover* p, size_t batch, uint8_t* out_proofs, uint8_t* out_status);
 int plonk_prover_challenges(plonk_prover* p, size_t b, uint8_t out_le32[6 * 32]);

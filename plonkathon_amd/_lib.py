@@ -40,6 +40,9 @@ SIGNATURES = {
     "plonk_g1_compress": (ctypes.c_int, [ctypes.c_void_p, _u8p, ctypes.c_size_t, ctypes.c_char_p]),
     "plonk_g1_decompress": (ctypes.c_int, [ctypes.c_void_p, _u8p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_char_p]),
     "plonk_prover_download_compressed": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_char_p]),
+    "plonk_host_alloc": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t, c_void_pp]),
+    "plonk_host_free": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    "plonk_prover_upload_variables_async": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]),
     "plonk_ntt_select_kernel": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint]),
     "plonk_ntt_set_split": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint, ctypes.c_uint]),
     "plonk_fr_coset_extend": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint, _u8p, ctypes.c_size_t]),

@@ -23,6 +23,10 @@ class Context:
         self.handle = ctypes.c_void_p()
         check(L.plonk_ctx_create(self.device, ctypes.byref(self.handle)))
         self.L = L
+        # Freed DeviceBuffers are kept for reuse, by size: hipFree waits for the device, and a reference-shaped proof
+        # creates ~400 short-lived Polynomials (2.6 ms of hipFree per proof at group_order 2^11).  A context has ONE
+        # stream, so a buffer's next user is ordered behind its last one — the same guarantee hipFreeAsync gives.
+        self._pool, self._pool_bytes = {}, 0
 
     def name(self):
         buf = ctypes.create_string_buffer(256)
@@ -65,6 +69,18 @@ class Context:
         raw = out.raw
         return [int.from_bytes(raw[32 * i : 32 * i + 32], "little") for i in range(n)]
 
+    def host_alloc(self, nbytes):
+        """A page-locked host buffer (hipHostMalloc) as a writable ctypes char array: what BatchProver.upload_values_async
+        copies from without a host wait.  Freed with host_free (or with the process)."""
+        ptr = ctypes.c_void_p()
+        check(self.L.plonk_host_alloc(self.handle, nbytes, ctypes.byref(ptr)))
+        buf = (ctypes.c_char * nbytes).from_address(ptr.value)
+        buf._plonk_hptr = ptr
+        return buf
+
+    def host_free(self, buf):
+        check(self.L.plonk_host_free(self.handle, buf._plonk_hptr))
+
     def timer_start(self):
         check(self.L.plonk_timer_start(self.handle))
 
@@ -93,8 +109,33 @@ class Context:
         check(self.L.plonk_profile_read(self.handle, kernel.encode(), ctypes.byref(ms), ctypes.byref(n), ctypes.byref(by)))
         return ms.value, n.value, by.value
 
+    POOL_MAX_BYTES = 1 << 30       # retained in total
+    POOL_MAX_BUFFER = 64 << 20     # larger buffers go straight back to the driver
+
+    def _pool_take(self, nbytes):
+        free = self._pool.get(nbytes)
+        if free:
+            self._pool_bytes -= nbytes
+            return free.pop()
+        return None
+
+    def _pool_give(self, ptr, nbytes):
+        if nbytes > self.POOL_MAX_BUFFER or self._pool_bytes + nbytes > self.POOL_MAX_BYTES:
+            return False
+        self._pool.setdefault(nbytes, []).append(ptr)
+        self._pool_bytes += nbytes
+        return True
+
+    def trim(self):
+        """Return every pooled buffer to the driver."""
+        for free in self._pool.values():
+            for ptr in free:
+                self.L.plonk_mem_free(self.handle, ptr)
+        self._pool, self._pool_bytes = {}, 0
+
     def close(self):
         if self.handle:
+            self.trim()
             self.L.plonk_ctx_destroy(self.handle)
             self.handle = None
 
@@ -105,8 +146,11 @@ class DeviceBuffer:
     def __init__(self, ctx, n_elems):
         self.ctx = ctx
         self.n = int(n_elems)
-        self.ptr = ctypes.c_void_p()
-        check(ctx.L.plonk_mem_alloc(ctx.handle, 32 * max(self.n, 1), ctypes.byref(self.ptr)))
+        self._nbytes = 32 * max(self.n, 1)
+        self.ptr = ctx._pool_take(self._nbytes)
+        if self.ptr is None:
+            self.ptr = ctypes.c_void_p()
+            check(ctx.L.plonk_mem_alloc(ctx.handle, self._nbytes, ctypes.byref(self.ptr)))
 
     def at(self, elem_offset):
         return ctypes.c_void_p(self.ptr.value + 32 * elem_offset)
@@ -114,7 +158,8 @@ class DeviceBuffer:
     def __del__(self):
         try:
             if self.ptr and self.ctx.handle:
-                self.ctx.L.plonk_mem_free(self.ctx.handle, self.ptr)
+                if not self.ctx._pool_give(self.ptr, self._nbytes):
+                    self.ctx.L.plonk_mem_free(self.ctx.handle, self.ptr)
                 self.ptr = None
         except Exception:
             pass

@@ -115,6 +115,15 @@ class BatchProver:
         check(self.ctx.L.plonk_prover_upload_variables(self._h, blob, B))
         self._resident = B
 
+    def upload_values_async(self, pinned, B):
+        """upload_values without a host wait: `pinned` = a Context.host_alloc buffer holding [B][V] canonical 32-byte
+        values, which must stay untouched until this batch has been downloaded.  The copy runs on the context's copy
+        stream and overlaps the kernels of the compute stream; a non-canonical value shows up as status bit 3."""
+        if len(pinned) < 32 * B * len(self._vars):
+            raise ValueError("upload_values_async: expected %d bytes" % (32 * B * len(self._vars)))
+        check(self.ctx.L.plonk_prover_upload_variables_async(self._h, ctypes.addressof(pinned), B))
+        self._resident = B
+
     @property
     def variables(self):
         """Variable names in the column order `upload_values` expects."""
@@ -166,6 +175,8 @@ class BatchProver:
         raw, status = self.download_raw(B)
         proofs = []
         for b, st in enumerate(status):
+            if st & 8:
+                raise ProofError("proof %d: an uploaded witness value is not a canonical Fr value (>= r)" % b)
             if st & 4:
                 raise ProofError("proof %d: witness does not satisfy the gate constraints "
                                  "(prover.py:108-116; quotient degree check prover.py:205-208)" % b)

@@ -45,6 +45,11 @@ int ctx_scratch(plonk_ctx* ctx, int slot, size_t bytes, void** out) {
     return PLONK_OK;
 }
 
+int ctx_copy_stream(plonk_ctx* ctx) {
+    if (!ctx->copy_stream) PLONK_CHECK_HIP(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    return PLONK_OK;
+}
+
 static int prof_event(plonk_ctx* ctx, hipEvent_t* e) {
     if (!ctx->event_pool.empty()) {
         *e = ctx->event_pool.back();
@@ -148,6 +153,7 @@ int plonk_ctx_destroy(plonk_ctx* ctx) {
     for (auto e : ctx->event_pool) hipEventDestroy(e);
     hipEventDestroy(ctx->ev_a);
     hipEventDestroy(ctx->ev_b);
+    if (ctx->copy_stream) hipStreamDestroy(ctx->copy_stream);
     hipStreamDestroy(ctx->stream);
     delete ctx;
     return PLONK_OK;
@@ -170,6 +176,25 @@ int plonk_ctx_device_name(plonk_ctx* ctx, char* buf, size_t buf_len) {
 }
 
 // ---- memory ------------------------------------------------------------------------------------
+// page-locked host memory: what an asynchronous host-to-device copy needs to be asynchronous
+int plonk_host_alloc(plonk_ctx* ctx, size_t bytes, void** out_hptr) {
+    PLONK_REQUIRE(ctx && out_hptr, PLONK_ERR_ARG, "bad argument");
+    PLONK_ENTER(ctx);
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1) != hipSuccess) {
+        plonk_set_error("hipHostMalloc of %zu bytes failed", bytes);
+        return PLONK_ERR_NOMEM;
+    }
+    *out_hptr = p;
+    return PLONK_OK;
+}
+int plonk_host_free(plonk_ctx* ctx, void* hptr) {
+    PLONK_REQUIRE(ctx, PLONK_ERR_ARG, "ctx is NULL");
+    PLONK_ENTER(ctx);
+    if (hptr) PLONK_CHECK_HIP(hipHostFree(hptr));
+    return PLONK_OK;
+}
+
 int plonk_mem_alloc(plonk_ctx* ctx, size_t bytes, void** out_dptr) {
     PLONK_REQUIRE(ctx && out_dptr, PLONK_ERR_ARG, "bad argument");
     PLONK_ENTER(ctx);

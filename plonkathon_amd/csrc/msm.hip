@@ -498,6 +498,41 @@ __global__ void __launch_bounds__(64) msm_lookup_finalize_kernel(const G1Xyzz* p
     }
 }
 
+// The same for few MSMs cut into many workgroups (a lone commitment: G = 64): one WAVE per MSM, lane g takes partial g and
+// the 64 of them are summed by the cross-lane butterfly of wave.h (six general additions instead of 63 in a row — the
+// serial form made a lone 2^11 commitment 0.75 ms, most of the reference-shaped Prover's latency); lane 0 finishes.
+__global__ void __launch_bounds__(64) msm_lookup_finalize_wave_kernel(const G1Xyzz* partial, size_t M, unsigned G, const G1Affine* lookup,
+                                                                      size_t table_n, unsigned c, unsigned W, const MsmDeferred* deferred,
+                                                                      size_t deferred_stride, const uint32_t* n_deferred, Fq* out_xy,
+                                                                      uint8_t* flags) {
+    const size_t m = blockIdx.x;
+    const unsigned lane = threadIdx.x;
+    G1Xyzz acc = g1_xyzz_identity();
+    for (unsigned g = lane; g < G; g += 64) {  // G <= 64 in practice: at most one partial per lane
+        if (g == lane) acc = partial[m * G + g];
+        else g1_add(acc, partial[m * G + g]);
+    }
+    g1_wave_reduce(acc, lane);
+    if (lane) return;
+    const uint32_t nd = n_deferred[m] < MSM_DEFER_CAP ? n_deferred[m] : MSM_DEFER_CAP;
+    for (uint32_t k = 0; k < nd; k++) {
+        const MsmDeferred e = deferred[m * deferred_stride + k];
+        const uint32_t i = e.bucket / W, w = e.bucket - i * W;
+        const int d = (int)e.entry;
+        const uint32_t ad = d < 0 ? (uint32_t)-d : (uint32_t)d;
+        const G1Affine* src = lookup + ((((size_t)w * table_n + i) << (c - 1)) + (ad - 1));
+        G1Affine pt;
+        pt.x = fp_load(&src->x);
+        pt.y = fp_load(&src->y);
+        if (d < 0) pt.y = fp_neg(pt.y);
+        g1_madd(acc, pt);
+    }
+    G1Affine a = g1_to_affine(acc);
+    flags[m] = g1_affine_is_identity(a) ? 1 : 0;
+    fp_store(out_xy + 2 * m, fp_from_mont(a.x));
+    fp_store(out_xy + 2 * m + 1, fp_from_mont(a.y));
+}
+
 // Recovery path (see MSM_DEFER_CAP): MSM m is recomputed with the general addition formulas, which handle every
 // exceptional case (identity, P == Q, P == -Q), and its output overwritten.  One workgroup per MSM; it exits at
 // once unless the MSM overflowed its deferred list, so the launch costs a few microseconds on the normal path.
@@ -585,6 +620,33 @@ static MsmLookupTable* lut_find(const plonk_srs* srs, unsigned bits) {  // g_lut
         if (bits ? t->bits == bits : (!best || t->bits > best->bits)) best = t;
     }
     return best;
+}
+
+// The registry key is a 64-bit FNV-1a of the loaded bytes — not collision resistant — so a candidate is only attached
+// after its d = 1 entries of window 0 (the bases themselves) have been compared with this SRS's bases on the device.
+__global__ void lut_verify_kernel(const G1Affine* bases, const G1Affine* lookup, size_t n, unsigned c, unsigned* mismatches) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const G1Affine* e = lookup + (i << (c - 1));
+    if (!fp_eq(fp_load(&bases[i].x), fp_load(&e->x)) || !fp_eq(fp_load(&bases[i].y), fp_load(&e->y))) atomicAdd(mismatches, 1u);
+}
+static MsmLookupTable* lut_verified(plonk_ctx* ctx, const plonk_srs* srs, MsmLookupTable* t) {  // g_lut_mu held
+    if (!t) return nullptr;
+    void* flag;
+    if (ctx_scratch(ctx, 3, 64, &flag) != PLONK_OK) return nullptr;
+    unsigned bad = 1;
+    if (hipMemsetAsync(flag, 0, 4, ctx->stream) != hipSuccess) return nullptr;
+    PLONK_LAUNCH(lut_verify_kernel, dim3((unsigned)((srs->n_points + 255) / 256)), dim3(256), 0, ctx->stream, (const G1Affine*)srs->bases,
+                 (const G1Affine*)t->data, srs->n_points, t->bits, (unsigned*)flag);
+    if (hipMemcpyAsync(&bad, flag, 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) return nullptr;
+    return bad ? nullptr : t;
+}
+// bytes of every table this process holds on a device (the automatic choice charges new tables against the same budget)
+static size_t lut_bytes_on_device(int device) {  // g_lut_mu held
+    size_t total = 0;
+    for (MsmLookupTable* t : g_luts)
+        if (t->device == device) total += t->bytes;
+    return total;
 }
 
 void msm_srs_release(plonk_srs* srs) {
@@ -723,7 +785,7 @@ static bool msm_lookup_prepare(plonk_ctx* ctx, plonk_srs* srs) {
     std::lock_guard<std::mutex> lk(g_lut_mu);
     if (ctx->msm_lookup_mode == 2) {  // forced window size, any base set
         if (srs->shared && srs->lookup_bits == want) return true;
-        if (MsmLookupTable* t = lut_find(srs, want)) {
+        if (MsmLookupTable* t = lut_verified(ctx, srs, lut_find(srs, want))) {
             lut_attach(srs, t);
             return true;
         }
@@ -732,7 +794,7 @@ static bool msm_lookup_prepare(plonk_ctx* ctx, plonk_srs* srs) {
     if (!srs->fixed) return false;
     if (srs->shared && (!want || want == srs->lookup_bits)) return true;
     if (want) {
-        if (MsmLookupTable* t = lut_find(srs, want)) {
+        if (MsmLookupTable* t = lut_verified(ctx, srs, lut_find(srs, want))) {
             lut_attach(srs, t);
             return true;
         }
@@ -741,12 +803,16 @@ static bool msm_lookup_prepare(plonk_ctx* ctx, plonk_srs* srs) {
     const size_t budget = ctx->msm_lookup_budget ? ctx->msm_lookup_budget : msm_default_lookup_budget();
     // A table another context of this device already built for these bases is taken as it is — unless this context's
     // budget affords a bigger one (more window bits = fewer additions), which is then built and shared in its turn.
-    MsmLookupTable* have = want ? nullptr : lut_find(srs, 0);
+    MsmLookupTable* have = want ? nullptr : lut_verified(ctx, srs, lut_find(srs, 0));
+    // The automatic choice charges every table this process already holds on the device against the budget: the
+    // Lagrange-basis view of an SRS is a base set of its own, and must not double what the caller granted.  An explicit
+    // window size (`want`) is an explicit request and only has to fit the budget by itself.
+    const size_t used = want ? 0 : lut_bytes_on_device(srs->device);
     // below 8 bits the table no longer beats the bucket method — which, however, cannot index more than 2^15 bases, so
     // larger base sets accept any table that fits
     const unsigned c_min = want ? want : (srs->n_points > 32768 ? 4 : 8);
     for (unsigned c = want ? want : 17; c >= c_min && (!have || c > have->bits); c--) {
-        if (msm_lookup_bytes(srs->n_points, c) > budget) continue;
+        if (msm_lookup_bytes(srs->n_points, c) + used > budget) continue;
         if (msm_lookup_build(ctx, srs, c) == PLONK_OK) return true;
     }
     if (have) {
@@ -784,9 +850,14 @@ static int msm_run_lookup(plonk_ctx* ctx, plonk_srs* srs, const Fr* d_scalars, s
                  (const G1Affine*)srs->lookup, srs->n_points, c, W, d_scalars, n, stride, inner, outer_stride, rc, G, partial,
                  deferred, (size_t)MSM_DEFER_CAP, n_deferred);
     PLONK_TRY(prof_end(ctx));
-    PLONK_LAUNCH(msm_lookup_finalize_kernel, dim3((unsigned)((M + 63) / 64)), dim3(64), 0, ctx->stream, (const G1Xyzz*)partial, M, G,
-                 (const G1Affine*)srs->lookup, srs->n_points, c, W, (const MsmDeferred*)deferred, (size_t)MSM_DEFER_CAP,
-                 (const uint32_t*)n_deferred, d_out_xy, d_flags);
+    if (G >= 8)  // few MSMs in many pieces: a wave per MSM sums the pieces in parallel
+        PLONK_LAUNCH(msm_lookup_finalize_wave_kernel, dim3((unsigned)M), dim3(64), 0, ctx->stream, (const G1Xyzz*)partial, M, G,
+                     (const G1Affine*)srs->lookup, srs->n_points, c, W, (const MsmDeferred*)deferred, (size_t)MSM_DEFER_CAP,
+                     (const uint32_t*)n_deferred, d_out_xy, d_flags);
+    else
+        PLONK_LAUNCH(msm_lookup_finalize_kernel, dim3((unsigned)((M + 63) / 64)), dim3(64), 0, ctx->stream, (const G1Xyzz*)partial, M, G,
+                     (const G1Affine*)srs->lookup, srs->n_points, c, W, (const MsmDeferred*)deferred, (size_t)MSM_DEFER_CAP,
+                     (const uint32_t*)n_deferred, d_out_xy, d_flags);
     PLONK_LAUNCH(msm_slow_kernel, dim3((unsigned)M), dim3(256), 0, ctx->stream, 0, (const G1Affine*)srs->lookup, srs->n_points, c, W,
                  d_scalars, n, stride, inner, outer_stride, rc, (const uint32_t*)n_deferred, d_out_xy, d_flags);
     PLONK_CHECK_HIP(hipGetLastError());

@@ -90,6 +90,7 @@ struct plonk_srs {
 struct plonk_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t copy_stream = nullptr;  // host-to-device staging that overlaps the compute stream (created on first use: ctx_copy_stream)
     NttTables tw;
     std::map<std::string, Fr*> power_tables;  // cached coset-offset power tables, keyed by (offset, n, kind)
     std::vector<void*> owned;                 // device allocations released with the context
@@ -115,6 +116,7 @@ struct plonk_ctx {
 
 // scratch slot use: 0 = NTT inter-pass buffer, 1 = MSM digits/partials, 2-3 = API-level temporaries
 int ctx_scratch(plonk_ctx* ctx, int slot, size_t bytes, void** out);
+int ctx_copy_stream(plonk_ctx* ctx);
 // bracket an instrumented launch: prof_begin before, prof_end after (no-ops unless profiling)
 int prof_begin(plonk_ctx* ctx, const char* name, double algo_bytes);
 int prof_end(plonk_ctx* ctx);

@@ -76,6 +76,9 @@ struct plonk_prover {
     size_t vars_cap;           // elements
     plonk_srs* lag_srs;        // Lagrange-basis view of srs (PLONK_PROVER_LAGRANGE_COMMITS), owned by srs
     size_t resident_b;         // batch size of the witnesses currently resident (run / download must match it)
+    unsigned long long* bad_input;  // device: index of the first uploaded value that was not below r, or ~0 (status bit 3)
+    hipEvent_t ev_copied, ev_vars_read;  // async upload: the copy stream's H2D is done / the gather kernels have read `vars`
+    bool vars_read_pending;
     Fq *commit_xy; // [9][B] x||y canonical
     uint8_t* commit_flags;  // [9][B]
     ProofState* state;      // [B]
@@ -847,6 +850,11 @@ int plonk_prover_destroy(plonk_prover* p) {
     void* bufs[] = {p->fixed_lag, p->fixed_coef, p->fixed_big, p->l0_big, p->x_big, p->g_pow, p->ginv_pow, p->li_big, p->cell_index, p->pub_index};
     for (void* q : bufs)
         if (q) hipFree(q);
+    if (p->bad_input) {
+        hipFree(p->bad_input);
+        hipEventDestroy(p->ev_copied);
+        hipEventDestroy(p->ev_vars_read);
+    }
     delete p;
     return PLONK_OK;
 }
@@ -893,8 +901,13 @@ int plonk_prover_set_wiring(plonk_prover* p, const uint32_t* cell_index, const u
 }
 
 // values of the n_vars variables of each witness, [B][n_vars] canonical LE (n_vars * 32 bytes per proof instead of
-// 3 * n * 32): the wire columns and the public inputs are gathered from them on the device (prover.py:94-103, 57-62)
-int plonk_prover_upload_variables(plonk_prover* p, const uint8_t* vars_le32, size_t B) {
+// 3 * n * 32): the wire columns and the public inputs are gathered from them on the device (prover.py:94-103, 57-62).
+// async: the host-to-device copy goes to the context's copy stream (it overlaps whatever the compute stream is running —
+// another prover's rounds, or this prover's previous batch, which no longer reads `vars`), the conversion and the gather
+// follow on the compute stream behind an event, nothing waits on the host; the canonical-range verdict stays on the
+// device and comes back as status bit 3 of plonk_prover_download.  The caller keeps vars_le32 alive (and, for a copy
+// that really is asynchronous, in pinned memory: plonk_host_alloc) until the batch has been downloaded.
+static int prover_upload_vars(plonk_prover* p, const uint8_t* vars_le32, size_t B, bool async) {
     PLONK_REQUIRE(p && vars_le32 && B, PLONK_ERR_ARG, "bad argument");
     PLONK_ENTER(p->ctx);
     PLONK_REQUIRE(p->n_vars, PLONK_ERR_STATE, "plonk_prover_set_wiring has not been called");
@@ -909,7 +922,23 @@ int plonk_prover_upload_variables(plonk_prover* p, const uint8_t* vars_le32, siz
         PLONK_TRY(dev_alloc((void**)&p->vars, B * V * sizeof(Fr)));
         p->vars_cap = B * V;
     }
-    PLONK_TRY(plonk_fr_upload(ctx, p->vars, vars_le32, B * V));
+    if (!p->bad_input) {
+        PLONK_TRY(dev_alloc((void**)&p->bad_input, sizeof(unsigned long long)));
+        PLONK_CHECK_HIP(hipEventCreate(&p->ev_copied));
+        PLONK_CHECK_HIP(hipEventCreate(&p->ev_vars_read));
+    }
+    p->resident_b = 0;  // until the new batch is in place (a failed upload leaves no batch to run)
+    if (async) {
+        PLONK_TRY(ctx_copy_stream(ctx));
+        if (p->vars_read_pending) PLONK_CHECK_HIP(hipStreamWaitEvent(ctx->copy_stream, p->ev_vars_read, 0));  // the previous gather has read vars
+        PLONK_CHECK_HIP(hipMemcpyAsync(p->vars, vars_le32, B * V * sizeof(Fr), hipMemcpyHostToDevice, ctx->copy_stream));
+        PLONK_CHECK_HIP(hipEventRecord(p->ev_copied, ctx->copy_stream));
+        PLONK_CHECK_HIP(hipStreamWaitEvent(ctx->stream, p->ev_copied, 0));
+        PLONK_TRY(k_fr_to_mont_checked(ctx, p->vars, B * V, p->bad_input));
+    } else {
+        PLONK_CHECK_HIP(hipMemsetAsync(p->bad_input, 0xff, sizeof(unsigned long long), ctx->stream));
+        PLONK_TRY(plonk_fr_upload(ctx, p->vars, vars_le32, B * V));  // waits, and reports a non-canonical value as PLONK_ERR_ARG
+    }
     PLONK_LAUNCH(witness_scatter_kernel, grid1(3 * B * n), dim3(256), 0, ctx->stream, (const Fr*)p->vars, (const uint32_t*)p->cell_index, V,
                  n, B, p->wit_lag);
     if (p->n_public) {
@@ -922,10 +951,15 @@ int plonk_prover_upload_variables(plonk_prover* p, const uint8_t* vars_le32, siz
         PLONK_CHECK_HIP(hipMemsetAsync(p->wit_lag + 3 * B * n, 0, B * n * sizeof(Fr), ctx->stream));
     }
     PLONK_CHECK_HIP(hipGetLastError());
-    PLONK_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    PLONK_CHECK_HIP(hipEventRecord(p->ev_vars_read, ctx->stream));
+    p->vars_read_pending = true;
+    if (!async) PLONK_CHECK_HIP(hipStreamSynchronize(ctx->stream));
     p->resident_b = B;
     return PLONK_OK;
 }
+
+int plonk_prover_upload_variables(plonk_prover* p, const uint8_t* vars_le32, size_t B) { return prover_upload_vars(p, vars_le32, B, false); }
+int plonk_prover_upload_variables_async(plonk_prover* p, const uint8_t* vars_le32, size_t B) { return prover_upload_vars(p, vars_le32, B, true); }
 
 // Enqueue all five rounds for the B resident witnesses.  Asynchronous.
 int plonk_prover_run(plonk_prover* p, size_t B) {
@@ -1045,9 +1079,12 @@ static int prover_download(plonk_prover* p, size_t B, uint8_t* out_proofs, uint8
     PLONK_CHECK_HIP(hipMemcpyAsync(st.data(), p->state, B * sizeof(ProofState), hipMemcpyDeviceToHost, ctx->stream));
     PLONK_CHECK_HIP(hipMemcpyAsync(closes.data(), p->den, 2 * B * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     PLONK_CHECK_HIP(hipMemcpyAsync(flags.data(), p->commit_flags, 9 * B, hipMemcpyDeviceToHost, ctx->stream));
+    unsigned long long bad_input = ~0ull;
+    if (p->bad_input) PLONK_CHECK_HIP(hipMemcpyAsync(&bad_input, p->bad_input, sizeof bad_input, hipMemcpyDeviceToHost, ctx->stream));
     PLONK_CHECK_HIP(hipStreamSynchronize(ctx->stream));
     for (size_t b = 0; b < B; b++) {
         uint8_t f = 0;
+        if (bad_input != ~0ull && p->n_vars && bad_input / p->n_vars == b) f |= 8;  // an asynchronously uploaded value was >= r
         for (int slot = 0; slot < 9; slot++) f |= flags[(size_t)slot * B + b] ? 1 : 0;
         if (st[b].error) f |= 1;
         if (!closes[b]) f |= 2;

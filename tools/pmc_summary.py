@@ -1,12 +1,17 @@
 #!/usr/bin/env python3
-"""Summarises rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/pmc_collect.sh) into profiles/<name>.json.
+"""Summarises the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/pmc_collect.sh into profiles/rNN_pmc_summary.json,
+the file bench.py reads its `traffic` fields from.
 
-HBM traffic per launch = FETCH_SIZE * 2 * 1024 + WRITE_SIZE * 1024 bytes: on gfx950 FETCH_SIZE counts 128-byte
-requests as 64 B (MI355X_MICROARCH.md §HBM); the factor is calibrated here on our own kernels — a 2^20-point NTT
-pass must read its 32 MiB tile set exactly once, and reports 16.3 MiB.  WRITE_SIZE needs no correction (the same
-pass writes 32 MiB and reports 32.0).  usage: python tools/pmc_summary.py gpurun_out/pmc profiles/r02_pmc_summary.json"""
+FETCH_SIZE / WRITE_SIZE count kilobytes.  On gfx950 FETCH_SIZE under-counts wide coalesced reads — a 128-byte request
+counts as 64 B (MI355X_MICROARCH.md, HBM section) — so the factor applied to it depends on the access pattern and is
+CALIBRATED here on kernels whose byte count is known exactly:
+  streaming  a pass of a 2^24-point NTT reads its 512 MiB input exactly once;
+  random64   tools/ubench/gather.bin reads blocks x 256 x 256 random 64-byte slots of an 8 GiB table per launch.
+HBM bytes per launch = factor * FETCH_SIZE * 1024 + WRITE_SIZE * 1024 (WRITE_SIZE needs no correction: the same NTT pass
+writes 512 MiB and reports it).   usage: python tools/pmc_summary.py <dir of the passes> <out.json>"""
 import collections
 import csv
+import glob
 import json
 import os
 import sys
@@ -14,37 +19,83 @@ import sys
 src, out = sys.argv[1], sys.argv[2]
 
 
-def load(name):
-    agg = collections.defaultdict(lambda: [0, 0.0])
-    path = os.path.join(src, name, "p_counter_collection.csv")
-    for r in csv.DictReader(open(path)):
-        k = (r["Kernel_Name"].split("(")[0], int(r["Grid_Size"]))
-        agg[k][0] += 1
-        agg[k][1] += float(r["Counter_Value"])
-    return {k: (n, v / n) for k, (n, v) in agg.items()}
+def rows(tag):
+    paths = glob.glob(os.path.join(src, tag, "**", "*counter_collection.csv"), recursive=True)
+    if not paths:
+        return []
+    rs = list(csv.DictReader(open(paths[0])))
+    rs.sort(key=lambda r: int(r.get("Dispatch_Id", 0)))
+    return [(r["Kernel_Name"].split("(")[0].replace("void ", ""), int(r["Grid_Size"]), float(r["Counter_Value"])) for r in rs]
 
 
-res = {"units": "bytes per launch; traffic = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (see tools/pmc_summary.py)", "kernels": []}
-for tag, algo in (("ntt", None), ("bench", None)):
-    f, w = load(tag + "_FETCH_SIZE"), load(tag + "_WRITE_SIZE")
-    for k in sorted(set(f) | set(w), key=lambda k: -(f.get(k, (0, 0))[1] + w.get(k, (0, 0))[1])):
-        name, grid = k
-        if name.startswith("__amd") or (f.get(k, (0, 0))[1] + w.get(k, (0, 0))[1]) < 1000:
-            continue
-        fk, wk = f.get(k, (0, 0.0)), w.get(k, (0, 0.0))
-        res["kernels"].append({
-            "run": tag, "kernel": name, "grid_threads": grid, "launches": max(fk[0], wk[0]),
-            "fetch_size_kb_raw": round(fk[1], 1), "write_size_kb": round(wk[1], 1),
-            "traffic_bytes": int(2 * fk[1] * 1024 + wk[1] * 1024),
-        })
-# the standalone 2^20 transform as a whole: tools/ntt_only.py runs NTT_REPS of them and no other NTT
-NTT_REPS = 4
-ntt_total = sum(k["traffic_bytes"] * k["launches"] for k in res["kernels"] if k["run"] == "ntt" and k["kernel"].find("ntt_") >= 0)
-if ntt_total:
-    res["kernels"].append({"run": "ntt", "kernel": "ntt_2^20", "grid_threads": 0, "launches": NTT_REPS,
-                           "fetch_size_kb_raw": 0, "write_size_kb": 0, "traffic_bytes": int(ntt_total / NTT_REPS),
-                           "note": "all pass kernels of one 2^20-point transform (algorithmic 64 MiB)"})
+res = {"units": "bytes; HBM traffic = factor * FETCH_SIZE * 1024 + WRITE_SIZE * 1024 (tools/pmc_summary.py)", "factors": {}, "ntt": {}, "bench": {}, "kernels": []}
+
+# ---- calibration: random 64-byte reads
+g = [r for r in rows("gather_FETCH_SIZE") if "k_gather" in r[0]]
+if g:
+    blocks_threads = g[-1][1]
+    expect = blocks_threads * 256 * 64.0  # iters = 256 reads of 64 B per lane
+    last = [v for _, _, v in g[-3:]]      # the largest table (8 GiB): no cache reuse
+    raw = sum(last) / len(last) * 1024.0
+    res["factors"]["random64"] = expect / raw
+    res["factors"]["random64_detail"] = {"expected_bytes_per_launch": expect, "fetch_size_bytes_raw": raw, "launches": len(last),
+                                         "all_launches_fetch_kb": [v for _, _, v in g]}
+
+# ---- the lone NTTs
+plan = None
+for line in open(os.path.join(src, "ntt_FETCH_SIZE.log")) if os.path.exists(os.path.join(src, "ntt_FETCH_SIZE.log")) else []:
+    if line.startswith("{"):
+        plan = json.loads(line)
+if plan:
+    f = [r for r in rows("ntt_FETCH_SIZE") if plan["kernel_substring"] in r[0]]
+    w = [r for r in rows("ntt_WRITE_SIZE") if plan["kernel_substring"] in r[0]]
+    per = {}
+    pos = 0
+    for log_n, reps, launches in plan["plan"]:
+        k = reps * launches
+        fs, ws = f[pos:pos + k], w[pos:pos + k]
+        pos += k
+        if len(fs) < k or len(ws) < k:
+            break
+        per[log_n] = {"fetch_kb_raw_per_transform": sum(v for _, _, v in fs) / reps, "write_kb_per_transform": sum(v for _, _, v in ws) / reps,
+                      "passes": [{"kernel": fs[i][0], "grid_threads": fs[i][1], "fetch_kb_raw": fs[i][2], "write_kb": ws[i][2]} for i in range(launches)]}
+    if 24 in per:  # streaming calibration: each pass of the 2^24 transform reads 512 MiB once
+        reads = [p["fetch_kb_raw"] for p in per[24]["passes"]]
+        res["factors"]["streaming"] = (512.0 * 1024) / (sum(reads) / len(reads))
+        res["factors"]["streaming_detail"] = {"expected_kb_per_pass": 512.0 * 1024, "fetch_kb_raw_per_pass": reads,
+                                              "write_kb_per_pass": [p["write_kb"] for p in per[24]["passes"]]}
+    fac = res["factors"].get("streaming", 2.0)
+    for log_n, d in per.items():
+        tr = fac * d["fetch_kb_raw_per_transform"] * 1024 + d["write_kb_per_transform"] * 1024
+        res["ntt"]["ntt_2^%d" % log_n] = tr
+        d["traffic_bytes_per_transform"] = tr
+        d["traffic_over_algorithmic"] = tr / (64.0 * (1 << log_n))
+        res["kernels"].append(dict(d, run="ntt", size="2^%d" % log_n))
+
+# ---- the prover
+fb, wb = rows("bench_FETCH_SIZE"), rows("bench_WRITE_SIZE")
+agg = collections.defaultdict(lambda: [0, 0.0, 0, 0.0])
+for name, grid, v in fb:
+    agg[name][0] += 1
+    agg[name][1] += v
+for name, grid, v in wb:
+    agg[name][2] += 1
+    agg[name][3] += v
+for name, (nf, vf, nw, vw) in sorted(agg.items(), key=lambda kv: -(kv[1][1] + kv[1][3])):
+    if name.startswith("__amd") or vf + vw < 1000:
+        continue
+    # the lookup MSM's reads are random 64-byte table entries; everything else streams
+    factor = res["factors"].get("random64", 1.0) if name == "msm_lookup_kernel" else res["factors"].get("streaming", 2.0)
+    fetch, write = (vf / nf if nf else 0.0), (vw / nw if nw else 0.0)
+    traffic = factor * fetch * 1024 + write * 1024
+    res["bench"][name] = traffic
+    res["kernels"].append({"run": "bench", "kernel": name, "launches": max(nf, nw), "fetch_kb_raw": fetch, "write_kb": write,
+                           "fetch_factor": factor, "traffic_bytes_per_launch": traffic})
 json.dump(res, open(out, "w"), indent=1)
+print(json.dumps(res["factors"], indent=1)[:1500])
+for k, v in res["ntt"].items():
+    print("%-10s %8.1f MiB per transform" % (k, v / 2**20))
 for k in res["kernels"]:
-    print("%-6s %-30s grid=%-9d n=%-3d fetch_raw=%10.0f KB write=%10.0f KB traffic=%8.1f MiB" % (
-        k["run"], k["kernel"][:30], k["grid_threads"], k["launches"], k["fetch_size_kb_raw"], k["write_size_kb"], k["traffic_bytes"] / 2**20))
+    if k["run"] == "bench":
+        print("bench %-40s n=%-3d fetch_raw=%10.0f KB write=%10.0f KB factor=%.2f traffic=%8.1f MiB" % (
+            k["kernel"][:40], k["launches"], k["fetch_kb_raw"], k["write_kb"], k["fetch_factor"], k["traffic_bytes_per_launch"] / 2**20))
