@@ -350,6 +350,8 @@ def main():
     ap.add_argument("--lookup-budget-gb", type=float, default=DEFAULT_TABLE_GB,
                     help="HBM budget for the MSM lookup table (the library's own default is 4 GiB; the c = 17 table of 2^11 bases is 128.8 GB)")
     ap.add_argument("--no-lookup", action="store_true", help="bucket-method MSM only")
+    ap.add_argument("--host-gather", action="store_true", help="N > 1 with RCCL: gather through host buffers (plonk_gather_results) instead of straight from the provers' device buffers (plonk_gather_proofs_device)")
+    ap.add_argument("--dump-proofs", default="", help="rank 0 writes the last step's gathered proofs (768 bytes each, global order) to this file")
     ap.add_argument("--lagrange-commits", action="store_true", help="commit rounds 1-2 from Lagrange values over the Lagrange-basis SRS (a second lookup table)")
     ap.add_argument("--msm-groups", type=int, default=0, help="plonk_msm_configure groups: workgroups per MSM (0 = library default)")
     ap.add_argument("--ntt-kind", type=int, default=0, help="plonk_ntt_select_kernel: 0 auto, 1 radix-2 stages, 2 Stockham, 4 auto among the LDS kernels (A/B), 5 wave kernels wherever they apply")
@@ -417,9 +419,14 @@ def main():
     provers[0].upload_values(blob, len(parts[0]))
     host_upload_packed_ms = 1e3 * (time.perf_counter() - t0) / len(parts[0])
 
+    device_gather = comm is not None and comm.kind == "rccl" and not args.host_gather
+
     def step():
         for pr in provers:
             pr.run()                   # five rounds + transcript: one stream of kernel launches each
+        if device_gather:              # proofs go from the provers' device buffers into the all-gather, one host copy at the end
+            gathered, status = D.gather_proofs_device(provers, B, total, comm)
+            return gathered.parts[rank], status, gathered
         blobs = [pr.download_raw() for pr in provers]   # sync + 768 B per proof back to the host
         local = b"".join(b[0] for b in blobs)
         status = b"".join(b[1] for b in blobs)
@@ -458,6 +465,9 @@ def main():
     gathered = proofs[2] if comm is not None else D.gather_proofs_lazy(proofs[0], total, None)
     n_results = len(gathered)
     assert n_results == total and gathered.complete() and len(gathered[total - 1]) == 768
+    if args.dump_proofs and rank == 0:
+        with open(args.dump_proofs, "wb") as f:
+            f.write(b"".join(gathered[i] for i in range(total)))
 
     # the dominant kernel: the lookup MSM when the table fits in HBM (default), else the bucket method's accumulate
     info = setup.device_bases(ctx).lookup_info()
@@ -508,6 +518,8 @@ def main():
             "ranks_in_communicator": comm.world if comm is not None else 1,
             "gather_transport": comm.kind if comm is not None else "none (single rank)",
             "gather_in_timed_region": comm is not None,
+            "gather_path": ("device buffers -> ncclAllGather -> host (plonk_gather_proofs_device)" if device_gather else
+                            ("host buffers (plonk_gather_results / sockets)" if comm is not None else "none")),
             "msm_method": ("lookup table, %d-bit windows" % lookup_bits) if lookup_bits else "bucket method, %d-bit windows" % MSM_WINDOW_BITS,
             "msm_table_bits": lookup_bits,
             "msm_table_bytes": info["bytes"],

@@ -89,6 +89,9 @@ int plonk_ntt_select_kernel(plonk_ctx* ctx, unsigned kind);
 /* two-pass wave transforms N = R1 R2 (R1-point column transforms, then R2-point row transforms): log2 R1 for one
  * log2 N in [16, 26]; 0 = the default (as square as possible).  Both factors must lie in 2^8 .. 2^13.  A/B runs, tests. */
 int plonk_ntt_set_split(plonk_ctx* ctx, unsigned log_n, unsigned log_r1);
+/* log2 R1 of the split in force for 2^log_n (ctx NULL: the library default, which is what the distributed transform
+ * uses on every rank — its column / frequency-strided layouts are [R1][R2 / W] and [R2][R1 / W]) */
+int plonk_ntt_get_split(plonk_ctx* ctx, unsigned log_n, unsigned* out_log_r1);
 /* Lower-level pieces used by the batched prover: coefficient form in, fixed offset table. */
 int plonk_fr_coset_ntt_from_coeffs(plonk_ctx* ctx, const void* d_coeffs, void* d_out, unsigned log_n,
                                    unsigned log_expand, const uint8_t offset_le32[32], size_t batch);
@@ -259,6 +262,12 @@ int plonk_comm_create(plonk_ctx* ctx, const uint8_t id[PLONK_COMM_ID_BYTES], int
 int plonk_comm_destroy(plonk_comm* comm);
 int plonk_comm_size(const plonk_comm* comm, int* out_rank, int* out_world);
 int plonk_gather_results(plonk_comm* comm, const uint8_t* h_send, size_t bytes_per_rank, uint8_t* h_recv);
+/* the same gather for the proofs of `n_provers` lock-step provers of this rank without a host round trip: each packs its
+ * resident batch (768-byte records, or 480-byte compressed ones: plonk_prover_download_compressed's form) and its status
+ * bytes into the send buffer on its own stream, one ncclAllGather, one copy to the host.  h_recv = world blocks of
+ * [n_provers * batch records | n_provers * batch status bytes, padded to a multiple of 16].                        */
+int plonk_gather_proofs_device(plonk_comm* comm, plonk_prover* const* provers, size_t n_provers, size_t batch, int compressed,
+                               uint8_t* h_recv);
 int plonk_comm_max_f64(plonk_comm* comm, double* inout);
 int plonk_comm_barrier(plonk_comm* comm);
 /* ---- one transform across the GPUs of a communicator (four-step NTT) ----------------------

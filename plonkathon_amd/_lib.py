@@ -43,8 +43,10 @@ SIGNATURES = {
     "plonk_host_alloc": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t, c_void_pp]),
     "plonk_host_free": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "plonk_prover_upload_variables_async": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]),
+    "plonk_gather_proofs_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, ctypes.c_char_p]),
     "plonk_ntt_select_kernel": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint]),
     "plonk_ntt_set_split": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint, ctypes.c_uint]),
+    "plonk_ntt_get_split": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint, ctypes.POINTER(ctypes.c_uint)]),
     "plonk_fr_coset_extend": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint, _u8p, ctypes.c_size_t]),
     "plonk_fr_coset_to_coeffs": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint, _u8p, ctypes.c_size_t]),
     "plonk_fr_coset_ntt_from_coeffs": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint, ctypes.c_uint, _u8p, ctypes.c_size_t]),

@@ -72,6 +72,7 @@ struct plonk_comm {
     int rank = 0, world = 1;
     uint8_t* d_buf = nullptr;  // [send | recv] staging in HBM
     size_t cap = 0;
+    std::vector<hipEvent_t> events;  // plonk_gather_proofs_device: one per prover stream
 };
 
 static int comm_staging(plonk_comm* c, size_t bytes) {
@@ -130,6 +131,7 @@ int plonk_comm_destroy(plonk_comm* c) {
     hipStreamSynchronize(c->ctx->stream);
     if (c->comm) g_rccl.CommDestroy(c->comm);
     if (c->d_buf) hipFree(c->d_buf);
+    for (hipEvent_t e : c->events) hipEventDestroy(e);
     delete c;
     return PLONK_OK;
 }
@@ -151,6 +153,42 @@ int plonk_gather_results(plonk_comm* c, const uint8_t* h_send, size_t bytes_per_
     uint8_t *d_send = c->d_buf, *d_recv = c->d_buf + bytes_per_rank;
     PLONK_CHECK_HIP(hipMemcpyAsync(d_send, h_send, bytes_per_rank, hipMemcpyHostToDevice, s));
     PLONK_CHECK_RCCL(g_rccl.AllGather(d_send, d_recv, bytes_per_rank, ncclUint8, c->comm, s));
+    PLONK_CHECK_HIP(hipMemcpyAsync(h_recv, d_recv, total, hipMemcpyDeviceToHost, s));
+    PLONK_CHECK_HIP(hipStreamSynchronize(s));
+    return PLONK_OK;
+}
+
+// The gather of a step's proofs without the host round trip of plonk_gather_results (D -> H -> D -> all-gather -> D -> H):
+// every prover of this rank packs its resident batch — records of 768 bytes, or 480 compressed — and its status bytes
+// straight into the send buffer on its own stream, the communicator's stream waits for those streams' events, ONE
+// ncclAllGather moves proofs and status bytes of all ranks over xGMI, and one copy brings them to the host.
+// h_recv[r] = [n_provers * batch records | n_provers * batch status bytes, padded to 16] of rank r.
+int plonk_gather_proofs_device(plonk_comm* c, plonk_prover* const* provers, size_t n_provers, size_t batch, int compressed, uint8_t* h_recv) {
+    PLONK_REQUIRE(c && provers && n_provers && batch && h_recv, PLONK_ERR_ARG, "bad argument");
+    PLONK_ENTER(c->ctx);
+    const size_t rec = compressed ? 480 : 768;
+    const size_t n = n_provers * batch;
+    const size_t per_rank = n * rec + ((n + 15) & ~(size_t)15);
+    const size_t total = per_rank * (size_t)c->world;
+    PLONK_TRY(comm_staging(c, per_rank + total));
+    hipStream_t s = c->ctx->stream;
+    uint8_t *d_send = c->d_buf, *d_recv = c->d_buf + per_rank;
+    while (c->events.size() < n_provers) {
+        hipEvent_t e;
+        PLONK_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        c->events.push_back(e);
+    }
+    PLONK_CHECK_HIP(hipMemsetAsync(d_send + n * rec, 0, per_rank - n * rec, s));
+    for (size_t k = 0; k < n_provers; k++) {
+        PLONK_REQUIRE(prover_ctx(provers[k])->device == c->ctx->device, PLONK_ERR_ARG, "prover %zu lives on another device than the communicator", k);
+        // the send buffer may still be read by the previous gather: order the packing behind the communicator's stream
+        PLONK_CHECK_HIP(hipEventRecord(c->events[k], s));
+        PLONK_CHECK_HIP(hipStreamWaitEvent(prover_ctx(provers[k])->stream, c->events[k], 0));
+        PLONK_TRY(prover_pack_device(provers[k], batch, compressed, d_send + k * batch * rec, d_send + n * rec + k * batch, c->events[k]));
+        PLONK_CHECK_HIP(hipStreamWaitEvent(s, c->events[k], 0));
+    }
+    if (c->world == 1) PLONK_CHECK_HIP(hipMemcpyAsync(d_recv, d_send, per_rank, hipMemcpyDeviceToDevice, s));
+    else PLONK_CHECK_RCCL(g_rccl.AllGather(d_send, d_recv, per_rank, ncclUint8, c->comm, s));
     PLONK_CHECK_HIP(hipMemcpyAsync(h_recv, d_recv, total, hipMemcpyDeviceToHost, s));
     PLONK_CHECK_HIP(hipStreamSynchronize(s));
     return PLONK_OK;

@@ -641,11 +641,14 @@ static MsmLookupTable* lut_verified(plonk_ctx* ctx, const plonk_srs* srs, MsmLoo
     if (hipMemcpyAsync(&bad, flag, 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) return nullptr;
     return bad ? nullptr : t;
 }
-// bytes of every table this process holds on a device (the automatic choice charges new tables against the same budget)
-static size_t lut_bytes_on_device(int device) {  // g_lut_mu held
+// A Lagrange-basis view is a base set of its own with a table of its own: the automatic choice charges the tables of its
+// parent SRS and of the parent's other views against the same budget, so that what the caller granted is not spent twice.
+static size_t lut_bytes_of_family(const plonk_srs* srs) {  // g_lut_mu held
+    const plonk_srs* root = srs->parent ? srs->parent : srs;
     size_t total = 0;
-    for (MsmLookupTable* t : g_luts)
-        if (t->device == device) total += t->bytes;
+    if (root != srs && root->shared) total += root->shared->bytes;
+    for (const auto& kv : root->lagrange)
+        if (kv.second != srs && kv.second->shared) total += kv.second->shared->bytes;
     return total;
 }
 
@@ -804,10 +807,9 @@ static bool msm_lookup_prepare(plonk_ctx* ctx, plonk_srs* srs) {
     // A table another context of this device already built for these bases is taken as it is — unless this context's
     // budget affords a bigger one (more window bits = fewer additions), which is then built and shared in its turn.
     MsmLookupTable* have = want ? nullptr : lut_verified(ctx, srs, lut_find(srs, 0));
-    // The automatic choice charges every table this process already holds on the device against the budget: the
-    // Lagrange-basis view of an SRS is a base set of its own, and must not double what the caller granted.  An explicit
-    // window size (`want`) is an explicit request and only has to fit the budget by itself.
-    const size_t used = want ? 0 : lut_bytes_on_device(srs->device);
+    // The automatic choice charges the tables of the same SRS family (an SRS and its Lagrange-basis views) against one
+    // budget.  An explicit window size (`want`) is an explicit request and only has to fit the budget by itself.
+    const size_t used = want ? 0 : lut_bytes_of_family(srs);
     // below 8 bits the table no longer beats the bucket method — which, however, cannot index more than 2^15 bases, so
     // larger base sets accept any table that fits
     const unsigned c_min = want ? want : (srs->n_points > 32768 ? 4 : 8);
@@ -933,6 +935,7 @@ int msm_lagrange_srs(plonk_ctx* ctx, plonk_srs* srs, unsigned log_n, plonk_srs**
     child->n_points = n;
     child->bases = (G1Affine*)bases;
     child->fixed = srs->fixed;
+    child->parent = srs;
     const uint64_t tag[2] = {srs->content_key, 0x4c61677200000000ull | log_n};  // "Lagr" | log_n
     child->content_key = plonk_fnv1a64(tag, sizeof tag);
     srs->lagrange[log_n] = child;

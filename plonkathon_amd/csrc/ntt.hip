@@ -503,8 +503,9 @@ struct NttWave {
     // all-to-all as W chunks [source rank][local row][source's columns]: position c of a row sits at
     // (c >> chunk_log) * chunk_stride + row * 2^chunk_log + (c & (2^chunk_log - 1)).  chunk_log = 0 means contiguous rows.
     unsigned sub_base, chunk_log, chunk_stride;
-    const int32_t* tw_lo;  // inter-pass twiddles w_N^e = tw_lo[e & 1023] * tw_hi[e >> 10], limb form   (mode 1)
-    const int32_t* tw_hi;
+    const int32_t* tw_lo;  // inter-pass twiddles w_N^e = tw_lo[e & 1023] * tw_hi[e >> 10], Shoup pairs: applied one after the other (mode 1)
+    const int32_t* tw_hi;  //   (for an inverse transform tw_hi carries the factor 1/N as well: tw_always)
+    unsigned tw_always;    // multiply even when e == 0 (tw_hi[0] = 1/N)
     const int32_t* roots;  // w_R^k, k < R, R = this kernel's transform size (direction of the transform): Shoup pairs (fpl.h)
     const Fr* in_scale;    // per-element factor at load (coset offset powers) or null
     const Fr* out_scale;   // per-element factor at store or null
@@ -761,10 +762,9 @@ __global__ void __launch_bounds__(64u << (2 * NLDS), (WavelCfg<LOG_E, NLDS>::WAV
         wave_for<E>([&](auto J) {
             constexpr unsigned j = decltype(J)::value;
             const unsigned e = (sub + p.sub_base) * (k | (j << shift));  // < N
-            if (e) {
-                FrL tw = wavel_ld_tw(p.tw_lo, e & ((1u << NTT_TW_LO_LOG) - 1));
-                if (p.log_n > NTT_TW_LO_LOG) tw = fpl_mul(tw, wavel_ld_tw(p.tw_hi, e >> NTT_TW_LO_LOG));
-                x[j] = fpl_mul(x[j], tw);
+            if (e || p.tw_always) {  // two multiplications by table constants (380 instructions) instead of forming their product first (434)
+                x[j] = fpl_mul_shoup(x[j], wavel_ld_root(p.tw_lo, e & ((1u << NTT_TW_LO_LOG) - 1)));
+                if (p.log_n > NTT_TW_LO_LOG) x[j] = fpl_mul_shoup(x[j], wavel_ld_root(p.tw_hi, e >> NTT_TW_LO_LOG));
             }
         });
     }
@@ -880,7 +880,7 @@ static unsigned plan_passes(const plonk_ctx* ctx, unsigned log_n, unsigned radic
 // N = R1 R2 with R1, R2 from that set in two passes (columns, then rows).  Default splits: the fastest measured on MI355X
 // for a lone transform (profiles/r03_b_ntt_splits.jsonl: the 4-element-per-thread kernels where a size allows them —
 // twice the waves —, and short column transforms for the largest sizes); plonk_ntt_set_split overrides one size.
-static bool ntt_wave_plan(const plonk_ctx* ctx, unsigned log_n, unsigned* log_r1, unsigned* log_r2) {
+bool ntt_wave_plan(const plonk_ctx* ctx, unsigned log_n, unsigned* log_r1, unsigned* log_r2) {
     if (log_n >= 8 && log_n <= 13) {
         *log_r1 = log_n;
         *log_r2 = 0;
@@ -945,13 +945,30 @@ static int ntt_get_roots_limbs(plonk_ctx* ctx, unsigned log_n, bool inverse, con
     return ntt_limb_table(ctx, ctx->tw.full_l, log_n | (inverse ? 256u : 0u), packed, (size_t)1 << log_n, true, out);
 }
 
-static int get_lo_hi_limbs(plonk_ctx* ctx, unsigned log_n, bool inverse, const int32_t** lo, const int32_t** hi) {
+// inter-pass twiddle tables as Shoup pairs; scaled: the hi table times 1/N (the inverse transform's factor, folded in)
+static int get_lo_hi_limbs(plonk_ctx* ctx, unsigned log_n, bool inverse, bool scaled, const int32_t** lo, const int32_t** hi) {
     const Fr *plo, *phi;
     PLONK_TRY(get_lo_hi(ctx, log_n, inverse, &plo, &phi));
     const unsigned key = log_n | (inverse ? 256u : 0u);
     const unsigned log_lo = log_n < NTT_TW_LO_LOG ? log_n : NTT_TW_LO_LOG;
-    PLONK_TRY(ntt_limb_table(ctx, ctx->tw.lo_l, key, plo, (size_t)1 << log_lo, false, lo));
-    return ntt_limb_table(ctx, ctx->tw.hi_l, key, phi, log_n > NTT_TW_LO_LOG ? ((size_t)1 << (log_n - NTT_TW_LO_LOG)) : 1, false, hi);
+    const size_t nhi = log_n > NTT_TW_LO_LOG ? ((size_t)1 << (log_n - NTT_TW_LO_LOG)) : 1;
+    PLONK_TRY(ntt_limb_table(ctx, ctx->tw.lo_l, key, plo, (size_t)1 << log_lo, true, lo));
+    if (!scaled) return ntt_limb_table(ctx, ctx->tw.hi_l, key, phi, nhi, true, hi);
+    if (ctx->tw.hi_l.find(key | 512u) == ctx->tw.hi_l.end()) {  // (1/N) * w_hi^k, built once
+        Fr whi = host_root_of_unity(log_n, inverse);
+        for (unsigned i = 0; i < NTT_TW_LO_LOG; i++) whi = fp_sqr(whi);
+        void* tmp = nullptr;  // (not a scratch slot: callers hold those across this call)
+        if (hipMalloc(&tmp, nhi * sizeof(Fr)) != hipSuccess) {
+            plonk_set_error("hipMalloc of a %zu-entry twiddle table failed", nhi);
+            return PLONK_ERR_NOMEM;
+        }
+        int rc = k_fr_powers(ctx, whi, fp_inv(host_fr_from_u64((uint64_t)1 << log_n)), (Fr*)tmp, nhi);
+        if (rc == PLONK_OK) rc = ntt_limb_table(ctx, ctx->tw.hi_l, key | 512u, (const Fr*)tmp, nhi, true, hi);
+        hipStreamSynchronize(ctx->stream);  // the packed copy must outlive the conversion kernel only
+        hipFree(tmp);
+        return rc;
+    }
+    return ntt_limb_table(ctx, ctx->tw.hi_l, key | 512u, nullptr, nhi, true, hi);
 }
 
 // fpl_reduce_small's table of j * m for the limb-form kernel: 49 entries of 12 words, built on the host once per context
@@ -1053,7 +1070,8 @@ static int ntt_run_wave(plonk_ctx* ctx, const Fr* in, Fr* out, unsigned log_n, b
     void* sc;
     PLONK_TRY(ctx_scratch(ctx, 0, batch * N * sizeof(Fr), &sc));
     Fr* tmp = (Fr*)sc;
-    PLONK_TRY(get_lo_hi_limbs(ctx, log_n, inverse, &p.tw_lo, &p.tw_hi));
+    PLONK_TRY(get_lo_hi_limbs(ctx, log_n, inverse, scale_by_n_inv, &p.tw_lo, &p.tw_hi));
+    p.tw_always = scale_by_n_inv ? 1u : 0u;
     NttWave a = p;
     a.mode = 1;
     a.log_other = log_r2;
@@ -1076,8 +1094,8 @@ static int ntt_run_wave(plonk_ctx* ctx, const Fr* in, Fr* out, unsigned log_n, b
     c.out_bstride = out_bstride;
     c.in_len = (unsigned)N;
     c.out_scale = out_scale;
-    c.out_scalar = n_inv;
-    c.has_out_scalar = scale_by_n_inv;
+    c.has_out_scalar = 0;  // 1/N went into the column pass's inter-pass twiddles (tw_hi)
+    c.tw_always = 0;
     PLONK_TRY(ntt_get_roots_limbs(ctx, log_r2, inverse, &c.roots));
     PLONK_TRY(prof_begin(ctx, "ntt_pass", 32.0 * (double)N * (double)batch));
     PLONK_TRY(ntt_wave_launch(ctx, c, log_r2, 1u << log_r1, (unsigned)batch));
@@ -1114,7 +1132,7 @@ int ntt_dist_columns(plonk_ctx* ctx, const Fr* in, Fr* out, unsigned log_n, unsi
     const unsigned log_cl = log_r2 - log_w;
     NttWave a;
     ntt_wave_consts(&a, log_n, inverse);
-    PLONK_TRY(get_lo_hi_limbs(ctx, log_n, inverse, &a.tw_lo, &a.tw_hi));
+    PLONK_TRY(get_lo_hi_limbs(ctx, log_n, inverse, false, &a.tw_lo, &a.tw_hi));
     PLONK_TRY(ntt_get_roots_limbs(ctx, log_r1, inverse, &a.roots));
     a.mode = 1;
     a.log_other = log_cl;

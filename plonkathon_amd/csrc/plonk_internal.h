@@ -84,6 +84,7 @@ struct plonk_srs {
     // Lagrange-basis SRS (setup.py:66-72 without the ifft): lagrange[log_n] = [L_i(tau)]_1, i < 2^log_n, built on
     // demand by an EC inverse NTT of the first 2^log_n bases (msm.hip); each is a plonk_srs of its own.
     std::map<unsigned, plonk_srs*> lagrange;
+    plonk_srs* parent = nullptr;  // a Lagrange view's SRS (its table is charged against the parent's budget)
 };
 
 #define PLONK_SCRATCH_SLOTS 4
@@ -144,6 +145,7 @@ int ntt_run(plonk_ctx*, const Fr* in, Fr* out, unsigned log_n, bool inverse, siz
             size_t in_bstride, size_t out_bstride, const Fr* in_scale, const Fr* out_scale, bool scale_by_n_inv);
 int ntt_get_roots(plonk_ctx*, unsigned log_n, bool inverse, const Fr** table_full);
 int ntt_dist_plan(unsigned log_n, unsigned log_w, unsigned* log_r1, unsigned* log_r2);
+bool ntt_wave_plan(const plonk_ctx* ctx /* null: the default splits */, unsigned log_n, unsigned* log_r1, unsigned* log_r2);
 int ntt_dist_columns(plonk_ctx*, const Fr* in, Fr* out, unsigned log_n, unsigned log_w, unsigned rank, bool inverse);
 int ntt_dist_rows(plonk_ctx*, const Fr* in, Fr* out, unsigned log_n, unsigned log_w, unsigned rank, bool inverse);
 // msm.hip
@@ -155,3 +157,7 @@ uint64_t plonk_fnv1a64(const void* data, size_t n);
 // MSM m reads its scalars at d_scalars + (m % inner) * stride + (m / inner) * outer_stride (inner = 0: inner = M)
 int msm_run_device(plonk_ctx*, plonk_srs*, const Fr* d_scalars, size_t n, size_t M, size_t stride, Fq* d_out_xy,
                    uint8_t* d_flags, size_t inner = 0, size_t outer_stride = 0);
+// prover.hip
+struct plonk_prover;
+int prover_pack_device(plonk_prover* p, size_t B, int compressed, uint8_t* d_proofs, uint8_t* d_status, hipEvent_t done);
+plonk_ctx* prover_ctx(plonk_prover* p);

@@ -683,6 +683,20 @@ __global__ void pack_proofs_kernel(const Fq* commit_xy, const ProofState* st, si
     }
 }
 
+// the status byte plonk_prover_download assembles on the host, on the device (plonk_gather_proofs_device)
+__global__ void pack_status_kernel(const ProofState* st, const uint32_t* closes, const uint8_t* flags, const unsigned long long* bad_input,
+                                   size_t n_vars, size_t B, uint8_t* out) {
+    const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    uint8_t f = 0;
+    for (int slot = 0; slot < 9; slot++) f |= flags[(size_t)slot * B + b] ? 1 : 0;
+    if (st[b].error) f |= 1;
+    if (!closes[b]) f |= 2;
+    if (closes[B + b]) f |= 4;
+    if (bad_input && *bad_input != ~0ull && n_vars && *bad_input / n_vars == b) f |= 8;
+    out[b] = f;
+}
+
 // ================================================================================================
 // host side
 static int dev_alloc(void** p, size_t bytes) {
@@ -1189,3 +1203,21 @@ int plonk_fr_quotient(plonk_ctx* ctx, unsigned log_n, const void* const d_evals[
 }
 
 }  // extern "C"
+
+// Packs the resident batch's proofs (768-byte records, or 480-byte compressed ones) and status bytes into caller-owned
+// DEVICE memory on the prover's own stream and records `done` there: the send side of plonk_gather_proofs_device.
+int prover_pack_device(plonk_prover* p, size_t B, int compressed, uint8_t* d_proofs, uint8_t* d_status, hipEvent_t done) {
+    PLONK_REQUIRE(p && B && d_proofs && d_status, PLONK_ERR_ARG, "bad argument");
+    PLONK_REQUIRE(B == p->resident_b, PLONK_ERR_STATE, "gather: batch %zu, but %zu witnesses are resident", B, p->resident_b);
+    plonk_ctx* ctx = p->ctx;
+    const unsigned tb = (unsigned)((B + 63) / 64);
+    PLONK_LAUNCH(pack_proofs_kernel, dim3(tb), dim3(64), 0, ctx->stream, (const Fq*)p->commit_xy, (const ProofState*)p->state, B, d_proofs,
+                 compressed ? 1 : 0);
+    PLONK_LAUNCH(pack_status_kernel, dim3(tb), dim3(64), 0, ctx->stream, (const ProofState*)p->state, (const uint32_t*)p->den,
+                 (const uint8_t*)p->commit_flags, (const unsigned long long*)p->bad_input, p->n_vars, B, d_status);
+    PLONK_CHECK_HIP(hipGetLastError());
+    PLONK_CHECK_HIP(hipEventRecord(done, ctx->stream));
+    return PLONK_OK;
+}
+
+plonk_ctx* prover_ctx(plonk_prover* p) { return p->ctx; }

@@ -54,8 +54,13 @@ def _send_msg(sock, payload: bytes):
     sock.sendall(struct.pack("<Q", len(payload)) + payload)
 
 
+_MAX_MSG = 1 << 32  # a step's proofs from 8 GPUs are tens of MB; a length beyond this is a corrupt or foreign stream
+
+
 def _recv_msg(sock):
     (n,) = struct.unpack("<Q", _recv_exact(sock, 8))
+    if n > _MAX_MSG:
+        raise RuntimeError("rendezvous: a peer announced a %d-byte message" % n)
     return _recv_exact(sock, n)
 
 
@@ -78,6 +83,9 @@ class _Star:
                 conn, _ = srv.accept()
                 conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
                 (r,) = struct.unpack("<I", _recv_exact(conn, 4))
+                if not 0 < r < world or r in self.peers:  # a stray or duplicate connection must not displace a rank
+                    conn.close()
+                    raise RuntimeError("rendezvous: a peer announced rank %d (world %d, ranks seen %s)" % (r, world, sorted(self.peers)))
                 self.peers[r] = conn
             srv.close()
         else:
@@ -281,8 +289,15 @@ class GatheredProofs:
         return self.parts[r][PROOF_BYTES * j : PROOF_BYTES * (j + 1)]
 
     def complete(self):
-        """every rank delivered its whole shard"""
-        return all(len(self.parts[r]) >= PROOF_BYTES * len(range(r, self.total, self.world)) for r in range(self.world))
+        """every rank delivered its whole shard: the blob covers it and its LAST proof is not the zero padding the gather
+        appends to short payloads (a commitment is never all-zero bytes unless every point is the identity)"""
+        for r in range(self.world):
+            k = len(range(r, self.total, self.world))
+            if len(self.parts[r]) < PROOF_BYTES * k:
+                return False
+            if k and not any(self.parts[r][PROOF_BYTES * (k - 1) : PROOF_BYTES * k]):
+                return False
+        return True
 
 
 def gather_proofs_lazy(local_blob: bytes, total: int, comm=None) -> GatheredProofs:
@@ -293,6 +308,21 @@ def gather_proofs_lazy(local_blob: bytes, total: int, comm=None) -> GatheredProo
     per = (total + comm.world - 1) // comm.world
     parts = comm.all_gather(bytes(local_blob) + bytes(PROOF_BYTES * per - len(local_blob)))
     return GatheredProofs(parts, total, comm.world)
+
+
+def gather_proofs_device(provers, batch: int, total: int, comm):
+    """The gather of a step's proofs without a host round trip (RCCL only): every prover of this rank packs its resident
+    batch into the send buffer on its own stream, one ncclAllGather, one copy to the host (plonk_gather_proofs_device).
+    -> (GatheredProofs, status bytes of this rank's proofs)."""
+    n = len(provers) * batch
+    per_rank = n * PROOF_BYTES + ((n + 15) & ~15)
+    out = ctypes.create_string_buffer(per_rank * comm.world)
+    handles = (ctypes.c_void_p * len(provers))(*[pr._h for pr in provers])
+    comm._check(comm.ctx.L.plonk_gather_proofs_device(comm._h, handles, len(provers), batch, 0, out))
+    raw = out.raw
+    parts = [raw[per_rank * r : per_rank * r + n * PROOF_BYTES] for r in range(comm.world)]
+    status = raw[per_rank * comm.rank + n * PROOF_BYTES : per_rank * comm.rank + n * PROOF_BYTES + n]
+    return GatheredProofs(parts, total, comm.world), status
 
 
 def max_over_ranks(value: float, comm=None) -> float:

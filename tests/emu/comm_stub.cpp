@@ -18,6 +18,16 @@ int plonk_comm_create(plonk_ctx*, const uint8_t*, int rank, int world, plonk_com
 int plonk_comm_destroy(plonk_comm* c) { delete c; return PLONK_OK; }
 int plonk_comm_size(const plonk_comm* c, int* r, int* w) { *r = c->rank; *w = c->world; return PLONK_OK; }
 int plonk_gather_results(plonk_comm*, const uint8_t* s, size_t n, uint8_t* r) { memcpy(r, s, n); return PLONK_OK; }
+int plonk_gather_proofs_device(plonk_comm*, plonk_prover* const* provers, size_t n_provers, size_t batch, int compressed, uint8_t* h_recv) {
+    const size_t rec = compressed ? 480 : 768, n = n_provers * batch;  // one rank: the layout of the real call, filled by downloads
+    memset(h_recv + n * rec, 0, (n + 15) & ~(size_t)15);
+    for (size_t k = 0; k < n_provers; k++) {
+        int rc = compressed ? plonk_prover_download_compressed(provers[k], batch, h_recv + k * batch * rec, h_recv + n * rec + k * batch)
+                            : plonk_prover_download(provers[k], batch, h_recv + k * batch * rec, h_recv + n * rec + k * batch);
+        if (rc != PLONK_OK) return rc;
+    }
+    return PLONK_OK;
+}
 int plonk_comm_max_f64(plonk_comm*, double*) { return PLONK_OK; }
 int plonk_comm_barrier(plonk_comm*) { return PLONK_OK; }
 int plonk_comm_all_to_all(plonk_comm*, const void* s, void* r, size_t n) { memcpy(r, s, n); return PLONK_OK; }

@@ -117,7 +117,8 @@ def _ntt_worker(rank, world, port, q):
     from plonkathon_amd import Context
     from plonkathon_amd import distributed as D
 
-    log_n, r1, r2 = 18, 512, 512
+    log_n = 18
+    r1, r2 = _split(log_n)
     cl = r2 // world
     full = rand_vec(77, 1 << log_n)
     mine = [full[i1 * r2 + rank * cl + c] for i1 in range(r1) for c in range(cl)]  # my columns, [R1][R2/W]
@@ -133,9 +134,20 @@ def _ntt_worker(rank, world, port, q):
     q.put((rank, out))
 
 
+def _split(log_n):
+    """(R1, R2) of the library's default two-pass split of 2^log_n: the layouts of the distributed transform follow it"""
+    import ctypes
+
+    from plonkathon_amd import _lib
+
+    r1 = ctypes.c_uint(0)
+    _lib.check(_lib.lib().plonk_ntt_get_split(None, log_n, ctypes.byref(r1)))
+    return 1 << r1.value, (1 << log_n) >> r1.value
+
+
 def test_two_rank_distributed_ntt(emu_cdll):
     """A 2^18-point transform split over two ranks (columns -> all-to-all -> rows; exchange over sockets, kernels emulated):
-    rank g must end with the frequencies k1 + 512 k2, k1 in its half, laid out [R2][R1/W], exact against the C oracle."""
+    rank g must end with the frequencies k1 + R1 k2, k1 in its half, laid out [R2][R1/W], exact against the C oracle."""
     from oracle import c_oracle
     from helpers import rand_vec
 
@@ -150,7 +162,7 @@ def test_two_rank_distributed_ntt(emu_cdll):
         p.join(timeout=60)
         assert p.exitcode == 0
     want = c_oracle.fr_ntt(rand_vec(77, 1 << 18))
-    r1 = r2 = 512
+    r1, r2 = _split(18)
     kl = r1 // 2
     for rank in (0, 1):
         exp = [want[(rank * kl + k1l) + r1 * k2] for k2 in range(r2) for k1l in range(kl)]
