@@ -279,6 +279,8 @@ int plonk_comm_barrier(plonk_comm* comm);
  * and the w_N^(c k1) twiddles) -> plonk_comm_all_to_all (d_recv block r = block `rank` of rank r's d_send: grouped
  * ncclSend / ncclRecv over xGMI, N / W^2 elements per pair) -> plonk_fr_ntt_dist_rows (local R2-point transforms).
  * The two local steps are exported so the exchange can run over another transport (tests: sockets on CPU).        */
+/* (the column pass's output is an intermediate: packed residues in [0, 2r), not canonical values — it is what
+ * plonk_fr_ntt_dist_rows, directly or after the all-to-all, takes as input) */
 int plonk_fr_ntt_dist_columns(plonk_ctx* ctx, const void* d_in, void* d_out, unsigned log_n, unsigned log_world, unsigned rank, int inverse);
 int plonk_fr_ntt_dist_rows(plonk_ctx* ctx, const void* d_in, void* d_out, unsigned log_n, unsigned log_world, unsigned rank, int inverse);
 int plonk_comm_all_to_all(plonk_comm* comm, const void* d_send, void* d_recv, size_t bytes_per_peer);

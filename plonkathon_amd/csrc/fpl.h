@@ -586,13 +586,15 @@ template <class P, bool FENCE = false> PLONK_HD FpL<P> fpl_mul_shoup(const FpL<P
 }
 
 // normalised value within (0, 2m), limbs non-negative (fpl_reduce_small<P, 1>'s result) -> canonical packed element
-template <class P> PLONK_HD Fp<P> fpl_pack_positive(const FpL<P>& a) {
+// canonical = false leaves the value as it is, in (0, 2m): a packed but redundant residue (what the column pass of a
+// two-pass NTT hands to the row pass, which unpacks it again)
+template <class P> PLONK_HD Fp<P> fpl_pack_positive(const FpL<P>& a, bool canonical = true) {
     FPL_CHECK(a.l[8] >= 0, "fpl_pack_positive: negative value");
     uint32_t u[9];
 #pragma unroll
     for (int i = 0; i < 9; i++) u[i] = (uint32_t)a.l[i];
     Fp<P> out;
     fp29_pack(u, out.v);
-    fp_reduce_once<P>(out.v);
+    if (canonical) fp_reduce_once<P>(out.v);
     return out;
 }

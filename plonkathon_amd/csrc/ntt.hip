@@ -20,6 +20,9 @@
 #include "plonk_internal.h"
 #include "wave.h"
 #include "fpl.h"
+#ifndef PLONK_EMU
+#include <hip/hip_cooperative_groups.h>
+#endif
 
 typedef FpL<FrParams> FrL;
 typedef FpLS<FrParams> FrLS;
@@ -640,10 +643,10 @@ template <unsigned LOG_E, unsigned NLDS> struct WavelCfg {
     static constexpr unsigned WAVES = (NLDS == 2 || LOG_E == 2) ? 4 : 3;
 };
 
+// One transform (or one column / row of a two-pass transform) by one workgroup: the body of both kernels below.
 template <unsigned LOG_E, unsigned NLDS>
-__global__ void __launch_bounds__(64u << (2 * NLDS), (WavelCfg<LOG_E, NLDS>::WAVES)) ntt_wavel_kernel(NttWave p) {
+PLONK_DEV void wavel_transform(const NttWave& p, unsigned char* smem) {
     constexpr unsigned E = 1u << LOG_E, LOG_N = LOG_E + 6 + 2 * NLDS, NT = 64u << (2 * NLDS), LOG_T = 6 + 2 * NLDS;
-    PLONK_DYN_SMEM(smem);
     u32x4* l_lo = reinterpret_cast<u32x4*>(smem);  // 4 * NT elements as two 16-byte planes and one 4-byte plane
     u32x4* l_hi = l_lo + 4 * NT;
     uint32_t* l_top = reinterpret_cast<uint32_t*>(l_hi + 4 * NT);
@@ -668,7 +671,7 @@ __global__ void __launch_bounds__(64u << (2 * NLDS), (WavelCfg<LOG_E, NLDS>::WAV
         constexpr unsigned j = decltype(J)::value;
         const unsigned pos = j * NT + tid0;
         const unsigned g = p.chunk_log ? (pos >> p.chunk_log) * p.chunk_stride + (pos & chunk_mask) + in_off : (pos << in_shift) + in_off;
-        x[j] = g < p.in_len ? fpl_from_fp(fp_load(wavel_at(in, g))) : fpl_zero<FrParams>();  // [0, 2m): the column pass hands on canonical values
+        x[j] = g < p.in_len ? fpl_from_fp(fp_load(wavel_at(in, g))) : fpl_zero<FrParams>();  // [0, 2m): canonical input, or the column pass's redundant residues
     });
     if (p.in_scale) {
         wave_for<E>([&](auto J) {
@@ -778,11 +781,33 @@ __global__ void __launch_bounds__(64u << (2 * NLDS), (WavelCfg<LOG_E, NLDS>::WAV
         const FrL sc = fpl_from_fp_uniform(p.out_scalar);
         wave_for<E>([&](auto J) { x[decltype(J)::value] = fpl_mul(x[decltype(J)::value], sc); });
     }
-    wave_for<E>([&](auto J) {  // |value| <= 16 m whatever happened above -> (-0.51 m, 0.51 m) -> canonical
+    wave_for<E>([&](auto J) {  // |value| <= 22.4 m whatever happened above -> (0.49 m, 1.51 m) -> canonical (the column pass skips that last step)
         constexpr unsigned j = decltype(J)::value;
-        fp_store(wavel_at(out, ((k | (j << shift)) << out_shift) + out_off), fpl_pack_positive(fpl_reduce_small<FrParams, 1>(x[j], jm)));
+        fp_store(wavel_at(out, ((k | (j << shift)) << out_shift) + out_off), fpl_pack_positive(fpl_reduce_small<FrParams, 1>(x[j], jm), p.mode != 1));
     });
 }
+
+template <unsigned LOG_E, unsigned NLDS>
+__global__ void __launch_bounds__(64u << (2 * NLDS), (WavelCfg<LOG_E, NLDS>::WAVES)) ntt_wavel_kernel(NttWave p) {
+    PLONK_DYN_SMEM(smem);
+    wavel_transform<LOG_E, NLDS>(p, smem);
+}
+
+// Both passes of a lone square two-pass transform (2^16 = 2^8 x 2^8, 2^20 = 2^10 x 2^10) in ONE cooperative launch: workgroup
+// b transforms column b, the grid synchronises (cooperative groups: release / acquire at device scope, so the columns
+// written through one XCD's L2 are visible to the rows read through another's), then it transforms row b.  Saves the
+// dispatch gap between two dependent launches — most of a lone 2^16's time.  Needs every workgroup resident at once:
+// the launch goes through hipLaunchCooperativeKernel, which refuses grids that are not, and the caller falls back.
+#ifndef PLONK_EMU
+struct NttWave2 { NttWave a, c; };
+template <unsigned LOG_E, unsigned NLDS>
+__global__ void __launch_bounds__(64u << (2 * NLDS), (WavelCfg<LOG_E, NLDS>::WAVES)) ntt_wavel_fused_kernel(NttWave2 q) {
+    PLONK_DYN_SMEM(smem);
+    wavel_transform<LOG_E, NLDS>(q.a, smem);
+    cooperative_groups::this_grid().sync();
+    wavel_transform<LOG_E, NLDS>(q.c, smem);
+}
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // host side: roots of unity, cached tables, pass planning
@@ -1082,9 +1107,6 @@ static int ntt_run_wave(plonk_ctx* ctx, const Fr* in, Fr* out, unsigned log_n, b
     a.in_len = in_len32;
     a.in_scale = in_scale;
     PLONK_TRY(ntt_get_roots_limbs(ctx, log_r1, inverse, &a.roots));
-    PLONK_TRY(prof_begin(ctx, "ntt_pass", 32.0 * (double)N * (double)batch));
-    PLONK_TRY(ntt_wave_launch(ctx, a, log_r1, 1u << log_r2, (unsigned)batch));
-    PLONK_TRY(prof_end(ctx));
     NttWave c = p;
     c.mode = 2;
     c.log_other = log_r1;
@@ -1097,6 +1119,29 @@ static int ntt_run_wave(plonk_ctx* ctx, const Fr* in, Fr* out, unsigned log_n, b
     c.has_out_scalar = 0;  // 1/N went into the column pass's inter-pass twiddles (tw_hi)
     c.tw_always = 0;
     PLONK_TRY(ntt_get_roots_limbs(ctx, log_r2, inverse, &c.roots));
+#ifndef PLONK_EMU
+    // a lone square transform whose workgroups are all resident at once: both passes in one cooperative launch
+    if (batch == 1 && log_r1 == log_r2 && ctx->ntt_fused && (log_r1 == 8 || log_r1 == 10)) {
+        NttWave2 q;
+        q.a = a;
+        q.c = c;
+        PLONK_TRY(ntt_get_jm(ctx, &q.a.jm));
+        q.c.jm = q.a.jm;
+        void* args[] = {&q};
+        const unsigned nt = log_r1 == 8 ? 64u : 256u;
+        const size_t shmem = log_r1 == 8 ? 0 : (size_t)4 * nt * 36;
+        const void* fn = log_r1 == 8 ? reinterpret_cast<const void*>(ntt_wavel_fused_kernel<2, 0>) : reinterpret_cast<const void*>(ntt_wavel_fused_kernel<2, 1>);
+        PLONK_TRY(prof_begin(ctx, "ntt_pass", 64.0 * (double)N));
+        const hipError_t e = hipLaunchCooperativeKernel(fn, dim3(1u << log_r2), dim3(nt), args, shmem, ctx->stream);
+        PLONK_TRY(prof_end(ctx));
+        if (e == hipSuccess) return PLONK_OK;
+        (void)hipGetLastError();  // not resident at once on this device (or no cooperative launch): two launches
+        ctx->ntt_fused = false;
+    }
+#endif
+    PLONK_TRY(prof_begin(ctx, "ntt_pass", 32.0 * (double)N * (double)batch));
+    PLONK_TRY(ntt_wave_launch(ctx, a, log_r1, 1u << log_r2, (unsigned)batch));
+    PLONK_TRY(prof_end(ctx));
     PLONK_TRY(prof_begin(ctx, "ntt_pass", 32.0 * (double)N * (double)batch));
     PLONK_TRY(ntt_wave_launch(ctx, c, log_r2, 1u << log_r1, (unsigned)batch));
     PLONK_TRY(prof_end(ctx));

@@ -214,6 +214,62 @@ def g1_encoding_cases(setup):
             raise AssertionError("oracle decoder accepted %s" % b.hex())
 
 
+def async_upload_and_device_gather(setup, rccl=False):
+    """plonk_prover_upload_variables_async from a page-locked buffer gives the proofs of the synchronous upload; a value that
+    is not below r marks its proof (status bit 3); plonk_gather_proofs_device through a one-rank communicator returns the
+    records and status bytes of plonk_prover_download for several provers in one call (768- and 480-byte forms)."""
+    import ctypes
+
+    from plonkathon_amd import BatchProver, get_context
+    from plonkathon_amd import distributed as D
+    from plonkathon_amd._lib import check
+    from plonkathon_amd.batch import _pack_witnesses
+
+    ctx = get_context()
+    n = 16
+    lines = ["x0 public"] + ["x%d <== x%d * x%d" % (i + 1, i, i) for i in range(n - 1)]
+    program = Program(lines, n)
+    wits = [program.fill_variable_assignments({"x0": 3 + i}) for i in range(5)]
+    a, b = BatchProver(setup, program), BatchProver(setup, program)
+    a.upload(wits)
+    a.run()
+    want, st = a.download_raw()
+    assert not any(st)
+    V = len(b.variables)
+    blob = _pack_witnesses(wits, b.variables, R_MOD)
+    pinned = ctx.host_alloc(len(blob))
+    pinned[: len(blob)] = blob
+    for _ in range(2):  # twice: the second upload must wait for the first batch's gather kernels, not trample them
+        b.upload_values_async(pinned, len(wits))
+        b.run()
+        got, st = b.download_raw()
+        assert got == want and not any(st)
+    assert b.download_compressed()[0][:480] == BatchProver.decode(want[:768]).to_bytes()
+    bad = bytearray(blob)
+    bad[32 * (2 * V + 1) : 32 * (2 * V + 2)] = R_MOD.to_bytes(32, "little")  # proof 2, variable 1: r itself
+    pinned[: len(blob)] = bytes(bad)
+    b.upload_values_async(pinned, len(wits))
+    b.run()
+    st = b.download_raw()[1]
+    assert st[2] & 8 and not any(x & 8 for i, x in enumerate(st) if i != 2)
+    pinned[: len(blob)] = blob
+    b.upload_values_async(pinned, len(wits))
+    b.run()
+    comm = D.RcclComm(ctx, 0, 1) if rccl else None
+    if comm is not None:
+        a.run()
+        gathered, status = D.gather_proofs_device([a, b], len(wits), 2 * len(wits), comm)
+        assert gathered.parts[0] == want + want and status == bytes(2 * len(wits)) and gathered.complete()
+        out = ctypes.create_string_buffer(2 * len(wits) * 480 + 16)
+        handles = (ctypes.c_void_p * 2)(a._h, b._h)
+        check(ctx.L.plonk_gather_proofs_device(comm._h, handles, 2, len(wits), 1, out))
+        assert out.raw[: 480 * len(wits)] == a.download_compressed()[0]
+        comm.close()
+    else:
+        assert b.download_raw()[0] == want
+    ctx.host_free(pinned)
+
+
 def poly_golden(max_log_n):
     """Every operator of poly.py on the reference-generated vectors (tests/golden/poly_vectors.json)."""
     for case in load("poly_vectors.json")["cases"]:

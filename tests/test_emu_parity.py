@@ -211,6 +211,12 @@ def test_ntt_two_pass_wave_kernel(emu):
         check(ctx.L.plonk_ntt_set_split(ctx.handle, 18, 0))
 
 
+def test_async_upload(emu):
+    from plonkathon_amd import Setup
+
+    pc.async_upload_and_device_gather(Setup.from_file(pc.PTAU))
+
+
 def test_g1_and_proof_encoding(emu):
     from plonkathon_amd import Setup
 

@@ -452,6 +452,10 @@ def test_lagrange_srs_paths(setup):
 
 
 @pytest.mark.gpu
+def test_async_upload_and_device_resident_gather(setup):
+    pc.async_upload_and_device_gather(setup, rccl=True)
+
+
 def test_g1_and_proof_encoding(setup):
     pc.g1_encoding_cases(setup)
 

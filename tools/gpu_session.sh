@@ -27,6 +27,13 @@ for step in "$@"; do
       ( cd /tmp && rocprofv3 --kernel-trace --stats -d "$OLDPWD/$out/rocprof" -o trace -- python "$OLDPWD/bench.py" $arg > "$OLDPWD/$out/bench_under_rocprof.json" 2> "$OLDPWD/$out/rocprof.err" ); echo "rocprof rc=$?"
       find "$out/rocprof" -name "*kernel_stats.csv" | head -1 | xargs -r head -12 ;;
     pmc) bash tools/pmc_collect.sh "$out" $arg ;;
+    env_sweep)   # "VAR=VALUE <ntt_sweep args>": the sweep under one environment setting, rows tagged VAR=VALUE
+      kv=${arg%% *}; rest=${arg#* }
+      env "$kv" timeout 300 python tools/ntt_sweep.py --tag "$kv" $rest >> "$out/ntt_sweep.jsonl" 2>> "$out/ntt_sweep.err"; echo "rc=$?" ;;
+    rocprof_named)   # "<name> <bench args>": kernel trace + stats of one bench configuration under profiles-style names
+      nm=${arg%% *}; rest=${arg#* }
+      ( cd /tmp && rocprofv3 --kernel-trace --stats -d "$OLDPWD/$out/rocprof_$nm" -o trace -- python "$OLDPWD/bench.py" $rest > "$OLDPWD/$out/bench_under_rocprof_$nm.json" 2> "$OLDPWD/$out/rocprof_$nm.err" ); echo "rocprof rc=$?"
+      find "$out/rocprof_$nm" -name "*kernel_stats.csv" | head -1 | xargs -r head -14 ;;
     latency) timeout 600 python tools/latency.py $arg > "$out/latency.json" 2> "$out/latency.err"; echo "rc=$?"; cat "$out/latency.json" ;;
     ubench) for b in tools/ubench/*.bin; do timeout 120 "$b" > "$out/$(basename $b .bin).json" 2>&1; done ;;
     *) echo "unknown step $name" ;;
