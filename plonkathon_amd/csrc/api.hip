@@ -134,7 +134,6 @@ int plonk_ctx_create(int device, plonk_ctx** out_ctx) {
     plonk_ctx* ctx = new plonk_ctx();
     ctx->device = device;
     if (const char* e = getenv("PLONK_NTT_ADAPTIVE_TILES")) ctx->ntt_adaptive_tiles = atoi(e) != 0;  // A/B knob (default on)
-    if (const char* e = getenv("PLONK_NTT_FUSED")) ctx->ntt_fused = atoi(e) != 0;                    // A/B knob (default on)
     PLONK_CHECK_HIP(hipStreamCreate(&ctx->stream));
     PLONK_CHECK_HIP(hipEventCreate(&ctx->ev_a));
     PLONK_CHECK_HIP(hipEventCreate(&ctx->ev_b));

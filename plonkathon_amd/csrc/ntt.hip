@@ -20,9 +20,6 @@
 #include "plonk_internal.h"
 #include "wave.h"
 #include "fpl.h"
-#ifndef PLONK_EMU
-#include <hip/hip_cooperative_groups.h>
-#endif
 
 typedef FpL<FrParams> FrL;
 typedef FpLS<FrParams> FrLS;
@@ -793,21 +790,6 @@ __global__ void __launch_bounds__(64u << (2 * NLDS), (WavelCfg<LOG_E, NLDS>::WAV
     wavel_transform<LOG_E, NLDS>(p, smem);
 }
 
-// Both passes of a lone square two-pass transform (2^16 = 2^8 x 2^8, 2^20 = 2^10 x 2^10) in ONE cooperative launch: workgroup
-// b transforms column b, the grid synchronises (cooperative groups: release / acquire at device scope, so the columns
-// written through one XCD's L2 are visible to the rows read through another's), then it transforms row b.  Saves the
-// dispatch gap between two dependent launches — most of a lone 2^16's time.  Needs every workgroup resident at once:
-// the launch goes through hipLaunchCooperativeKernel, which refuses grids that are not, and the caller falls back.
-#ifndef PLONK_EMU
-struct NttWave2 { NttWave a, c; };
-template <unsigned LOG_E, unsigned NLDS>
-__global__ void __launch_bounds__(64u << (2 * NLDS), (WavelCfg<LOG_E, NLDS>::WAVES)) ntt_wavel_fused_kernel(NttWave2 q) {
-    PLONK_DYN_SMEM(smem);
-    wavel_transform<LOG_E, NLDS>(q.a, smem);
-    cooperative_groups::this_grid().sync();
-    wavel_transform<LOG_E, NLDS>(q.c, smem);
-}
-#endif
 
 // ------------------------------------------------------------------------------------------------
 // host side: roots of unity, cached tables, pass planning
@@ -1119,26 +1101,6 @@ static int ntt_run_wave(plonk_ctx* ctx, const Fr* in, Fr* out, unsigned log_n, b
     c.has_out_scalar = 0;  // 1/N went into the column pass's inter-pass twiddles (tw_hi)
     c.tw_always = 0;
     PLONK_TRY(ntt_get_roots_limbs(ctx, log_r2, inverse, &c.roots));
-#ifndef PLONK_EMU
-    // a lone square transform whose workgroups are all resident at once: both passes in one cooperative launch
-    if (batch == 1 && log_r1 == log_r2 && ctx->ntt_fused && (log_r1 == 8 || log_r1 == 10)) {
-        NttWave2 q;
-        q.a = a;
-        q.c = c;
-        PLONK_TRY(ntt_get_jm(ctx, &q.a.jm));
-        q.c.jm = q.a.jm;
-        void* args[] = {&q};
-        const unsigned nt = log_r1 == 8 ? 64u : 256u;
-        const size_t shmem = log_r1 == 8 ? 0 : (size_t)4 * nt * 36;
-        const void* fn = log_r1 == 8 ? reinterpret_cast<const void*>(ntt_wavel_fused_kernel<2, 0>) : reinterpret_cast<const void*>(ntt_wavel_fused_kernel<2, 1>);
-        PLONK_TRY(prof_begin(ctx, "ntt_pass", 64.0 * (double)N));
-        const hipError_t e = hipLaunchCooperativeKernel(fn, dim3(1u << log_r2), dim3(nt), args, shmem, ctx->stream);
-        PLONK_TRY(prof_end(ctx));
-        if (e == hipSuccess) return PLONK_OK;
-        (void)hipGetLastError();  // not resident at once on this device (or no cooperative launch): two launches
-        ctx->ntt_fused = false;
-    }
-#endif
     PLONK_TRY(prof_begin(ctx, "ntt_pass", 32.0 * (double)N * (double)batch));
     PLONK_TRY(ntt_wave_launch(ctx, a, log_r1, 1u << log_r2, (unsigned)batch));
     PLONK_TRY(prof_end(ctx));

@@ -110,7 +110,6 @@ struct plonk_ctx {
     std::vector<hipEvent_t> event_pool;
     unsigned ntt_tile_log = 12, ntt_single_log = 11, ntt_radix_log = 10;
     bool ntt_adaptive_tiles = true;
-    bool ntt_fused = true;  // lone square two-pass transforms in one cooperative launch (PLONK_NTT_FUSED=0 turns it off: A/B runs)
     const int32_t* ntt_jm = nullptr;  // fpl_reduce_small's table (device), built on first use by the limb-form NTT kernel
     unsigned char ntt_split[32] = {0};  // plonk_ntt_set_split: log2 R1 of the two-pass wave plan per log2 N (0 = default)
     unsigned ntt_kind = 0;  // 0 = auto (wave kernels where they apply, else LDS kernels), 1 / 2 = force an LDS kernel, 4 = auto among the LDS kernels, 5 = force wave

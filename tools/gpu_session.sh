@@ -27,6 +27,7 @@ for step in "$@"; do
       ( cd /tmp && rocprofv3 --kernel-trace --stats -d "$OLDPWD/$out/rocprof" -o trace -- python "$OLDPWD/bench.py" $arg > "$OLDPWD/$out/bench_under_rocprof.json" 2> "$OLDPWD/$out/rocprof.err" ); echo "rocprof rc=$?"
       find "$out/rocprof" -name "*kernel_stats.csv" | head -1 | xargs -r head -12 ;;
     pmc) bash tools/pmc_collect.sh "$out" $arg ;;
+    pmcu) bash tools/pmc_ntt_util.sh "$out/pmcu" ;;
     env_sweep)   # "VAR=VALUE <ntt_sweep args>": the sweep under one environment setting, rows tagged VAR=VALUE
       kv=${arg%% *}; rest=${arg#* }
       env "$kv" timeout 300 python tools/ntt_sweep.py --tag "$kv" $rest >> "$out/ntt_sweep.jsonl" 2>> "$out/ntt_sweep.err"; echo "rc=$?" ;;

@@ -16,7 +16,7 @@ def fill(n):
     return buf
 kind = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 check(L.plonk_ntt_select_kernel(H, kind))
-for log_n, batch, reps in ((11, 1536, 3), (13, 2048, 3), (20, 1, 3), (16, 1, 3)):
+for log_n, batch, reps in ((8, 16384, 3), (9, 8192, 3), (10, 4096, 3), (11, 2048, 3), (12, 1024, 3), (13, 512, 3), (20, 16, 2)):
     n = 1 << log_n
     buf, out = fill(n * batch), ctx.alloc(n * batch)
     for _ in range(reps):
