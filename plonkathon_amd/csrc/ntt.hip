@@ -555,15 +555,21 @@ template <unsigned E, unsigned RB, unsigned MASK> PLONK_DEV void wavel_swap_bit(
     });
 }
 
+// the kernels compiled for 128 VGPRs with 8 elements per thread (WavelCfg::TIGHT): 2^13 and 2^11
+#ifdef PLONK_NTT_W11_3
+#define WAVEL_TIGHT_LOG_N(log_n) ((log_n) == 13)
+#else
+#define WAVEL_TIGHT_LOG_N(log_n) ((log_n) == 13 || (log_n) == 11)
+#endif
 // x[BASE + f] *= roots[(low * f * mult) mod N], f = 1 .. COUNT-1;  x[BASE] (no factor) is range-reduced instead
 template <unsigned LOG_N, unsigned BASE, unsigned COUNT, unsigned E>
 PLONK_DEV void wavel_twiddle(FrL (&x)[E], unsigned low, unsigned mult, const int32_t* roots, const int32_t* jm) {
     x[BASE] = fpl_reduce_small(x[BASE], jm);
     wave_for<COUNT - 1>([&](auto F) {
         constexpr unsigned f = decltype(F)::value + 1;
-        x[BASE + f] = fpl_mul_shoup<FrParams, LOG_N == 13>(x[BASE + f], wavel_ld_root(roots, (low * f * mult) & ((1u << LOG_N) - 1)));
+        x[BASE + f] = fpl_mul_shoup<FrParams, WAVEL_TIGHT_LOG_N(LOG_N)>(x[BASE + f], wavel_ld_root(roots, (low * f * mult) & ((1u << LOG_N) - 1)));
 #ifndef PLONK_NTT_NO_FENCE13
-        if constexpr (LOG_N == 13) PLONK_SCHED_FENCE();  // 1024 threads: 128 VGPRs; keeps the scheduler from holding several twiddles in flight
+        if constexpr (WAVEL_TIGHT_LOG_N(LOG_N)) PLONK_SCHED_FENCE();  // 128 VGPRs: keeps the scheduler from holding several twiddles in flight
 #endif
     });
 }
@@ -637,7 +643,14 @@ PLONK_DEV Fr* wavel_at(Fr* base, unsigned g) { return reinterpret_cast<Fr*>(rein
 // faster without spills at 3 (measured in round 2: 18.1 vs 16.8 G elements/s at 2^11 x 2048); E = 4 fits 4 without spills
 template <unsigned LOG_E, unsigned NLDS> struct WavelCfg {
     static constexpr unsigned E = 1u << LOG_E, LOG_N = LOG_E + 6 + 2 * NLDS, NT = 64u << (2 * NLDS);
-    static constexpr unsigned WAVES = (NLDS == 2 || LOG_E == 2) ? 4 : 3;
+    // TIGHT: the kernel is compiled for 128 VGPRs with the register-saving measures of the 1024-thread kernel (opaque
+    // threadIdx re-reads per stage, scheduling fences around the twiddle multiplications)
+#ifdef PLONK_NTT_W11_3  // A/B: the 256-thread E = 8 kernel at 3 waves per SIMD (158 VGPRs), as in round 2
+    static constexpr bool TIGHT = NLDS == 2;
+#else
+    static constexpr bool TIGHT = NLDS == 2 || (LOG_E == 3 && NLDS == 1);
+#endif
+    static constexpr unsigned WAVES = (NLDS == 2 || LOG_E == 2) ? 4 : (TIGHT ? 4 : 3);
 };
 
 // One transform (or one column / row of a two-pass transform) by one workgroup: the body of both kernels below.
@@ -684,7 +697,7 @@ PLONK_DEV void wavel_transform(const NttWave& p, unsigned char* smem) {
     wave_for<NLDS>([&](auto S) {
         constexpr unsigned s = decltype(S)::value;
         constexpr unsigned tb = 6 + 2 * (NLDS - 1 - s);
-        const unsigned tid = wavel_tid<NLDS == 2>();
+        const unsigned tid = wavel_tid<WavelCfg<LOG_E, NLDS>::TIGHT>();
         const unsigned mine = (tid >> tb) & 3u, rest = tid & ~(3u << tb);
         wave_for<E / 4>([&](auto R2) {
             constexpr unsigned r2 = decltype(R2)::value;
@@ -701,7 +714,7 @@ PLONK_DEV void wavel_transform(const NttWave& p, unsigned char* smem) {
             wavel_twiddle<LOG_N, 4 * r2, 4>(x, low, mult, p.roots, jm);
         });
     });
-    const unsigned lane = wavel_tid<NLDS == 2>() & 63u;
+    const unsigned lane = wavel_tid<WavelCfg<LOG_E, NLDS>::TIGHT>() & 63u;
     if constexpr (E == 8) {
         // stage on lane bits 5..3
         wavel_swap_bit<E, 2, 32>(x, lane);
@@ -731,7 +744,7 @@ PLONK_DEV void wavel_transform(const NttWave& p, unsigned char* smem) {
     }
     // frequency of register j: digits in processing order, first digit least significant
     unsigned k, shift;
-    const unsigned tid = wavel_tid<NLDS == 2>();
+    const unsigned tid = wavel_tid<WavelCfg<LOG_E, NLDS>::TIGHT>();
     if constexpr (E == 8) {
         //   d_A = (lane bit 5) * 4 + thread bits (top pair);  then the remaining wave pairs;  (lane bits 4, 3);  (lane bits 2..0);  j
         //   (without wave stages the first digit is simply lane bits 5..3)
