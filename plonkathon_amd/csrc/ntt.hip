@@ -506,7 +506,7 @@ struct NttWave {
     const int32_t* tw_lo;  // inter-pass twiddles w_N^e = tw_lo[e & 1023] * tw_hi[e >> 10], Shoup pairs: applied one after the other (mode 1)
     const int32_t* tw_hi;  //   (for an inverse transform tw_hi carries the factor 1/N as well: tw_always)
     unsigned tw_always;    // multiply even when e == 0 (tw_hi[0] = 1/N)
-    const int32_t* roots;  // w_R^k, k < R, R = this kernel's transform size (direction of the transform): Shoup pairs (fpl.h)
+    const int32_t* roots;  // the twiddles of this kernel's transform size and direction, Shoup pairs in program order (wavel_tw_*)
     const Fr* in_scale;    // per-element factor at load (coset offset powers) or null
     const Fr* out_scale;   // per-element factor at store or null
     Fr out_scalar;
@@ -555,22 +555,71 @@ template <unsigned E, unsigned RB, unsigned MASK> PLONK_DEV void wavel_swap_bit(
     });
 }
 
+// ---- twiddle tables in the order the kernel consumes them ("program order") ----------------------------------------------
+// Stage s of a wave kernel multiplies register f (f = 1 .. count) by w_R^(low f mult), low < nb: the table holds, stage after
+// stage and f after f, one BLOCK of nb Shoup pairs indexed by low — stored as five planes of nb x 16 bytes, so that a load
+// instruction of 64 lanes with consecutive `low` reads 1 KB of consecutive bytes (8 cache lines).  The natural-order table
+// (80-byte entries at index low f mult) made every one of the five loads of a twiddle touch 40 .. 120 different lines and
+// use a fifth to a fifteenth of each: at 2^10 .. 2^13, whose tables do not fit the 32 KB L1, that was ~0.5 MB of L2 -> L1
+// traffic per 64 KB transform.  Entries: ~N per kernel size (1020 at 2^10, 2040 at 2^11).
+//   twiddled stages: A (digit in the registers at load), the L wave-bit stages, the lane stages except the last
+PLONK_HD constexpr unsigned wavel_tw_stages(unsigned log_e, unsigned nlds) { return 1 + nlds + (log_e == 3 ? 1 : 2); }
+PLONK_HD constexpr unsigned wavel_tw_nb(unsigned log_e, unsigned nlds, unsigned s) {  // distinct values of `low` in stage s
+    if (s == 0) return 64u << (2 * nlds);
+    if (s <= nlds) return 1u << (6 + 2 * (nlds - s));
+    return log_e == 3 ? 8u : (s == nlds + 1 ? 16u : 4u);
+}
+PLONK_HD constexpr unsigned wavel_tw_count(unsigned log_e, unsigned nlds, unsigned s) {  // factors f = 1 .. count
+    return (s >= 1 && s <= nlds) ? 3u : (1u << log_e) - 1;
+}
+PLONK_HD constexpr unsigned wavel_tw_mult(unsigned log_e, unsigned nlds, unsigned s) {  // N / S of stage s
+    const unsigned log_n = log_e + 6 + 2 * nlds;
+    if (s == 0) return 1;
+    if (s <= nlds) return 1u << (log_n - (6 + 2 * (nlds - s) + 2));
+    return log_e == 3 ? 1u << (log_n - 6) : (s == nlds + 1 ? 1u << (log_n - 6) : 1u << (log_n - 4));
+}
+PLONK_HD constexpr unsigned wavel_tw_offset(unsigned log_e, unsigned nlds, unsigned s) {  // first entry of stage s's blocks
+    unsigned o = 0;
+    for (unsigned t = 0; t < s; t++) o += wavel_tw_nb(log_e, nlds, t) * wavel_tw_count(log_e, nlds, t);
+    return o;
+}
+#define NTT_PLANE_WORDS 4  // a plane holds 16 bytes of every entry of its block; five planes per block
+
+// entry `low` of a block of nb entries
+PLONK_DEV FrLS wavel_ld_root_planar(const int32_t* block, unsigned nb, unsigned low) {
+    // (each plane as "uniform base + 32-bit lane offset": SGPR-base addressing, no 64-bit address arithmetic per lane)
+    const unsigned off = low * 16u;
+    const auto plane = [&](unsigned pl) PLONK_LAMBDA_INLINE {
+        return *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(block + pl * nb * NTT_PLANE_WORDS) + off);
+    };
+    const u32x4 a = plane(0), b = plane(1), c = plane(2), d = plane(3), e = plane(4);
+    FrLS r;
+    r.w[0] = (int32_t)a.x; r.w[1] = (int32_t)a.y; r.w[2] = (int32_t)a.z; r.w[3] = (int32_t)a.w;
+    r.w[4] = (int32_t)b.x; r.w[5] = (int32_t)b.y; r.w[6] = (int32_t)b.z; r.w[7] = (int32_t)b.w;
+    r.w[8] = (int32_t)c.x; r.wp[0] = (int32_t)c.y; r.wp[1] = (int32_t)c.z; r.wp[2] = (int32_t)c.w;
+    r.wp[3] = (int32_t)d.x; r.wp[4] = (int32_t)d.y; r.wp[5] = (int32_t)d.z; r.wp[6] = (int32_t)d.w;
+    r.wp[7] = (int32_t)e.x; r.wp[8] = (int32_t)e.y;
+    return r;
+}
+
 // the kernels compiled for 128 VGPRs with 8 elements per thread (WavelCfg::TIGHT): 2^13 and 2^11
 #ifdef PLONK_NTT_W11_3
 #define WAVEL_TIGHT_LOG_N(log_n) ((log_n) == 13)
 #else
-#define WAVEL_TIGHT_LOG_N(log_n) ((log_n) == 13 || (log_n) == 11)
+#define WAVEL_TIGHT_LOG_N(log_n) ((log_n) == 13 || (log_n) == 11 || (log_n) == 9)
 #endif
-// x[BASE + f] *= roots[(low * f * mult) mod N], f = 1 .. COUNT-1;  x[BASE] (no factor) is range-reduced instead
-template <unsigned LOG_N, unsigned BASE, unsigned COUNT, unsigned E>
-PLONK_DEV void wavel_twiddle(FrL (&x)[E], unsigned low, unsigned mult, const int32_t* roots, const int32_t* jm) {
+// x[BASE + f] *= w^(low f mult), f = 1 .. COUNT-1, from stage STAGE's blocks of the program-order table;  x[BASE] (no
+// factor) is range-reduced instead
+template <unsigned LOG_E, unsigned NLDS, unsigned STAGE, unsigned BASE, unsigned COUNT, unsigned E>
+PLONK_DEV void wavel_twiddle(FrL (&x)[E], unsigned low, const int32_t* roots, const int32_t* jm) {
+    constexpr unsigned LOG_N = LOG_E + 6 + 2 * NLDS, NB = wavel_tw_nb(LOG_E, NLDS, STAGE);
+    static_assert(COUNT - 1 == wavel_tw_count(LOG_E, NLDS, STAGE), "twiddle layout");
+    const int32_t* blocks = roots + (size_t)wavel_tw_offset(LOG_E, NLDS, STAGE) * NTT_SHOUP_STRIDE;
     x[BASE] = fpl_reduce_small(x[BASE], jm);
     wave_for<COUNT - 1>([&](auto F) {
         constexpr unsigned f = decltype(F)::value + 1;
-        x[BASE + f] = fpl_mul_shoup<FrParams, WAVEL_TIGHT_LOG_N(LOG_N)>(x[BASE + f], wavel_ld_root(roots, (low * f * mult) & ((1u << LOG_N) - 1)));
-#ifndef PLONK_NTT_NO_FENCE13
+        x[BASE + f] = fpl_mul_shoup<FrParams, WAVEL_TIGHT_LOG_N(LOG_N)>(x[BASE + f], wavel_ld_root_planar(blocks + (f - 1) * NB * NTT_SHOUP_STRIDE, NB, low));
         if constexpr (WAVEL_TIGHT_LOG_N(LOG_N)) PLONK_SCHED_FENCE();  // 128 VGPRs: keeps the scheduler from holding several twiddles in flight
-#endif
     });
 }
 // inputs N-form, |value| < 2.8.  Outputs: x0 in [0, 2^31) (for fpl_reduce_small), x1..x3 multiplicands; |value| < 11.2
@@ -633,6 +682,16 @@ template <bool OPAQUE> PLONK_DEV unsigned wavel_tid() {
 #endif
     return t;
 }
+// the same, pinned behind a value the previous stage produces last (the compiler moved the plain form up to the last barrier)
+template <bool OPAQUE> PLONK_DEV unsigned wavel_tid_after(int32_t dep) {
+    unsigned t = threadIdx.x;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (OPAQUE) asm volatile("" : "+v"(t) : "v"(dep));
+#else
+    (void)dep;
+#endif
+    return t;
+}
 
 // element g of a uniform base as a 32-bit byte offset (g < 2^27: the wave kernels' transforms have at most 2^26 points):
 // SGPR-base addressing, one VGPR per address instead of two and no 64-bit address arithmetic
@@ -648,7 +707,7 @@ template <unsigned LOG_E, unsigned NLDS> struct WavelCfg {
 #ifdef PLONK_NTT_W11_3  // A/B: the 256-thread E = 8 kernel at 3 waves per SIMD (158 VGPRs), as in round 2
     static constexpr bool TIGHT = NLDS == 2;
 #else
-    static constexpr bool TIGHT = NLDS == 2 || (LOG_E == 3 && NLDS == 1);
+    static constexpr bool TIGHT = NLDS == 2 || LOG_E == 3;
 #endif
     static constexpr unsigned WAVES = (NLDS == 2 || LOG_E == 2) ? 4 : (TIGHT ? 4 : 3);
 };
@@ -692,7 +751,7 @@ PLONK_DEV void wavel_transform(const NttWave& p, unsigned char* smem) {
     }
     // stage A: digit = the top LOG_E index bits, low = tid0
     wavel_dft<E>(x, w8_1, w8_2, w8_3);
-    wavel_twiddle<LOG_N, 0, E>(x, tid0, 1, p.roots, jm);
+    wavel_twiddle<LOG_E, NLDS, 0, 0, E>(x, tid0, p.roots, jm);
     // L radix-4 stages on the wave bits: swap register bits (1, 0) with thread bits (tb + 1, tb)
     wave_for<NLDS>([&](auto S) {
         constexpr unsigned s = decltype(S)::value;
@@ -707,21 +766,20 @@ PLONK_DEV void wavel_transform(const NttWave& p, unsigned char* smem) {
             __syncthreads();
         });
         const unsigned low = tid & ((1u << tb) - 1);
-        const unsigned mult = 1u << (LOG_N - (tb + 2));  // N / S, S = 2^(tb + 2)
         wave_for<E / 4>([&](auto R2) {
             constexpr unsigned r2 = decltype(R2)::value;
             dft4l(x[4 * r2], x[4 * r2 + 1], x[4 * r2 + 2], x[4 * r2 + 3], w8_2);
-            wavel_twiddle<LOG_N, 4 * r2, 4>(x, low, mult, p.roots, jm);
+            wavel_twiddle<LOG_E, NLDS, 1 + s, 4 * r2, 4>(x, low, p.roots, jm);
         });
     });
-    const unsigned lane = wavel_tid<WavelCfg<LOG_E, NLDS>::TIGHT>() & 63u;
+    const unsigned lane = wavel_tid_after<WavelCfg<LOG_E, NLDS>::TIGHT>(x[E - 1].l[8]) & 63u;
     if constexpr (E == 8) {
         // stage on lane bits 5..3
         wavel_swap_bit<E, 2, 32>(x, lane);
         wavel_swap_bit<E, 1, 16>(x, lane);
         wavel_swap_bit<E, 0, 8>(x, lane);
         dft8l(x, w8_1, w8_2, w8_3);
-        wavel_twiddle<LOG_N, 0, 8>(x, lane & 7u, 1u << (LOG_N - 6), p.roots, jm);
+        wavel_twiddle<LOG_E, NLDS, NLDS + 1, 0, 8>(x, lane & 7u, p.roots, jm);
         // stage on lane bits 2..0
         wavel_swap_bit<E, 2, 4>(x, lane);
         wavel_swap_bit<E, 1, 2>(x, lane);
@@ -732,11 +790,11 @@ PLONK_DEV void wavel_transform(const NttWave& p, unsigned char* smem) {
         wavel_swap_bit<E, 1, 32>(x, lane);
         wavel_swap_bit<E, 0, 16>(x, lane);
         dft4l(x[0], x[1], x[2], x[3], w8_2);
-        wavel_twiddle<LOG_N, 0, 4>(x, lane & 15u, 1u << (LOG_N - 6), p.roots, jm);
+        wavel_twiddle<LOG_E, NLDS, NLDS + 1, 0, 4>(x, lane & 15u, p.roots, jm);
         wavel_swap_bit<E, 1, 8>(x, lane);
         wavel_swap_bit<E, 0, 4>(x, lane);
         dft4l(x[0], x[1], x[2], x[3], w8_2);
-        wavel_twiddle<LOG_N, 0, 4>(x, lane & 3u, 1u << (LOG_N - 4), p.roots, jm);
+        wavel_twiddle<LOG_E, NLDS, NLDS + 2, 0, 4>(x, lane & 3u, p.roots, jm);
         wavel_swap_bit<E, 1, 2>(x, lane);
         wavel_swap_bit<E, 0, 1>(x, lane);
         dft4l(x[0], x[1], x[2], x[3], w8_2);
@@ -959,10 +1017,50 @@ static int ntt_limb_table(plonk_ctx* ctx, std::map<unsigned, int32_t*>& cache, u
     return PLONK_OK;
 }
 
+// one block of a program-order twiddle table (wavel_tw_*): entry low = the Shoup pair of roots[(low f mult) mod N], five planes
+__global__ void ntt_program_block_kernel(const Fr* roots, unsigned log_n, unsigned nb, unsigned f, unsigned mult, int32_t* block, Ninv261 ninv) {
+    const unsigned low = blockIdx.x * blockDim.x + threadIdx.x;
+    if (low >= nb) return;
+    const FrLS a = fpl_shoup_from_mont(fp_load(roots + ((low * f * mult) & ((1u << log_n) - 1))), ninv.l);
+    int32_t e[NTT_SHOUP_STRIDE];
+    for (int w = 0; w < 9; w++) {
+        e[w] = a.w[w];
+        e[9 + w] = a.wp[w];
+    }
+    e[18] = e[19] = 0;
+    for (unsigned pl = 0; pl < 5; pl++)
+        for (unsigned w = 0; w < NTT_PLANE_WORDS; w++) block[((size_t)pl * nb + low) * NTT_PLANE_WORDS + w] = e[pl * NTT_PLANE_WORDS + w];
+}
+
+// the twiddles of the wave kernel serving 2^log_n, in program order (built once per size and direction)
 static int ntt_get_roots_limbs(plonk_ctx* ctx, unsigned log_n, bool inverse, const int32_t** out) {
-    const Fr* packed;
-    PLONK_TRY(ntt_get_roots(ctx, log_n, inverse, &packed));
-    return ntt_limb_table(ctx, ctx->tw.full_l, log_n | (inverse ? 256u : 0u), packed, (size_t)1 << log_n, true, out);
+    const unsigned key = log_n | (inverse ? 256u : 0u);
+    auto it = ctx->tw.full_l.find(key);
+    if (it == ctx->tw.full_l.end()) {
+        const Fr* packed;
+        PLONK_TRY(ntt_get_roots(ctx, log_n, inverse, &packed));
+        const unsigned log_e = (log_n & 1) ? 3 : 2, nlds = (log_n - 6 - log_e) / 2, stages = wavel_tw_stages(log_e, nlds);
+        const size_t entries = wavel_tw_offset(log_e, nlds, stages);
+        void* d = nullptr;
+        if (hipMalloc(&d, entries * NTT_SHOUP_STRIDE * sizeof(int32_t)) != hipSuccess) {
+            plonk_set_error("hipMalloc of a %zu-entry twiddle table failed", entries);
+            return PLONK_ERR_NOMEM;
+        }
+        ctx->owned.push_back(d);
+        Ninv261 ninv;
+        fpl_ninv261<FrParams>(ninv.l);
+        for (unsigned st = 0; st < stages; st++) {
+            const unsigned nb = wavel_tw_nb(log_e, nlds, st), count = wavel_tw_count(log_e, nlds, st), mult = wavel_tw_mult(log_e, nlds, st);
+            for (unsigned f = 1; f <= count; f++) {
+                int32_t* block = (int32_t*)d + ((size_t)wavel_tw_offset(log_e, nlds, st) + (size_t)(f - 1) * nb) * NTT_SHOUP_STRIDE;
+                PLONK_LAUNCH(ntt_program_block_kernel, dim3((nb + 63) / 64), dim3(64), 0, ctx->stream, packed, log_n, nb, f, mult, block, ninv);
+            }
+        }
+        PLONK_CHECK_HIP(hipGetLastError());
+        it = ctx->tw.full_l.emplace(key, (int32_t*)d).first;
+    }
+    *out = it->second;
+    return PLONK_OK;
 }
 
 // inter-pass twiddle tables as Shoup pairs; scaled: the hi table times 1/N (the inverse transform's factor, folded in)
