@@ -59,7 +59,10 @@ int plonk_mem_d2d(plonk_ctx* ctx, void* d_dst, const void* d_src, size_t bytes);
 int plonk_mem_zero(plonk_ctx* ctx, void* d_dst, size_t bytes);
 
 /* ---- Fr vectors: host canonical LE  <->  device Montgomery ----------------------------------
- * Replaces building `list[Scalar]` (curve.py:10-11; poly.py:14-18). Conversion runs on the GPU. */
+ * Replaces building `list[Scalar]` (curve.py:10-11; poly.py:14-18). Conversion runs on the GPU, the range check
+ * `value < r` with it: when plonk_fr_upload returns PLONK_ERR_ARG (an element >= r; plonk_last_error names the first) the
+ * destination has ALREADY been overwritten with the converted input and must not be used; plonk_prover_upload_variables
+ * then leaves the prover with no resident batch (run / download return PLONK_ERR_STATE until the next good upload). */
 int plonk_fr_upload(plonk_ctx* ctx, void* d_dst, const uint8_t* h_src_le32, size_t count);
 int plonk_fr_download(plonk_ctx* ctx, uint8_t* h_dst_le32, const void* d_src, size_t count);
 
