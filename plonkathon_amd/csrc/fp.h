@@ -183,82 +183,6 @@ template <class P> PLONK_FP_CALL Fp<P> fp_mul(const Fp<P> a, const Fp<P> b) {
     return out;
 }
 
-// ---- redundant residues in [0, 2m) ------------------------------------------------------------------------------
-// For chains of butterflies (the NTT wave kernel): values are kept below 2m instead of m.  With R = 2^261 a product of
-// two such values reduces below m (4 m / R + 1) < 1.03 m, so the multiplication needs NO final conditional subtraction;
-// additions and subtractions wrap at 2m (same cost as the canonical ones); one fp_reduce_once at the very end gives
-// the canonical result.  Canonical values are valid redundant values.
-template <class P> PLONK_HD constexpr uint32_t fp_mod2_limb(int i) {  // limb i of 2m
-    return (P::mod(i) << 1) | (i ? P::mod(i - 1) >> 31 : 0u);
-}
-template <class P> PLONK_HD Fp<P> fp_add2(const Fp<P>& a, const Fp<P>& b) {
-    Fp<P> r;
-    uint32_t c = 0, d[8], br = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) r.v[i] = fp_adc(a.v[i], b.v[i], c);  // < 4m < 2^256: no carry out
-#pragma unroll
-    for (int i = 0; i < 8; i++) d[i] = fp_sbb(r.v[i], fp_mod2_limb<P>(i), br);
-#pragma unroll
-    for (int i = 0; i < 8; i++) r.v[i] = br ? r.v[i] : d[i];
-    return r;
-}
-template <class P> PLONK_HD Fp<P> fp_sub2(const Fp<P>& a, const Fp<P>& b) {
-    Fp<P> r;
-    uint32_t d[8], br = 0, c = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) d[i] = fp_sbb(a.v[i], b.v[i], br);
-    const uint32_t mask = 0u - br;  // add 2m back when the difference went negative
-#pragma unroll
-    for (int i = 0; i < 8; i++) r.v[i] = fp_adc(d[i], fp_mod2_limb<P>(i) & mask, c);
-    return r;
-}
-// a * b * 2^-261 for a, b < 2m; result < 1.03 m (not canonical: no final subtraction)
-template <class P> PLONK_FP_CALL Fp<P> fp_mul2(const Fp<P> a, const Fp<P> b) {
-    uint32_t x[9], y[9], r[9];
-    fp29_unpack(a.v, x);
-    fp29_unpack(b.v, y);
-    const uint32_t ninv = P::NINV & FP29_MASK;
-    uint32_t q[9];
-    uint64_t acc = 0;
-    PLONK_CHAIN_BEGIN();
-#pragma unroll
-    for (int k = 0; k < 9; k++) {
-#pragma unroll
-        for (int i = 0; i <= k; i++) {
-            acc += (uint64_t)x[i] * y[k - i];
-            PLONK_CHAIN(acc);
-        }
-#pragma unroll
-        for (int i = 0; i < k; i++) {
-            acc += (uint64_t)q[i] * fp29_mod_limb<P>(k - i);
-            PLONK_CHAIN(acc);
-        }
-        q[k] = ((uint32_t)acc * ninv) & FP29_MASK;
-        acc += (uint64_t)q[k] * fp29_mod_limb<P>(0);
-        acc >>= 29;
-    }
-#pragma unroll
-    for (int k = 9; k < 17; k++) {
-#pragma unroll
-        for (int i = k - 8; i < 9; i++) {
-            acc += (uint64_t)x[i] * y[k - i];
-            PLONK_CHAIN(acc);
-        }
-#pragma unroll
-        for (int i = k - 8; i < 9; i++) {
-            acc += (uint64_t)q[i] * fp29_mod_limb<P>(k - i);
-            PLONK_CHAIN(acc);
-        }
-        r[k - 9] = (uint32_t)acc & FP29_MASK;
-        acc >>= 29;
-    }
-    r[8] = (uint32_t)acc;
-    PLONK_CHAIN_END(r[8]);
-    Fp<P> out;
-    fp29_pack(r, out.v);
-    return out;
-}
-
 // Squaring: the 81 cross products collapse to 45 (off-diagonal terms doubled).
 template <class P> PLONK_FP_CALL Fp<P> fp_sqr(const Fp<P> a) {
     uint32_t x[9], x2[9], r[9];
