@@ -24,7 +24,9 @@ Rank 0 prints ONE JSON line: the contract fields, plus
   "roofline_ntt"  the standalone Fr NTT at 2^20 (BASELINE configs[3]) against the HBM roofline;
   "ntt"           BASELINE configs[3]: 2^16 / 18 / 20 / 22 / 24, forward and inverse, out of place and in place, a lone
                   transform and the constant-work batch [2^24 / N][N], each with GF-elems/s, the HBM-roofline fraction
-                  and the PMC traffic; the prover's own sizes (2^10 .. 2^13, batched); N replicas for N GPUs;
+                  and the PMC traffic, plus the same sizes over the BLS12-381 scalar field (`bls12_381_*`: plonk_bls_fr_ntt,
+                  the field the upstream metric is quoted on); the prover's own sizes (2^10 .. 2^13, batched); N replicas
+                  for N GPUs;
   "msm"           MSMs/s at 2^11;
   "configs"       BASELINE configs[2]: the mini-Poseidon circuit (test.py:216-239) at group_order 2^10 (the reference's
                   own size) and 2^11, a lock-step batch of distinct witnesses: proofs/s, and whether proof 0 — inputs
@@ -187,9 +189,13 @@ def cpu_baseline():
 _NTT_SRC = {}
 
 
-def ntt_microbench(ctx, log_n, batch, reps=5, inverse=False, in_place=False):
-    """ms of one plonk_fr_ntt call (best of `reps`, HIP events on the library's stream) on `batch` transforms of 2^log_n."""
+def ntt_microbench(ctx, log_n, batch, reps=5, inverse=False, in_place=False, field="bn254"):
+    """ms of one plonk_fr_ntt call (best of `reps`, HIP events on the library's stream) on `batch` transforms of 2^log_n.
+    field = "bls12_381": plonk_bls_fr_ntt, the same kernels over the BLS12-381 scalar field (the buffer's 256-bit words are
+    below both moduli: valid residues for either)."""
     from plonkathon_amd._lib import check
+
+    ntt = ctx.L.plonk_bls_fr_ntt if field == "bls12_381" else ctx.L.plonk_fr_ntt
 
     n = 1 << log_n
     import random
@@ -204,12 +210,12 @@ def ntt_microbench(ctx, log_n, batch, reps=5, inverse=False, in_place=False):
     out = buf if in_place else ctx.alloc(n * batch)
     inv = 1 if inverse else 0
     for _ in range(2):
-        check(ctx.L.plonk_fr_ntt(ctx.handle, buf.ptr, out.ptr, log_n, inv, batch))  # warm: tables + scratch
+        check(ntt(ctx.handle, buf.ptr, out.ptr, log_n, inv, batch))  # warm: tables + scratch
     ctx.sync()
     best = None
     for _ in range(reps):
         ctx.timer_start()
-        check(ctx.L.plonk_fr_ntt(ctx.handle, buf.ptr, out.ptr, log_n, inv, batch))
+        check(ntt(ctx.handle, buf.ptr, out.ptr, log_n, inv, batch))
         ms = ctx.timer_stop_ms()
         best = ms if best is None or ms < best else best
     return best
@@ -232,6 +238,13 @@ def ntt_sweep(ctx, comm, world, pmc):
             ms = D.max_over_ranks(ntt_microbench(ctx, log_n, batch, inverse=inverse, in_place=in_place), comm)
             gbs = 64.0 * n * batch / (ms * 1e-3) / 1e9
             entry[name] = {"ms": ms, "batch": batch, "gf_elems_per_s": world * n * batch / (ms * 1e-3), "hbm_frac": gbs / HBM_PEAK_GBS}
+        # the field the configs[3] metric is quoted on upstream (BLS12-381 Fr): the same kernels, plonk_bls_fr_ntt
+        for name, inverse, batch in (("bls12_381_fwd", False, 1), ("bls12_381_inv", True, 1), ("bls12_381_fwd_batched", False, (1 << 24) >> log_n)):
+            if name.endswith("batched") and batch == 1:
+                continue
+            ms = D.max_over_ranks(ntt_microbench(ctx, log_n, batch, inverse=inverse, field="bls12_381"), comm)
+            entry[name] = {"ms": ms, "batch": batch, "gf_elems_per_s": world * n * batch / (ms * 1e-3),
+                           "hbm_frac": 64.0 * n * batch / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
         tr = pmc.get("ntt_2^%d" % log_n)
         if tr:
             entry["pmc_traffic_bytes"] = tr

@@ -95,6 +95,20 @@ int plonk_ntt_set_split(plonk_ctx* ctx, unsigned log_n, unsigned log_r1);
 /* log2 R1 of the split in force for 2^log_n (ctx NULL: the library default, which is what the distributed transform
  * uses on every rank — its column / frequency-strided layouts are [R1][R2 / W] and [R2][R1 / W]) */
 int plonk_ntt_get_split(plonk_ctx* ctx, unsigned log_n, unsigned* out_log_r1);
+/* Two-pass transforms multiply every output of the column pass by w_N^(column * frequency).  Within this budget (bytes per
+ * context, default 4 GiB; 0 = never) the library keeps those N factors per (size, direction) as one table in the order
+ * the kernel reads them — 80 bytes per point: 84 MB at 2^20, 1.3 GB at 2^24 — and spends one multiplication per element
+ * instead of two (factors from two small tables).  Same results either way. */
+int plonk_ntt_set_table_budget(plonk_ctx* ctx, size_t bytes);
+/* ---- the same transform over the BLS12-381 scalar field (ntt_bls.hip) -------------------------
+ * r = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001, w = 7^((r-1)/N): the field BASELINE.json's
+ * standalone-NTT metric is quoted on.  The reference has no such field (curve.py:2: BN254 throughout), so this replaces no
+ * reference call: it is poly.py:113-148's transform (natural order in and out, the inverse includes 1/N) with the modulus
+ * and generator swapped, on the same wave kernels.  Elements are 32 bytes on the device like Fr (Montgomery form, R = 2^261);
+ * plonk_mem_* allocate and move them.  Sizes: 2^8 .. 2^13 and 2^16 .. 2^26 (PLONK_ERR_ARG otherwise); in may equal out. */
+int plonk_bls_fr_upload(plonk_ctx* ctx, void* d_dst, const uint8_t* h_src_le32, size_t count);
+int plonk_bls_fr_download(plonk_ctx* ctx, uint8_t* h_dst_le32, const void* d_src, size_t count);
+int plonk_bls_fr_ntt(plonk_ctx* ctx, const void* d_in, void* d_out, unsigned log_n, int inverse, size_t batch);
 /* Lower-level pieces used by the batched prover: coefficient form in, fixed offset table. */
 int plonk_fr_coset_ntt_from_coeffs(plonk_ctx* ctx, const void* d_coeffs, void* d_out, unsigned log_n,
                                    unsigned log_expand, const uint8_t offset_le32[32], size_t batch);

@@ -5,6 +5,7 @@
  *   oracle_fr_ntt   Polynomial.fft / ifft, /root/reference/poly.py:113-148: plain DFT
  *                   X[k] = sum_j x[j] w^(jk), w = 5^((r-1)/N) (curve.py:14-16), natural order in and
  *                   out; the inverse uses w^-1 and multiplies by 1/N (poly.py:131-139).
+ *   oracle_bls_fr_ntt  the same transform over the BLS12-381 scalar field (generator 7); see its definition below.
  *   oracle_g1_lincomb  ec_lincomb, /root/reference/curve.py:38-44 (the `Equivalent to:` form at
  *                   curve.py:45-49: o = add(o, multiply(pt, coeff))), on the py_ecc group law.
  *
@@ -144,19 +145,20 @@ void oracle_fr_mul(const uint64_t a[4], const uint64_t b[4], uint64_t out[4]) {
 }
 
 /* ---- exported: NTT ---------------------------------------------------------------------------- */
-int oracle_fr_ntt(uint64_t* data, unsigned log_n, int inverse) {
-    if (log_n > 28) return -1;
+/* The transform over any prime field of up to 256 bits: w = generator^((m-1)/n). */
+static int ntt_over(uint64_t* data, unsigned log_n, int inverse, const fe* modulus, uint64_t generator, unsigned two_adicity) {
+    if (log_n > two_adicity) return -1;
     const size_t n = (size_t)1 << log_n;
     mont M;
-    mont_init(&M, &FR_MOD);
+    mont_init(&M, modulus);
     fe* x = (fe*)data;
     for (size_t i = 0; i < n; i++) mont_mul(&x[i], &x[i], &M.r2, &M); /* to Montgomery */
-    /* w = 5^((r-1)/n), or its inverse */
-    fe five = {{5, 0, 0, 0}}, e, w;
+    /* w = generator^((m-1)/n), or its inverse */
+    fe five = {{generator, 0, 0, 0}}, e, w;
     mont_mul(&five, &five, &M.r2, &M);
     fe rm1;
     fe one_raw = {{1, 0, 0, 0}};
-    fe_sub_raw(&rm1, &FR_MOD, &one_raw);
+    fe_sub_raw(&rm1, modulus, &one_raw);
     /* e = (r-1) >> log_n */
     e = rm1;
     for (unsigned s = 0; s < log_n; s++) {
@@ -165,7 +167,7 @@ int oracle_fr_ntt(uint64_t* data, unsigned log_n, int inverse) {
     mont_pow(&w, &five, &e, &M);
     if (inverse) {
         fe rm2, two_raw = {{2, 0, 0, 0}};
-        fe_sub_raw(&rm2, &FR_MOD, &two_raw);
+        fe_sub_raw(&rm2, modulus, &two_raw);
         mont_pow(&w, &w, &rm2, &M);
     }
     /* bit reversal */
@@ -186,8 +188,8 @@ int oracle_fr_ntt(uint64_t* data, unsigned log_n, int inverse) {
             for (size_t j = 0; j < half; j++) {
                 fe t, u = x[i + j];
                 mont_mul(&t, &x[i + j + half], &tw[j * step], &M);
-                fe_add(&x[i + j], &u, &t, &FR_MOD);
-                fe_sub(&x[i + j + half], &u, &t, &FR_MOD);
+                fe_add(&x[i + j], &u, &t, modulus);
+                fe_sub(&x[i + j + half], &u, &t, modulus);
             }
     }
     free(tw);
@@ -195,7 +197,7 @@ int oracle_fr_ntt(uint64_t* data, unsigned log_n, int inverse) {
     if (inverse) {
         fe nn = {{(uint64_t)n, 0, 0, 0}}, rm2, two_raw = {{2, 0, 0, 0}};
         mont_mul(&nn, &nn, &M.r2, &M);
-        fe_sub_raw(&rm2, &FR_MOD, &two_raw);
+        fe_sub_raw(&rm2, modulus, &two_raw);
         mont_pow(&nn, &nn, &rm2, &M);          /* 1/n in Montgomery form */
         mont_mul(&scale, &nn, &scale, &M);     /* -> canonical 1/n */
         for (size_t i = 0; i < n; i++) {
@@ -209,6 +211,15 @@ int oracle_fr_ntt(uint64_t* data, unsigned log_n, int inverse) {
     }
     return 0;
 }
+
+int oracle_fr_ntt(uint64_t* data, unsigned log_n, int inverse) { return ntt_over(data, log_n, inverse, &FR_MOD, 5, 28); }
+
+/* The same transform over the BLS12-381 scalar field (the field of BASELINE.json's standalone-NTT metric; the reference
+ * itself has no such field — curve.py:2 is BN254 throughout): generator 7, 2-adicity 32, so that w_{2^32} = 7^((r-1)/2^32)
+ * is the ROOT_OF_UNITY constant of the `bls12_381` crate (checked in tests/test_oracle_c.py).  Pinned by definition only:
+ * against the O(n^2) DFT sum in Python integers at small sizes. */
+static const fe BLS_FR_MOD = {{0xffffffff00000001ULL, 0x53bda402fffe5bfeULL, 0x3339d80809a1d805ULL, 0x73eda753299d7d48ULL}};
+int oracle_bls_fr_ntt(uint64_t* data, unsigned log_n, int inverse) { return ntt_over(data, log_n, inverse, &BLS_FR_MOD, 7, 32); }
 
 /* ---- exported: G1 linear combination (Jacobian double-and-add, a = 0, b = 3) ------------------- */
 typedef struct { fe x, y, z; } jac; /* z == 0 <=> identity */

@@ -31,15 +31,20 @@ def fr_ntt(values, inverse=False):
     return [int.from_bytes(out[32 * i : 32 * i + 32], "little") for i in range(n)]
 
 
-def fr_ntt_bytes(raw, inverse=False):
-    """The same transform on canonical 32-byte little-endian elements back to back (sizes where Python ints are too slow)."""
+def fr_ntt_bytes(raw, inverse=False, field="bn254"):
+    """The same transform on canonical 32-byte little-endian elements back to back (sizes where Python ints are too slow).
+    field = "bls12_381": the BLS12-381 scalar field, generator 7 (no counterpart in the reference; see bn254_oracle.c)."""
     n = len(raw) // 32
     log_n = n.bit_length() - 1
     assert 1 << log_n == n and len(raw) == 32 * n
     buf = (ctypes.c_uint64 * (4 * n)).from_buffer_copy(raw)
-    rc = lib().oracle_fr_ntt(buf, ctypes.c_uint(log_n), ctypes.c_int(1 if inverse else 0))
+    fn = {"bn254": lib().oracle_fr_ntt, "bls12_381": lib().oracle_bls_fr_ntt}[field]
+    rc = fn(buf, ctypes.c_uint(log_n), ctypes.c_int(1 if inverse else 0))
     assert rc == 0
     return bytes(buf)
+
+
+BLS12_381_FR_MODULUS = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
 
 
 def g1_lincomb(points, scalars):

@@ -315,6 +315,12 @@ int plonk_ntt_get_split(plonk_ctx* ctx, unsigned log_n, unsigned* out_log_r1) {
     return PLONK_OK;
 }
 
+int plonk_ntt_set_table_budget(plonk_ctx* ctx, size_t bytes) {
+    PLONK_REQUIRE(ctx, PLONK_ERR_ARG, "ctx is NULL");
+    ctx->ntt_table_budget = bytes;
+    return PLONK_OK;
+}
+
 int plonk_fr_ntt(plonk_ctx* ctx, const void* d_in, void* d_out, unsigned log_n, int inverse, size_t batch) {
     PLONK_REQUIRE(ctx && d_in && d_out, PLONK_ERR_ARG, "bad argument");
     PLONK_ENTER(ctx);

@@ -393,9 +393,21 @@ template <class P> PLONK_HD Fp<P> fp_inv(const Fp<P>& a) {
         l[i] = (uint32_t)acc & FP30_MASK;
         acc >>= 30;
     }
+    if constexpr (P::mod(7) >= 0x40000000u) {  // 4m >= 2^256 (BLS12-381 Fr): bring (0, 4m) into (0, 2m) before packing to 256 bits
+        uint32_t t[9];
+        int64_t bw = 0;
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+            bw += (int64_t)l[i] - 2 * (int64_t)fp30_mod_limb<P>(i);
+            t[i] = (uint32_t)bw & FP30_MASK;
+            bw >>= 30;
+        }
+#pragma unroll
+        for (int i = 0; i < 9; i++) l[i] = bw < 0 ? l[i] : t[i];
+    }
     Fp<P> y;
 #pragma unroll
-    for (int j = 0; j < 8; j++) {  // 9 x 30 bits -> 8 x 32 bits (value < 4m < 2^256)
+    for (int j = 0; j < 8; j++) {  // 9 x 30 bits -> 8 x 32 bits (value < 4m < 2^256, or < 2m after the step above)
         const int bit = 32 * j, i = bit / 30, sh = bit % 30;
         uint64_t w = (uint64_t)l[i] >> sh;
         w |= (uint64_t)l[i + 1] << (30 - sh);

@@ -39,7 +39,7 @@ struct FpL {
             abort();                                                                \
         }                                                                           \
     } while (0)
-template <class L> inline long double fpl_dbg_value(const L& a) {  // ~ value / 2^232 (good to 64 bits: enough for bounds)
+template <class L> inline long double fpl_dbg_value(const L& a) {  // the value, good to 64 bits: enough for bounds
     long double v = 0;
     for (int i = 8; i >= 0; i--) v = v * 536870912.0L + (long double)a.l[i];
     return v;
@@ -65,7 +65,11 @@ template <class P, class L> inline void fpl_dbg_check_product(const L& a, const 
     if (!(col < 9223372036854775808.0L))
         fprintf(stderr, "fpl.h: max |limb| a %lld b %lld c %lld d %lld\n", fpl_dbg_maxlimb(a), fpl_dbg_maxlimb(b), c ? fpl_dbg_maxlimb(*c) : 0LL, d ? fpl_dbg_maxlimb(*d) : 0LL);
     FPL_CHECK(col < 9223372036854775808.0L, "column sum of a product exceeds 64 bits");
-    FPL_CHECK(val <= 128.0L * mm * mm, "|a||b| exceeds 128 m^2");
+    // (-m, 2m) needs |a||b| <= R m: 169 m^2 for BN254 (the documented 128 leaves slack), 70 m^2 for BLS12-381 Fr
+    const long double r_over_m = ldexpl(1.0L, 261) / mm;
+    if (!(val <= (r_over_m < 128.0L ? r_over_m : 128.0L) * mm * mm))
+        fprintf(stderr, "fpl.h: |a| = %.3Lf m, |b| = %.3Lf m, R / m = %.2Lf\n", fabsl(fpl_dbg_value(a)) / mm, fabsl(fpl_dbg_value(b)) / mm, r_over_m);
+    FPL_CHECK(val <= (r_over_m < 128.0L ? r_over_m : 128.0L) * mm * mm, "|a||b| exceeds min(128, R / m) m^2");
 }
 #define FPL_CHECK_I32(expr64, what) FPL_CHECK((expr64) >= -2147483648LL && (expr64) <= 2147483647LL, what)
 #else
@@ -459,7 +463,9 @@ template <class P> PLONK_HD Fp<P> fpl_pack_canonical(const FpL<P>& a) {
 // 53 + 45 + 45 = 143 multiply-adds and 19 column steps against fpl_mul's 171 and 17, and no serial q_k = acc * (-1/m)
 // chain.  The data stays in Montgomery form (a = x R): a w = (x w) R, so w is the PLAIN value of the constant.
 //   a: limbs within fpl_mul's operand range (|limb| < 1.27 * 2^30), |value| < 128 m.
-//   result: normalised, value within (-1.8 m, 2.8 m)   [exact r in (-0.76 m, 1.76 m); q off by at most one either way]
+//   result: normalised, value within (-(1 + A) m, (2 + A) m) with A = |a| / R   [exact r in (-A m, (1 + A) m); q off by at
+//   most one either way].  BN254 (R / m = 169): (-1.8 m, 2.8 m) for any |a| < 128 m.  BLS12-381 Fr (R / m = 70.7): the same
+//   interval as long as |a| < 56 m — the NTT's multiplicands are sums of at most eight such results, |a| < 18.1 m.
 // wp from the Montgomery form wt = w R mod m of the constant (what the root tables hold): w R = wp m + wt, hence
 // wp = wt * (-1/m) mod 2^261 — one bottom-half product with the 261-bit constant fpl_ninv261.
 template <class P> struct FpLS {
@@ -578,7 +584,8 @@ template <class P, bool FENCE = false> PLONK_HD FpL<P> fpl_mul_shoup(const FpL<P
     {
         long double mm = 0;
         for (int i = 8; i >= 0; i--) mm = mm * 536870912.0L + (long double)fp29_mod_limb<P>(i);
-        const long double v = fpl_dbg_value(r);
+        const long double v = fpl_dbg_value(r), A = fabsl(fpl_dbg_value(a)) / ldexpl(1.0L, 261);  // |a| / R
+        FPL_CHECK(v > -(1.0L + A) * mm - 1.0L && v < (2.0L + A) * mm + 1.0L, "fpl_mul_shoup: result outside (-(1 + |a|/R) m, (2 + |a|/R) m)");
         FPL_CHECK(v > -1.8L * mm && v < 2.8L * mm, "fpl_mul_shoup: result outside (-1.8 m, 2.8 m)");
     }
 #endif

@@ -17,7 +17,7 @@
 // and the inverse-coset scaling are fused into the first-pass load / last-pass store.
 #include <string.h>
 
-#include "ntt_wave.h"
+#include "ntt_wave_host.h"
 
 typedef FpL<FrParams> FrL;
 typedef FpLS<FrParams> FrLS;
@@ -557,213 +557,20 @@ bool ntt_wave_plan(const plonk_ctx* ctx, unsigned log_n, unsigned* log_r1, unsig
     return true;
 }
 
-static int ntt_limb_table(plonk_ctx* ctx, std::map<unsigned, int32_t*>& cache, unsigned key, const Fr* packed, size_t n, bool shoup, const int32_t** out) {
-    auto it = cache.find(key);
-    if (it == cache.end()) {
-        void* d = nullptr;
-        Ninv261 ninv;
-        fpl_ninv261<FrParams>(ninv.l);
-        if (hipMalloc(&d, n * (shoup ? NTT_SHOUP_STRIDE : NTT_LIMB_STRIDE) * sizeof(int32_t)) != hipSuccess) {
-            plonk_set_error("hipMalloc of a %zu-entry limb-form twiddle table failed", n);
-            return PLONK_ERR_NOMEM;
-        }
-        ctx->owned.push_back(d);
-        PLONK_LAUNCH(ntt_limb_table_kernel<FrParams>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, packed, (int32_t*)d, n, shoup ? 1 : 0, ninv);
-        PLONK_CHECK_HIP(hipGetLastError());
-        it = cache.emplace(key, (int32_t*)d).first;
-    }
-    *out = it->second;
-    return PLONK_OK;
-}
-
-// the twiddles of the wave kernel serving 2^log_n, in program order (built once per size and direction)
-static int ntt_get_roots_limbs(plonk_ctx* ctx, unsigned log_n, bool inverse, const int32_t** out) {
-    const unsigned key = log_n | (inverse ? 256u : 0u);
-    auto it = ctx->tw.full_l.find(key);
-    if (it == ctx->tw.full_l.end()) {
-        const Fr* packed;
-        PLONK_TRY(ntt_get_roots(ctx, log_n, inverse, &packed));
-        const unsigned log_e = (log_n & 1) ? 3 : 2, nlds = (log_n - 6 - log_e) / 2, stages = wavel_tw_stages(log_e, nlds);
-        const size_t entries = wavel_tw_offset(log_e, nlds, stages);
-        void* d = nullptr;
-        if (hipMalloc(&d, entries * NTT_SHOUP_STRIDE * sizeof(int32_t)) != hipSuccess) {
-            plonk_set_error("hipMalloc of a %zu-entry twiddle table failed", entries);
-            return PLONK_ERR_NOMEM;
-        }
-        ctx->owned.push_back(d);
-        Ninv261 ninv;
-        fpl_ninv261<FrParams>(ninv.l);
-        for (unsigned st = 0; st < stages; st++) {
-            const unsigned nb = wavel_tw_nb(log_e, nlds, st), count = wavel_tw_count(log_e, nlds, st), mult = wavel_tw_mult(log_e, nlds, st);
-            for (unsigned f = 1; f <= count; f++) {
-                int32_t* block = (int32_t*)d + ((size_t)wavel_tw_offset(log_e, nlds, st) + (size_t)(f - 1) * nb) * NTT_SHOUP_STRIDE;
-                PLONK_LAUNCH(ntt_program_block_kernel<FrParams>, dim3((nb + 63) / 64), dim3(64), 0, ctx->stream, packed, log_n, nb, f, mult, block, ninv);
-            }
-        }
-        PLONK_CHECK_HIP(hipGetLastError());
-        it = ctx->tw.full_l.emplace(key, (int32_t*)d).first;
-    }
-    *out = it->second;
-    return PLONK_OK;
-}
-
-// inter-pass twiddle tables as Shoup pairs; scaled: the hi table times 1/N (the inverse transform's factor, folded in)
-static int get_lo_hi_limbs(plonk_ctx* ctx, unsigned log_n, bool inverse, bool scaled, const int32_t** lo, const int32_t** hi) {
-    const Fr *plo, *phi;
-    PLONK_TRY(get_lo_hi(ctx, log_n, inverse, &plo, &phi));
-    const unsigned key = log_n | (inverse ? 256u : 0u);
-    const unsigned log_lo = log_n < NTT_TW_LO_LOG ? log_n : NTT_TW_LO_LOG;
-    const size_t nhi = log_n > NTT_TW_LO_LOG ? ((size_t)1 << (log_n - NTT_TW_LO_LOG)) : 1;
-    PLONK_TRY(ntt_limb_table(ctx, ctx->tw.lo_l, key, plo, (size_t)1 << log_lo, true, lo));
-    if (!scaled) return ntt_limb_table(ctx, ctx->tw.hi_l, key, phi, nhi, true, hi);
-    if (ctx->tw.hi_l.find(key | 512u) == ctx->tw.hi_l.end()) {  // (1/N) * w_hi^k, built once
-        Fr whi = host_root_of_unity(log_n, inverse);
-        for (unsigned i = 0; i < NTT_TW_LO_LOG; i++) whi = fp_sqr(whi);
-        void* tmp = nullptr;  // (not a scratch slot: callers hold those across this call)
-        if (hipMalloc(&tmp, nhi * sizeof(Fr)) != hipSuccess) {
-            plonk_set_error("hipMalloc of a %zu-entry twiddle table failed", nhi);
-            return PLONK_ERR_NOMEM;
-        }
-        int rc = k_fr_powers(ctx, whi, fp_inv(host_fr_from_u64((uint64_t)1 << log_n)), (Fr*)tmp, nhi);
-        if (rc == PLONK_OK) rc = ntt_limb_table(ctx, ctx->tw.hi_l, key | 512u, (const Fr*)tmp, nhi, true, hi);
-        hipStreamSynchronize(ctx->stream);  // the packed copy must outlive the conversion kernel only
-        hipFree(tmp);
-        return rc;
-    }
-    return ntt_limb_table(ctx, ctx->tw.hi_l, key | 512u, nullptr, nhi, true, hi);
-}
-
-// fpl_reduce_small's table of j * m for the limb-form kernel: 49 entries of 12 words, built on the host once per context
-static int ntt_get_jm(plonk_ctx* ctx, const int32_t** out) {
-    if (!ctx->ntt_jm) {
-        int32_t host[(2 * FPL_RS_J + 1) * 12];
-        for (int j = -FPL_RS_J; j <= FPL_RS_J; j++) fpl_jm_entry<FrParams>(j, host + (j + FPL_RS_J) * 12);
-        void* d = nullptr;
-        if (hipMalloc(&d, sizeof host) != hipSuccess) {
-            plonk_set_error("hipMalloc of the NTT range-reduction table failed");
-            return PLONK_ERR_NOMEM;
-        }
-        ctx->owned.push_back(d);
-        PLONK_CHECK_HIP(hipMemcpy(d, host, sizeof host, hipMemcpyHostToDevice));
-        ctx->ntt_jm = (const int32_t*)d;
-    }
-    *out = ctx->ntt_jm;
-    return PLONK_OK;
-}
-
-// the radix-8 / radix-4 roots w_8^k of a transform direction as Shoup pairs (kernel arguments)
-static void ntt_wave_w8(NttWave* p, bool inverse) {
-    uint32_t ninv[9];
-    fpl_ninv261<FrParams>(ninv);
-    const Fr w8 = host_root_of_unity(3, inverse), w4 = fp_sqr(w8);
-    p->w8[0] = fpl_shoup_from_mont(w8, ninv);
-    p->w8[1] = fpl_shoup_from_mont(w4, ninv);
-    p->w8[2] = fpl_shoup_from_mont(fp_mul(w4, w8), ninv);
-}
-
-template <unsigned LOG_E, unsigned NLDS> static int ntt_wavel_launch_as(plonk_ctx* ctx, const NttWave& q, unsigned grid_x, unsigned grid_y) {
-    constexpr unsigned nt = 64u << (2 * NLDS);
-    const size_t shmem = NLDS ? (size_t)4 * nt * 36 : 0;  // one round of the wave-bit exchange: 4 elements of 9 words per thread
-    if (NLDS == 2 && !ctx->ntt_wavel_attr_set[LOG_E - 2]) {  // 144 KiB: above the default limit; a per-device attribute, tracked per context
-        PLONK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ntt_wavel_kernel<FrParams, LOG_E, NLDS>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)(144 * 1024)));
-        ctx->ntt_wavel_attr_set[LOG_E - 2] = true;
-    }
-    void (*const kern)(NttWave) = ntt_wavel_kernel<FrParams, LOG_E, NLDS>;  // (a template-id's comma would split the macro's arguments)
-    PLONK_LAUNCH(kern, dim3(grid_x, grid_y), dim3(nt), shmem, ctx->stream, q);
-    return PLONK_OK;
-}
-
-// log_r = 8, 10, 12: 4 elements per thread; 9, 11, 13: 8 elements per thread
-static int ntt_wave_launch(plonk_ctx* ctx, const NttWave& p, unsigned log_r, unsigned grid_x, unsigned grid_y) {
-    NttWave q = p;
-    PLONK_TRY(ntt_get_jm(ctx, &q.jm));
-    switch (log_r) {
-        case 8: return ntt_wavel_launch_as<2, 0>(ctx, q, grid_x, grid_y);
-        case 10: return ntt_wavel_launch_as<2, 1>(ctx, q, grid_x, grid_y);
-        case 12: return ntt_wavel_launch_as<2, 2>(ctx, q, grid_x, grid_y);
-        case 9: return ntt_wavel_launch_as<3, 0>(ctx, q, grid_x, grid_y);
-        case 11: return ntt_wavel_launch_as<3, 1>(ctx, q, grid_x, grid_y);
-        case 13: return ntt_wavel_launch_as<3, 2>(ctx, q, grid_x, grid_y);
-    }
-    plonk_set_error("no wave kernel for a 2^%u-point transform", log_r);
-    return PLONK_ERR_ARG;
-}
+// ---- the wave kernels' host side for BN254 Fr: ntt_wave_host.h over this context's tables ---------------------------------
+struct Bn254FrField {
+    typedef FrParams P;
+    static Fr root_of_unity(unsigned log_n, bool inverse) { return host_root_of_unity(log_n, inverse); }
+    static Fr from_u64(uint64_t x) { return host_fr_from_u64(x); }
+    static int packed_roots(plonk_ctx* ctx, unsigned log_n, bool inverse, const Fr** out) { return ntt_get_roots(ctx, log_n, inverse, out); }
+    static int packed_lo_hi(plonk_ctx* ctx, unsigned log_n, bool inverse, const Fr** lo, const Fr** hi) { return get_lo_hi(ctx, log_n, inverse, lo, hi); }
+    static int powers(plonk_ctx* ctx, const Fr& base, const Fr& first, Fr* out, size_t n) { return k_fr_powers(ctx, base, first, out, n); }
+    static WaveTables& tables(plonk_ctx* ctx) { return ctx->tw.wave; }
+};
 
 static int ntt_run_wave(plonk_ctx* ctx, const Fr* in, Fr* out, unsigned log_n, bool inverse, size_t batch, size_t in_len,
                         size_t in_bstride, size_t out_bstride, const Fr* in_scale, const Fr* out_scale, bool scale_by_n_inv) {
-    const size_t N = (size_t)1 << log_n;
-    unsigned log_r1 = 0, log_r2 = 0;
-    ntt_wave_plan(ctx, log_n, &log_r1, &log_r2);
-    NttWave p;
-    memset(&p, 0, sizeof p);
-    p.log_n = log_n;
-    ntt_wave_w8(&p, inverse);
-    Fr n_inv = fp_zero<FrParams>();
-    if (scale_by_n_inv) n_inv = fp_inv(host_fr_from_u64((uint64_t)N));
-    const unsigned in_len32 = (unsigned)(in_len < N ? in_len : N);
-    if (!log_r2) {
-        p.in = in;
-        p.out = out;
-        p.in_bstride = in_bstride;
-        p.out_bstride = out_bstride;
-        p.in_len = in_len32;
-        PLONK_TRY(ntt_get_roots_limbs(ctx, log_n, inverse, &p.roots));
-        p.in_scale = in_scale;
-        p.out_scale = out_scale;
-        p.out_scalar = n_inv;
-        p.has_out_scalar = scale_by_n_inv;
-        // an in-place transform is safe: every thread has read all of its inputs before any thread stores (the stages
-        // in between are separated by barriers for L > 0; for L = 0 the single wave runs in lock step)
-        PLONK_TRY(prof_begin(ctx, "ntt_pass", 64.0 * (double)N * (double)batch));
-        for (size_t b0 = 0; b0 < batch; b0 += (size_t)1 << 30) {  // grid.x carries the batch
-            const size_t nb = batch - b0 < ((size_t)1 << 30) ? batch - b0 : (size_t)1 << 30;
-            NttWave q = p;
-            q.in = in + b0 * in_bstride;
-            q.out = out + b0 * out_bstride;
-            PLONK_TRY(ntt_wave_launch(ctx, q, log_n, (unsigned)nb, 1));
-        }
-        PLONK_TRY(prof_end(ctx));
-        PLONK_CHECK_HIP(hipGetLastError());
-        return PLONK_OK;
-    }
-    // two passes through a scratch copy: columns (R1 points each, stride R2), then rows (R2 points each)
-    PLONK_REQUIRE(batch <= 65535, PLONK_ERR_ARG, "NTT batch %zu exceeds 65535", batch);
-    void* sc;
-    PLONK_TRY(ctx_scratch(ctx, 0, batch * N * sizeof(Fr), &sc));
-    Fr* tmp = (Fr*)sc;
-    PLONK_TRY(get_lo_hi_limbs(ctx, log_n, inverse, scale_by_n_inv, &p.tw_lo, &p.tw_hi));
-    p.tw_always = scale_by_n_inv ? 1u : 0u;
-    NttWave a = p;
-    a.mode = 1;
-    a.log_other = log_r2;
-    a.in = in;
-    a.out = tmp;
-    a.in_bstride = in_bstride;
-    a.out_bstride = N;
-    a.in_len = in_len32;
-    a.in_scale = in_scale;
-    PLONK_TRY(ntt_get_roots_limbs(ctx, log_r1, inverse, &a.roots));
-    NttWave c = p;
-    c.mode = 2;
-    c.log_other = log_r1;
-    c.in = tmp;
-    c.out = out;
-    c.in_bstride = N;
-    c.out_bstride = out_bstride;
-    c.in_len = (unsigned)N;
-    c.out_scale = out_scale;
-    c.has_out_scalar = 0;  // 1/N went into the column pass's inter-pass twiddles (tw_hi)
-    c.tw_always = 0;
-    PLONK_TRY(ntt_get_roots_limbs(ctx, log_r2, inverse, &c.roots));
-    PLONK_TRY(prof_begin(ctx, "ntt_pass", 32.0 * (double)N * (double)batch));
-    PLONK_TRY(ntt_wave_launch(ctx, a, log_r1, 1u << log_r2, (unsigned)batch));
-    PLONK_TRY(prof_end(ctx));
-    PLONK_TRY(prof_begin(ctx, "ntt_pass", 32.0 * (double)N * (double)batch));
-    PLONK_TRY(ntt_wave_launch(ctx, c, log_r2, 1u << log_r1, (unsigned)batch));
-    PLONK_TRY(prof_end(ctx));
-    PLONK_CHECK_HIP(hipGetLastError());
-    return PLONK_OK;
+    return wave_run<Bn254FrField>(ctx, in, out, log_n, inverse, batch, in_len, in_bstride, out_bstride, in_scale, out_scale, scale_by_n_inv);
 }
 
 // ---- distributed four-step transform: the two local steps (the all-to-all between them is comm.hip's) ------------------
@@ -782,11 +589,7 @@ int ntt_dist_plan(unsigned log_n, unsigned log_w, unsigned* log_r1, unsigned* lo
     return PLONK_OK;
 }
 
-static void ntt_wave_consts(NttWave* p, unsigned log_n, bool inverse) {
-    memset(p, 0, sizeof *p);
-    p->log_n = log_n;
-    ntt_wave_w8(p, inverse);
-}
+static void ntt_wave_consts(NttWave* p, unsigned log_n, bool inverse) { wave_params_init<Bn254FrField>(p, log_n, inverse); }
 
 int ntt_dist_columns(plonk_ctx* ctx, const Fr* in, Fr* out, unsigned log_n, unsigned log_w, unsigned rank, bool inverse) {
     unsigned log_r1, log_r2;
@@ -794,8 +597,8 @@ int ntt_dist_columns(plonk_ctx* ctx, const Fr* in, Fr* out, unsigned log_n, unsi
     const unsigned log_cl = log_r2 - log_w;
     NttWave a;
     ntt_wave_consts(&a, log_n, inverse);
-    PLONK_TRY(get_lo_hi_limbs(ctx, log_n, inverse, false, &a.tw_lo, &a.tw_hi));
-    PLONK_TRY(ntt_get_roots_limbs(ctx, log_r1, inverse, &a.roots));
+    PLONK_TRY(wave_lo_hi<Bn254FrField>(ctx, log_n, inverse, false, &a.tw_lo, &a.tw_hi));
+    PLONK_TRY(wave_program_table<Bn254FrField>(ctx, log_r1, inverse, &a.roots));
     a.mode = 1;
     a.log_other = log_cl;
     a.sub_base = rank << log_cl;
@@ -803,7 +606,7 @@ int ntt_dist_columns(plonk_ctx* ctx, const Fr* in, Fr* out, unsigned log_n, unsi
     a.out = out;
     a.in_len = 1u << (log_n - log_w);
     PLONK_TRY(prof_begin(ctx, "ntt_pass", 32.0 * (double)((size_t)1 << (log_n - log_w))));
-    PLONK_TRY(ntt_wave_launch(ctx, a, log_r1, 1u << log_cl, 1));
+    PLONK_TRY(wave_launch<Bn254FrField>(ctx, a, log_r1, 1u << log_cl, 1));
     PLONK_TRY(prof_end(ctx));
     PLONK_CHECK_HIP(hipGetLastError());
     return PLONK_OK;
@@ -816,7 +619,7 @@ int ntt_dist_rows(plonk_ctx* ctx, const Fr* in, Fr* out, unsigned log_n, unsigne
     const unsigned log_cl = log_r2 - log_w, log_kl = log_r1 - log_w;
     NttWave c;
     ntt_wave_consts(&c, log_n, inverse);
-    PLONK_TRY(ntt_get_roots_limbs(ctx, log_r2, inverse, &c.roots));
+    PLONK_TRY(wave_program_table<Bn254FrField>(ctx, log_r2, inverse, &c.roots));
     c.mode = 2;
     c.log_other = log_kl;  // output stride: frequency k2 of local row kl at out[k2 * R1/W + kl]
     if (log_w) {           // W chunks [source rank][R1/W][R2/W]; one rank: plain contiguous rows
@@ -831,7 +634,7 @@ int ntt_dist_rows(plonk_ctx* ctx, const Fr* in, Fr* out, unsigned log_n, unsigne
         c.has_out_scalar = 1;
     }
     PLONK_TRY(prof_begin(ctx, "ntt_pass", 32.0 * (double)((size_t)1 << (log_n - log_w))));
-    PLONK_TRY(ntt_wave_launch(ctx, c, log_r2, 1u << log_kl, 1));
+    PLONK_TRY(wave_launch<Bn254FrField>(ctx, c, log_r2, 1u << log_kl, 1));
     PLONK_TRY(prof_end(ctx));
     PLONK_CHECK_HIP(hipGetLastError());
     return PLONK_OK;

@@ -67,7 +67,8 @@ template <class P> struct NttWaveT {
     unsigned sub_base, chunk_log, chunk_stride;
     const int32_t* tw_lo;  // inter-pass twiddles w_N^e = tw_lo[e & 1023] * tw_hi[e >> 10], Shoup pairs: applied one after the other (mode 1)
     const int32_t* tw_hi;  //   (for an inverse transform tw_hi carries the factor 1/N as well: tw_always)
-    unsigned tw_always;    // multiply even when e == 0 (tw_hi[0] = 1/N)
+    unsigned tw_always;    // 1: multiply even when e == 0 (tw_hi[0] = 1/N); 2: tw_lo is the FULL table of this pass in usage
+                           //   order (ntt_interpass_table_kernel; the host launches ntt_wavel_column_kernel): one multiplication per element
     const int32_t* roots;  // the twiddles of this kernel's transform size and direction, Shoup pairs in program order (wavel_tw_*)
     const Fp<P>* in_scale;   // per-element factor at load (coset offset powers) or null
     const Fp<P>* out_scale;  // per-element factor at store or null
@@ -275,7 +276,9 @@ template <unsigned LOG_E, unsigned NLDS> struct WavelCfg {
 };
 
 // One transform (or one column / row of a two-pass transform) by one workgroup: the body of both kernels below.
-template <class P, unsigned LOG_E, unsigned NLDS>
+// FULL: the column pass of a two-pass transform with its inter-pass twiddles in ONE table (p.tw_lo; see the end of this file)
+// — a kernel of its own, for E = 4 only: the E = 8 kernels sit at 128 registers and any change to this epilogue spills
+template <class P, unsigned LOG_E, unsigned NLDS, bool FULL = false>
 PLONK_DEV void wavel_transform(const NttWaveT<P>& p, unsigned char* smem) {
     constexpr unsigned E = 1u << LOG_E, LOG_N = LOG_E + 6 + 2 * NLDS, NT = 64u << (2 * NLDS), LOG_T = 6 + 2 * NLDS;
     u32x4* l_lo = reinterpret_cast<u32x4*>(smem);  // 4 * NT elements as two 16-byte planes and one 4-byte plane
@@ -391,7 +394,13 @@ PLONK_DEV void wavel_transform(const NttWaveT<P>& p, unsigned char* smem) {
         });
         shift = LOG_T;
     }
-    if (p.mode == 1) {  // inter-pass twiddle w_N^(column * frequency)
+    if constexpr (FULL) {  // inter-pass twiddle w_N^(column * frequency) from the table in usage order (ntt_interpass_table_kernel)
+        const int32_t* blocks = p.tw_lo + (size_t)sub * (E * NT * NTT_SHOUP_STRIDE);  // this column's E blocks of NT entries: uniform
+        wave_for<E>([&](auto J) {
+            constexpr unsigned j = decltype(J)::value;
+            x[j] = fpl_mul_shoup(x[j], wavel_ld_root_planar<P>(blocks + j * (NT * NTT_SHOUP_STRIDE), NT, tid));
+        });
+    } else if (p.mode == 1) {  // ... or as two factors from the small tables
         wave_for<E>([&](auto J) {
             constexpr unsigned j = decltype(J)::value;
             const unsigned e = (sub + p.sub_base) * (k | (j << shift));  // < N
@@ -421,6 +430,11 @@ template <class P, unsigned LOG_E, unsigned NLDS>
 __global__ void __launch_bounds__(64u << (2 * NLDS), (WavelCfg<LOG_E, NLDS>::WAVES)) ntt_wavel_kernel(NttWaveT<P> p) {
     PLONK_DYN_SMEM(smem);
     wavel_transform<P, LOG_E, NLDS>(p, smem);
+}
+template <class P, unsigned LOG_E, unsigned NLDS>
+__global__ void __launch_bounds__(64u << (2 * NLDS), (WavelCfg<LOG_E, NLDS>::WAVES)) ntt_wavel_column_kernel(NttWaveT<P> p) {
+    PLONK_DYN_SMEM(smem);
+    wavel_transform<P, LOG_E, NLDS, true>(p, smem);
 }
 
 
@@ -464,3 +478,60 @@ template <class P> __global__ void ntt_program_block_kernel(const Fp<P>* roots, 
         for (unsigned w = 0; w < NTT_PLANE_WORDS; w++) block[((size_t)pl * nb + low) * NTT_PLANE_WORDS + w] = e[pl * NTT_PLANE_WORDS + w];
 }
 
+// ---- the inter-pass twiddles of a column pass as ONE table in usage order ------------------------------------------------
+// The column pass of N = R1 R2 multiplies output k1 of column c by w_N^(c k1).  From the two small tables that is two
+// multiplications per element (lo[e & 1023] * hi[e >> 10]); with 288 GB of HBM at a tenth of its bandwidth in these
+// ALU-bound kernels, a table of all N products read as one coalesced 80-byte stream trades a multiplication (9 % of a
+// two-pass transform's instructions) for bytes.  Layout: for column c, register j: a block of NT Shoup pairs indexed by
+// thread (five planes of NT x 16 bytes, wavel_ld_root_planar) at ((c E + j) NT) entries.
+// frequency (without the register digit) of thread tid's outputs and the bit position of the register digit: the
+// run-time restatement of the index arithmetic at the end of wavel_transform (the parity tests compare both paths)
+PLONK_HD unsigned wavel_freq(unsigned log_e, unsigned nlds, unsigned tid, unsigned* shift_out) {
+    const unsigned lane = tid & 63u, log_t = 6 + 2 * nlds;
+    unsigned k = 0, shift;
+    if (log_e == 3) {
+        shift = 3;
+        if (nlds) {
+            k = (((lane >> 5) & 1u) << 2) | ((tid >> (6 + 2 * (nlds - 1))) & 3u);
+            for (unsigned s = 1; s < nlds; s++) {
+                k |= ((tid >> (6 + 2 * (nlds - 1 - s))) & 3u) << shift;
+                shift += 2;
+            }
+            k |= ((lane >> 3) & 3u) << shift;
+            shift += 2;
+        } else {
+            k = (lane >> 3) & 7u;
+        }
+        k |= (lane & 7u) << shift;
+        shift += 3;
+    } else {
+        for (unsigned i = 0; i < log_t / 2; i++) k |= ((tid >> (log_t - 2 - 2 * i)) & 3u) << (2 * i);
+        shift = log_t;
+    }
+    *shift_out = shift;
+    return k;
+}
+
+// entry i = (c E + j) NT + tid of that table: the Shoup pair of scale * lo[e & 1023] * hi[e >> 10], e = c * k1(tid, j)
+template <class P>
+__global__ void ntt_interpass_table_kernel(const Fp<P>* lo, const Fp<P>* hi, Fp<P> scale, unsigned log_n, unsigned log_r1, int32_t* out, Ninv261 ninv) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >> log_n) return;
+    const unsigned log_e = (log_r1 & 1) ? 3 : 2, nlds = (log_r1 - 6 - log_e) / 2, log_t = 6 + 2 * nlds;
+    const unsigned tid = (unsigned)i & ((1u << log_t) - 1), j = (unsigned)(i >> log_t) & ((1u << log_e) - 1), c = (unsigned)(i >> log_r1);
+    unsigned shift;
+    const unsigned k1 = wavel_freq(log_e, nlds, tid, &shift) | (j << shift);
+    const unsigned e = c * k1;  // < N
+    Fp<P> w = fp_mul(fp_load(lo + (e & ((1u << NTT_TW_LO_LOG) - 1))), scale);
+    if (log_n > NTT_TW_LO_LOG) w = fp_mul(w, fp_load(hi + (e >> NTT_TW_LO_LOG)));
+    const FpLS<P> a = fpl_shoup_from_mont(w, ninv.l);
+    int32_t v[NTT_SHOUP_STRIDE];
+    for (int q = 0; q < 9; q++) {
+        v[q] = a.w[q];
+        v[9 + q] = a.wp[q];
+    }
+    v[18] = v[19] = 0;
+    int32_t* block = out + (i >> log_t << log_t) * NTT_SHOUP_STRIDE;  // the block of (c, j)
+    for (unsigned pl = 0; pl < 5; pl++)
+        for (unsigned q = 0; q < NTT_PLANE_WORDS; q++) block[((size_t)pl << log_t | tid) * NTT_PLANE_WORDS + q] = v[pl * NTT_PLANE_WORDS + q];
+}

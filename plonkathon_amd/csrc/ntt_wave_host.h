@@ -1,0 +1,288 @@
+// ntt_wave_host.h — host side of the wave NTT kernels (ntt_wave.h), generic over the field: tables, launches and the
+// one- / two-pass driver.  A field is a traits type F with
+//   typedef ... P;                                            the Montgomery parameters (fp.h)
+//   static Fp<P> root_of_unity(unsigned log_n, bool inverse)  w = g^((m-1)/2^log_n), Montgomery form (host)
+//   static Fp<P> from_u64(uint64_t)                           Montgomery form of a small integer (host)
+//   static int packed_roots(ctx, log_n, inverse, const Fp<P>** out)            w^k, k < 2^log_n, on the device
+//   static int packed_lo_hi(ctx, log_n, inverse, const Fp<P>** lo, const Fp<P>** hi)   w^e = lo[e & 1023] * hi[e >> 10]
+//   static int powers(ctx, base, first, Fp<P>* out, n)        out[i] = first * base^i on the device
+//   static WaveTables& tables(plonk_ctx*)                     this field's table cache of the context
+// ntt.hip instantiates it for BN254 Fr (the prover's field), ntt_bls.hip for BLS12-381 Fr (standalone transform).
+#pragma once
+#include <string.h>
+
+#include "ntt_wave.h"
+
+// the two-pass plan of a size (ntt.hip; field independent)
+bool ntt_wave_plan(const plonk_ctx* ctx, unsigned log_n, unsigned* log_r1, unsigned* log_r2);
+
+template <class P> static int wave_limb_table(plonk_ctx* ctx, std::map<unsigned, int32_t*>& cache, unsigned key, const Fp<P>* packed, size_t n,
+                                              const int32_t** out) {
+    auto it = cache.find(key);
+    if (it == cache.end()) {
+        void* d = nullptr;
+        Ninv261 ninv;
+        fpl_ninv261<P>(ninv.l);
+        if (hipMalloc(&d, n * NTT_SHOUP_STRIDE * sizeof(int32_t)) != hipSuccess) {
+            plonk_set_error("hipMalloc of a %zu-entry twiddle table failed", n);
+            return PLONK_ERR_NOMEM;
+        }
+        ctx->owned.push_back(d);
+        PLONK_LAUNCH(ntt_limb_table_kernel<P>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, packed, (int32_t*)d, n, 1, ninv);
+        PLONK_CHECK_HIP(hipGetLastError());
+        it = cache.emplace(key, (int32_t*)d).first;
+    }
+    *out = it->second;
+    return PLONK_OK;
+}
+
+// the twiddles of the wave kernel serving 2^log_n, in program order (built once per size and direction)
+template <class F> static int wave_program_table(plonk_ctx* ctx, unsigned log_n, bool inverse, const int32_t** out) {
+    typedef typename F::P P;
+    WaveTables& T = F::tables(ctx);
+    const unsigned key = log_n | (inverse ? 256u : 0u);
+    auto it = T.prog.find(key);
+    if (it == T.prog.end()) {
+        const Fp<P>* packed;
+        PLONK_TRY(F::packed_roots(ctx, log_n, inverse, &packed));
+        const unsigned log_e = (log_n & 1) ? 3 : 2, nlds = (log_n - 6 - log_e) / 2, stages = wavel_tw_stages(log_e, nlds);
+        const size_t entries = wavel_tw_offset(log_e, nlds, stages);
+        void* d = nullptr;
+        if (hipMalloc(&d, entries * NTT_SHOUP_STRIDE * sizeof(int32_t)) != hipSuccess) {
+            plonk_set_error("hipMalloc of a %zu-entry twiddle table failed", entries);
+            return PLONK_ERR_NOMEM;
+        }
+        ctx->owned.push_back(d);
+        Ninv261 ninv;
+        fpl_ninv261<P>(ninv.l);
+        for (unsigned st = 0; st < stages; st++) {
+            const unsigned nb = wavel_tw_nb(log_e, nlds, st), count = wavel_tw_count(log_e, nlds, st), mult = wavel_tw_mult(log_e, nlds, st);
+            for (unsigned f = 1; f <= count; f++) {
+                int32_t* block = (int32_t*)d + ((size_t)wavel_tw_offset(log_e, nlds, st) + (size_t)(f - 1) * nb) * NTT_SHOUP_STRIDE;
+                PLONK_LAUNCH(ntt_program_block_kernel<P>, dim3((nb + 63) / 64), dim3(64), 0, ctx->stream, packed, log_n, nb, f, mult, block, ninv);
+            }
+        }
+        PLONK_CHECK_HIP(hipGetLastError());
+        it = T.prog.emplace(key, (int32_t*)d).first;
+    }
+    *out = it->second;
+    return PLONK_OK;
+}
+
+// inter-pass twiddle tables as Shoup pairs; scaled: the hi table times 1/N (the inverse transform's factor, folded in)
+template <class F> static int wave_lo_hi(plonk_ctx* ctx, unsigned log_n, bool inverse, bool scaled, const int32_t** lo, const int32_t** hi) {
+    typedef typename F::P P;
+    WaveTables& T = F::tables(ctx);
+    const Fp<P>*plo, *phi;
+    PLONK_TRY(F::packed_lo_hi(ctx, log_n, inverse, &plo, &phi));
+    const unsigned key = log_n | (inverse ? 256u : 0u);
+    const unsigned log_lo = log_n < NTT_TW_LO_LOG ? log_n : NTT_TW_LO_LOG;
+    const size_t nhi = log_n > NTT_TW_LO_LOG ? ((size_t)1 << (log_n - NTT_TW_LO_LOG)) : 1;
+    PLONK_TRY(wave_limb_table<P>(ctx, T.lo, key, plo, (size_t)1 << log_lo, lo));
+    if (!scaled) return wave_limb_table<P>(ctx, T.hi, key, phi, nhi, hi);
+    if (T.hi.find(key | 512u) == T.hi.end()) {  // (1/N) * w_hi^k, built once
+        Fp<P> whi = F::root_of_unity(log_n, inverse);
+        for (unsigned i = 0; i < NTT_TW_LO_LOG; i++) whi = fp_sqr(whi);
+        void* tmp = nullptr;  // (not a scratch slot: callers hold those across this call)
+        if (hipMalloc(&tmp, nhi * sizeof(Fp<P>)) != hipSuccess) {
+            plonk_set_error("hipMalloc of a %zu-entry twiddle table failed", nhi);
+            return PLONK_ERR_NOMEM;
+        }
+        int rc = F::powers(ctx, whi, fp_inv(F::from_u64((uint64_t)1 << log_n)), (Fp<P>*)tmp, nhi);
+        if (rc == PLONK_OK) rc = wave_limb_table<P>(ctx, T.hi, key | 512u, (const Fp<P>*)tmp, nhi, hi);
+        hipStreamSynchronize(ctx->stream);  // the packed copy must outlive the conversion kernel only
+        hipFree(tmp);
+        return rc;
+    }
+    return wave_limb_table<P>(ctx, T.hi, key | 512u, (const Fp<P>*)nullptr, nhi, hi);
+}
+
+// the column pass's inter-pass twiddles as one table in usage order (ntt_interpass_table_kernel), when the context's
+// table budget allows its N * 80 bytes; *out = null otherwise (the caller falls back to the two small tables)
+template <class F> static int wave_interpass_table(plonk_ctx* ctx, unsigned log_n, unsigned log_r1, bool inverse, bool scaled, const int32_t** out) {
+    typedef typename F::P P;
+    WaveTables& T = F::tables(ctx);
+    *out = nullptr;
+    if (!ctx->ntt_table_budget || (log_r1 & 1)) return PLONK_OK;  // switched off (tables built earlier stay allocated, unused); E = 4 column kernels only
+    const unsigned key = log_n | (inverse ? 256u : 0u) | (scaled ? 512u : 0u) | (log_r1 << 12);
+    auto it = T.interpass.find(key);
+    if (it == T.interpass.end()) {
+        const size_t bytes = ((size_t)NTT_SHOUP_STRIDE * sizeof(int32_t)) << log_n;
+        if (ctx->ntt_tables_bytes + bytes > ctx->ntt_table_budget) return PLONK_OK;
+        const Fp<P>*plo, *phi;
+        PLONK_TRY(F::packed_lo_hi(ctx, log_n, inverse, &plo, &phi));
+        void* d = nullptr;
+        if (hipMalloc(&d, bytes) != hipSuccess) {
+            (void)hipGetLastError();  // not an error of the transform: the two small tables serve it
+            return PLONK_OK;
+        }
+        ctx->owned.push_back(d);
+        ctx->ntt_tables_bytes += bytes;
+        Ninv261 ninv;
+        fpl_ninv261<P>(ninv.l);
+        const Fp<P> scale = scaled ? fp_inv(F::from_u64((uint64_t)1 << log_n)) : fp_one<P>();
+        PLONK_LAUNCH(ntt_interpass_table_kernel<P>, dim3((unsigned)((((size_t)1 << log_n) + 255) / 256)), dim3(256), 0, ctx->stream, plo, phi, scale, log_n,
+                     log_r1, (int32_t*)d, ninv);
+        PLONK_CHECK_HIP(hipGetLastError());
+        it = T.interpass.emplace(key, (int32_t*)d).first;
+    }
+    *out = it->second;
+    return PLONK_OK;
+}
+
+// fpl_reduce_small's table of j * m: 2 FPL_RS_J + 1 entries of 12 words, built on the host once per context and field
+template <class F> static int wave_jm(plonk_ctx* ctx, const int32_t** out) {
+    WaveTables& T = F::tables(ctx);
+    if (!T.jm) {
+        int32_t host[(2 * FPL_RS_J + 1) * 12];
+        for (int j = -FPL_RS_J; j <= FPL_RS_J; j++) fpl_jm_entry<typename F::P>(j, host + (j + FPL_RS_J) * 12);
+        void* d = nullptr;
+        if (hipMalloc(&d, sizeof host) != hipSuccess) {
+            plonk_set_error("hipMalloc of the NTT range-reduction table failed");
+            return PLONK_ERR_NOMEM;
+        }
+        ctx->owned.push_back(d);
+        PLONK_CHECK_HIP(hipMemcpy(d, host, sizeof host, hipMemcpyHostToDevice));
+        T.jm = (const int32_t*)d;
+    }
+    *out = T.jm;
+    return PLONK_OK;
+}
+
+// the radix-8 / radix-4 roots w_8^k of a transform direction as Shoup pairs (kernel arguments), and the rest zeroed
+template <class F> static void wave_params_init(NttWaveT<typename F::P>* p, unsigned log_n, bool inverse) {
+    typedef typename F::P P;
+    memset(p, 0, sizeof *p);
+    p->log_n = log_n;
+    uint32_t ninv[9];
+    fpl_ninv261<P>(ninv);
+    const Fp<P> w8 = F::root_of_unity(3, inverse), w4 = fp_sqr(w8);
+    p->w8[0] = fpl_shoup_from_mont(w8, ninv);
+    p->w8[1] = fpl_shoup_from_mont(w4, ninv);
+    p->w8[2] = fpl_shoup_from_mont(fp_mul(w4, w8), ninv);
+}
+
+template <class F, unsigned LOG_E, unsigned NLDS> static int wave_launch_as(plonk_ctx* ctx, const NttWaveT<typename F::P>& q, unsigned grid_x, unsigned grid_y) {
+    typedef typename F::P P;
+    constexpr unsigned nt = 64u << (2 * NLDS);
+    const size_t shmem = NLDS ? (size_t)4 * nt * 36 : 0;  // one round of the wave-bit exchange: 4 elements of 9 words per thread
+    WaveTables& T = F::tables(ctx);
+    if (NLDS == 2 && !T.attr_set[LOG_E - 2]) {  // 144 KiB: above the default limit; a per-device attribute, tracked per context
+        PLONK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ntt_wavel_kernel<P, LOG_E, NLDS>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)(144 * 1024)));
+        T.attr_set[LOG_E - 2] = true;
+    }
+    void (*kern)(NttWaveT<P>) = ntt_wavel_kernel<P, LOG_E, NLDS>;  // (a template-id's comma would split the macro's arguments)
+    if constexpr (LOG_E == 2) {
+        if (q.tw_always == 2u) {  // column pass on the full inter-pass table
+            kern = ntt_wavel_column_kernel<P, LOG_E, NLDS>;
+            if (NLDS == 2 && !T.attr_set[2]) {
+                PLONK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(144 * 1024)));
+                T.attr_set[2] = true;
+            }
+        }
+    }
+    PLONK_LAUNCH(kern, dim3(grid_x, grid_y), dim3(nt), shmem, ctx->stream, q);
+    return PLONK_OK;
+}
+
+// log_r = 8, 10, 12: 4 elements per thread; 9, 11, 13: 8 elements per thread
+template <class F> static int wave_launch(plonk_ctx* ctx, const NttWaveT<typename F::P>& p, unsigned log_r, unsigned grid_x, unsigned grid_y) {
+    NttWaveT<typename F::P> q = p;
+    PLONK_TRY(wave_jm<F>(ctx, &q.jm));
+    switch (log_r) {
+        case 8: return wave_launch_as<F, 2, 0>(ctx, q, grid_x, grid_y);
+        case 10: return wave_launch_as<F, 2, 1>(ctx, q, grid_x, grid_y);
+        case 12: return wave_launch_as<F, 2, 2>(ctx, q, grid_x, grid_y);
+        case 9: return wave_launch_as<F, 3, 0>(ctx, q, grid_x, grid_y);
+        case 11: return wave_launch_as<F, 3, 1>(ctx, q, grid_x, grid_y);
+        case 13: return wave_launch_as<F, 3, 2>(ctx, q, grid_x, grid_y);
+    }
+    plonk_set_error("no wave kernel for a 2^%u-point transform", log_r);
+    return PLONK_ERR_ARG;
+}
+
+// one transform per batch entry: a single launch for 2^8 .. 2^13, columns then rows through scratch slot 0 for 2^16 .. 2^26
+template <class F>
+static int wave_run(plonk_ctx* ctx, const Fp<typename F::P>* in, Fp<typename F::P>* out, unsigned log_n, bool inverse, size_t batch, size_t in_len,
+                    size_t in_bstride, size_t out_bstride, const Fp<typename F::P>* in_scale, const Fp<typename F::P>* out_scale, bool scale_by_n_inv) {
+    typedef typename F::P P;
+    typedef Fp<P> E;
+    const size_t N = (size_t)1 << log_n;
+    unsigned log_r1 = 0, log_r2 = 0;
+    PLONK_REQUIRE(ntt_wave_plan(ctx, log_n, &log_r1, &log_r2), PLONK_ERR_ARG, "no wave-kernel plan for 2^%u points", log_n);
+    NttWaveT<P> p;
+    wave_params_init<F>(&p, log_n, inverse);
+    E n_inv = fp_zero<P>();
+    if (scale_by_n_inv) n_inv = fp_inv(F::from_u64((uint64_t)N));
+    const unsigned in_len32 = (unsigned)(in_len < N ? in_len : N);
+    if (!log_r2) {
+        p.in = in;
+        p.out = out;
+        p.in_bstride = in_bstride;
+        p.out_bstride = out_bstride;
+        p.in_len = in_len32;
+        PLONK_TRY(wave_program_table<F>(ctx, log_n, inverse, &p.roots));
+        p.in_scale = in_scale;
+        p.out_scale = out_scale;
+        p.out_scalar = n_inv;
+        p.has_out_scalar = scale_by_n_inv;
+        // an in-place transform is safe: every thread has read all of its inputs before any thread stores (the stages
+        // in between are separated by barriers for L > 0; for L = 0 the single wave runs in lock step)
+        PLONK_TRY(prof_begin(ctx, "ntt_pass", 64.0 * (double)N * (double)batch));
+        for (size_t b0 = 0; b0 < batch; b0 += (size_t)1 << 30) {  // grid.x carries the batch
+            const size_t nb = batch - b0 < ((size_t)1 << 30) ? batch - b0 : (size_t)1 << 30;
+            NttWaveT<P> q = p;
+            q.in = in + b0 * in_bstride;
+            q.out = out + b0 * out_bstride;
+            PLONK_TRY(wave_launch<F>(ctx, q, log_n, (unsigned)nb, 1));
+        }
+        PLONK_TRY(prof_end(ctx));
+        PLONK_CHECK_HIP(hipGetLastError());
+        return PLONK_OK;
+    }
+    // two passes through a scratch copy: columns (R1 points each, stride R2), then rows (R2 points each)
+    PLONK_REQUIRE(batch <= 65535, PLONK_ERR_ARG, "NTT batch %zu exceeds 65535", batch);
+    void* sc;
+    PLONK_TRY(ctx_scratch(ctx, 0, batch * N * sizeof(E), &sc));
+    E* tmp = (E*)sc;
+    const int32_t* full;
+    PLONK_TRY(wave_interpass_table<F>(ctx, log_n, log_r1, inverse, scale_by_n_inv, &full));
+    if (full) {
+        p.tw_lo = full;
+        p.tw_always = 2u;
+    } else {
+        PLONK_TRY(wave_lo_hi<F>(ctx, log_n, inverse, scale_by_n_inv, &p.tw_lo, &p.tw_hi));
+        p.tw_always = scale_by_n_inv ? 1u : 0u;
+    }
+    NttWaveT<P> a = p;
+    a.mode = 1;
+    a.log_other = log_r2;
+    a.in = in;
+    a.out = tmp;
+    a.in_bstride = in_bstride;
+    a.out_bstride = N;
+    a.in_len = in_len32;
+    a.in_scale = in_scale;
+    PLONK_TRY(wave_program_table<F>(ctx, log_r1, inverse, &a.roots));
+    NttWaveT<P> c = p;
+    c.mode = 2;
+    c.log_other = log_r1;
+    c.in = tmp;
+    c.out = out;
+    c.in_bstride = N;
+    c.out_bstride = out_bstride;
+    c.in_len = (unsigned)N;
+    c.out_scale = out_scale;
+    c.has_out_scalar = 0;  // 1/N went into the column pass's inter-pass twiddles (tw_hi)
+    c.tw_always = 0;
+    PLONK_TRY(wave_program_table<F>(ctx, log_r2, inverse, &c.roots));
+    PLONK_TRY(prof_begin(ctx, "ntt_pass", 32.0 * (double)N * (double)batch));
+    PLONK_TRY(wave_launch<F>(ctx, a, log_r1, 1u << log_r2, (unsigned)batch));
+    PLONK_TRY(prof_end(ctx));
+    PLONK_TRY(prof_begin(ctx, "ntt_pass", 32.0 * (double)N * (double)batch));
+    PLONK_TRY(wave_launch<F>(ctx, c, log_r2, 1u << log_r1, (unsigned)batch));
+    PLONK_TRY(prof_end(ctx));
+    PLONK_CHECK_HIP(hipGetLastError());
+    return PLONK_OK;
+}

@@ -45,12 +45,21 @@ int plonk_use_device(int device);
         if (rc_ != PLONK_OK) return rc_; \
     } while (0)
 
+// device tables of the wave NTT kernels for one field, cached per context (the memory is in plonk_ctx::owned)
+struct WaveTables {
+    std::map<unsigned, int32_t*> prog, lo, hi;  // keys: log2(size) | inverse << 8 (| 512: hi scaled by 1/N)
+    std::map<unsigned, int32_t*> interpass;     // full inter-pass tables: log2 N | inverse << 8 | scaled << 9 | log2 R1 << 12
+    const int32_t* jm = nullptr;                // fpl_reduce_small's multiples of the modulus
+    bool attr_set[3] = {false, false, false};   // hipFuncSetAttribute is per device: tracked per context (E = 4, E = 8, E = 4 column kernel)
+    std::map<unsigned, void*> packed[3];        // packed source tables (full, lo, hi) of a field that has no cache of its own (BLS12-381 Fr)
+};
+
 struct NttTables {
     // keys are log2(size) | inverse << 8
     std::map<unsigned, Fr*> small;   // w_R^k, k < R/2              (per-pass LDS twiddles)
     std::map<unsigned, Fr*> lo, hi;  // w_N^e = lo[e & 1023] * hi[e >> 10]   (inter-pass twiddles)
     std::map<unsigned, Fr*> full;    // w_N^k, k < N                 (barycentric / permutation argument)
-    std::map<unsigned, int32_t*> full_l, lo_l, hi_l;  // the same tables as 29-bit limbs, 12 words per entry (wave NTT kernels)
+    WaveTables wave;                 // the wave NTT kernels' tables for BN254 Fr (ntt_wave_host.h)
 };
 
 // One lookup table per (process, device, base set), shared by every plonk_srs / context / stream that
@@ -102,7 +111,7 @@ struct plonk_ctx {
     int msm_lookup_mode = 0;         // 0 auto (fixed SRS only), 1 off, 2 force msm_lookup_bits for every base set
     unsigned msm_lookup_bits = 0;    // 0 = largest window whose table fits the budget
     size_t msm_lookup_budget = 0;    // bytes; 0 = default (PLONK_MSM_TABLE_GB if set, else 4 GiB)
-    bool ntt_attr_set = false, msm_attr_set = false, ntt_wavel_attr_set[2] = {false, false};  // hipFuncSetAttribute is per device: tracked per context
+    bool ntt_attr_set = false, msm_attr_set = false;  // hipFuncSetAttribute is per device: tracked per context
     // per-kernel HIP-event profiling (bench.py roofline): one record per instrumented launch
     struct ProfRec { const char* name; hipEvent_t a, b; double algo_bytes; };
     bool profiling = false;
@@ -110,7 +119,8 @@ struct plonk_ctx {
     std::vector<hipEvent_t> event_pool;
     unsigned ntt_tile_log = 12, ntt_single_log = 11, ntt_radix_log = 10;
     bool ntt_adaptive_tiles = true;
-    const int32_t* ntt_jm = nullptr;  // fpl_reduce_small's table (device), built on first use by the limb-form NTT kernel
+    WaveTables wave_bls;  // the same for the standalone BLS12-381 Fr transform (ntt_bls.hip)
+    size_t ntt_table_budget = (size_t)4 << 30, ntt_tables_bytes = 0;  // full inter-pass twiddle tables (80 B per point and direction): plonk_ntt_set_table_budget
     unsigned char ntt_split[32] = {0};  // plonk_ntt_set_split: log2 R1 of the two-pass wave plan per log2 N (0 = default)
     unsigned ntt_kind = 0;  // 0 = auto (wave kernels where they apply, else LDS kernels), 1 / 2 = force an LDS kernel, 4 = auto among the LDS kernels, 5 = force wave
 };

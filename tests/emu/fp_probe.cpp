@@ -2,6 +2,7 @@
 // TEST INFRASTRUCTURE ONLY: lets tests/test_emu_primitives.py compare the primitives with Python ints.
 #include "fp.h"
 #include "g1.h"
+#include "bls12_381_constants.h"
 
 template <class P> static void binop(int op, const uint32_t* a, const uint32_t* b, uint32_t* out) {
     Fp<P> x, y, r;
@@ -23,6 +24,7 @@ template <class P> static void binop(int op, const uint32_t* a, const uint32_t* 
 }
 extern "C" void probe_fr(int op, const uint32_t* a, const uint32_t* b, uint32_t* out) { binop<FrParams>(op, a, b, out); }
 extern "C" void probe_fq(int op, const uint32_t* a, const uint32_t* b, uint32_t* out) { binop<FqParams>(op, a, b, out); }
+extern "C" void probe_bls_fr(int op, const uint32_t* a, const uint32_t* b, uint32_t* out) { binop<BlsFrParams>(op, a, b, out); }
 
 // points: affine in = 16 words (x,y Montgomery; (0,0) = identity); xyzz = 32 words
 extern "C" void probe_g1(int op, const uint32_t* p, const uint32_t* q, uint32_t* out) {
@@ -105,18 +107,20 @@ extern "C" void probe_fpl(int op, const int32_t* a, const int32_t* b, const int3
     memcpy(out, r.l, 36);
 }
 
-// fpl_mul_shoup on Fr: a = 9 signed limbs, wt = a constant in canonical Montgomery form (8 packed words);
-// out[0..8] = a * w (limbs), out[9..17] = w, out[18..26] = wp = floor(w 2^261 / r)
-extern "C" void probe_fpl_shoup(const int32_t* a, const uint32_t* wt, int32_t* out) {
-    FpL<FrParams> x;
+// fpl_mul_shoup: a = 9 signed limbs, wt = a constant in canonical Montgomery form (8 packed words);
+// out[0..8] = a * w (limbs), out[9..17] = w, out[18..26] = wp = floor(w 2^261 / m)
+template <class P> static void shoup_probe(const int32_t* a, const uint32_t* wt, int32_t* out) {
+    FpL<P> x;
     memcpy(x.l, a, 36);
-    Fp<FrParams> c;
+    Fp<P> c;
     memcpy(c.v, wt, 32);
     uint32_t ninv[9];
-    fpl_ninv261<FrParams>(ninv);
-    const FpLS<FrParams> s = fpl_shoup_from_mont(c, ninv);
-    const FpL<FrParams> r = fpl_mul_shoup(x, s);
+    fpl_ninv261<P>(ninv);
+    const FpLS<P> s = fpl_shoup_from_mont(c, ninv);
+    const FpL<P> r = fpl_mul_shoup(x, s);
     memcpy(out, r.l, 36);
     memcpy(out + 9, s.w, 36);
     memcpy(out + 18, s.wp, 36);
 }
+extern "C" void probe_fpl_shoup(const int32_t* a, const uint32_t* wt, int32_t* out) { shoup_probe<FrParams>(a, wt, out); }
+extern "C" void probe_fpl_shoup_bls(const int32_t* a, const uint32_t* wt, int32_t* out) { shoup_probe<BlsFrParams>(a, wt, out); }

@@ -100,6 +100,55 @@ def ntt_roundtrip_and_linearity(log_n, seed=5):
     assert roots[:4] == [1, w, w * w % R_MOD, pow(w, 3, R_MOD)] and roots[n - 1] == pow(w, n - 1, R_MOD)
 
 
+def bls_ntt_vs_oracle(log_ns, seed0=40, batch=1):
+    """The standalone BLS12-381 Fr transform (plonk_bls_fr_ntt) against the C oracle's oracle_bls_fr_ntt: random inputs,
+    inputs at the field's extremes (every element r - 1; Montgomery representations with every limb at 2^29 - 1), forward
+    and inverse, in place, and batched."""
+    import random
+
+    from oracle import c_oracle
+    from plonkathon_amd import bls12_381 as bls
+
+    m = bls.MODULUS
+    le = lambda v: b"".join(int(x).to_bytes(32, "little") for x in v)
+    r_inv = pow(1 << 261, -1, m)
+    max_mont = ((((m >> 232) - 1) << 232) | ((1 << 232) - 1)) * r_inv % m
+    for log_n in log_ns:
+        n = 1 << log_n
+        rng = random.Random(seed0 + log_n)
+        slots_n = 8 if log_n & 1 else 4
+        nt = n // slots_n
+        cases = [("random", [rng.randrange(m) for _ in range(n)]), ("max", [m - 1] * n), ("alt", [(m - 1) * (i & 1) for i in range(n)]),
+                 ("limbs_all", [max_mont] * n), ("limbs_even", [max_mont if (0x55 >> (i // nt)) & 1 else 0 for i in range(n)]),
+                 ("limbs_low", [max_mont if i // nt < slots_n // 2 else 0 for i in range(n)])]
+        if log_n > 13:
+            cases = cases[:2]
+        for name, v in cases:
+            raw = le(v)
+            for inverse in (False, True):
+                want = c_oracle.fr_ntt_bytes(raw, inverse, "bls12_381")
+                d = bls.upload(raw)
+                assert bls.download(bls.ntt(d, log_n, inverse)) == want, (name, log_n, inverse)
+                assert bls.download(bls.ntt(d, log_n, inverse, out=d)) == want, ("in place", name, log_n, inverse)
+        if batch > 1:
+            vs = [le([rng.randrange(m) for _ in range(n)]) for _ in range(batch)]
+            got = bls.download(bls.ntt(bls.upload(b"".join(vs)), log_n, False, batch))
+            assert got == b"".join(c_oracle.fr_ntt_bytes(v, False, "bls12_381") for v in vs), ("batch", log_n)
+    # the delta at index 1 transforms to the powers of the crate's root of unity squared down; bad inputs are refused
+    n = 1 << log_ns[0]
+    roots = bls.ntt_ints([0, 1] + [0] * (n - 2))
+    w = bls.root_of_unity(n)
+    assert roots[:3] == [1, w, w * w % m] and roots[n - 1] == pow(w, n - 1, m)
+    assert bls.root_of_unity(1 << 32) == 0x16A2A19EDFE81F20D09B681922C813B4B63683508C2280B93829971F439F0D2B
+    for bad in (lambda: bls.upload(le([m])), lambda: bls.ntt(bls.upload(le([1] * 128)), 7), lambda: bls.ntt(bls.upload(bytes(32 << 14)), 14)):
+        try:
+            bad()
+        except Exception as e:
+            assert "BLS12-381" in str(e) or "canonical" in str(e), e
+        else:
+            raise AssertionError("bad BLS12-381 input accepted")
+
+
 def round_kernels_vs_oracle(log_ns=(3, 4, 6)):
     """The fused round kernels of the C-ABI on their own against the oracle's Polynomial arithmetic (the reference's
     formulas of prover.py:121-146 and 188-203 spelled out operator by operator), plus plonk_fr_powers / plonk_fr_equal."""

@@ -52,6 +52,12 @@ def test_ntt_extreme_inputs(emu):
     pc.ntt_extreme_limbs((8, 9, 10, 11, 12))
 
 
+def test_bls12_381_ntt(emu):
+    """One size per wave kernel (E = 4 and 8; 0, 1, 2 LDS stages) with the emulator's range checks on the 255-bit modulus."""
+    pc.bls_ntt_vs_oracle((8, 9, 10, 11), batch=3)
+    pc.bls_ntt_vs_oracle((12, 13), seed0=77)
+
+
 def test_poly_golden(emu):
     pc.poly_golden(max_log_n=11)
 
@@ -200,6 +206,14 @@ def test_ntt_two_pass_wave_kernel(emu):
     for log_n in (16, 17):
         v = pc.rand_vec(4000 + log_n, 1 << log_n)
         assert pc.ints(pc.P(v, Basis.MONOMIAL).fft()) == c_oracle.fr_ntt(v), log_n
+    try:  # the inter-pass twiddles as two factors from the small tables (no budget for the full table), both directions
+        check(ctx.L.plonk_ntt_set_table_budget(ctx.handle, 0))
+        v = pc.rand_vec(4016, 1 << 16)
+        assert pc.ints(pc.P(v, Basis.MONOMIAL).fft()) == c_oracle.fr_ntt(v)
+        assert pc.ints(pc.P(v, Basis.LAGRANGE).ifft()) == c_oracle.fr_ntt(v, True)
+    finally:
+        check(ctx.L.plonk_ntt_set_table_budget(ctx.handle, 4 << 30))
+    assert pc.ints(pc.P(v, Basis.LAGRANGE).ifft()) == c_oracle.fr_ntt(v, True)  # ... and from the full table (1/N folded in)
     try:
         check(ctx.L.plonk_ntt_set_split(ctx.handle, 18, 10))
         v = pc.rand_vec(4018, 1 << 18)
@@ -209,6 +223,11 @@ def test_ntt_two_pass_wave_kernel(emu):
         assert ctx.L.plonk_ntt_set_split(ctx.handle, 18, 14) != 0 and ctx.L.plonk_ntt_set_split(ctx.handle, 15, 8) != 0
     finally:
         check(ctx.L.plonk_ntt_set_split(ctx.handle, 18, 0))
+
+
+def test_bls12_381_ntt_two_pass(emu):
+    """2^16 = 2^8 x 2^8 over the BLS12-381 scalar field (inter-pass twiddles, 1/N folded into the hi table)."""
+    pc.bls_ntt_vs_oracle((16,), seed0=91)
 
 
 def test_async_upload(emu):

@@ -36,7 +36,10 @@ def _call(fn, op, a, b=0):
     return _f(out)
 
 
-@pytest.mark.parametrize("name,m", [("probe_fr", field.R_MOD), ("probe_fq", field.Q_MOD)])
+BLS_R = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001  # BLS12-381 Fr (ntt_bls.hip): 255 bits, 4m > 2^256
+
+
+@pytest.mark.parametrize("name,m", [("probe_fr", field.R_MOD), ("probe_fq", field.Q_MOD), ("probe_bls_fr", BLS_R)])
 def test_field_ops(probe, name, m):
     fn = getattr(probe, name)
     Rm, Ri = R261 % m, pow(R261 % m, -1, m)
@@ -199,11 +202,11 @@ def test_signed_limb_arithmetic_at_the_bounds(probe):
                 assert got % m == v % m
 
 
-def test_shoup_multiplication_by_a_constant(probe):
+@pytest.mark.parametrize("fn_name,m,gen,reach", [("probe_fpl_shoup", field.R_MOD, 5, 128), ("probe_fpl_shoup_bls", BLS_R, 7, 56)])
+def test_shoup_multiplication_by_a_constant(probe, fn_name, m, gen, reach):
     """fpl_mul_shoup (the NTT kernels' twiddle multiplication): the Shoup pair (w, floor(w 2^261 / r)) derived from the
-    Montgomery form of a constant, and a * w for operands across fpl_mul's operand range — congruence mod r, result
-    within (-1.8 r, 2.8 r), limbs normalised."""
-    m = field.R_MOD
+    Montgomery form of a constant, and a * w for operands across the documented range (|a| < 128 r for BN254, < 56 r for
+    BLS12-381 Fr where R / r is 70.7 instead of 169) — congruence mod r, result within (-1.8 r, 2.8 r), limbs normalised."""
     L = (1 << 29) - 1
     rng = random.Random(11)
     I9, U8, I27 = ctypes.c_int32 * 9, ctypes.c_uint32 * 8, ctypes.c_int32 * 27
@@ -211,22 +214,22 @@ def test_shoup_multiplication_by_a_constant(probe):
     def val(l):
         return sum(int(v) << (29 * i) for i, v in enumerate(l))
 
-    consts = [0, 1, 2, m - 1, m - 2, (m - 1) // 2, 5, pow(5, (m - 1) // 2048, m)] + [rng.randrange(m) for _ in range(24)]
+    consts = [0, 1, 2, m - 1, m - 2, (m - 1) // 2, gen, pow(gen, (m - 1) // 2048, m)] + [rng.randrange(m) for _ in range(24)]
     for w in consts:
         wt = w * R261 % m
         words = U8(*[(wt >> (32 * i)) & 0xFFFFFFFF for i in range(8)])
         operands = []
-        for top in (-120, -17, -2, -1, 0, 1, 2, 16, 127):  # |value| up to 128 r
+        for top in (-120, -55, -17, -2, -1, 0, 1, 2, 16, 55, 127):  # |value| up to 128 r
             for kind in range(4):
                 lo = [L] * 8 if kind == 0 else [-L] * 8 if kind == 1 else [2 * L if i % 2 else -L for i in range(8)] if kind == 2 else [rng.randrange(-L, 2 * L) for _ in range(8)]
                 operands.append(lo + [(top * m) >> 232])
         operands.append([int(1.26 * (1 << 30))] * 8 + [0])   # the largest limbs fpl_mul's callers produce
         operands.append([-int(1.26 * (1 << 30))] * 8 + [0])
         for a in operands:
-            if abs(val(a)) >= 128 * m:
+            if abs(val(a)) >= reach * m:
                 continue
             out = I27()
-            probe.probe_fpl_shoup(I9(*a), words, out)
+            getattr(probe, fn_name)(I9(*a), words, out)
             out = list(out)
             r, wl, wp = out[:9], out[9:18], out[18:]
             assert val(wl) == w and val(wp) == (w << 261) // m

@@ -297,6 +297,49 @@ def test_ntt_exact_vs_c_oracle_at_full_size(log_n, split):
         check(ctx.L.plonk_ntt_set_split(ctx.handle, log_n, 0))
 
 
+def test_ntt_inter_pass_twiddles_from_the_small_tables():
+    """Two-pass transforms with no budget for the full inter-pass table (plonk_ntt_set_table_budget(0): two factors per element
+    from the 1 K and N / 1 K tables): 2^18 and 2^20 exact in both directions; the default path is every other test."""
+    from oracle import c_oracle
+    from plonkathon_amd import Basis, get_context
+    from plonkathon_amd._lib import check
+
+    ctx = get_context()
+    try:
+        check(ctx.L.plonk_ntt_set_table_budget(ctx.handle, 0))
+        for log_n in (18, 20):
+            v = pc.rand_vec(4400 + log_n, 1 << log_n)
+            assert pc.ints(pc.P(v, Basis.MONOMIAL).fft()) == c_oracle.fr_ntt(v)
+            assert pc.ints(pc.P(v, Basis.LAGRANGE).ifft()) == c_oracle.fr_ntt(v, True)
+    finally:
+        check(ctx.L.plonk_ntt_set_table_budget(ctx.handle, 4 << 30))
+
+
+def test_bls12_381_ntt_every_wave_kernel():
+    """The standalone BLS12-381 Fr transform, one size per wave kernel plus a two-pass size: random and extreme inputs, both
+    directions, in place, batched, bad inputs refused — bit-exact against the C oracle's oracle_bls_fr_ntt."""
+    pc.bls_ntt_vs_oracle((8, 9, 10, 11, 12, 13), batch=5)
+    pc.bls_ntt_vs_oracle((16, 17, 19), seed0=300)
+
+
+@pytest.mark.parametrize("log_n", [20, 22, 24])
+def test_bls12_381_ntt_exact_at_microbench_sizes(log_n):
+    """BASELINE configs[3]'s sizes over the field its metric is quoted on: bit-exact forward, inverse in place, on bytes."""
+    import numpy as np
+
+    from oracle import c_oracle
+    from plonkathon_amd import bls12_381 as bls
+
+    n = 1 << log_n
+    a = np.random.default_rng(7000 + log_n).integers(0, 256, size=(n, 32), dtype=np.uint8)
+    a[:, 31] &= 0x3F  # < 2^254 < r
+    raw = a.tobytes()
+    d = bls.upload(raw)
+    assert bls.download(bls.ntt(d, log_n)) == c_oracle.fr_ntt_bytes(raw, False, "bls12_381"), "forward"
+    bls.ntt(d, log_n, True, out=d)
+    assert bls.download(d) == c_oracle.fr_ntt_bytes(raw, True, "bls12_381"), "inverse"
+
+
 def test_batched_msm_vs_c_oracle(setup):
     """A batch of 12 full-size MSMs over the shared SRS (the shape rounds 1-5 launch) against the C oracle."""
     import ctypes

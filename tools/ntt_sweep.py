@@ -26,11 +26,16 @@ ap.add_argument("--reps", type=int, default=7)
 ap.add_argument("--tag", default="")
 ap.add_argument("--directions", default="fwd")      # fwd,inv
 ap.add_argument("--placements", default="out")      # out,in
+ap.add_argument("--table-gb", type=float, default=-1.0)  # budget of the full inter-pass twiddle tables (0 = two small tables; default: the library's 4 GiB)
+ap.add_argument("--field", default="bn254")         # bn254 | bls12_381 (plonk_bls_fr_ntt: the wave kernels' sizes only)
 args = ap.parse_args()
 
 ctx = Context(0)
 set_context(ctx)
 L, H = ctx.L, ctx.handle
+NTT = L.plonk_bls_fr_ntt if args.field == "bls12_381" else L.plonk_fr_ntt
+if args.table_gb >= 0:
+    check(L.plonk_ntt_set_table_budget(H, int(args.table_gb * (1 << 30))))
 rng = random.Random(1)
 src = ctx.upload_ints([rng.randrange(1 << 253) for _ in range(4096)])
 
@@ -52,6 +57,8 @@ else:
     shapes = [(k, (1 << 22) >> k, 0) for k in range(8, 14)] + [(11, 512, 0), (13, 512, 0), (10, 512, 0), (12, 512, 0)]
     shapes += [(k, 1, 0) for k in range(14, 25)]
     shapes += [(16, 256, 0), (18, 64, 0), (20, 16, 0), (22, 4, 0)]  # constant work: 2^24 elements
+    if args.field == "bls12_381":
+        shapes = [s for s in shapes if s[0] not in (14, 15)]
 
 for kind in [int(k) for k in args.kinds.split(",")]:
     check(L.plonk_ntt_select_kernel(H, kind))
@@ -66,15 +73,15 @@ for kind in [int(k) for k in args.kinds.split(",")]:
             for place in args.placements.split(","):
                 o = buf if place == "in" else dst
                 for _ in range(2):
-                    check(L.plonk_fr_ntt(H, buf.ptr, o.ptr, log_n, inv, batch))
+                    check(NTT(H, buf.ptr, o.ptr, log_n, inv, batch))
                 ctx.sync()
                 times = []
                 for _ in range(args.reps):
                     ctx.timer_start()
-                    check(L.plonk_fr_ntt(H, buf.ptr, o.ptr, log_n, inv, batch))
+                    check(NTT(H, buf.ptr, o.ptr, log_n, inv, batch))
                     times.append(ctx.timer_stop_ms())
                 best = min(times)
-                print(json.dumps({"what": "ntt", "tag": args.tag, "kind": kind, "log_n": log_n, "batch": batch, "split": split,
+                print(json.dumps({"what": "ntt", "field": args.field, "tag": args.tag, "kind": kind, "log_n": log_n, "batch": batch, "split": split,
                                   "dir": direction, "place": place, "ms": round(best, 5), "ms_median": round(sorted(times)[len(times) // 2], 5),
                                   "Gelem_s": round(n * batch / best / 1e6, 3),
                                   "hbm_frac": round(64.0 * n * batch / (best * 1e-3) / HBM_PEAK, 4)}), flush=True)

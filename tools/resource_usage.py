@@ -9,7 +9,7 @@ import subprocess
 import sys
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "plonkathon_amd", "csrc")
-FILES = sys.argv[1:] or ["ntt.hip", "fr_ops.hip", "msm.hip", "prover.hip", "api.hip", "transcript_api.hip"]
+FILES = sys.argv[1:] or ["ntt.hip", "ntt_bls.hip", "g1_codec.hip", "fr_ops.hip", "msm.hip", "prover.hip", "api.hip", "transcript_api.hip"]
 KEYS = ("VGPRs", "AGPRs", "TotalSGPRs", "ScratchSize [bytes/lane]", "Occupancy [waves/SIMD]", "LDS Size [bytes/block]", "SGPRs Spill", "VGPRs Spill")
 
 print("%-78s %6s %6s %6s %8s %5s %8s %7s %7s" % ("kernel", "VGPR", "AGPR", "SGPR", "scratch", "occ", "LDS", "sSpill", "vSpill"))
