@@ -246,8 +246,10 @@ static int wave_run(plonk_ctx* ctx, const Fp<typename F::P>* in, Fp<typename F::
     void* sc;
     PLONK_TRY(ctx_scratch(ctx, 0, batch * N * sizeof(E), &sc));
     E* tmp = (E*)sc;
-    const int32_t* full;
-    PLONK_TRY(wave_interpass_table<F>(ctx, log_n, log_r1, inverse, scale_by_n_inv, &full));
+    // (measured, profiles/r03_m_ntt_sweep.jsonl: the table wins 4-10 % wherever the column pass fills the chip; a lone 2^18 —
+    // one workgroup per CU, every load latency exposed — is 5 % faster on the small, L2-resident tables)
+    const int32_t* full = nullptr;
+    if (log_n <= 16 || ((size_t)batch << log_n) >= ((size_t)1 << 19)) PLONK_TRY(wave_interpass_table<F>(ctx, log_n, log_r1, inverse, scale_by_n_inv, &full));
     if (full) {
         p.tw_lo = full;
         p.tw_always = 2u;

@@ -29,4 +29,4 @@ for log_n in SHAPES:
         check(L.plonk_fr_ntt(H, buf.ptr, out.ptr, log_n, 0, 1))
     ctx.sync()
     del buf, out
-print(json.dumps({"plan": [[log_n, REPS, 2] for log_n in SHAPES], "kernel_substring": "ntt_wavel_kernel"}))
+print(json.dumps({"plan": [[log_n, REPS, 2] for log_n in SHAPES], "kernel_substring": "ntt_wavel_"}))
