@@ -795,10 +795,13 @@ def main():
         line["msm"] = {"msms_per_s_2^11_x4608": world * 4608 / (ms_msm * 1e-3), "ms_4608": ms_msm, "replicas": world}
         ms20 = sweep["2^20"]["fwd"]["ms"]
         ach = 64.0 * (1 << 20) / (ms20 * 1e-3) / 1e9  # per GPU
-        line["roofline_ntt"] = {"kernel": "ntt_wavel_kernel (N = 2^20 = 2^10 x 2^10, two launches)", "bound": "hbm", "achieved": ach,
-                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": pmc.get("ntt", {}).get("ntt_2^20"),
-                                "traffic_source": pmc_src,
-                                "note": "ALU-bound on the 254-bit multiplication: ~10.5 N multiplications (two passes + inter-pass "
+        line["roofline_ntt"] = {"kernel": "ntt_wavel_column_kernel + ntt_wavel_kernel (N = 2^20 = 2^10 x 2^10, two launches)", "bound": "hbm",
+                                "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                                "traffic": pmc.get("ntt", {}).get("ntt_2^20"), "traffic_source": pmc_src,
+                                "traffic_note": "includes 80 N bytes of inter-pass twiddles read from the table in usage order (one "
+                                                "multiplication per element instead of two, a deliberate bytes-for-instructions trade; "
+                                                "plonk_ntt_set_table_budget(0) gives 2.07 x the algorithmic 64 N instead of 3.3 x and a 6 % slower transform)",
+                                "note": "ALU-bound on the 254-bit multiplication: ~9.5 N multiplications (two passes + inter-pass "
                                         "twiddles) at ~150-170 G/s chip-wide bound the transform near 10 % of HBM peak (DESIGN.md 4.1)"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         dt, oproof, prim = cpu_baseline()
