@@ -548,7 +548,7 @@ bool ntt_wave_plan(const plonk_ctx* ctx, unsigned log_n, unsigned* log_r1, unsig
     }
     if (log_n < 16 || log_n > 26) return false;
     //                                   2^16 17  18  19  20  21  22  23  24  25  26
-    static const unsigned char best[] = {8,   9, 10, 10, 10, 11, 13, 10, 11, 12, 13};  // (2^23: 10 + 13 since the column pass reads its twiddles from one table)
+    static const unsigned char best[] = {8,   8, 10, 10, 10, 11, 11, 10, 11, 12, 13};  // (profiles/r03_r_ntt_splits_final.jsonl: every admissible split, final kernels)
     unsigned r1 = best[log_n - 16];
     if (ctx && log_n < sizeof ctx->ntt_split / sizeof ctx->ntt_split[0] && ctx->ntt_split[log_n]) r1 = ctx->ntt_split[log_n];
     if (r1 < 8 || r1 > 13 || log_n - r1 < 8 || log_n - r1 > 13) return false;

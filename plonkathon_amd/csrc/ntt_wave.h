@@ -431,6 +431,9 @@ __global__ void __launch_bounds__(64u << (2 * NLDS), (WavelCfg<LOG_E, NLDS>::WAV
     PLONK_DYN_SMEM(smem);
     wavel_transform<P, LOG_E, NLDS>(p, smem);
 }
+// (E = 4 only.  The E = 8 forms spill at 128 registers with every variant of the table epilogue; compiled for three waves per
+// SIMD — 132-135 registers, no scratch — they were measured: batches gain 4-5 %, but a lone 2^21 loses 8 % and a lone 2^24
+// 8 %, profiles/r03_q_ntt_e8_column_table_ab.jsonl)
 template <class P, unsigned LOG_E, unsigned NLDS>
 __global__ void __launch_bounds__(64u << (2 * NLDS), (WavelCfg<LOG_E, NLDS>::WAVES)) ntt_wavel_column_kernel(NttWaveT<P> p) {
     PLONK_DYN_SMEM(smem);
