@@ -270,10 +270,11 @@ def _random_canonical_bytes(seed, n):
     return a.tobytes()
 
 
-@pytest.mark.parametrize("log_n,split", [(24, 0), (24, 13), (23, 0)])
+@pytest.mark.parametrize("log_n,split", [(24, 0), (24, 13), (24, 12), (23, 0)])
 def test_ntt_exact_vs_c_oracle_at_full_size(log_n, split):
     """BASELINE configs[3]'s largest size (and its neighbours), bit-exact in both directions against the C oracle, on bytes
-    (16 M Python ints would take minutes); 2^24 on both of its splits (2^12 x 2^12, the default, and 2^13 x 2^11)."""
+    (16 M Python ints would take minutes); 2^24 on three splits (2^11 x 2^13, the default; 2^13 x 2^11; 2^12 x 2^12, whose column
+    pass reads its inter-pass twiddles from the 1.3 GB table), 2^23 on its default (2^10 x 2^13, on the table as well)."""
     import ctypes
 
     from oracle import c_oracle
@@ -311,6 +312,10 @@ def test_ntt_inter_pass_twiddles_from_the_small_tables():
             v = pc.rand_vec(4400 + log_n, 1 << log_n)
             assert pc.ints(pc.P(v, Basis.MONOMIAL).fft()) == c_oracle.fr_ntt(v)
             assert pc.ints(pc.P(v, Basis.LAGRANGE).ifft()) == c_oracle.fr_ntt(v, True)
+        # a budget nothing new fits into: tables built by earlier tests keep serving, a size without one falls back
+        check(ctx.L.plonk_ntt_set_table_budget(ctx.handle, 1))
+        v = pc.rand_vec(4419, 1 << 19)
+        assert pc.ints(pc.P(v, Basis.MONOMIAL).fft()) == c_oracle.fr_ntt(v)
     finally:
         check(ctx.L.plonk_ntt_set_table_budget(ctx.handle, 4 << 30))
 
