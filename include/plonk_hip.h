@@ -84,7 +84,8 @@ int plonk_fr_coset_to_coeffs(plonk_ctx* ctx, const void* d_in, void* d_out, unsi
 int plonk_ntt_configure(plonk_ctx* ctx, unsigned tile_log, unsigned single_pass_log, unsigned radix_log);
 /* kernel family: 0 = auto (what measures fastest on MI355X: the in-register "wave" kernels — 4 or 8 elements per
  * thread as signed 29-bit limbs, digits exchanged inside a wave by DPP / v_permlane16_swap / v_permlane32_swap, LDS only
- * across waves — for 2^8 .. 2^13 in one launch and 2^16 .. 2^26 as two passes of those; the LDS kernels elsewhere:
+ * across waves — for 2^8 .. 2^13 in one launch, 2^16 .. 2^26 as two passes of those, 2^14 and 2^15 as four-point column
+ * transforms + one pass; the LDS kernels elsewhere:
  * Stockham radix-8 for single-pass sizes, radix-2 stages otherwise), 1 = radix-2 stages, 2 = Stockham radix-8,
  * 4 = auto among the LDS kernels only (A/B runs), 5 = the wave kernels wherever they apply, whatever
  * plonk_ntt_configure says.  (3, round 2's packed-residue wave kernel, is gone.) */
@@ -105,7 +106,7 @@ int plonk_ntt_set_table_budget(plonk_ctx* ctx, size_t bytes);
  * standalone-NTT metric is quoted on.  The reference has no such field (curve.py:2: BN254 throughout), so this replaces no
  * reference call: it is poly.py:113-148's transform (natural order in and out, the inverse includes 1/N) with the modulus
  * and generator swapped, on the same wave kernels.  Elements are 32 bytes on the device like Fr (Montgomery form, R = 2^261);
- * plonk_mem_* allocate and move them.  Sizes: 2^8 .. 2^13 and 2^16 .. 2^26 (PLONK_ERR_ARG otherwise); in may equal out. */
+ * plonk_mem_* allocate and move them.  Sizes: 2^8 .. 2^26 (PLONK_ERR_ARG otherwise); in may equal out. */
 int plonk_bls_fr_upload(plonk_ctx* ctx, void* d_dst, const uint8_t* h_src_le32, size_t count);
 int plonk_bls_fr_download(plonk_ctx* ctx, uint8_t* h_dst_le32, const void* d_src, size_t count);
 int plonk_bls_fr_ntt(plonk_ctx* ctx, const void* d_in, void* d_out, unsigned log_n, int inverse, size_t batch);

@@ -3,7 +3,7 @@
 The reference is BN254 throughout (/root/reference/curve.py:2, 10-11); this module exists because BASELINE.json's
 north_star quotes a standalone NTT metric on this field.  It is the reference's transform (poly.py:113-148: natural order
 in and out, the inverse includes 1/N) with the modulus and generator swapped: w = 7^((r-1)/N), so w_{2^32} is the
-ROOT_OF_UNITY constant of the `bls12_381` crate.  Sizes: 2^8 .. 2^13 (one launch) and 2^16 .. 2^26 (two).
+ROOT_OF_UNITY constant of the `bls12_381` crate.  Sizes: 2^8 .. 2^13 (one launch) and 2^14 .. 2^26 (two).
 """
 from ._lib import check
 from .backend import DeviceBuffer, get_context

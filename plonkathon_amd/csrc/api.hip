@@ -310,7 +310,7 @@ int plonk_ntt_set_split(plonk_ctx* ctx, unsigned log_n, unsigned log_r1) {
 int plonk_ntt_get_split(plonk_ctx* ctx, unsigned log_n, unsigned* out_log_r1) {
     PLONK_REQUIRE(out_log_r1, PLONK_ERR_ARG, "bad argument");
     unsigned r1 = 0, r2 = 0;
-    PLONK_REQUIRE(ntt_wave_plan(ctx, log_n, &r1, &r2) && r2, PLONK_ERR_ARG, "2^%u is not a two-pass wave transform (2^16 .. 2^26)", log_n);
+    PLONK_REQUIRE(ntt_wave_plan(ctx, log_n, &r1, &r2) && r2 && r1 >= 8, PLONK_ERR_ARG, "2^%u is not a two-pass wave transform (2^16 .. 2^26)", log_n);
     *out_log_r1 = r1;
     return PLONK_OK;
 }

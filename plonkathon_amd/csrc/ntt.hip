@@ -546,6 +546,11 @@ bool ntt_wave_plan(const plonk_ctx* ctx, unsigned log_n, unsigned* log_r1, unsig
         *log_r2 = 0;
         return true;
     }
+    if (log_n == 14 || log_n == 15) {  // 4 x 2^12, 4 x 2^13: four-point column transforms (ntt_quad_column_kernel), then the wave kernel's rows
+        *log_r1 = 2;
+        *log_r2 = log_n - 2;
+        return true;
+    }
     if (log_n < 16 || log_n > 26) return false;
     //                                   2^16 17  18  19  20  21  22  23  24  25  26
     static const unsigned char best[] = {8,   8, 10, 10, 10, 11, 11, 10, 11, 12, 13};  // (profiles/r03_r_ntt_splits_final.jsonl: every admissible split, final kernels)
@@ -581,7 +586,7 @@ static int ntt_run_wave(plonk_ctx* ctx, const Fr* in, Fr* out, unsigned log_n, b
 int ntt_dist_plan(unsigned log_n, unsigned log_w, unsigned* log_r1, unsigned* log_r2) {
     unsigned r1 = 0, r2 = 0;
     // the default split (no per-context override: every rank must pick the same one)
-    PLONK_REQUIRE(ntt_wave_plan(nullptr, log_n, &r1, &r2) && r2, PLONK_ERR_ARG,
+    PLONK_REQUIRE(ntt_wave_plan(nullptr, log_n, &r1, &r2) && r2 && r1 >= 8, PLONK_ERR_ARG,
                   "distributed NTT supports sizes 2^16 .. 2^26 (got 2^%u)", log_n);
     PLONK_REQUIRE(log_w + 5 <= r2 && log_w + 5 <= r1, PLONK_ERR_ARG, "2^%u ranks are too many for a 2^%u-point transform", log_w, log_n);
     *log_r1 = r1;

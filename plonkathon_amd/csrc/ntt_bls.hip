@@ -11,7 +11,7 @@
 // What differs from BN254 for the kernels: R / m = 2^261 / r = 70.7 instead of 169, so a Shoup product of a multiplicand a
 // lands in (-(1 + |a|/R) m, (2 + |a|/R) m) = (-1.26 m, 2.26 m) for the NTT's |a| < 18.1 m — inside the interval the
 // butterflies assume; the emulator build asserts it on every multiplication (fpl.h).  Sizes: the wave kernels' own,
-// 2^8 .. 2^13 in one launch and 2^16 .. 2^26 in two.
+// 2^8 .. 2^13 in one launch and 2^14 .. 2^26 in two.
 #include "ntt_wave_host.h"
 #include "bls12_381_constants.h"
 
@@ -143,7 +143,7 @@ int plonk_bls_fr_ntt(plonk_ctx* ctx, const void* d_in, void* d_out, unsigned log
     if (!batch) return PLONK_OK;
     unsigned r1, r2;
     PLONK_REQUIRE(ntt_wave_plan(ctx, log_n, &r1, &r2), PLONK_ERR_ARG,
-                  "the BLS12-381 transform covers 2^8 .. 2^13 and 2^16 .. 2^26 points (the wave kernels' sizes), not 2^%u", log_n);
+                  "the BLS12-381 transform covers 2^8 .. 2^26 points (the wave kernels' sizes), not 2^%u", log_n);
     const size_t N = (size_t)1 << log_n;
     return wave_run<BlsFrField>(ctx, (const BlsFr*)d_in, (BlsFr*)d_out, log_n, inverse != 0, batch, N, N, N, nullptr, nullptr, inverse != 0);
 }

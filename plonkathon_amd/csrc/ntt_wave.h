@@ -538,3 +538,49 @@ __global__ void ntt_interpass_table_kernel(const Fp<P>* lo, const Fp<P>* hi, Fp<
     for (unsigned pl = 0; pl < 5; pl++)
         for (unsigned q = 0; q < NTT_PLANE_WORDS; q++) block[((size_t)pl << log_t | tid) * NTT_PLANE_WORDS + q] = v[pl * NTT_PLANE_WORDS + q];
 }
+
+// ---- 2^14 and 2^15: N = 4 R2 ----------------------------------------------------------------------------------------------
+// Too small for two wave-kernel passes (both factors would have to reach 2^8), too large for one launch: the column pass is
+// four-point transforms, one thread per column on packed residues — x[i1 R2 + c] -> X[k1] w_N^(c k1) at out[k1 R2 + c],
+// coalesced both ways, with zero padding, the coset factors and 1/N where the wave kernels' column pass has them — and the
+// row pass is the 2^12 / 2^13 wave kernel in mode 2 with R1 = 4 (four workgroups per transform).
+template <class P> struct NttQuadT {
+    const Fp<P>* in;
+    Fp<P>* out;
+    size_t in_bstride, out_bstride;
+    unsigned in_len, log_n;
+    const Fp<P>* tw_lo;  // packed: w_N^e = tw_lo[e & 1023] * tw_hi[e >> 10]
+    const Fp<P>* tw_hi;
+    const Fp<P>* in_scale;
+    Fp<P> w4;     // the fourth root of unity of the transform direction
+    Fp<P> scale;  // 1/N (inverse transforms) ...
+    unsigned has_scale;
+};
+template <class P> __global__ void __launch_bounds__(256) ntt_quad_column_kernel(NttQuadT<P> p) {
+    const unsigned log_r2 = p.log_n - 2, c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >> log_r2) return;
+    const Fp<P>* in = p.in + (size_t)blockIdx.y * p.in_bstride;
+    Fp<P>* out = p.out + (size_t)blockIdx.y * p.out_bstride;
+    Fp<P> x[4];
+#pragma unroll
+    for (unsigned i = 0; i < 4; i++) {
+        const unsigned g = (i << log_r2) + c;
+        x[i] = g < p.in_len ? fp_load(in + g) : fp_zero<P>();
+        if (p.in_scale && g < p.in_len) x[i] = fp_mul(x[i], fp_load(p.in_scale + g));
+    }
+    const Fp<P> a0 = fp_add(x[0], x[2]), a1 = fp_add(x[1], x[3]), d0 = fp_sub(x[0], x[2]), d1 = fp_mul(fp_sub(x[1], x[3]), p.w4);
+    x[0] = fp_add(a0, a1);
+    x[1] = fp_add(d0, d1);
+    x[2] = fp_sub(a0, a1);
+    x[3] = fp_sub(d0, d1);
+#pragma unroll
+    for (unsigned k = 0; k < 4; k++) {
+        const unsigned e = c * k;  // < N
+        if (e) {
+            x[k] = fp_mul(x[k], fp_load(p.tw_lo + (e & ((1u << NTT_TW_LO_LOG) - 1))));
+            x[k] = fp_mul(x[k], fp_load(p.tw_hi + (e >> NTT_TW_LO_LOG)));
+        }
+        if (p.has_scale) x[k] = fp_mul(x[k], p.scale);
+        fp_store(out + ((size_t)k << log_r2) + c, x[k]);
+    }
+}

@@ -202,7 +202,7 @@ template <class F> static int wave_launch(plonk_ctx* ctx, const NttWaveT<typenam
     return PLONK_ERR_ARG;
 }
 
-// one transform per batch entry: a single launch for 2^8 .. 2^13, columns then rows through scratch slot 0 for 2^16 .. 2^26
+// one transform per batch entry: a single launch for 2^8 .. 2^13, columns then rows through scratch slot 0 for 2^14 .. 2^26
 template <class F>
 static int wave_run(plonk_ctx* ctx, const Fp<typename F::P>* in, Fp<typename F::P>* out, unsigned log_n, bool inverse, size_t batch, size_t in_len,
                     size_t in_bstride, size_t out_bstride, const Fp<typename F::P>* in_scale, const Fp<typename F::P>* out_scale, bool scale_by_n_inv) {
@@ -246,6 +246,39 @@ static int wave_run(plonk_ctx* ctx, const Fp<typename F::P>* in, Fp<typename F::
     void* sc;
     PLONK_TRY(ctx_scratch(ctx, 0, batch * N * sizeof(E), &sc));
     E* tmp = (E*)sc;
+    if (log_r1 == 2) {  // 2^14, 2^15: four-point column transforms on packed residues (ntt_quad_column_kernel), then the wave kernel's row pass
+        NttQuadT<P> a;
+        memset(&a, 0, sizeof a);
+        a.in = in;
+        a.out = tmp;
+        a.in_bstride = in_bstride;
+        a.out_bstride = N;
+        a.in_len = in_len32;
+        a.log_n = log_n;
+        a.in_scale = in_scale;
+        PLONK_TRY(F::packed_lo_hi(ctx, log_n, inverse, &a.tw_lo, &a.tw_hi));
+        a.w4 = F::root_of_unity(2, inverse);
+        a.scale = n_inv;
+        a.has_scale = scale_by_n_inv ? 1u : 0u;
+        NttWaveT<P> c = p;
+        c.mode = 2;
+        c.log_other = log_r1;
+        c.in = tmp;
+        c.out = out;
+        c.in_bstride = N;
+        c.out_bstride = out_bstride;
+        c.in_len = (unsigned)N;
+        c.out_scale = out_scale;
+        PLONK_TRY(wave_program_table<F>(ctx, log_r2, inverse, &c.roots));
+        PLONK_TRY(prof_begin(ctx, "ntt_pass", 32.0 * (double)N * (double)batch));
+        PLONK_LAUNCH(ntt_quad_column_kernel<P>, dim3((1u << log_r2) / 256, (unsigned)batch), dim3(256), 0, ctx->stream, a);
+        PLONK_TRY(prof_end(ctx));
+        PLONK_TRY(prof_begin(ctx, "ntt_pass", 32.0 * (double)N * (double)batch));
+        PLONK_TRY(wave_launch<F>(ctx, c, log_r2, 1u << log_r1, (unsigned)batch));
+        PLONK_TRY(prof_end(ctx));
+        PLONK_CHECK_HIP(hipGetLastError());
+        return PLONK_OK;
+    }
     // (measured, profiles/r03_m_ntt_sweep.jsonl: the table wins 4-10 % wherever the column pass fills the chip; a lone 2^18 —
     // one workgroup per CU, every load latency exposed — is 5 % faster on the small, L2-resident tables)
     const int32_t* full = nullptr;

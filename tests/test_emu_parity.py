@@ -232,6 +232,14 @@ def test_ntt_two_pass_wave_kernel(emu):
         check(ctx.L.plonk_ntt_set_split(ctx.handle, 18, 0))
 
 
+def test_ntt_2_14_and_2_15(emu):
+    pc.ntt_quad_sizes()
+
+
+def test_bls12_381_ntt_2_14_and_2_15(emu):
+    pc.bls_ntt_vs_oracle((14, 15), seed0=55, batch=2)
+
+
 def test_bls12_381_ntt_two_pass(emu):
     """2^16 = 2^8 x 2^8 over the BLS12-381 scalar field (inter-pass twiddles, 1/N folded into the hi table)."""
     pc.bls_ntt_vs_oracle((16,), seed0=91)

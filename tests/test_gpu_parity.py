@@ -320,6 +320,12 @@ def test_ntt_inter_pass_twiddles_from_the_small_tables():
         check(ctx.L.plonk_ntt_set_table_budget(ctx.handle, 4 << 30))
 
 
+def test_ntt_2_14_and_2_15():
+    """4 x 2^12 and 4 x 2^13: the four-point column pass + the wave kernel's row pass, with the fused coset forms."""
+    pc.ntt_quad_sizes()
+    pc.bls_ntt_vs_oracle((14, 15), seed0=55, batch=3)
+
+
 def test_bls12_381_ntt_every_wave_kernel():
     """The standalone BLS12-381 Fr transform, one size per wave kernel plus a two-pass size: random and extreme inputs, both
     directions, in place, batched, bad inputs refused — bit-exact against the C oracle's oracle_bls_fr_ntt."""

@@ -27,7 +27,7 @@ ap.add_argument("--tag", default="")
 ap.add_argument("--directions", default="fwd")      # fwd,inv
 ap.add_argument("--placements", default="out")      # out,in
 ap.add_argument("--table-gb", type=float, default=-1.0)  # budget of the full inter-pass twiddle tables (0 = two small tables; default: the library's 4 GiB)
-ap.add_argument("--field", default="bn254")         # bn254 | bls12_381 (plonk_bls_fr_ntt: the wave kernels' sizes only)
+ap.add_argument("--field", default="bn254")         # bn254 | bls12_381 (plonk_bls_fr_ntt: 2^8 .. 2^26)
 args = ap.parse_args()
 
 ctx = Context(0)
@@ -57,8 +57,6 @@ else:
     shapes = [(k, (1 << 22) >> k, 0) for k in range(8, 14)] + [(11, 512, 0), (13, 512, 0), (10, 512, 0), (12, 512, 0)]
     shapes += [(k, 1, 0) for k in range(14, 25)]
     shapes += [(16, 256, 0), (18, 64, 0), (20, 16, 0), (22, 4, 0)]  # constant work: 2^24 elements
-    if args.field == "bls12_381":
-        shapes = [s for s in shapes if s[0] not in (14, 15)]
 
 for kind in [int(k) for k in args.kinds.split(",")]:
     check(L.plonk_ntt_select_kernel(H, kind))
