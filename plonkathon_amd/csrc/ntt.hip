@@ -655,7 +655,11 @@ int ntt_run(plonk_ctx* ctx, const Fr* in, Fr* out, unsigned log_n, bool inverse,
     // they beat the LDS kernels at every such size and batch (profiles/r02_e_ntt_kinds.json, r02_v_ntt_kinds.json,
     // r03_*).  kind 4 = automatic choice among the LDS kernels only (A/B runs); a plonk_ntt_configure with small tiles
     // (the multi-pass tests) also keeps a transform on the LDS kernels.
-    if ((ctx->ntt_kind == 0 || ctx->ntt_kind == 5) && ntt_wave_plan(ctx, log_n, &wr1, &wr2) && ((ctx->ntt_single_log >= 11 && ctx->ntt_radix_log >= 10) || ctx->ntt_kind == 5))
+    // 2^14 / 2^15 (four-point columns + four 1024-thread row workgroups per transform) stay on the LDS kernels unless forced: measured,
+    // a lone 2^15 takes 0.101 ms that way against 0.038, batches are level (profiles/r03_w_ntt_quad_sizes.jsonl) — the plan exists for
+    // the fields that have no LDS kernels (ntt_bls.hip)
+    if ((ctx->ntt_kind == 0 || ctx->ntt_kind == 5) && ntt_wave_plan(ctx, log_n, &wr1, &wr2) && (!wr2 || wr1 >= 8 || ctx->ntt_kind == 5) &&
+        ((ctx->ntt_single_log >= 11 && ctx->ntt_radix_log >= 10) || ctx->ntt_kind == 5))
         return ntt_run_wave(ctx, in, out, log_n, inverse, batch, in_len, in_bstride, out_bstride, in_scale, out_scale, scale_by_n_inv);
     PLONK_REQUIRE(batch <= 65535, PLONK_ERR_ARG, "NTT batch %zu exceeds 65535", batch);
     unsigned radices[4];

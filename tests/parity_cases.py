@@ -45,7 +45,8 @@ def ntt_vs_oracle(log_ns, seed0=0):
 
 
 def ntt_quad_sizes(seed0=60):
-    """2^14 and 2^15 = 4 x 2^12 / 4 x 2^13 (four-point column transforms on packed residues, then the wave kernel's row pass):
+    """2^14 and 2^15 = 4 x 2^12 / 4 x 2^13 (four-point column transforms on packed residues, then the wave kernel's row pass;
+    forced with kernel kind 5 for BN254, the only path of the BLS12-381 transform):
     plain transforms both ways, in place through the C-ABI, a batch, and the fused forms the prover's sizes would use — zero
     padding + coset factors on the way in (to_coset_extended_lagrange of 2^12 values -> 2^14) and coset^-1 / N on the way out."""
     import ctypes
@@ -53,8 +54,18 @@ def ntt_quad_sizes(seed0=60):
     from plonkathon_amd import get_context
     from plonkathon_amd._lib import check
 
-    ntt_vs_oracle((14, 15), seed0=seed0)
     ctx = get_context()
+    check(ctx.L.plonk_ntt_select_kernel(ctx.handle, 5))  # BN254's default for these two sizes is the LDS kernels (faster for a lone transform)
+    try:
+        _ntt_quad_sizes_body(ctx, seed0)
+    finally:
+        check(ctx.L.plonk_ntt_select_kernel(ctx.handle, 0))
+
+
+def _ntt_quad_sizes_body(ctx, seed0):
+    from plonkathon_amd._lib import check
+
+    ntt_vs_oracle((14, 15), seed0=seed0)
     for log_n in (14, 15):
         n = 1 << log_n
         vs = [rand_vec(seed0 + 7 * log_n + b, n) for b in range(3)]
