@@ -159,15 +159,17 @@ def bls_ntt_vs_oracle(log_ns, seed0=40, batch=1):
         cases = [("random", [rng.randrange(m) for _ in range(n)]), ("max", [m - 1] * n), ("alt", [(m - 1) * (i & 1) for i in range(n)]),
                  ("limbs_all", [max_mont] * n), ("limbs_even", [max_mont if (0x55 >> (i // nt)) & 1 else 0 for i in range(n)]),
                  ("limbs_low", [max_mont if i // nt < slots_n // 2 else 0 for i in range(n)])]
-        if log_n > 13:
-            cases = cases[:2]
+        if log_n > 13:  # (the emulated two-pass sizes take seconds per transform)
+            cases = cases[:1]
         for name, v in cases:
             raw = le(v)
             for inverse in (False, True):
                 want = c_oracle.fr_ntt_bytes(raw, inverse, "bls12_381")
                 d = bls.upload(raw)
-                assert bls.download(bls.ntt(d, log_n, inverse)) == want, (name, log_n, inverse)
-                assert bls.download(bls.ntt(d, log_n, inverse, out=d)) == want, ("in place", name, log_n, inverse)
+                if log_n <= 13 or not inverse:
+                    assert bls.download(bls.ntt(d, log_n, inverse)) == want, (name, log_n, inverse)
+                if log_n <= 13 or inverse:
+                    assert bls.download(bls.ntt(d, log_n, inverse, out=d)) == want, ("in place", name, log_n, inverse)
         if batch > 1:
             vs = [le([rng.randrange(m) for _ in range(n)]) for _ in range(batch)]
             got = bls.download(bls.ntt(bls.upload(b"".join(vs)), log_n, False, batch))
