@@ -110,6 +110,10 @@ int plonk_ntt_set_table_budget(plonk_ctx* ctx, size_t bytes);
 int plonk_bls_fr_upload(plonk_ctx* ctx, void* d_dst, const uint8_t* h_src_le32, size_t count);
 int plonk_bls_fr_download(plonk_ctx* ctx, uint8_t* h_dst_le32, const void* d_src, size_t count);
 int plonk_bls_fr_ntt(plonk_ctx* ctx, const void* d_in, void* d_out, unsigned log_n, int inverse, size_t batch);
+/* poly.py:156-163 and 169-177 over that field (what plonk_fr_coset_extend / plonk_fr_coset_to_coeffs are for BN254):
+ * n Lagrange values -> their 4n values on the coset offset * <w_4n>; M coset values -> M coefficients. */
+int plonk_bls_fr_coset_extend(plonk_ctx* ctx, const void* d_in, void* d_out, unsigned log_n, const uint8_t offset_le32[32], size_t batch);
+int plonk_bls_fr_coset_to_coeffs(plonk_ctx* ctx, const void* d_in, void* d_out, unsigned log_m, const uint8_t offset_le32[32], size_t batch);
 /* Lower-level pieces used by the batched prover: coefficient form in, fixed offset table. */
 int plonk_fr_coset_ntt_from_coeffs(plonk_ctx* ctx, const void* d_coeffs, void* d_out, unsigned log_n,
                                    unsigned log_expand, const uint8_t offset_le32[32], size_t batch);

@@ -36,6 +36,8 @@ SIGNATURES = {
     "plonk_bls_fr_upload": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, _u8p, ctypes.c_size_t]),
     "plonk_bls_fr_download": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]),
     "plonk_bls_fr_ntt": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint, ctypes.c_int, ctypes.c_size_t]),
+    "plonk_bls_fr_coset_extend": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint, _u8p, ctypes.c_size_t]),
+    "plonk_bls_fr_coset_to_coeffs": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint, _u8p, ctypes.c_size_t]),
     "plonk_ntt_configure": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint, ctypes.c_uint, ctypes.c_uint]),
     "plonk_fr_powers": (ctypes.c_int, [ctypes.c_void_p, _u8p, _u8p, ctypes.c_size_t, ctypes.c_void_p]),
     "plonk_fr_equal": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_int)]),

@@ -47,6 +47,24 @@ def ntt(buf: DeviceBuffer, log_n: int, inverse=False, batch=1, out: DeviceBuffer
     return out
 
 
+def coset_extend(buf: DeviceBuffer, log_n: int, offset: int, batch=1) -> DeviceBuffer:
+    """poly.py:156-163 over this field: `batch` vectors of 2^log_n Lagrange values -> their 4 * 2^log_n values on offset * <w_4n>."""
+    ctx = get_context()
+    assert buf.n >= batch << log_n
+    out = ctx.alloc(batch << (log_n + 2))
+    check(ctx.L.plonk_bls_fr_coset_extend(ctx.handle, buf.ptr, out.ptr, log_n, int(offset).to_bytes(32, "little"), batch))
+    return out
+
+
+def coset_to_coeffs(buf: DeviceBuffer, log_m: int, offset: int, batch=1) -> DeviceBuffer:
+    """poly.py:169-177 over this field: 2^log_m values on the coset -> 2^log_m coefficients."""
+    ctx = get_context()
+    assert buf.n >= batch << log_m
+    out = ctx.alloc(batch << log_m)
+    check(ctx.L.plonk_bls_fr_coset_to_coeffs(ctx.handle, buf.ptr, out.ptr, log_m, int(offset).to_bytes(32, "little"), batch))
+    return out
+
+
 def ntt_ints(values, inverse=False):
     """Convenience: one transform of a list of ints."""
     n = len(values)

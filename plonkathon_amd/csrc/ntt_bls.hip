@@ -12,6 +12,8 @@
 // lands in (-(1 + |a|/R) m, (2 + |a|/R) m) = (-1.26 m, 2.26 m) for the NTT's |a| < 18.1 m — inside the interval the
 // butterflies assume; the emulator build asserts it on every multiplication (fpl.h).  Sizes: the wave kernels' own,
 // 2^8 .. 2^13 in one launch and 2^14 .. 2^26 in two.
+#include <string>
+
 #include "ntt_wave_host.h"
 #include "bls12_381_constants.h"
 
@@ -135,6 +137,82 @@ int plonk_bls_fr_download(plonk_ctx* ctx, uint8_t* h_dst_le32, const void* d_src
     PLONK_CHECK_HIP(hipMemcpyAsync(h_dst_le32, tmp, count * 32, hipMemcpyDeviceToHost, ctx->stream));
     PLONK_CHECK_HIP(hipStreamSynchronize(ctx->stream));
     return PLONK_OK;
+}
+
+// first * base^i, i < n, cached per context beside BN254's tables (key prefix "bls"; ctx_destroy frees the map's values)
+static int bls_power_table(plonk_ctx* ctx, const BlsFr& base, const BlsFr& first, size_t n, const BlsFr** out) {
+    std::string key("bls");
+    key.append((const char*)base.v, 32);
+    key.append((const char*)first.v, 32);
+    key.append((const char*)&n, sizeof n);
+    auto it = ctx->power_tables.find(key);
+    if (it == ctx->power_tables.end()) {
+        void* p = nullptr;
+        if (hipMalloc(&p, n * sizeof(BlsFr)) != hipSuccess) {
+            plonk_set_error("hipMalloc of a %zu-entry power table failed", n);
+            return PLONK_ERR_NOMEM;
+        }
+        int rc = bls_powers(ctx, base, first, (BlsFr*)p, n);
+        if (rc != PLONK_OK) {
+            hipFree(p);
+            return rc;
+        }
+        it = ctx->power_tables.emplace(key, (Fr*)p).first;
+    }
+    *out = (const BlsFr*)it->second;
+    return PLONK_OK;
+}
+
+// canonical little-endian bytes -> Montgomery form; false if the value is not below r
+static bool bls_from_le32(const uint8_t* b, BlsFr* out) {
+    BlsFr a;
+    memcpy(a.v, b, 32);
+    for (int i = 7; i >= 0; i--) {
+        if (a.v[i] < BlsFrParams::mod(i)) {
+            *out = fp_to_mont(a);
+            return true;
+        }
+        if (a.v[i] > BlsFrParams::mod(i)) return false;
+    }
+    return false;
+}
+
+static bool bls_size_ok(const plonk_ctx* ctx, unsigned log_n) {
+    unsigned r1, r2;
+    return ntt_wave_plan(ctx, log_n, &r1, &r2);
+}
+
+// poly.py:156-163 over this field: n Lagrange values -> coefficients (ifft) -> c_i offset^i, zero-padded to 4n -> forward transform:
+// the values on the coset offset * <w_4n>.  The scaling and the padding ride in the first load of the 4n-point transform.
+int plonk_bls_fr_coset_extend(plonk_ctx* ctx, const void* d_in, void* d_out, unsigned log_n, const uint8_t offset_le32[32], size_t batch) {
+    PLONK_REQUIRE(ctx && d_in && d_out && offset_le32, PLONK_ERR_ARG, "bad argument");
+    PLONK_ENTER(ctx);
+    if (!batch) return PLONK_OK;
+    BlsFr off;
+    PLONK_REQUIRE(bls_from_le32(offset_le32, &off), PLONK_ERR_ARG, "offset is not a canonical BLS12-381 Fr value");
+    PLONK_REQUIRE(bls_size_ok(ctx, log_n) && bls_size_ok(ctx, log_n + 2), PLONK_ERR_ARG,
+                  "the BLS12-381 coset extension covers 2^8 .. 2^24 values (4n <= 2^26), not 2^%u", log_n);
+    const size_t n = (size_t)1 << log_n, big = n << 2;
+    void* coeffs;
+    PLONK_TRY(ctx_scratch(ctx, 2, batch * n * sizeof(BlsFr), &coeffs));
+    PLONK_TRY(wave_run<BlsFrField>(ctx, (const BlsFr*)d_in, (BlsFr*)coeffs, log_n, true, batch, n, n, n, nullptr, nullptr, true));
+    const BlsFr* pw;
+    PLONK_TRY(bls_power_table(ctx, off, fp_one<BlsFrParams>(), n, &pw));
+    return wave_run<BlsFrField>(ctx, (const BlsFr*)coeffs, (BlsFr*)d_out, log_n + 2, false, batch, n, n, big, pw, nullptr, false);
+}
+
+// poly.py:169-177 over this field: M coset values -> ifft -> v_i (1/offset)^i; the 1/M of the ifft rides in the power table
+int plonk_bls_fr_coset_to_coeffs(plonk_ctx* ctx, const void* d_in, void* d_out, unsigned log_m, const uint8_t offset_le32[32], size_t batch) {
+    PLONK_REQUIRE(ctx && d_in && d_out && offset_le32, PLONK_ERR_ARG, "bad argument");
+    PLONK_ENTER(ctx);
+    if (!batch) return PLONK_OK;
+    BlsFr off;
+    PLONK_REQUIRE(bls_from_le32(offset_le32, &off), PLONK_ERR_ARG, "offset is not a canonical BLS12-381 Fr value");
+    PLONK_REQUIRE(bls_size_ok(ctx, log_m), PLONK_ERR_ARG, "the BLS12-381 transform covers 2^8 .. 2^26 points (the wave kernels' sizes), not 2^%u", log_m);
+    const size_t M = (size_t)1 << log_m;
+    const BlsFr* pw;
+    PLONK_TRY(bls_power_table(ctx, fp_inv(off), fp_inv(BlsFrField::from_u64((uint64_t)M)), M, &pw));
+    return wave_run<BlsFrField>(ctx, (const BlsFr*)d_in, (BlsFr*)d_out, log_m, true, batch, M, M, M, nullptr, pw, false);
 }
 
 int plonk_bls_fr_ntt(plonk_ctx* ctx, const void* d_in, void* d_out, unsigned log_n, int inverse, size_t batch) {

@@ -191,6 +191,47 @@ def bls_ntt_vs_oracle(log_ns, seed0=40, batch=1):
             raise AssertionError("bad BLS12-381 input accepted")
 
 
+def bls_coset_vs_oracle(log_ns, seed0=70, batch=1):
+    """plonk_bls_fr_coset_extend / plonk_bls_fr_coset_to_coeffs against poly.py:156-177 spelled out over the BLS12-381 scalar
+    field: coefficients by the C oracle's inverse transform, the offset powers in Python integers, the 4n-point forward transform
+    by the C oracle again; then the way back; a non-canonical offset is refused."""
+    import random
+
+    from oracle import c_oracle
+    from plonkathon_amd import bls12_381 as bls
+
+    m = bls.MODULUS
+    le = lambda v: b"".join(int(x).to_bytes(32, "little") for x in v)
+    un = lambda raw: [int.from_bytes(raw[32 * i:32 * i + 32], "little") for i in range(len(raw) // 32)]
+    for log_n in log_ns:
+        n = 1 << log_n
+        rng = random.Random(seed0 + log_n)
+        off = rng.randrange(2, m)
+        vs = [[rng.randrange(m) for _ in range(n)] for _ in range(batch)]
+        want = []
+        for v in vs:
+            coeffs = un(c_oracle.fr_ntt_bytes(le(v), True, "bls12_381"))
+            p, scaled = 1, []
+            for c in coeffs:
+                scaled.append(c * p % m)
+                p = p * off % m
+            want.append(c_oracle.fr_ntt_bytes(le(scaled + [0] * (3 * n)), False, "bls12_381"))
+        d = bls.upload(le([x for v in vs for x in v]))
+        big = bls.coset_extend(d, log_n, off, batch)
+        assert bls.download(big) == b"".join(want), ("coset_extend", log_n)
+        back = bls.coset_to_coeffs(big, log_n + 2, off, batch)        # the coefficients of the degree < n polynomial, zero above
+        got = un(bls.download(back))
+        for b, v in enumerate(vs):
+            coeffs = un(c_oracle.fr_ntt_bytes(le(v), True, "bls12_381"))
+            assert got[b * 4 * n:b * 4 * n + n] == coeffs and not any(got[b * 4 * n + n:(b + 1) * 4 * n]), ("coset_to_coeffs", log_n, b)
+    try:
+        bls.coset_extend(bls.upload(bytes(32 << 8)), 8, m)
+    except Exception as e:
+        assert "canonical" in str(e), e
+    else:
+        raise AssertionError("non-canonical offset accepted")
+
+
 def round_kernels_vs_oracle(log_ns=(3, 4, 6)):
     """The fused round kernels of the C-ABI on their own against the oracle's Polynomial arithmetic (the reference's
     formulas of prover.py:121-146 and 188-203 spelled out operator by operator), plus plonk_fr_powers / plonk_fr_equal."""

@@ -237,6 +237,12 @@ def test_bls12_381_ntt_2_14_and_2_15(emu):
     pc.bls_ntt_vs_oracle((14, 15), seed0=55, batch=2)
 
 
+def test_bls12_381_coset_transforms(emu):
+    """n = 2^8 -> 4n = 2^10 (both E = 4), 2^9 -> 2^11 (both E = 8), 2^11 -> 2^13, 2^12 -> 2^14 (the four-point column path)."""
+    pc.bls_coset_vs_oracle((8, 9), batch=2)
+    pc.bls_coset_vs_oracle((11, 12), seed0=170)
+
+
 def test_bls12_381_ntt_two_pass(emu):
     """2^16 = 2^8 x 2^8 over the BLS12-381 scalar field (inter-pass twiddles, 1/N folded into the hi table)."""
     pc.bls_ntt_vs_oracle((16,), seed0=91)

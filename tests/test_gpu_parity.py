@@ -326,6 +326,12 @@ def test_ntt_2_14_and_2_15():
     pc.bls_ntt_vs_oracle((14, 15), seed0=55, batch=3)
 
 
+def test_bls12_381_coset_transforms():
+    """coset_extend / coset_to_coeffs over the BLS12-381 scalar field at n = 2^8 .. 2^13 (batched), 2^14 -> 2^16 and 2^18 -> 2^20."""
+    pc.bls_coset_vs_oracle((8, 9, 10, 11, 12, 13), batch=3)
+    pc.bls_coset_vs_oracle((14, 18), seed0=270)
+
+
 def test_bls12_381_ntt_every_wave_kernel():
     """The standalone BLS12-381 Fr transform, one size per wave kernel plus a two-pass size: random and extreme inputs, both
     directions, in place, batched, bad inputs refused — bit-exact against the C oracle's oracle_bls_fr_ntt."""
