@@ -1,4 +1,4 @@
-"""The standalone NTT over the BLS12-381 scalar field, on the MI355X (csrc/ntt_bls.hip behind plonk_bls_fr_*).
+"""The standalone NTT / iNTT / coset-NTT over the BLS12-381 scalar field, on the MI355X (csrc/ntt_bls.hip behind plonk_bls_fr_*).
 
 The reference is BN254 throughout (/root/reference/curve.py:2, 10-11); this module exists because BASELINE.json's
 north_star quotes a standalone NTT metric on this field.  It is the reference's transform (poly.py:113-148: natural order
