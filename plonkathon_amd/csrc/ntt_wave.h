@@ -561,20 +561,20 @@ template <class P> __global__ void __launch_bounds__(256) ntt_quad_column_kernel
     if (c >> log_r2) return;
     const Fp<P>* in = p.in + (size_t)blockIdx.y * p.in_bstride;
     Fp<P>* out = p.out + (size_t)blockIdx.y * p.out_bstride;
-    Fp<P> x[4];
-#pragma unroll
-    for (unsigned i = 0; i < 4; i++) {
+    Fp<P> x[4];  // (compile-time indices only: wave_for, not loops — see the note at wave_for)
+    wave_for<4>([&](auto I) {
+        constexpr unsigned i = decltype(I)::value;
         const unsigned g = (i << log_r2) + c;
         x[i] = g < p.in_len ? fp_load(in + g) : fp_zero<P>();
         if (p.in_scale && g < p.in_len) x[i] = fp_mul(x[i], fp_load(p.in_scale + g));
-    }
+    });
     const Fp<P> a0 = fp_add(x[0], x[2]), a1 = fp_add(x[1], x[3]), d0 = fp_sub(x[0], x[2]), d1 = fp_mul(fp_sub(x[1], x[3]), p.w4);
     x[0] = fp_add(a0, a1);
     x[1] = fp_add(d0, d1);
     x[2] = fp_sub(a0, a1);
     x[3] = fp_sub(d0, d1);
-#pragma unroll
-    for (unsigned k = 0; k < 4; k++) {
+    wave_for<4>([&](auto K) {
+        constexpr unsigned k = decltype(K)::value;
         const unsigned e = c * k;  // < N
         if (e) {
             x[k] = fp_mul(x[k], fp_load(p.tw_lo + (e & ((1u << NTT_TW_LO_LOG) - 1))));
@@ -582,5 +582,5 @@ template <class P> __global__ void __launch_bounds__(256) ntt_quad_column_kernel
         }
         if (p.has_scale) x[k] = fp_mul(x[k], p.scale);
         fp_store(out + ((size_t)k << log_r2) + c, x[k]);
-    }
+    });
 }
