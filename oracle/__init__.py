@@ -14,7 +14,8 @@ transcript.py in the build container (tools/gen_golden.py -> tests/golden/*.json
 
 One exception, stated where it lives (oracle/c/bn254_oracle.c, oracle_bls_fr_ntt): the BLS12-381 scalar-field transform has NO
 reference counterpart (the reference is BN254 throughout) — parity unpinned against the reference, pinned by definition only
-(DFT sum in Python integers, the bls12_381 crate's published root of unity; tests/test_oracle_c.py).
+(DFT sum in Python integers, the bls12_381 crate's published root of unity, the committed vectors of tools/gen_bls_vectors.py;
+tests/test_oracle_c.py).
 
 Third-party arithmetic that is NOT under /root/reference and is restated from its published
 algorithm: py-ecc 6.0.0 (bn128 FQ + affine G1 add/double/multiply; pyproject.toml:11,

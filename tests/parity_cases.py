@@ -191,6 +191,31 @@ def bls_ntt_vs_oracle(log_ns, seed0=40, batch=1):
             raise AssertionError("bad BLS12-381 input accepted")
 
 
+def bls_golden(max_log_n=13):
+    """plonk_bls_fr_* against the committed known-answer vectors (tests/golden/bls12_381_ntt_vectors.json, written by
+    tools/gen_bls_vectors.py from the definition in Python integers — independent of the C oracle): fft, ifft and, where the
+    fixture has them, the coset forms."""
+    import random
+
+    from plonkathon_amd import bls12_381 as bls
+
+    m = bls.MODULUS
+    un = lambda raw: [int.from_bytes(raw[32 * i:32 * i + 32], "little") for i in range(len(raw) // 32)]
+    for case in load("bls12_381_ntt_vectors.json")["cases"]:
+        log_n = case["log_n"]
+        if log_n > max_log_n:
+            continue
+        rng = random.Random(case["seed"])
+        raw = b"".join(rng.randrange(m).to_bytes(32, "little") for _ in range(1 << log_n))
+        d = bls.upload(raw)
+        check_summary(un(bls.download(bls.ntt(d, log_n))), case["fft"])
+        check_summary(un(bls.download(bls.ntt(d, log_n, True))), case["ifft"])
+        if "offset" in case:
+            off = int(case["offset"])
+            check_summary(un(bls.download(bls.coset_extend(d, log_n, off))), case["coset_extend"])
+            check_summary(un(bls.download(bls.coset_to_coeffs(d, log_n, off))), case["coset_to_coeffs"])
+
+
 def bls_coset_vs_oracle(log_ns, seed0=70, batch=1):
     """plonk_bls_fr_coset_extend / plonk_bls_fr_coset_to_coeffs against poly.py:156-177 spelled out over the BLS12-381 scalar
     field: coefficients by the C oracle's inverse transform, the offset powers in Python integers, the 4n-point forward transform

@@ -237,6 +237,10 @@ def test_bls12_381_ntt_2_14_and_2_15(emu):
     pc.bls_ntt_vs_oracle((14, 15), seed0=55, batch=2)
 
 
+def test_bls12_381_golden_vectors(emu):
+    pc.bls_golden(max_log_n=13)
+
+
 def test_bls12_381_coset_transforms(emu):
     """n = 2^8 -> 4n = 2^10 (both E = 4), 2^9 -> 2^11 (both E = 8), 2^11 -> 2^13, 2^12 -> 2^14 (the four-point column path)."""
     pc.bls_coset_vs_oracle((8, 9), batch=2)

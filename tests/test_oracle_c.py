@@ -43,6 +43,20 @@ def test_c_bls12_381_ntt_is_the_dft_over_that_field():
         assert c_oracle.fr_ntt_bytes(out, True, "bls12_381") == raw
 
 
+def test_c_bls12_381_ntt_matches_the_committed_vectors():
+    """tests/golden/bls12_381_ntt_vectors.json (tools/gen_bls_vectors.py: a recursive transform in Python integers, itself checked
+    against the DFT sum) pins oracle_bls_fr_ntt at 2^8 .. 2^13 and 2^16, forward and inverse."""
+    import random
+
+    r = c_oracle.BLS12_381_FR_MODULUS
+    un = lambda raw: [int.from_bytes(raw[32 * i:32 * i + 32], "little") for i in range(len(raw) // 32)]
+    for case in load("bls12_381_ntt_vectors.json")["cases"]:
+        rng = random.Random(case["seed"])
+        raw = b"".join(rng.randrange(r).to_bytes(32, "little") for _ in range(1 << case["log_n"]))
+        check_summary(un(c_oracle.fr_ntt_bytes(raw, False, "bls12_381")), case["fft"])
+        check_summary(un(c_oracle.fr_ntt_bytes(raw, True, "bls12_381")), case["ifft"])
+
+
 def test_c_lincomb_matches_reference_vectors():
     setup = Setup.from_file(os.path.join(GOLDEN, "srs_2048.ptau"))
     P = setup.powers_of_x
