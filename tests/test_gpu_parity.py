@@ -326,11 +326,6 @@ def test_ntt_2_14_and_2_15():
     pc.bls_ntt_vs_oracle((14, 15), seed0=55, batch=3)
 
 
-def test_bls12_381_golden_vectors():
-    """The committed known-answer vectors of the BLS12-381 scalar-field transforms (definition in Python integers), 2^8 .. 2^16."""
-    pc.bls_golden(max_log_n=16)
-
-
 def test_bls12_381_coset_transforms():
     """coset_extend / coset_to_coeffs over the BLS12-381 scalar field at n = 2^8 .. 2^13 (batched), 2^14 -> 2^16 and 2^18 -> 2^20."""
     pc.bls_coset_vs_oracle((8, 9, 10, 11, 12, 13), batch=3)
@@ -616,3 +611,8 @@ def test_wave_kernel_two_pass_splits_and_batches(log_n, split):
         assert ctx.download_bytes(out) == b"".join(raws)
     finally:
         check(ctx.L.plonk_ntt_set_split(ctx.handle, log_n, 0))
+
+
+def test_bls12_381_golden_vectors():
+    """The committed known-answer vectors of the BLS12-381 scalar-field transforms (definition in Python integers), 2^8 .. 2^16."""
+    pc.bls_golden(max_log_n=16)
