@@ -221,6 +221,35 @@ def ntt_microbench(ctx, log_n, batch, reps=5, inverse=False, in_place=False, fie
     return best
 
 
+def ntt_queue_microbench(ctx, log_n, queue=16, reps=5, field="bn254"):
+    """`queue` independent lone transforms of 2^log_n (one input, `queue` distinct outputs) enqueued back to back between ONE
+    event pair -> ms per transform (best of `reps`).  The difference to `fwd` (one transform between an event pair, where the
+    device idles while the host prepares the call) is the host cost per C-ABI call that is NOT hidden behind device work."""
+    from plonkathon_amd._lib import check
+
+    ntt = ctx.L.plonk_bls_fr_ntt if field == "bls12_381" else ctx.L.plonk_fr_ntt
+    n = 1 << log_n
+    src = _NTT_SRC[id(ctx)]
+    buf = ctx.alloc(n)
+    for off in range(0, n, 4096):
+        check(ctx.L.plonk_mem_d2d(ctx.handle, buf.at(off), src.ptr, 32 * min(4096, n - off)))
+    outs = [ctx.alloc(n) for _ in range(queue)]
+    check(ntt(ctx.handle, buf.ptr, outs[0].ptr, log_n, 0, 1))
+    ctx.sync()
+    best = None
+    for _ in range(reps):
+        ctx.timer_start()
+        for o in outs:
+            check(ntt(ctx.handle, buf.ptr, o.ptr, log_n, 0, 1))
+        ms = ctx.timer_stop_ms() / queue
+        best = ms if best is None or ms < best else best
+    return best
+
+
+BLS_PIN_NOTE = ("parity pinned BY DEFINITION only (O(n^2) DFT in Python integers + the published root of unity, tools/gen_bls_vectors.py): "
+                "the reference has no BLS12-381 field (curve.py:2 imports py_ecc.bn128), so no reference-held vector can exist")
+
+
 def ntt_sweep(ctx, comm, world, pmc):
     """BASELINE configs[3] / SURVEY.md 8(d): N = 2^16 .. 2^24 on random scalars — forward and inverse, out of place and in
     place, one transform alone and the constant-work batch [2^24 / N][N] (poly.py:113-148).  Per row: ms (slowest rank),
@@ -238,13 +267,17 @@ def ntt_sweep(ctx, comm, world, pmc):
             ms = D.max_over_ranks(ntt_microbench(ctx, log_n, batch, inverse=inverse, in_place=in_place), comm)
             gbs = 64.0 * n * batch / (ms * 1e-3) / 1e9
             entry[name] = {"ms": ms, "batch": batch, "gf_elems_per_s": world * n * batch / (ms * 1e-3), "hbm_frac": gbs / HBM_PEAK_GBS}
+        # sixteen lone transforms behind one another between ONE event pair: the device never waits for the host
+        ms = D.max_over_ranks(ntt_queue_microbench(ctx, log_n), comm)
+        entry["fwd_queue16"] = {"ms_per_transform": ms, "queue": 16, "gf_elems_per_s": world * n / (ms * 1e-3), "hbm_frac": 64.0 * n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                "host_gap_ms_vs_fwd": entry["fwd"]["ms"] - ms}
         # the field the configs[3] metric is quoted on upstream (BLS12-381 Fr): the same kernels, plonk_bls_fr_ntt
         for name, inverse, batch in (("bls12_381_fwd", False, 1), ("bls12_381_inv", True, 1), ("bls12_381_fwd_batched", False, (1 << 24) >> log_n)):
             if name.endswith("batched") and batch == 1:
                 continue
             ms = D.max_over_ranks(ntt_microbench(ctx, log_n, batch, inverse=inverse, field="bls12_381"), comm)
             entry[name] = {"ms": ms, "batch": batch, "gf_elems_per_s": world * n * batch / (ms * 1e-3),
-                           "hbm_frac": 64.0 * n * batch / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                           "hbm_frac": 64.0 * n * batch / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "parity": "pinned by definition only"}
         tr = pmc.get("ntt_2^%d" % log_n)
         if tr:
             entry["pmc_traffic_bytes"] = tr
@@ -362,6 +395,9 @@ def main():
                     help="transport of the final gather for N > 1: rccl = RCCL over xGMI through the C-ABI (default); sockets = TCP, lets ranks share one GPU")
     ap.add_argument("--lookup-budget-gb", type=float, default=DEFAULT_TABLE_GB,
                     help="HBM budget for the MSM lookup table (the library's own default is 4 GiB; the c = 17 table of 2^11 bases is 128.8 GB)")
+    ap.add_argument("--force-comm", action="store_true",
+                    help="with --gpus 1: still create a ONE-rank RCCL communicator and run the gather (plonk_gather_proofs_device), the "
+                         "max over ranks and the barrier inside the timed region — the code path of an N-GPU run, exercised on one GPU")
     ap.add_argument("--no-lookup", action="store_true", help="bucket-method MSM only")
     ap.add_argument("--host-gather", action="store_true", help="N > 1 with RCCL: gather through host buffers (plonk_gather_results) instead of straight from the provers' device buffers (plonk_gather_proofs_device)")
     ap.add_argument("--dump-proofs", default="", help="rank 0 writes the last step's gathered proofs (768 bytes each, global order) to this file")
@@ -393,6 +429,8 @@ def main():
     ctx = Context(local_rank)
     set_context(ctx)
     comm = D.init_from_env(ctx, args.dist_backend) if world > 1 else None
+    if comm is None and args.force_comm:
+        comm = D.RcclComm(ctx, 0, 1) if args.dist_backend == "rccl" else D.SocketComm(0, 1)
     if comm is not None and comm.world != world:
         sys.exit("bench.py: communicator has %d ranks, expected %d" % (comm.world, world))
     budget = 0 if args.no_lookup else int(args.lookup_budget_gb * 1e9)
@@ -447,16 +485,26 @@ def main():
 
     device_gather = comm is not None and comm.kind == "rccl" and not args.host_gather
 
+    gather_ms = [0.0, 0.0, 0]  # this rank: collective ms, copy-to-host ms, gathers (reset before the timed region)
+
     def step():
         for pr in provers:
             pr.run()                   # five rounds + transcript: one stream of kernel launches each
         if device_gather:              # proofs go from the provers' device buffers into the all-gather, one host copy at the end
             gathered, status = D.gather_proofs_device(provers, B, total, comm)
+            a_ms, h_ms = comm.last_gather_ms()   # HIP events around the ncclAllGather and the copy to the host
+            gather_ms[0] += a_ms
+            gather_ms[1] += h_ms
+            gather_ms[2] += 1
             return gathered.parts[rank], status, gathered
         blobs = [pr.download_raw() for pr in provers]   # sync + 768 B per proof back to the host
         local = b"".join(b[0] for b in blobs)
         status = b"".join(b[1] for b in blobs)
+        tg = time.perf_counter()
         gathered = D.gather_proofs_lazy(local, total, comm) if comm is not None else None  # the path's one collective
+        if comm is not None:
+            gather_ms[0] += 1e3 * (time.perf_counter() - tg)  # host wall time of the whole exchange (staging included)
+            gather_ms[2] += 1
         return local, status, gathered
 
     def barrier():
@@ -474,9 +522,13 @@ def main():
     sampler = ClockSampler(local_rank) if rank == 0 else None  # one sampler per job: rank 0's GPU
     if sampler:
         sampler.start()
+    gather_ms[:] = [0.0, 0.0, 0]
     t0 = time.perf_counter()
     for _ in range(args.steps):
         proofs = step()
+    for c in ctxs:
+        c.sync()
+    own_elapsed = time.perf_counter() - t0   # this rank's own clock, before it waits for the others
     barrier()
     elapsed = D.max_over_ranks(time.perf_counter() - t0, comm)
     clocks = sampler.summary() if sampler else None
@@ -552,8 +604,10 @@ def main():
             "msm_table_build_s": info["build_s"],
             "msm_table_budget_bytes": budget,
             "msm_table_shared_by": info["sharers"],
+            "msm_table_fraction_of_hbm": info["bytes"] / ctx.mem_info()[1],
             "lagrange_commits": bool(args.lagrange_commits),
             "timed_region_s": elapsed,
+            "torch_imported": "torch" in sys.modules,  # the product and this file import no PyTorch: RCCL is reached through the C-ABI
         },
         "host": {
             "host_upload_ms_per_proof": host_upload_ms,
@@ -565,16 +619,41 @@ def main():
                     "(all batches); both synchronous and outside `value` (inputs are resident before the timed region)",
         },
     }
+    if comm is not None:
+        # per-rank figures, so that a scaling record explains itself: every rank's own rate (its steps over its own clock, before
+        # the barrier), the seconds its MSM table took to build, and the time of the step's one collective
+        import struct
+
+        mine_stats = struct.pack("<4d", args.steps * per_gpu / own_elapsed, info["build_s"],
+                                 1e3 * gather_ms[0] / max(gather_ms[2], 1), 1e3 * gather_ms[1] / max(gather_ms[2], 1))
+        rows = [struct.unpack("<4d", b[:32]) for b in comm.all_gather(mine_stats)]
+        rates = [r[0] for r in rows]
+        line["per_rank"] = {
+            "proofs_per_s": rates, "proofs_per_s_min": min(rates), "proofs_per_s_max": max(rates), "proofs_per_s_sum": sum(rates),
+            "msm_table_build_s": [r[1] for r in rows],
+            "allgather_us_per_step": [r[2] for r in rows], "allgather_us_per_step_max": max(r[2] for r in rows),
+            "gather_to_host_us_per_step": [r[3] for r in rows],
+            "allgather_fraction_of_step": max(r[2] for r in rows) * 1e-6 / (elapsed / args.steps),
+            "note": ("proofs_per_s: each rank's own steps over its own clock (value = all proofs over the slowest rank's clock, barrier "
+                     "included); allgather_us_per_step: " + ("HIP events around the ncclAllGather of the step's proofs on the communicator's "
+                     "stream, gather_to_host: the copy of all ranks' records to the host behind it" if device_gather else
+                     "host wall time of the exchange through host buffers")),
+        }
+        if comm.kind == "rccl":
+            ri = comm.info()
+            line["config"]["rccl_path"], line["config"]["rccl_version"] = ri["path"], ri["version"]
+            line["config"]["rccl_calls_issued"] = ri["collectives"]
     line["host"]["end_to_end_proofs_per_s_from_dicts_per_gpu"] = per_gpu / (t_up + per_gpu * elapsed / total_proofs * world)
     line["clocks"] = clocks  # rank 0's GPU; None when amdgpu's hwmon files are not visible
 
     # HBM bytes per launch / per transform from the committed PMC passes of this round's build (rocprofv3 cannot run
     # inside this process): profiles/r03_pmc_summary.json, written by tools/pmc_summary.py from tools/pmc_collect.sh
     pmc, pmc_src = {"bench": {}, "ntt": {}, "factors": {}}, None
-    for name in ("r03_pmc_summary.json",):
+    for name in ("r04_pmc_summary.json", "r03_pmc_summary.json"):
         path = os.path.join(REPO, "profiles", name)
         if os.path.exists(path):
             pmc, pmc_src = json.load(open(path)), "profiles/" + name
+            break
 
     if msm_launches:
         avg_s = msm_ms * 1e-3 / msm_launches
@@ -645,7 +724,7 @@ def main():
                                            "addition in a register-only loop (tools/ubench) timed in a millisecond burst at the "
                                            "nominal clock; the sustained prover load runs at the lower clock in `clocks`, and "
                                            "its additions also fetch 64 table bytes each" % (windows * GROUP_ORDER)}
-    ntt_ms, ntt_launches, ntt_bytes = profile_sum("ntt_pass")
+    ntt_ms, ntt_launches, ntt_bytes = profile_sum("ntt_pass*")
     if ntt_launches:
         line["prover_ntt"] = {"kernel": "ntt passes inside the timed prover steps", "launches": ntt_launches, "total_ms": ntt_ms,
                               "achieved_GBps": ntt_bytes / (ntt_ms * 1e-3) / 1e9, "frac_of_hbm_peak": ntt_bytes / (ntt_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
@@ -653,9 +732,12 @@ def main():
     if not args.no_fallbacks and lookup_bits and world == 1:
         # the same prover when the HBM for the big table is not available: a 40 GB budget, and no table at all
         fb = {}
+        c75 = max(c for c in range(8, 18) if lookup_table_bytes(GROUP_ORDER, c) <= 80e9)
         c40 = max(c for c in range(8, 18) if lookup_table_bytes(GROUP_ORDER, c) <= 40e9)
         c4 = max(c for c in range(8, 18) if lookup_table_bytes(GROUP_ORDER, c) <= 4 << 30)
-        for name, conf in (("library_default_4GiB", (0, c4, 4 << 30)), ("table_budget_40GB", (0, c40, int(40e9))), ("bucket_method", (1, 0, 0))):
+        hbm_total = ctx.mem_info()[1]
+        for name, conf in (("library_default_4GiB", (0, c4, 4 << 30)), ("table_budget_40GB", (0, c40, int(40e9))),
+                           ("table_budget_80GB", (0, c75, int(80e9))), ("bucket_method", (1, 0, 0))):
             c2 = Context(local_rank)
             c2.msm_lookup(*conf)
             pr = BatchProver(setup, program, c2)
@@ -671,10 +753,13 @@ def main():
             assert not any(st)
             i2 = setup.device_bases(c2).lookup_info()
             fb[name] = {"proofs_per_s": B / dt, "ms_per_batch_of_%d" % B: 1e3 * dt, "msm_table_bits": i2["bits"],
-                        "msm_table_bytes": i2["bytes"], "msm_table_build_s": i2["build_s"]}
+                        "msm_table_bytes": i2["bytes"], "msm_table_build_s": i2["build_s"],
+                        "msm_table_fraction_of_hbm": i2["bytes"] / hbm_total, "fraction_of_value": (B / dt) / (total_proofs / elapsed), "streams": 1}
             del pr
             c2.close()
         line["fallbacks"] = fb
+        for k, v in fb.items():  # scalars inside `config`, where the driver's record keeps them
+            line["config"]["fallback_%s_proofs_s" % k] = round(v["proofs_per_s"], 1)
 
     if not args.no_end_to_end and world == 1 and provers[0].variables:
         # What a caller who produces witnesses natively gets: every lock-step batch of a step is uploaded afresh inside the
@@ -710,6 +795,7 @@ def main():
             "note": "a fresh pre-packed batch per lock-step batch inside the timed region: plonk_prover_upload_variables_async "
                     "from page-locked memory on a copy stream, overlapped with the other streams' rounds; witness generation "
                     "and packing (the caller's side) are outside, `host` has their Python cost"}
+        line["config"]["end_to_end_fraction"] = line["end_to_end"]["fraction_of_value"]
         for pr, buf in zip(provers, pinned):
             pr.ctx.host_free(buf)
 
@@ -741,6 +827,8 @@ def main():
                 "proofs_per_s": PB / dt, "ms_per_batch_of_%d" % PB: 1e3 * dt, "constraints": len(lines), "streams": 1,
                 "witness_generation_ms_per_proof": 1e3 * t_wit / PB,
                 "proof_0_bit_identical_to_fixture": proof_matches_fixture(BatchProver.decode(raw[:768]), "poseidon_%d" % n_p)}
+            line["config"]["poseidon_2^%d_proofs_s" % (n_p.bit_length() - 1)] = round(PB / dt, 1)
+            line["config"]["poseidon_2^%d_proof_0_matches_fixture" % (n_p.bit_length() - 1)] = cfg["poseidon_group_order_%d" % n_p]["proof_0_bit_identical_to_fixture"]
             del pr
         line["configs"] = {"configs[2]": cfg,
                            "note": "one stream, one lock-step batch resident (the headline runs 20 batches on 4 streams); fixture = "
@@ -775,6 +863,9 @@ def main():
         lt["proof_bytes"] = len(api.prove(dict(wit0)).to_bytes())
         lt["note"] = "wall time of one prove() call incl. witness staging and the download of the proof, warm (tables, Lagrange SRS and kernels loaded)"
         line["latency"] = lt
+        line["config"]["latency_api_ms"] = lt["api_prover"]["median_ms"]
+        line["config"]["latency_api_with_asserts_ms"] = lt["api_prover_with_asserts"]["median_ms"]
+        line["config"]["latency_batch_of_one_ms"] = lt["batch_prover_b1"]["median_ms"]
         del b1
 
     if not args.no_microbench:
@@ -795,14 +886,36 @@ def main():
         line["msm"] = {"msms_per_s_2^11_x4608": world * 4608 / (ms_msm * 1e-3), "ms_4608": ms_msm, "replicas": world}
         ms20 = sweep["2^20"]["fwd"]["ms"]
         ach = 64.0 * (1 << 20) / (ms20 * 1e-3) / 1e9  # per GPU
+        # the two launches of the 2^20 transform one by one: HIP events recorded around each pass on the library's stream
+        # (profiles/r04_ntt_kernel_stats.txt holds the rocprofv3 --kernel-trace --stats durations of the same transforms)
+        ctx.profile_reset()
+        ctx.profile(True)
+        ntt_microbench(ctx, 20, 1, reps=8)
+        ctx.profile(False)
+        pc, pr_ = ctx.profile_read("ntt_pass_columns"), ctx.profile_read("ntt_pass_rows")
+        per_pass = {"columns_us": 1e3 * pc[0] / max(pc[1], 1), "rows_us": 1e3 * pr_[0] / max(pr_[1], 1)}
+        ctx.profile_reset()
+        tr20 = pmc.get("ntt", {}).get("ntt_2^20")
+        q20 = sweep["2^20"]["fwd_queue16"]["ms_per_transform"]
         line["roofline_ntt"] = {"kernel": "ntt_wavel_column_kernel + ntt_wavel_kernel (N = 2^20 = 2^10 x 2^10, two launches)", "bound": "hbm",
                                 "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                                "traffic": pmc.get("ntt", {}).get("ntt_2^20"), "traffic_source": pmc_src,
+                                "per_pass_us": per_pass, "ms_lone": ms20, "ms_in_a_queue_of_16": q20,
+                                "frac_in_a_queue_of_16": 64.0 * (1 << 20) / (q20 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                "traffic": tr20, "traffic_over_algorithmic": tr20 / (64.0 * (1 << 20)) if tr20 else None, "traffic_source": pmc_src,
                                 "traffic_note": "includes 80 N bytes of inter-pass twiddles read from the table in usage order (one "
                                                 "multiplication per element instead of two, a deliberate bytes-for-instructions trade; "
                                                 "plonk_ntt_set_table_budget(0) gives 2.07 x the algorithmic 64 N instead of 3.3 x and a 6 % slower transform)",
                                 "note": "ALU-bound on the 254-bit multiplication: ~9.5 N multiplications (two passes + inter-pass "
                                         "twiddles) at ~150-170 G/s chip-wide bound the transform near 10 % of HBM peak (DESIGN.md 4.1)"}
+        if "roofline" in line:  # the kernel north_star puts a number on, inside the block the driver's record keeps
+            line["roofline"]["secondary"] = {k: line["roofline_ntt"][k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "per_pass_us",
+                                                                                     "ms_lone", "ms_in_a_queue_of_16", "frac_in_a_queue_of_16", "traffic",
+                                                                                     "traffic_over_algorithmic", "traffic_source")}
+        line["config"]["ntt_2^20_ms"] = ms20
+        line["config"]["ntt_2^16_ms"] = sweep["2^16"]["fwd"]["ms"]
+        line["config"]["ntt_2^24_ms"] = sweep["2^24"]["fwd"]["ms"]
+        line["config"]["ntt_2^11_x2048_gf_elems_s"] = small["2^11_x2048"]["gf_elems_per_s"]
+        line["config"]["bls12_381_ntt_parity"] = BLS_PIN_NOTE
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         dt, oproof, prim = cpu_baseline()
         line["cpu_baseline"] = {

@@ -53,6 +53,7 @@ int plonk_host_alloc(plonk_ctx* ctx, size_t bytes, void** out_hptr);
 int plonk_host_free(plonk_ctx* ctx, void* hptr);
 int plonk_mem_alloc(plonk_ctx* ctx, size_t bytes, void** out_dptr);
 int plonk_mem_free(plonk_ctx* ctx, void* dptr);
+int plonk_mem_info(plonk_ctx* ctx, size_t* out_free, size_t* out_total); /* hipMemGetInfo of the context's device */
 int plonk_mem_h2d(plonk_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);
 int plonk_mem_d2h(plonk_ctx* ctx, void* h_dst, const void* d_src, size_t bytes);
 int plonk_mem_d2d(plonk_ctx* ctx, void* d_dst, const void* d_src, size_t bytes);
@@ -137,6 +138,17 @@ int plonk_fr_rotate(plonk_ctx* ctx, const void* d_in, void* d_out, size_t count,
 int plonk_fr_batch_inverse(plonk_ctx* ctx, const void* d_in, void* d_out, size_t count);
 int plonk_fr_barycentric(plonk_ctx* ctx, const void* d_vals, unsigned log_n, const uint8_t x_le32[32],
                          uint8_t out_le32[32]);
+/* batches of the operators above, for callers that issue them in runs (each call of the single forms is a launch, and each
+ * barycentric_eval a host synchronisation):
+ * plonk_fr_barycentric_many  n_polys <= 16 polynomials (separate buffers, 2^log_n Lagrange values each), polynomial k
+ *                       evaluated at xs[k]: the six evaluations of prover.py:228-239 in one kernel and one synchronisation
+ * plonk_fr_lincomb      d_out[i] = constant + sum_k scalars[k] * d_terms[k][i]: a run of `Polynomial * Scalar`, `+`, `-`
+ *                       (poly.py:23-83) such as the linearisation polynomial and the opening numerators of
+ *                       prover.py:245-288, in one pass; n_terms <= 20; d_out may alias a term                          */
+int plonk_fr_barycentric_many(plonk_ctx* ctx, size_t n_polys, const void* const* d_vals, unsigned log_n, const uint8_t* xs_le32,
+                              uint8_t* out_le32);
+int plonk_fr_lincomb(plonk_ctx* ctx, size_t n_terms, const void* const* d_terms, const uint8_t* scalars_le32,
+                     const uint8_t constant_le32[32], void* d_out, size_t count);
 
 /* plonk_fr_powers       out[k] = first * base^k, k < count: Scalar.roots_of_unity (curve.py:19-24), and the coset points
  *                       X_big[k] = fft_cofactor * mu^k the prover divides by (prover.py:160-161, 271-283)
@@ -292,6 +304,13 @@ int plonk_gather_proofs_device(plonk_comm* comm, plonk_prover* const* provers, s
                                uint8_t* h_recv);
 int plonk_comm_max_f64(plonk_comm* comm, double* inout);
 int plonk_comm_barrier(plonk_comm* comm);
+/* device time of the last plonk_gather_proofs_device on this communicator: the ncclAllGather itself and the copy of every
+ * rank's records to the host (HIP events on the communicator's stream).                                              */
+int plonk_comm_last_gather_ms(plonk_comm* comm, float* out_allgather_ms, float* out_to_host_ms);
+/* which RCCL this process talks to: the file the loaded ncclGetUniqueId lives in (load order: $PLONK_RCCL_LIB, then
+ * $ROCM_PATH/lib/librccl.so.1, /opt/rocm/lib/librccl.so.1, then the sonames), ncclGetVersion's code, and how many RCCL
+ * collectives / point-to-point groups `comm` has issued (comm may be NULL; any out pointer may be NULL).              */
+int plonk_comm_info(const plonk_comm* comm, char* out_path, size_t path_cap, int* out_version, uint64_t* out_collectives);
 /* ---- one transform across the GPUs of a communicator (four-step NTT) ----------------------
  * Polynomial.fft / ifft (poly.py:113-148) for N = 2^log_n = R1 R2 points that need not fit one GPU (log_n = 18, 20, 22,
  * 24, 26: R1 x R2 = 2^9 x 2^9, 2^11 x 2^9, 2^11 x 2^11, 2^13 x 2^11, 2^13 x 2^13), over W = 2^k ranks, W <= min(R1, R2) / 32.

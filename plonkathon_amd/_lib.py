@@ -24,6 +24,7 @@ SIGNATURES = {
     "plonk_ctx_sync": (ctypes.c_int, [ctypes.c_void_p]),
     "plonk_ctx_device_name": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t]),
     "plonk_mem_alloc": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t, c_void_pp]),
+    "plonk_mem_info": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]),
     "plonk_mem_free": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "plonk_mem_h2d": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]),
     "plonk_mem_d2h": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]),
@@ -61,6 +62,8 @@ SIGNATURES = {
     "plonk_fr_rotate": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t]),
     "plonk_fr_batch_inverse": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]),
     "plonk_fr_barycentric": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint, _u8p, ctypes.c_void_p]),
+    "plonk_fr_barycentric_many": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint, ctypes.c_char_p, ctypes.c_char_p]),
+    "plonk_fr_lincomb": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p), ctypes.c_char_p, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_size_t]),
     "plonk_srs_load_ptau": (ctypes.c_int, [ctypes.c_void_p, _u8p, ctypes.c_size_t, c_void_pp]),
     "plonk_srs_load_affine": (ctypes.c_int, [ctypes.c_void_p, _u8p, ctypes.c_size_t, c_void_pp]),
     "plonk_srs_lagrange": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint, c_void_pp]),
@@ -87,6 +90,8 @@ SIGNATURES = {
     "plonk_gather_results": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "plonk_comm_max_f64": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double)]),
     "plonk_comm_barrier": (ctypes.c_int, [ctypes.c_void_p]),
+    "plonk_comm_last_gather_ms": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]),
+    "plonk_comm_info": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_uint64)]),
     "plonk_fr_ntt_dist_columns": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint, ctypes.c_uint, ctypes.c_uint, ctypes.c_int]),
     "plonk_fr_ntt_dist_rows": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint, ctypes.c_uint, ctypes.c_uint, ctypes.c_int]),
     "plonk_comm_all_to_all": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]),

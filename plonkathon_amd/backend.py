@@ -81,6 +81,12 @@ class Context:
     def host_free(self, buf):
         check(self.L.plonk_host_free(self.handle, buf._plonk_hptr))
 
+    def mem_info(self):
+        """(free, total) bytes of this context's device (hipMemGetInfo)."""
+        free, total = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        check(self.L.plonk_mem_info(self.handle, ctypes.byref(free), ctypes.byref(total)))
+        return free.value, total.value
+
     def timer_start(self):
         check(self.L.plonk_timer_start(self.handle))
 
@@ -127,7 +133,8 @@ class Context:
         return True
 
     def trim(self):
-        """Return every pooled buffer to the driver."""
+        """Return every pooled buffer to the driver (call it before a large allocation elsewhere — an MSM table, a second
+        context's twiddle tables — when HBM is nearly full: the C side does not know about this pool)."""
         for free in self._pool.values():
             for ptr in free:
                 self.L.plonk_mem_free(self.handle, ptr)
@@ -150,7 +157,12 @@ class DeviceBuffer:
         self.ptr = ctx._pool_take(self._nbytes)
         if self.ptr is None:
             self.ptr = ctypes.c_void_p()
-            check(ctx.L.plonk_mem_alloc(ctx.handle, self._nbytes, ctypes.byref(self.ptr)))
+            rc = ctx.L.plonk_mem_alloc(ctx.handle, self._nbytes, ctypes.byref(self.ptr))
+            if rc == _lib.PLONK_ERR_NOMEM and ctx._pool_bytes:
+                # the pool may hold up to 1 GiB of freed buffers of OTHER sizes: hand them back to the driver and retry once
+                ctx.trim()
+                rc = ctx.L.plonk_mem_alloc(ctx.handle, self._nbytes, ctypes.byref(self.ptr))
+            check(rc)
 
     def at(self, elem_offset):
         return ctypes.c_void_p(self.ptr.value + 32 * elem_offset)
@@ -163,6 +175,17 @@ class DeviceBuffer:
                 self.ptr = None
         except Exception:
             pass
+
+
+class DeviceView:
+    """`n` elements of another buffer starting at element `offset`: no storage of its own, keeps the parent alive."""
+
+    def __init__(self, parent, offset, n_elems):
+        self.ctx, self.parent, self.n = parent.ctx, parent, int(n_elems)
+        self.ptr = ctypes.c_void_p(parent.ptr.value + 32 * offset)
+
+    def at(self, elem_offset):
+        return ctypes.c_void_p(self.ptr.value + 32 * elem_offset)
 
 
 _default = None

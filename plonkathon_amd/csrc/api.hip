@@ -206,6 +206,12 @@ int plonk_mem_alloc(plonk_ctx* ctx, size_t bytes, void** out_dptr) {
     *out_dptr = p;
     return PLONK_OK;
 }
+int plonk_mem_info(plonk_ctx* ctx, size_t* out_free, size_t* out_total) {
+    PLONK_REQUIRE(ctx && out_free && out_total, PLONK_ERR_ARG, "bad argument");
+    PLONK_ENTER(ctx);
+    PLONK_CHECK_HIP(hipMemGetInfo(out_free, out_total));
+    return PLONK_OK;
+}
 int plonk_mem_free(plonk_ctx* ctx, void* dptr) {
     PLONK_REQUIRE(ctx, PLONK_ERR_ARG, "ctx is NULL");
     PLONK_ENTER(ctx);
@@ -286,6 +292,7 @@ int plonk_ntt_configure(plonk_ctx* ctx, unsigned tile_log, unsigned single_pass_
     ctx->ntt_tile_log = tile_log;
     ctx->ntt_single_log = single_pass_log;
     ctx->ntt_radix_log = radix_log;
+    ctx->ntt_cfg_epoch++;
     return PLONK_OK;
 }
 
@@ -294,6 +301,7 @@ int plonk_ntt_select_kernel(plonk_ctx* ctx, unsigned kind) {
     PLONK_ENTER(ctx);
     PLONK_REQUIRE(kind <= 5 && kind != 3, PLONK_ERR_ARG, "kernel kind must be 0 (auto), 1 (radix-2 stages), 2 (Stockham radix-8), 4 (auto among the LDS kernels) or 5 (in-register wave kernels wherever they apply)");
     ctx->ntt_kind = kind;
+    ctx->ntt_cfg_epoch++;
     return PLONK_OK;
 }
 
@@ -304,6 +312,7 @@ int plonk_ntt_set_split(plonk_ctx* ctx, unsigned log_n, unsigned log_r1) {
     PLONK_REQUIRE(log_r1 == 0 || (log_r1 >= 8 && log_r1 <= 13 && log_n - log_r1 >= 8 && log_n - log_r1 <= 13), PLONK_ERR_ARG,
                   "2^%u = 2^%u x 2^%u: both factors must lie in 2^8 .. 2^13", log_n, log_r1, log_n - log_r1);
     ctx->ntt_split[log_n] = (unsigned char)log_r1;
+    ctx->ntt_cfg_epoch++;
     return PLONK_OK;
 }
 
@@ -318,6 +327,7 @@ int plonk_ntt_get_split(plonk_ctx* ctx, unsigned log_n, unsigned* out_log_r1) {
 int plonk_ntt_set_table_budget(plonk_ctx* ctx, size_t bytes) {
     PLONK_REQUIRE(ctx, PLONK_ERR_ARG, "ctx is NULL");
     ctx->ntt_table_budget = bytes;
+    ctx->ntt_cfg_epoch++;
     return PLONK_OK;
 }
 
@@ -493,6 +503,55 @@ int plonk_fr_barycentric(plonk_ctx* ctx, const void* d_vals, unsigned log_n, con
     return PLONK_OK;
 }
 
+// n_polys <= 16 polynomials of 2^log_n Lagrange values in separate buffers, polynomial k at its own point xs[k]: ONE kernel
+// (a workgroup per polynomial) and ONE host synchronisation — the six evaluations of round 4 (prover.py:228-239) cost six
+// round trips through plonk_fr_barycentric
+int plonk_fr_barycentric_many(plonk_ctx* ctx, size_t n_polys, const void* const* d_vals, unsigned log_n, const uint8_t* xs_le32, uint8_t* out_le32) {
+    PLONK_REQUIRE(ctx && d_vals && xs_le32 && out_le32 && n_polys >= 1 && n_polys <= 16, PLONK_ERR_ARG, "bad argument (1 .. 16 polynomials)");
+    PLONK_ENTER(ctx);
+    PLONK_REQUIRE(log_n <= PLONK_FR_TWO_ADICITY, PLONK_ERR_ARG, "size 2^%u exceeds the 2-adicity of Fr", log_n);
+    Fr* xs = ctx->host_tmp;  // (context-owned: an asynchronous copy from pageable memory must not outlive its source)
+    const Fr* polys[16];
+    for (size_t k = 0; k < n_polys; k++) {
+        PLONK_REQUIRE(d_vals[k], PLONK_ERR_ARG, "polynomial %zu is NULL", k);
+        PLONK_REQUIRE(le32_below_modulus(xs_le32 + 32 * k, false), PLONK_ERR_ARG, "x[%zu] is not a canonical Fr value", k);
+        xs[k] = fr_from_le32(xs_le32 + 32 * k);
+        polys[k] = (const Fr*)d_vals[k];
+    }
+    const Fr* roots;
+    PLONK_TRY(ntt_get_roots(ctx, log_n, false, &roots));
+    void* tmp;
+    PLONK_TRY(ctx_scratch(ctx, 2, 32 * sizeof(Fr), &tmp));
+    Fr* dx = (Fr*)tmp;
+    PLONK_CHECK_HIP(hipMemcpyAsync(dx, xs, n_polys * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+    Fr nn = fp_zero<FrParams>();
+    nn.v[0] = (uint32_t)((uint64_t)1 << log_n);
+    const Fr n_inv = fp_inv(fp_to_mont(nn));
+    PLONK_TRY(k_fr_barycentric_ptrs(ctx, polys, roots, log_n, dx, n_inv, dx + 16, n_polys));
+    PLONK_TRY(k_fr_from_mont(ctx, dx + 16, dx + 16, n_polys));
+    PLONK_CHECK_HIP(hipMemcpyAsync(out_le32, dx + 16, 32 * n_polys, hipMemcpyDeviceToHost, ctx->stream));
+    PLONK_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    return PLONK_OK;
+}
+
+// d_out[i] = constant + sum_k scalars[k] * d_terms[k][i], i < count; n_terms <= 20; d_out may be one of the terms
+int plonk_fr_lincomb(plonk_ctx* ctx, size_t n_terms, const void* const* d_terms, const uint8_t* scalars_le32, const uint8_t constant_le32[32],
+                     void* d_out, size_t count) {
+    PLONK_REQUIRE(ctx && n_terms <= 20 && (n_terms == 0 || (d_terms && scalars_le32)) && constant_le32 && (count == 0 || d_out), PLONK_ERR_ARG,
+                  "bad argument (at most 20 terms)");
+    PLONK_ENTER(ctx);
+    Fr sc[20];
+    const Fr* terms[20];
+    for (size_t k = 0; k < n_terms; k++) {
+        PLONK_REQUIRE(d_terms[k] || !count, PLONK_ERR_ARG, "term %zu is NULL", k);
+        PLONK_REQUIRE(le32_below_modulus(scalars_le32 + 32 * k, false), PLONK_ERR_ARG, "scalar %zu is not a canonical Fr value", k);
+        sc[k] = fr_from_le32(scalars_le32 + 32 * k);
+        terms[k] = (const Fr*)d_terms[k];
+    }
+    PLONK_REQUIRE(le32_below_modulus(constant_le32, false), PLONK_ERR_ARG, "the constant is not a canonical Fr value");
+    return k_fr_lincomb(ctx, terms, sc, (unsigned)n_terms, fr_from_le32(constant_le32), (Fr*)d_out, count);
+}
+
 // ---- G1 ----------------------------------------------------------------------------------------
 static int srs_alloc(plonk_ctx* ctx, size_t n_points, plonk_srs** out) {
     plonk_srs* s = new plonk_srs();
@@ -643,7 +702,8 @@ int plonk_profile_read(plonk_ctx* ctx, const char* kernel, double* total_ms, uin
     double ms = 0, bytes = 0;
     uint64_t n = 0;
     for (auto& r : ctx->prof) {
-        if (strcmp(r.name, kernel) != 0) continue;
+        const size_t kl = strlen(kernel);  // "name" matches exactly, "prefix*" every record whose name starts with prefix
+        if (kl && kernel[kl - 1] == '*' ? strncmp(r.name, kernel, kl - 1) != 0 : strcmp(r.name, kernel) != 0) continue;
         float t = 0;
         PLONK_CHECK_HIP(hipEventElapsedTime(&t, r.a, r.b));
         ms += t;

@@ -9,6 +9,7 @@
 // (plonkathon_amd/distributed.py does it over a loopback socket).  librccl is dlopen'ed on first use so that
 // single-GPU users never load it.
 #include <dlfcn.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <rccl/rccl.h>  // types and enums only: every call goes through the dlsym table below
@@ -27,17 +28,37 @@ struct Rccl {
     ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*GetVersion)(int*) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    std::string asked;  // the name dlopen accepted
 };
 Rccl g_rccl;
 
+// Load order, explicit so that the process decides which RCCL it talks to and not whatever an earlier import left in the
+// link map: $PLONK_RCCL_LIB (a path), then the ROCm installation's own library ($ROCM_PATH/lib, /opt/rocm/lib), then the
+// bare sonames.  (A process that imported PyTorch first has torch's bundled librccl mapped; with a bare soname dlopen
+// would hand that one back.  bench.py and the product import no torch: they get the system library either way.)
 int rccl_load() {
     if (g_rccl.handle) return PLONK_OK;
-    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    std::vector<std::string> names;
+    if (const char* e = getenv("PLONK_RCCL_LIB"))
+        if (*e) names.push_back(e);
+    if (const char* e = getenv("ROCM_PATH"))
+        if (*e) names.push_back(std::string(e) + "/lib/librccl.so.1");
+    names.push_back("/opt/rocm/lib/librccl.so.1");
+    names.push_back("librccl.so.1");
+    names.push_back("librccl.so");
     void* h = nullptr;
-    for (const char* nm : names)
-        if ((h = dlopen(nm, RTLD_NOW | RTLD_LOCAL))) break;
-    PLONK_REQUIRE(h, PLONK_ERR_STATE, "librccl could not be loaded: %s", dlerror());
+    std::string tried;
+    for (const std::string& nm : names) {
+        if ((h = dlopen(nm.c_str(), RTLD_NOW | RTLD_LOCAL))) {
+            g_rccl.asked = nm;
+            break;
+        }
+        tried += nm + " ";
+        if (getenv("PLONK_RCCL_LIB") && nm == getenv("PLONK_RCCL_LIB")) break;  // an explicit choice does not fall through
+    }
+    PLONK_REQUIRE(h, PLONK_ERR_STATE, "librccl could not be loaded (tried: %s): %s", tried.c_str(), dlerror());
 #define PLONK_RCCL_SYM(field, sym)                                                        \
     *(void**)(&g_rccl.field) = dlsym(h, sym);                                             \
     PLONK_REQUIRE(g_rccl.field, PLONK_ERR_STATE, "librccl does not export %s", sym)
@@ -50,6 +71,7 @@ int rccl_load() {
     PLONK_RCCL_SYM(Recv, "ncclRecv");
     PLONK_RCCL_SYM(GroupStart, "ncclGroupStart");
     PLONK_RCCL_SYM(GroupEnd, "ncclGroupEnd");
+    PLONK_RCCL_SYM(GetVersion, "ncclGetVersion");
     PLONK_RCCL_SYM(GetErrorString, "ncclGetErrorString");
 #undef PLONK_RCCL_SYM
     g_rccl.handle = h;
@@ -73,6 +95,10 @@ struct plonk_comm {
     uint8_t* d_buf = nullptr;  // [send | recv] staging in HBM
     size_t cap = 0;
     std::vector<hipEvent_t> events;  // plonk_gather_proofs_device: one per prover stream
+    hipEvent_t ev_free = nullptr;    //   "the send buffer may be overwritten": recorded on the communicator's stream
+    hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr, ev_t2 = nullptr;  // timing: collective start / end, host copy end
+    bool timed = false;
+    uint64_t collectives = 0;  // RCCL calls issued through this communicator (tests: the one-rank legs really call RCCL)
 };
 
 static int comm_staging(plonk_comm* c, size_t bytes) {
@@ -121,6 +147,12 @@ int plonk_comm_create(plonk_ctx* ctx, const uint8_t id_bytes[PLONK_COMM_ID_BYTES
         delete c;
         return PLONK_ERR_HIP;
     }
+    if (hipEventCreateWithFlags(&c->ev_free, hipEventDisableTiming) != hipSuccess || hipEventCreate(&c->ev_t0) != hipSuccess ||
+        hipEventCreate(&c->ev_t1) != hipSuccess || hipEventCreate(&c->ev_t2) != hipSuccess) {
+        plonk_set_error("hipEventCreate for a communicator failed");
+        plonk_comm_destroy(c);
+        return PLONK_ERR_HIP;
+    }
     *out = c;
     return PLONK_OK;
 }
@@ -132,6 +164,8 @@ int plonk_comm_destroy(plonk_comm* c) {
     if (c->comm) g_rccl.CommDestroy(c->comm);
     if (c->d_buf) hipFree(c->d_buf);
     for (hipEvent_t e : c->events) hipEventDestroy(e);
+    for (hipEvent_t e : {c->ev_free, c->ev_t0, c->ev_t1, c->ev_t2})
+        if (e) hipEventDestroy(e);
     delete c;
     return PLONK_OK;
 }
@@ -153,6 +187,7 @@ int plonk_gather_results(plonk_comm* c, const uint8_t* h_send, size_t bytes_per_
     uint8_t *d_send = c->d_buf, *d_recv = c->d_buf + bytes_per_rank;
     PLONK_CHECK_HIP(hipMemcpyAsync(d_send, h_send, bytes_per_rank, hipMemcpyHostToDevice, s));
     PLONK_CHECK_RCCL(g_rccl.AllGather(d_send, d_recv, bytes_per_rank, ncclUint8, c->comm, s));
+    c->collectives++;
     PLONK_CHECK_HIP(hipMemcpyAsync(h_recv, d_recv, total, hipMemcpyDeviceToHost, s));
     PLONK_CHECK_HIP(hipStreamSynchronize(s));
     return PLONK_OK;
@@ -173,24 +208,71 @@ int plonk_gather_proofs_device(plonk_comm* c, plonk_prover* const* provers, size
     PLONK_TRY(comm_staging(c, per_rank + total));
     hipStream_t s = c->ctx->stream;
     uint8_t *d_send = c->d_buf, *d_recv = c->d_buf + per_rank;
+    // nothing is enqueued before every argument has been checked
+    for (size_t k = 0; k < n_provers; k++)
+        PLONK_REQUIRE(provers[k] && prover_ctx(provers[k])->device == c->ctx->device, PLONK_ERR_ARG, "prover %zu lives on another device than the communicator", k);
     while (c->events.size() < n_provers) {
         hipEvent_t e;
         PLONK_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         c->events.push_back(e);
     }
     PLONK_CHECK_HIP(hipMemsetAsync(d_send + n * rec, 0, per_rank - n * rec, s));
-    for (size_t k = 0; k < n_provers; k++) {
-        PLONK_REQUIRE(prover_ctx(provers[k])->device == c->ctx->device, PLONK_ERR_ARG, "prover %zu lives on another device than the communicator", k);
-        // the send buffer may still be read by the previous gather: order the packing behind the communicator's stream
-        PLONK_CHECK_HIP(hipEventRecord(c->events[k], s));
-        PLONK_CHECK_HIP(hipStreamWaitEvent(prover_ctx(provers[k])->stream, c->events[k], 0));
-        PLONK_TRY(prover_pack_device(provers[k], batch, compressed, d_send + k * batch * rec, d_send + n * rec + k * batch, c->events[k]));
-        PLONK_CHECK_HIP(hipStreamWaitEvent(s, c->events[k], 0));
+    // the send buffer may still be read by the previous gather: ONE "buffer free" event on the communicator's stream, which
+    // every prover stream waits for — the provers then pack concurrently, each on its own stream (recording the event once per
+    // prover, behind the wait on the previous prover's pack, serialised them) — and the communicator's stream waits for all
+    PLONK_CHECK_HIP(hipEventRecord(c->ev_free, s));
+    int rc = PLONK_OK;
+    size_t packed = 0;
+    for (; packed < n_provers && rc == PLONK_OK; packed++) {
+        hipStream_t ps = prover_ctx(provers[packed])->stream;
+        if (hipStreamWaitEvent(ps, c->ev_free, 0) != hipSuccess) {
+            plonk_set_error("hipStreamWaitEvent on prover %zu's stream failed", packed);
+            rc = PLONK_ERR_HIP;
+            break;
+        }
+        rc = prover_pack_device(provers[packed], batch, compressed, d_send + packed * batch * rec, d_send + n * rec + packed * batch, c->events[packed]);
     }
-    if (c->world == 1) PLONK_CHECK_HIP(hipMemcpyAsync(d_recv, d_send, per_rank, hipMemcpyDeviceToDevice, s));
-    else PLONK_CHECK_RCCL(g_rccl.AllGather(d_send, d_recv, per_rank, ncclUint8, c->comm, s));
+    for (size_t k = 0; k < packed; k++) (void)hipStreamWaitEvent(s, c->events[k], 0);  // also on failure: the packs enqueued so far finish before the buffer is reused
+    if (rc != PLONK_OK) {
+        (void)hipStreamSynchronize(s);
+        return rc;
+    }
+    // one rank is not a special case: the all-gather of a one-rank communicator is RCCL's own copy (and the only way this
+    // call path can be exercised on a one-GPU box)
+    PLONK_CHECK_HIP(hipEventRecord(c->ev_t0, s));
+    PLONK_CHECK_RCCL(g_rccl.AllGather(d_send, d_recv, per_rank, ncclUint8, c->comm, s));
+    c->collectives++;
+    PLONK_CHECK_HIP(hipEventRecord(c->ev_t1, s));
     PLONK_CHECK_HIP(hipMemcpyAsync(h_recv, d_recv, total, hipMemcpyDeviceToHost, s));
+    PLONK_CHECK_HIP(hipEventRecord(c->ev_t2, s));
     PLONK_CHECK_HIP(hipStreamSynchronize(s));
+    c->timed = true;
+    return PLONK_OK;
+}
+
+// device time of the last plonk_gather_proofs_device: the ncclAllGather itself, and the copy of all ranks' records to the host
+int plonk_comm_last_gather_ms(plonk_comm* c, float* out_allgather_ms, float* out_to_host_ms) {
+    PLONK_REQUIRE(c && out_allgather_ms && out_to_host_ms, PLONK_ERR_ARG, "bad argument");
+    PLONK_REQUIRE(c->timed, PLONK_ERR_STATE, "no plonk_gather_proofs_device has completed on this communicator");
+    PLONK_ENTER(c->ctx);
+    PLONK_CHECK_HIP(hipEventElapsedTime(out_allgather_ms, c->ev_t0, c->ev_t1));
+    PLONK_CHECK_HIP(hipEventElapsedTime(out_to_host_ms, c->ev_t1, c->ev_t2));
+    return PLONK_OK;
+}
+
+// which RCCL this process talks to: the file the loaded ncclGetUniqueId lives in (dladdr), ncclGetVersion's code
+// (major * 10000 + minor * 100 + patch), and the number of RCCL collectives / point-to-point groups this communicator has
+// issued (comm may be NULL: the library is loaded if it was not).
+int plonk_comm_info(const plonk_comm* c, char* out_path, size_t path_cap, int* out_version, uint64_t* out_collectives) {
+    PLONK_TRY(rccl_load());
+    if (out_path && path_cap) {
+        Dl_info di;
+        const char* nm = (dladdr((void*)g_rccl.GetUniqueId, &di) && di.dli_fname) ? di.dli_fname : g_rccl.asked.c_str();
+        strncpy(out_path, nm, path_cap - 1);
+        out_path[path_cap - 1] = 0;
+    }
+    if (out_version) PLONK_CHECK_RCCL(g_rccl.GetVersion(out_version));
+    if (out_collectives) *out_collectives = c ? c->collectives : 0;
     return PLONK_OK;
 }
 
@@ -203,6 +285,7 @@ int plonk_comm_max_f64(plonk_comm* c, double* inout) {
     double* d = (double*)c->d_buf;
     PLONK_CHECK_HIP(hipMemcpyAsync(d, inout, sizeof(double), hipMemcpyHostToDevice, s));
     PLONK_CHECK_RCCL(g_rccl.AllReduce(d, d, 1, ncclDouble, ncclMax, c->comm, s));
+    c->collectives++;
     PLONK_CHECK_HIP(hipMemcpyAsync(inout, d, sizeof(double), hipMemcpyDeviceToHost, s));
     PLONK_CHECK_HIP(hipStreamSynchronize(s));
     return PLONK_OK;
@@ -214,16 +297,14 @@ int plonk_comm_all_to_all(plonk_comm* c, const void* d_send, void* d_recv, size_
     PLONK_REQUIRE(c && d_send && d_recv && bytes_per_peer, PLONK_ERR_ARG, "bad argument");
     PLONK_ENTER(c->ctx);
     hipStream_t s = c->ctx->stream;
-    if (c->world == 1) {
-        PLONK_CHECK_HIP(hipMemcpyAsync(d_recv, d_send, bytes_per_peer, hipMemcpyDeviceToDevice, s));
-        return PLONK_OK;
-    }
+    // (one rank included: a send / receive pair to oneself inside a group is RCCL's own copy)
     PLONK_CHECK_RCCL(g_rccl.GroupStart());
     for (int r = 0; r < c->world; r++) {
         PLONK_CHECK_RCCL(g_rccl.Send((const uint8_t*)d_send + (size_t)r * bytes_per_peer, bytes_per_peer, ncclUint8, r, c->comm, s));
         PLONK_CHECK_RCCL(g_rccl.Recv((uint8_t*)d_recv + (size_t)r * bytes_per_peer, bytes_per_peer, ncclUint8, r, c->comm, s));
     }
     PLONK_CHECK_RCCL(g_rccl.GroupEnd());
+    c->collectives++;
     return PLONK_OK;
 }
 

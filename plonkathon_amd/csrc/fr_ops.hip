@@ -98,6 +98,39 @@ int k_fr_pointwise_scalar(plonk_ctx* ctx, int op, const Fr* a, const Fr& s_mont,
 }
 
 // ------------------------------------------------------------------------------------------------
+// out[i] = constant + sum_k scalar[k] * term[k][i]: a whole run of `Polynomial * Scalar`, `+`, `-` (the linearisation
+// polynomial R and the opening numerators of prover.py:245-288 are such runs: ~40 operator calls, each a launch and a
+// pass over 4n elements) as ONE pass — every term read once, one store.
+#define FR_LINCOMB_MAX 20
+struct FrLincomb {
+    const Fr* term[FR_LINCOMB_MAX];
+    Fr scalar[FR_LINCOMB_MAX];
+    Fr constant;
+    unsigned n_terms;
+};
+__global__ void fr_lincomb_kernel(FrLincomb a, Fr* out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        Fr acc = a.constant;
+        for (unsigned k = 0; k < a.n_terms; k++) acc = fp_add(acc, fp_mul(fp_load(a.term[k] + i), a.scalar[k]));
+        fp_store(out + i, acc);
+    }
+}
+int k_fr_lincomb(plonk_ctx* ctx, const Fr* const* terms, const Fr* scalars_mont, unsigned n_terms, const Fr& constant_mont, Fr* out, size_t n) {
+    if (!n) return PLONK_OK;
+    FrLincomb a;
+    memset(&a, 0, sizeof a);
+    for (unsigned k = 0; k < n_terms; k++) {
+        a.term[k] = terms[k];
+        a.scalar[k] = scalars_mont[k];
+    }
+    a.constant = constant_mont;
+    a.n_terms = n_terms;
+    PLONK_LAUNCH(fr_lincomb_kernel, grid_for(n), dim3(256), 0, ctx->stream, a, out, n);
+    PLONK_CHECK_HIP(hipGetLastError());
+    return PLONK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // out[b][i] = in[b][(i + shift) mod n]        poly.py:102-109
 __global__ void fr_rotate_kernel(const Fr* in, Fr* out, size_t n, size_t shift, size_t total) {
     for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
@@ -203,10 +236,12 @@ int k_fr_powers(plonk_ctx* ctx, const Fr& base_mont, const Fr& first_mont, Fr* o
 // accumulates v_i * w^i * d_i^-1 and the block tree-reduces the partial sums through LDS.
 // `roots` is the full table w^0..w^(N-1).  x values: one per polynomial (x_stride = 1) or shared (0).
 #define BARY_CHUNK 8
-__global__ void fr_barycentric_kernel(const Fr* vals, const Fr* roots, unsigned log_n, const Fr* xs, size_t x_stride,
+#define FR_BARY_MANY_MAX 16
+struct FrBaryPtrs { const Fr* p[FR_BARY_MANY_MAX]; };  // vals == null: polynomial b lives at ptrs.p[b] (plonk_fr_barycentric_many)
+__global__ void fr_barycentric_kernel(const Fr* vals, FrBaryPtrs ptrs, const Fr* roots, unsigned log_n, const Fr* xs, size_t x_stride,
                                       Fr n_inv, Fr* out) {
     const size_t n = (size_t)1 << log_n;
-    const Fr* v = vals + (size_t)blockIdx.x * n;
+    const Fr* v = vals ? vals + (size_t)blockIdx.x * n : ptrs.p[blockIdx.x];
     const Fr x = fp_load(xs + (size_t)blockIdx.x * x_stride);
     Fr sum = fp_zero<FrParams>();
     size_t nchunks = (n + BARY_CHUNK - 1) / BARY_CHUNK;
@@ -252,8 +287,25 @@ int k_fr_barycentric(plonk_ctx* ctx, const Fr* vals, const Fr* roots, unsigned l
     size_t n = (size_t)1 << log_n;
     unsigned block = 256;
     while (block > 64 && (size_t)block * BARY_CHUNK > n) block >>= 1;
-    PLONK_LAUNCH(fr_barycentric_kernel, dim3((unsigned)n_polys), dim3(block), 0, ctx->stream, vals, roots, log_n,
+    FrBaryPtrs none;
+    memset(&none, 0, sizeof none);
+    PLONK_LAUNCH(fr_barycentric_kernel, dim3((unsigned)n_polys), dim3(block), 0, ctx->stream, vals, none, roots, log_n,
                  xs_dev, x_stride, n_inv_mont, out_dev);
+    PLONK_CHECK_HIP(hipGetLastError());
+    return PLONK_OK;
+}
+// the same for up to FR_BARY_MANY_MAX polynomials that live in separate buffers, each with its own point
+int k_fr_barycentric_ptrs(plonk_ctx* ctx, const Fr* const* polys, const Fr* roots, unsigned log_n, const Fr* xs_dev, const Fr& n_inv_mont,
+                          Fr* out_dev, size_t n_polys) {
+    if (!n_polys) return PLONK_OK;
+    size_t n = (size_t)1 << log_n;
+    unsigned block = 256;
+    while (block > 64 && (size_t)block * BARY_CHUNK > n) block >>= 1;
+    FrBaryPtrs ptrs;
+    memset(&ptrs, 0, sizeof ptrs);
+    for (size_t k = 0; k < n_polys; k++) ptrs.p[k] = polys[k];
+    PLONK_LAUNCH(fr_barycentric_kernel, dim3((unsigned)n_polys), dim3(block), 0, ctx->stream, (const Fr*)nullptr, ptrs, roots, log_n, xs_dev,
+                 (size_t)1, n_inv_mont, out_dev);
     PLONK_CHECK_HIP(hipGetLastError());
     return PLONK_OK;
 }

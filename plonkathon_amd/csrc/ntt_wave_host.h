@@ -189,7 +189,7 @@ template <class F, unsigned LOG_E, unsigned NLDS> static int wave_launch_as(plon
 // log_r = 8, 10, 12: 4 elements per thread; 9, 11, 13: 8 elements per thread
 template <class F> static int wave_launch(plonk_ctx* ctx, const NttWaveT<typename F::P>& p, unsigned log_r, unsigned grid_x, unsigned grid_y) {
     NttWaveT<typename F::P> q = p;
-    PLONK_TRY(wave_jm<F>(ctx, &q.jm));
+    if (!q.jm) PLONK_TRY(wave_jm<F>(ctx, &q.jm));  // (wave_run's cached plans carry it)
     switch (log_r) {
         case 8: return wave_launch_as<F, 2, 0>(ctx, q, grid_x, grid_y);
         case 10: return wave_launch_as<F, 2, 1>(ctx, q, grid_x, grid_y);
@@ -202,60 +202,52 @@ template <class F> static int wave_launch(plonk_ctx* ctx, const NttWaveT<typenam
     return PLONK_ERR_ARG;
 }
 
-// one transform per batch entry: a single launch for 2^8 .. 2^13, columns then rows through scratch slot 0 for 2^14 .. 2^26
-template <class F>
-static int wave_run(plonk_ctx* ctx, const Fp<typename F::P>* in, Fp<typename F::P>* out, unsigned log_n, bool inverse, size_t batch, size_t in_len,
-                    size_t in_bstride, size_t out_bstride, const Fp<typename F::P>* in_scale, const Fp<typename F::P>* out_scale, bool scale_by_n_inv) {
+// Everything of a transform's launches that does not depend on the call's buffers: the split, the kernel arguments with their
+// table pointers and constants (the radix-8 roots as Shoup pairs, 1/N, the range-reduction table).  Built on the first
+// call of a (size, direction, scaling, table choice) and cached per context and field: the host-side field arithmetic —
+// a root of unity by repeated squaring, a 261-bit Hensel lift, a modular inversion, ~20 us in all — used to run on EVERY
+// call, and a lone 2^16 transform is ~10 us of device time (0.031 ms measured).
+template <class P> struct WavePlan {
+    unsigned log_r1 = 0, log_r2 = 0;
+    NttWaveT<P> a, c;  // single pass: a;  two passes: a = columns, c = rows
+    NttQuadT<P> q;     // 2^14 / 2^15: the four-point column pass
+};
+
+template <class F> static int wave_plan_get(plonk_ctx* ctx, unsigned log_n, bool inverse, bool scale_by_n_inv, bool want_full, const WavePlan<typename F::P>** out) {
     typedef typename F::P P;
     typedef Fp<P> E;
+    WaveTables& T = F::tables(ctx);
+    if (T.plan_epoch != ctx->ntt_cfg_epoch) {  // a split, budget or kernel choice changed: plans are rebuilt
+        T.plans.clear();
+        T.plan_epoch = ctx->ntt_cfg_epoch;
+    }
+    const unsigned key = log_n | (inverse ? 256u : 0u) | (scale_by_n_inv ? 512u : 0u) | (want_full ? 1024u : 0u);
+    auto it = T.plans.find(key);
+    if (it != T.plans.end()) {
+        *out = static_cast<const WavePlan<P>*>(it->second.get());
+        return PLONK_OK;
+    }
+    std::shared_ptr<WavePlan<P>> plan(new WavePlan<P>());
     const size_t N = (size_t)1 << log_n;
     unsigned log_r1 = 0, log_r2 = 0;
     PLONK_REQUIRE(ntt_wave_plan(ctx, log_n, &log_r1, &log_r2), PLONK_ERR_ARG, "no wave-kernel plan for 2^%u points", log_n);
+    plan->log_r1 = log_r1;
+    plan->log_r2 = log_r2;
     NttWaveT<P> p;
     wave_params_init<F>(&p, log_n, inverse);
+    PLONK_TRY(wave_jm<F>(ctx, &p.jm));
     E n_inv = fp_zero<P>();
     if (scale_by_n_inv) n_inv = fp_inv(F::from_u64((uint64_t)N));
-    const unsigned in_len32 = (unsigned)(in_len < N ? in_len : N);
     if (!log_r2) {
-        p.in = in;
-        p.out = out;
-        p.in_bstride = in_bstride;
-        p.out_bstride = out_bstride;
-        p.in_len = in_len32;
         PLONK_TRY(wave_program_table<F>(ctx, log_n, inverse, &p.roots));
-        p.in_scale = in_scale;
-        p.out_scale = out_scale;
         p.out_scalar = n_inv;
         p.has_out_scalar = scale_by_n_inv;
-        // an in-place transform is safe: every thread has read all of its inputs before any thread stores (the stages
-        // in between are separated by barriers for L > 0; for L = 0 the single wave runs in lock step)
-        PLONK_TRY(prof_begin(ctx, "ntt_pass", 64.0 * (double)N * (double)batch));
-        for (size_t b0 = 0; b0 < batch; b0 += (size_t)1 << 30) {  // grid.x carries the batch
-            const size_t nb = batch - b0 < ((size_t)1 << 30) ? batch - b0 : (size_t)1 << 30;
-            NttWaveT<P> q = p;
-            q.in = in + b0 * in_bstride;
-            q.out = out + b0 * out_bstride;
-            PLONK_TRY(wave_launch<F>(ctx, q, log_n, (unsigned)nb, 1));
-        }
-        PLONK_TRY(prof_end(ctx));
-        PLONK_CHECK_HIP(hipGetLastError());
-        return PLONK_OK;
-    }
-    // two passes through a scratch copy: columns (R1 points each, stride R2), then rows (R2 points each)
-    PLONK_REQUIRE(batch <= 65535, PLONK_ERR_ARG, "NTT batch %zu exceeds 65535", batch);
-    void* sc;
-    PLONK_TRY(ctx_scratch(ctx, 0, batch * N * sizeof(E), &sc));
-    E* tmp = (E*)sc;
-    if (log_r1 == 2) {  // 2^14, 2^15: four-point column transforms on packed residues (ntt_quad_column_kernel), then the wave kernel's row pass
-        NttQuadT<P> a;
+        plan->a = p;
+    } else if (log_r1 == 2) {  // 2^14, 2^15: four-point column transforms on packed residues (ntt_quad_column_kernel), then the wave kernel's row pass
+        NttQuadT<P>& a = plan->q;
         memset(&a, 0, sizeof a);
-        a.in = in;
-        a.out = tmp;
-        a.in_bstride = in_bstride;
         a.out_bstride = N;
-        a.in_len = in_len32;
         a.log_n = log_n;
-        a.in_scale = in_scale;
         PLONK_TRY(F::packed_lo_hi(ctx, log_n, inverse, &a.tw_lo, &a.tw_hi));
         a.w4 = F::root_of_unity(2, inverse);
         a.scale = n_inv;
@@ -263,59 +255,108 @@ static int wave_run(plonk_ctx* ctx, const Fp<typename F::P>* in, Fp<typename F::
         NttWaveT<P> c = p;
         c.mode = 2;
         c.log_other = log_r1;
-        c.in = tmp;
-        c.out = out;
         c.in_bstride = N;
-        c.out_bstride = out_bstride;
         c.in_len = (unsigned)N;
-        c.out_scale = out_scale;
         PLONK_TRY(wave_program_table<F>(ctx, log_r2, inverse, &c.roots));
-        PLONK_TRY(prof_begin(ctx, "ntt_pass", 32.0 * (double)N * (double)batch));
-        PLONK_LAUNCH(ntt_quad_column_kernel<P>, dim3((1u << log_r2) / 256, (unsigned)batch), dim3(256), 0, ctx->stream, a);
+        plan->c = c;
+    } else {
+        // (measured, profiles/r03_m_ntt_sweep.jsonl: the table wins 4-10 % wherever the column pass fills the chip; a lone 2^18 —
+        // one workgroup per CU, every load latency exposed — is 5 % faster on the small, L2-resident tables)
+        const int32_t* full = nullptr;
+        if (want_full) PLONK_TRY(wave_interpass_table<F>(ctx, log_n, log_r1, inverse, scale_by_n_inv, &full));
+        if (full) {
+            p.tw_lo = full;
+            p.tw_always = 2u;
+        } else {
+            PLONK_TRY(wave_lo_hi<F>(ctx, log_n, inverse, scale_by_n_inv, &p.tw_lo, &p.tw_hi));
+            p.tw_always = scale_by_n_inv ? 1u : 0u;
+        }
+        NttWaveT<P> a = p;
+        a.mode = 1;
+        a.log_other = log_r2;
+        a.out_bstride = N;
+        PLONK_TRY(wave_program_table<F>(ctx, log_r1, inverse, &a.roots));
+        NttWaveT<P> c = p;
+        c.mode = 2;
+        c.log_other = log_r1;
+        c.in_bstride = N;
+        c.in_len = (unsigned)N;
+        c.has_out_scalar = 0;  // 1/N went into the column pass's inter-pass twiddles (tw_hi)
+        c.tw_always = 0;
+        PLONK_TRY(wave_program_table<F>(ctx, log_r2, inverse, &c.roots));
+        plan->a = a;
+        plan->c = c;
+    }
+    PLONK_CHECK_HIP(hipGetLastError());
+    *out = plan.get();
+    T.plans.emplace(key, std::static_pointer_cast<void>(plan));
+    return PLONK_OK;
+}
+
+// one transform per batch entry: a single launch for 2^8 .. 2^13, columns then rows through scratch slot 0 for 2^14 .. 2^26
+template <class F>
+static int wave_run(plonk_ctx* ctx, const Fp<typename F::P>* in, Fp<typename F::P>* out, unsigned log_n, bool inverse, size_t batch, size_t in_len,
+                    size_t in_bstride, size_t out_bstride, const Fp<typename F::P>* in_scale, const Fp<typename F::P>* out_scale, bool scale_by_n_inv) {
+    typedef typename F::P P;
+    typedef Fp<P> E;
+    const size_t N = (size_t)1 << log_n;
+    const bool want_full = log_n >= 16 && (log_n == 16 || ((size_t)batch << log_n) >= ((size_t)1 << 19));
+    const WavePlan<P>* plan;
+    PLONK_TRY(wave_plan_get<F>(ctx, log_n, inverse, scale_by_n_inv, want_full, &plan));
+    const unsigned log_r1 = plan->log_r1, log_r2 = plan->log_r2;
+    const unsigned in_len32 = (unsigned)(in_len < N ? in_len : N);
+    if (!log_r2) {
+        NttWaveT<P> p = plan->a;
+        p.in_bstride = in_bstride;
+        p.out_bstride = out_bstride;
+        p.in_len = in_len32;
+        p.in_scale = in_scale;
+        p.out_scale = out_scale;
+        // an in-place transform is safe: every thread has read all of its inputs before any thread stores (the stages
+        // in between are separated by barriers for L > 0; for L = 0 the single wave runs in lock step)
+        PLONK_TRY(prof_begin(ctx, "ntt_pass", 64.0 * (double)N * (double)batch));
+        for (size_t b0 = 0; b0 < batch; b0 += (size_t)1 << 30) {  // grid.x carries the batch
+            const size_t nb = batch - b0 < ((size_t)1 << 30) ? batch - b0 : (size_t)1 << 30;
+            p.in = in + b0 * in_bstride;
+            p.out = out + b0 * out_bstride;
+            PLONK_TRY(wave_launch<F>(ctx, p, log_n, (unsigned)nb, 1));
+        }
         PLONK_TRY(prof_end(ctx));
-        PLONK_TRY(prof_begin(ctx, "ntt_pass", 32.0 * (double)N * (double)batch));
-        PLONK_TRY(wave_launch<F>(ctx, c, log_r2, 1u << log_r1, (unsigned)batch));
-        PLONK_TRY(prof_end(ctx));
-        PLONK_CHECK_HIP(hipGetLastError());
+        PLONK_CHECK_HIP(hipGetLastError());  // a refused launch (thread-local, no synchronisation)
         return PLONK_OK;
     }
-    // (measured, profiles/r03_m_ntt_sweep.jsonl: the table wins 4-10 % wherever the column pass fills the chip; a lone 2^18 —
-    // one workgroup per CU, every load latency exposed — is 5 % faster on the small, L2-resident tables)
-    const int32_t* full = nullptr;
-    if (log_n <= 16 || ((size_t)batch << log_n) >= ((size_t)1 << 19)) PLONK_TRY(wave_interpass_table<F>(ctx, log_n, log_r1, inverse, scale_by_n_inv, &full));
-    if (full) {
-        p.tw_lo = full;
-        p.tw_always = 2u;
-    } else {
-        PLONK_TRY(wave_lo_hi<F>(ctx, log_n, inverse, scale_by_n_inv, &p.tw_lo, &p.tw_hi));
-        p.tw_always = scale_by_n_inv ? 1u : 0u;
-    }
-    NttWaveT<P> a = p;
-    a.mode = 1;
-    a.log_other = log_r2;
-    a.in = in;
-    a.out = tmp;
-    a.in_bstride = in_bstride;
-    a.out_bstride = N;
-    a.in_len = in_len32;
-    a.in_scale = in_scale;
-    PLONK_TRY(wave_program_table<F>(ctx, log_r1, inverse, &a.roots));
-    NttWaveT<P> c = p;
-    c.mode = 2;
-    c.log_other = log_r1;
+    // two passes through a scratch copy: columns (R1 points each, stride R2), then rows (R2 points each)
+    PLONK_REQUIRE(batch <= 65535, PLONK_ERR_ARG, "NTT batch %zu exceeds 65535", batch);
+    void* sc;
+    PLONK_TRY(ctx_scratch(ctx, 0, batch * N * sizeof(E), &sc));
+    E* tmp = (E*)sc;
+    NttWaveT<P> c = plan->c;
     c.in = tmp;
     c.out = out;
-    c.in_bstride = N;
     c.out_bstride = out_bstride;
-    c.in_len = (unsigned)N;
     c.out_scale = out_scale;
-    c.has_out_scalar = 0;  // 1/N went into the column pass's inter-pass twiddles (tw_hi)
-    c.tw_always = 0;
-    PLONK_TRY(wave_program_table<F>(ctx, log_r2, inverse, &c.roots));
-    PLONK_TRY(prof_begin(ctx, "ntt_pass", 32.0 * (double)N * (double)batch));
-    PLONK_TRY(wave_launch<F>(ctx, a, log_r1, 1u << log_r2, (unsigned)batch));
-    PLONK_TRY(prof_end(ctx));
-    PLONK_TRY(prof_begin(ctx, "ntt_pass", 32.0 * (double)N * (double)batch));
+    if (log_r1 == 2) {
+        NttQuadT<P> a = plan->q;
+        a.in = in;
+        a.out = tmp;
+        a.in_bstride = in_bstride;
+        a.in_len = in_len32;
+        a.in_scale = in_scale;
+        PLONK_TRY(prof_begin(ctx, "ntt_pass_columns", 32.0 * (double)N * (double)batch));
+        PLONK_LAUNCH(ntt_quad_column_kernel<P>, dim3((1u << log_r2) / 256, (unsigned)batch), dim3(256), 0, ctx->stream, a);
+        PLONK_TRY(prof_end(ctx));
+    } else {
+        NttWaveT<P> a = plan->a;
+        a.in = in;
+        a.out = tmp;
+        a.in_bstride = in_bstride;
+        a.in_len = in_len32;
+        a.in_scale = in_scale;
+        PLONK_TRY(prof_begin(ctx, "ntt_pass_columns", 32.0 * (double)N * (double)batch));
+        PLONK_TRY(wave_launch<F>(ctx, a, log_r1, 1u << log_r2, (unsigned)batch));
+        PLONK_TRY(prof_end(ctx));
+    }
+    PLONK_TRY(prof_begin(ctx, "ntt_pass_rows", 32.0 * (double)N * (double)batch));
     PLONK_TRY(wave_launch<F>(ctx, c, log_r2, 1u << log_r1, (unsigned)batch));
     PLONK_TRY(prof_end(ctx));
     PLONK_CHECK_HIP(hipGetLastError());

@@ -4,6 +4,7 @@
 #include <stdio.h>
 
 #include <map>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -52,6 +53,8 @@ struct WaveTables {
     const int32_t* jm = nullptr;                // fpl_reduce_small's multiples of the modulus
     bool attr_set[3] = {false, false, false};   // hipFuncSetAttribute is per device: tracked per context (E = 4, E = 8, E = 4 column kernel)
     std::map<unsigned, void*> packed[3];        // packed source tables (full, lo, hi) of a field that has no cache of its own (BLS12-381 Fr)
+    std::map<unsigned, std::shared_ptr<void>> plans;  // WavePlan<P> per (log2 N | inverse << 8 | 1/N << 9 | full table << 10): ntt_wave_host.h
+    unsigned plan_epoch = 0;                    // plonk_ctx::ntt_cfg_epoch the plans were built under
 };
 
 struct NttTables {
@@ -107,6 +110,7 @@ struct plonk_ctx {
     void* scratch[PLONK_SCRATCH_SLOTS] = {nullptr, nullptr, nullptr, nullptr};
     size_t scratch_bytes[PLONK_SCRATCH_SLOTS] = {0, 0, 0, 0};
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
+    Fr host_tmp[16];                 // small host-side staging that must outlive an asynchronous copy (every user synchronises before returning)
     unsigned msm_window_bits = 0, msm_groups = 0;
     int msm_lookup_mode = 0;         // 0 auto (fixed SRS only), 1 off, 2 force msm_lookup_bits for every base set
     unsigned msm_lookup_bits = 0;    // 0 = largest window whose table fits the budget
@@ -122,6 +126,7 @@ struct plonk_ctx {
     WaveTables wave_bls;  // the same for the standalone BLS12-381 Fr transform (ntt_bls.hip)
     size_t ntt_table_budget = (size_t)4 << 30, ntt_tables_bytes = 0;  // full inter-pass twiddle tables (80 B per point and direction): plonk_ntt_set_table_budget
     unsigned char ntt_split[32] = {0};  // plonk_ntt_set_split: log2 R1 of the two-pass wave plan per log2 N (0 = default)
+    unsigned ntt_cfg_epoch = 0;  // bumped by every plonk_ntt_* setter: cached launch plans are rebuilt
     unsigned ntt_kind = 0;  // 0 = auto (wave kernels where they apply, else LDS kernels), 1 / 2 = force an LDS kernel, 4 = auto among the LDS kernels, 5 = force wave
 };
 
@@ -144,6 +149,9 @@ int k_fr_powers(plonk_ctx*, const Fr& base_mont, const Fr& first_mont, Fr* out, 
 int k_fr_rotate(plonk_ctx*, const Fr* in, Fr* out, size_t n, size_t shift, size_t batch);
 int k_fr_barycentric(plonk_ctx*, const Fr* vals, const Fr* roots, unsigned log_n, const Fr* xs_dev, size_t x_stride,
                      const Fr& n_inv_mont, Fr* out_dev, size_t n_polys);
+int k_fr_barycentric_ptrs(plonk_ctx*, const Fr* const* polys, const Fr* roots, unsigned log_n, const Fr* xs_dev, const Fr& n_inv_mont,
+                          Fr* out_dev, size_t n_polys);  // <= 16 polynomials in separate buffers, one point each
+int k_fr_lincomb(plonk_ctx*, const Fr* const* terms, const Fr* scalars_mont, unsigned n_terms, const Fr& constant_mont, Fr* out, size_t n);  // <= 20 terms
 int k_fr_count_diff(plonk_ctx*, const Fr* a, const Fr* b_or_null, size_t n, unsigned long long* d_count);
 // api.hip
 Fr fr_from_le32(const uint8_t* b);                 // canonical little-endian bytes -> Montgomery form (host)

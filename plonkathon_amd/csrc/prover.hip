@@ -880,6 +880,9 @@ int plonk_prover_upload_witness(plonk_prover* p, const uint8_t* abc_le32, const 
     PLONK_TRY(ensure_batch(p, B));
     plonk_ctx* ctx = p->ctx;
     const size_t n = p->n;
+    // a verdict left by an earlier asynchronous upload does not belong to this batch (plonk_fr_upload reports its own
+    // non-canonical values synchronously, as PLONK_ERR_ARG)
+    if (p->bad_input) PLONK_CHECK_HIP(hipMemsetAsync(p->bad_input, 0xff, sizeof(unsigned long long), ctx->stream));
     PLONK_TRY(plonk_fr_upload(ctx, p->wit_lag, abc_le32, 3 * B * n));
     if (p->n_public) {
         PLONK_TRY(plonk_fr_upload(ctx, p->pub, public_le32, B * p->n_public));

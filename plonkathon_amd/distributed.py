@@ -54,7 +54,7 @@ def _send_msg(sock, payload: bytes):
     sock.sendall(struct.pack("<Q", len(payload)) + payload)
 
 
-_MAX_MSG = 1 << 32  # a step's proofs from 8 GPUs are tens of MB; a length beyond this is a corrupt or foreign stream
+_MAX_MSG = 1 << 28  # a step's proofs from 8 GPUs are 8 x 7.5 MiB; a length beyond 256 MiB is a corrupt or foreign stream
 
 
 def _recv_msg(sock):
@@ -78,14 +78,31 @@ class _Star:
             srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
             srv.bind((host, port))
             srv.listen(world)
-            srv.settimeout(timeout)
+            deadline = time.time() + timeout
             while len(self.peers) < world - 1:
-                conn, _ = srv.accept()
-                conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-                (r,) = struct.unpack("<I", _recv_exact(conn, 4))
-                if not 0 < r < world or r in self.peers:  # a stray or duplicate connection must not displace a rank
+                left = deadline - time.time()
+                if left <= 0:
+                    srv.close()
+                    raise TimeoutError("rendezvous: %d of %d ranks connected within %.0f s (seen %s)"
+                                       % (len(self.peers) + 1, world, timeout, sorted(self.peers)))
+                srv.settimeout(left)
+                try:
+                    conn, _ = srv.accept()
+                except socket.timeout:
+                    continue
+                # a stray connection (a port scanner, a retried worker) must neither displace a rank, nor abort the launch,
+                # nor hold the accept loop for long: two seconds for its 4-byte hello, then it is dropped and the loop goes on
+                try:
+                    conn.settimeout(min(2.0, max(left, 0.1)))
+                    (r,) = struct.unpack("<I", _recv_exact(conn, 4))
+                except (OSError, ConnectionError, struct.error):
                     conn.close()
-                    raise RuntimeError("rendezvous: a peer announced rank %d (world %d, ranks seen %s)" % (r, world, sorted(self.peers)))
+                    continue
+                if not 0 < r < world or r in self.peers:
+                    conn.close()
+                    continue
+                conn.settimeout(timeout)
+                conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
                 self.peers[r] = conn
             srv.close()
         else:
@@ -204,6 +221,19 @@ class RcclComm:
 
     def barrier(self):
         self._check(self.ctx.L.plonk_comm_barrier(self._h))
+
+    def info(self):
+        """{"path": the librccl file this process loaded, "version": "major.minor.patch", "collectives": RCCL calls issued}"""
+        path, ver, n = ctypes.create_string_buffer(1024), ctypes.c_int(0), ctypes.c_uint64(0)
+        self._check(self.ctx.L.plonk_comm_info(self._h, path, len(path), ctypes.byref(ver), ctypes.byref(n)))
+        v = ver.value
+        return {"path": path.value.decode(), "version": "%d.%d.%d" % (v // 10000, v // 100 % 100, v % 100), "collectives": n.value}
+
+    def last_gather_ms(self):
+        """(ncclAllGather, copy to the host) device milliseconds of the last gather_proofs_device"""
+        a, b = ctypes.c_float(0), ctypes.c_float(0)
+        self._check(self.ctx.L.plonk_comm_last_gather_ms(self._h, ctypes.byref(a), ctypes.byref(b)))
+        return a.value, b.value
 
     def close(self):
         if self._h:

@@ -293,6 +293,29 @@ class Setup:
         lag = bases.lagrange(log_n)
         return _msm(lag, values.device().ptr, n, 1, n)[0]
 
+    def commit_many(self, polys):
+        """[commit(p) for p in polys] (Lagrange values) or [commit_coeffs(p) ...] (MONOMIAL) for polynomials of one size and
+        basis as ONE batched MSM call: a lone 2^11 commitment is latency-bound (64 workgroups and a host synchronisation), so
+        the three commitments of round 1 or round 3 (prover.py:105-107, 221-223) cost the time of one.  The scalar vectors
+        are read in place when they are consecutive views of one buffer, gathered into one buffer otherwise."""
+        polys = list(polys)
+        n, basis = len(polys[0]), polys[0].basis
+        assert all(len(p) == n and p.basis == basis for p in polys) and n <= self._n
+        bases = self.device_bases()
+        if basis == Basis.LAGRANGE:
+            log_n = _log2_exact(n)
+            if log_n > LAGRANGE_SRS_MAX_LOG and log_n not in bases._views:
+                return [self.commit(p) for p in polys]
+            bases = bases.lagrange(log_n)
+        ctx = bases.ctx
+        ptrs = [p.device().ptr.value for p in polys]
+        if all(ptrs[k] == ptrs[0] + 32 * n * k for k in range(len(ptrs))):
+            return _msm(bases, polys[0].device().ptr, n, len(polys), n)
+        stacked = ctx.alloc(n * len(polys))
+        for k, p in enumerate(polys):
+            check(ctx.L.plonk_mem_d2d(ctx.handle, stacked.at(n * k), p.device().ptr, 32 * n))
+        return _msm(bases, stacked.ptr, n, len(polys), n)
+
     def commit_coeffs(self, coeffs: Polynomial):
         """KZG commitment of a polynomial already in MONOMIAL basis (skips the ifft)."""
         assert coeffs.basis == Basis.MONOMIAL

@@ -127,8 +127,10 @@ class Prover:
         variables, cell_index = self.program.wiring_table()
         table = np.frombuffer(_pack_witnesses([witness], variables, R_MOD) + bytes(32), dtype=np.uint64).reshape(len(variables) + 1, 4)
         cols = np.take(table, cell_index.ravel(), axis=0).reshape(3, n, 4)
-        self.A, self.B, self.C = (Polynomial.from_bytes(cols[k].tobytes(), Basis.LAGRANGE) for k in range(3))
-        a_1, b_1, c_1 = (self.setup.commit(p) for p in (self.A, self.B, self.C))
+        # one upload of [3][n]; A, B, C share its storage, and their three commitments are one batched MSM (Setup.commit_many)
+        abc = Polynomial.from_bytes(cols.tobytes(), Basis.LAGRANGE)
+        self.A, self.B, self.C = (abc.view(k * n, (k + 1) * n) for k in range(3))
+        a_1, b_1, c_1 = self.setup.commit_many((self.A, self.B, self.C))
         if self.check:
             pk = self.pk
             assert (
@@ -178,7 +180,7 @@ class Prover:
         coeffs = self.expanded_evals_to_coeffs(QUOT_big)
         if self.check:
             assert coeffs.is_zero(3 * n, 4 * n)  # prover.py:205-208
-        T1c, T2c, T3c = (coeffs.slice(k * n, (k + 1) * n, Basis.MONOMIAL) for k in range(3))
+        T1c, T2c, T3c = (coeffs.view(k * n, (k + 1) * n, Basis.MONOMIAL) for k in range(3))
         self.T1, self.T2, self.T3 = T1c.fft(), T2c.fft(), T3c.fft()
         if self.check:  # prover.py:215-219
             assert (
@@ -186,18 +188,15 @@ class Prover:
                 + self.T2.barycentric_eval(cof) * cof**n
                 + self.T3.barycentric_eval(cof) * cof ** (n * 2)
             ) == QUOT_big.value_at(0)
-        return Message3(*(self.setup.commit_coeffs(t) for t in (T1c, T2c, T3c)))
+        return Message3(*self.setup.commit_many((T1c, T2c, T3c)))
 
     # ---------------------------------------------------------------- round 4  (prover.py:228-239)
     def round_4(self) -> Message4:
         zeta = self.zeta
         w = Scalar.root_of_unity(self.group_order)
-        self.a_eval = self.A.barycentric_eval(zeta)
-        self.b_eval = self.B.barycentric_eval(zeta)
-        self.c_eval = self.C.barycentric_eval(zeta)
-        self.s1_eval = self.pk.S1.barycentric_eval(zeta)
-        self.s2_eval = self.pk.S2.barycentric_eval(zeta)
-        self.z_shifted_eval = self.Z.barycentric_eval(zeta * w)
+        # a = A.barycentric_eval(zeta), ..., z_w = Z.barycentric_eval(zeta * w): six evaluations, one kernel, one synchronisation
+        self.a_eval, self.b_eval, self.c_eval, self.s1_eval, self.s2_eval, self.z_shifted_eval = Polynomial.barycentric_eval_many(
+            [(self.A, zeta), (self.B, zeta), (self.C, zeta), (self.pk.S1, zeta), (self.pk.S2, zeta), (self.Z, zeta * w)])
         return Message4(self.a_eval, self.b_eval, self.c_eval, self.s1_eval, self.s2_eval, self.z_shifted_eval)
 
     # ---------------------------------------------------------------- round 5  (prover.py:241-306)
@@ -215,12 +214,19 @@ class Prover:
         Z_big, S3_big = ex(self.Z), ex(pk.S3)
         k1 = self.rlc(a, zeta) * self.rlc(b, 2 * zeta) * self.rlc(c, 3 * zeta)
         k2 = self.rlc(a, s1) * self.rlc(b, s2) * zw
-        R_big = (
-            QM_big * (a * b) + QL_big * a + QR_big * b + QO_big * c + PI_ev + QC_big
-            + (Z_big * k1 - (S3_big * beta + (c + gamma)) * k2) * alpha
-            + (Z_big - Scalar(1)) * (L0_ev * alpha * alpha)
-            - (T1_big + T2_big * zeta**n + T3_big * zeta ** (2 * n)) * ZH_ev
-        )
+        # R_big (prover.py:245-264), as the reference writes it:
+        #     QM_big * (a * b) + QL_big * a + QR_big * b + QO_big * c + PI_ev + QC_big
+        #     + (Z_big * k1 - (S3_big * beta + (c + gamma)) * k2) * alpha
+        #     + (Z_big - Scalar(1)) * (L0_ev * alpha * alpha)
+        #     - (T1_big + T2_big * zeta**n + T3_big * zeta ** (2 * n)) * ZH_ev
+        # — a linear combination of ten polynomials and a constant: collected per polynomial and evaluated in one pass
+        # (Polynomial.linear_combination) instead of ~30 operator launches over 4n values each
+        zn = zeta**n
+        R_big = Polynomial.linear_combination(
+            [(QM_big, a * b), (QL_big, a), (QR_big, b), (QO_big, c), (QC_big, Scalar(1)),
+             (Z_big, k1 * alpha + L0_ev * alpha * alpha), (S3_big, -(beta * k2 * alpha)),
+             (T1_big, -ZH_ev), (T2_big, -(zn * ZH_ev)), (T3_big, -(zn * zn * ZH_ev))],
+            PI_ev - (c + gamma) * k2 * alpha - L0_ev * alpha * alpha)
         if self.check:
             R_coeffs = self.expanded_evals_to_coeffs(R_big)
             assert R_coeffs.is_zero(n, 4 * n)
@@ -229,24 +235,21 @@ class Prover:
         X_big = self._X_big
         A_big, B_big, C_big = ex(self.A), ex(self.B), ex(self.C)
         S1_big, S2_big = ex(pk.S1), ex(pk.S2)
-        W_z_big = (
-            R_big
-            + (A_big - a) * v
-            + (B_big - b) * v**2
-            + (C_big - c) * v**3
-            + (S1_big - s1) * v**4
-            + (S2_big - s2) * v**5
+        # W_z's numerator R + v (A - a) + v^2 (B - b) + v^3 (C - c) + v^4 (S1 - s1) + v^5 (S2 - s2) (prover.py:277-286), one pass
+        W_z_big = Polynomial.linear_combination(
+            [(R_big, Scalar(1)), (A_big, v), (B_big, v**2), (C_big, v**3), (S1_big, v**4), (S2_big, v**5)],
+            -(a * v + b * v**2 + c * v**3 + s1 * v**4 + s2 * v**5),
         ) / (X_big - zeta)
         W_z_coeffs = self.expanded_evals_to_coeffs(W_z_big)
         if self.check:
             assert W_z_coeffs.is_zero(n, 4 * n)  # prover.py:288
-        W_z_1 = self.setup.commit_coeffs(W_z_coeffs.slice(0, n, Basis.MONOMIAL))
 
         W_zw_big = (Z_big - zw) / (X_big - zeta * Scalar.root_of_unity(n))
         W_zw_coeffs = self.expanded_evals_to_coeffs(W_zw_big)
         if self.check:
             assert W_zw_coeffs.is_zero(n, 4 * n)  # prover.py:299
-        W_zw_1 = self.setup.commit_coeffs(W_zw_coeffs.slice(0, n, Basis.MONOMIAL))
+        # the two opening commitments as one batched MSM (prover.py:290, 301)
+        W_z_1, W_zw_1 = self.setup.commit_many((W_z_coeffs.view(0, n, Basis.MONOMIAL), W_zw_coeffs.view(0, n, Basis.MONOMIAL)))
         return Message5(W_z_1, W_zw_1)
 
     def fft_expand(self, x: Polynomial):  # prover.py:308-309

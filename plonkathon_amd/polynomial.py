@@ -10,7 +10,7 @@ from enum import Enum
 
 from . import _lib
 from ._lib import OP_ADD, OP_DIV, OP_MUL, OP_SUB, check
-from .backend import DeviceBuffer, get_context
+from .backend import DeviceBuffer, DeviceView, get_context
 from .field import Scalar, le32
 
 
@@ -201,6 +201,38 @@ class Polynomial:
         out = ctypes.create_string_buffer(32)
         check(ctx.L.plonk_fr_barycentric(ctx.handle, self.device().ptr, _log2_exact(self._n), le32(x.n), out))
         return Scalar(int.from_bytes(out.raw, "little"))
+
+    # ---- batches of the operations above (one launch / one synchronisation for a run of them) ------------------
+    @classmethod
+    def barycentric_eval_many(cls, pairs):
+        """[p.barycentric_eval(x) for p, x in pairs] (poly.py:181-195) for up to 16 polynomials of one size: one kernel and one
+        host synchronisation instead of one round trip per evaluation (plonk_fr_barycentric_many)."""
+        pairs = [(p, Scalar(x)) for p, x in pairs]
+        assert pairs and all(p.basis == Basis.LAGRANGE and len(p) == len(pairs[0][0]) for p, _ in pairs)
+        ctx = get_context()
+        ptrs = (ctypes.c_void_p * len(pairs))(*[p.device().ptr.value for p, _ in pairs])
+        out = ctypes.create_string_buffer(32 * len(pairs))
+        check(ctx.L.plonk_fr_barycentric_many(ctx.handle, len(pairs), ptrs, _log2_exact(len(pairs[0][0])), b"".join(le32(x.n) for _, x in pairs), out))
+        return [Scalar(int.from_bytes(out.raw[32 * k : 32 * k + 32], "little")) for k in range(len(pairs))]
+
+    @classmethod
+    def linear_combination(cls, terms, constant=0):
+        """constant + sum(p * s for p, s in terms) with the reference's operator semantics (poly.py:23-83: every p in the
+        LAGRANGE basis, so a Scalar addend is added to every value) in ONE pass over the data (plonk_fr_lincomb; up to 20 terms)
+        — what a run of `Polynomial * Scalar`, `+`, `-` such as prover.py:245-288 computes with a launch per operator."""
+        terms = [(p, Scalar(s)) for p, s in terms]
+        assert terms and all(p.basis == Basis.LAGRANGE and len(p) == len(terms[0][0]) for p, _ in terms)
+        ctx = get_context()
+        n = len(terms[0][0])
+        out = ctx.alloc(n)
+        ptrs = (ctypes.c_void_p * len(terms))(*[p.device().ptr.value for p, _ in terms])
+        check(ctx.L.plonk_fr_lincomb(ctx.handle, len(terms), ptrs, b"".join(le32(s.n) for _, s in terms), le32(Scalar(constant).n), out.ptr, n))
+        return cls._from_device(out, Basis.LAGRANGE, n)
+
+    def view(self, start, stop, basis=None):
+        """values[start:stop] as a Polynomial that SHARES this one's device storage (no copy; read-only by convention, as every
+        operator returns a new Polynomial)."""
+        return Polynomial._from_device(DeviceView(self.device(), start, stop - start), basis or self.basis, stop - start)
 
     # ---- helpers used by the prover -------------------------------------------------------------
     def slice(self, start, stop, basis=None):

@@ -30,6 +30,13 @@ int plonk_gather_proofs_device(plonk_comm*, plonk_prover* const* provers, size_t
 }
 int plonk_comm_max_f64(plonk_comm*, double*) { return PLONK_OK; }
 int plonk_comm_barrier(plonk_comm*) { return PLONK_OK; }
+int plonk_comm_last_gather_ms(plonk_comm*, float* a, float* b) { *a = *b = 0; return PLONK_OK; }
+int plonk_comm_info(const plonk_comm*, char* path, size_t cap, int* version, uint64_t* n) {
+    if (path && cap) { strncpy(path, "(emulation: no RCCL)", cap - 1); path[cap - 1] = 0; }
+    if (version) *version = 0;
+    if (n) *n = 0;
+    return PLONK_OK;
+}
 int plonk_comm_all_to_all(plonk_comm*, const void* s, void* r, size_t n) { memcpy(r, s, n); return PLONK_OK; }
 int plonk_fr_ntt_distributed(plonk_comm*, const void*, void*, unsigned, int) {
     plonk_set_error("the emulation build has no RCCL: run plonk_fr_ntt_dist_columns / _rows around another transport");

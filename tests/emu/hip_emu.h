@@ -139,6 +139,7 @@ hipError_t hipGetDevice(int* d);
 hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int d);
 hipError_t hipMalloc(void** p, size_t n);
 hipError_t hipFree(void* p);
+inline hipError_t hipMemGetInfo(size_t* free_b, size_t* total_b) { *free_b = *total_b = (size_t)1 << 34; return hipSuccess; }
 hipError_t hipHostMalloc(void** p, size_t n, unsigned flags = 0);
 hipError_t hipHostFree(void* p);
 hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind k);

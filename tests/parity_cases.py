@@ -409,6 +409,12 @@ def async_upload_and_device_gather(setup, rccl=False):
     b.run()
     st = b.download_raw()[1]
     assert st[2] & 8 and not any(x & 8 for i, x in enumerate(st) if i != 2)
+    # the verdict belongs to the batch it was raised for: a valid batch uploaded next as wire COLUMNS
+    # (plonk_prover_upload_witness never runs the checked conversion) must not inherit it (prover.hip)
+    b._upload_columns(wits)
+    b.run()
+    got, st = b.download_raw()
+    assert got == want and not any(st), list(st)
     pinned[: len(blob)] = blob
     b.upload_values_async(pinned, len(wits))
     b.run()
@@ -487,6 +493,54 @@ def poly_asserts():
     assert (a / Scalar(0)) == P([0, 0, 0, 0])  # x / 0 == 0
     x = Scalar.roots_of_unity(4)[2]
     assert a.barycentric_eval(x) == OPoly([1, 2, 3, 4], OBasis.LAGRANGE).barycentric_eval(x.n)
+
+
+def batched_operators(setup, sizes=(8, 64, 2048)):
+    """The batch forms of the operators against the single forms and against Python integers: Polynomial.linear_combination
+    (plonk_fr_lincomb) = a run of `* Scalar`, `+` (poly.py:23-83), barycentric_eval_many = barycentric_eval per polynomial
+    (poly.py:181-195), view = values[start:stop] without a copy, Setup.commit_many = commit / commit_coeffs per polynomial
+    (setup.py:66-72) in both bases and for scattered as well as consecutive scalar vectors."""
+    import pytest
+
+    for n in sizes:
+        vecs = [rand_vec(900 + k, n) for k in range(6)]
+        polys = [P(v) for v in vecs]
+        scal = rand_vec(950, 6)
+        scal[1], scal[2] = 0, R_MOD - 1
+        const = rand_vec(951, 1)[0]
+        got = Polynomial.linear_combination(list(zip(polys, map(Scalar, scal))), Scalar(const))
+        want = [(const + sum(s * v[i] for s, v in zip(scal, vecs))) % R_MOD for i in range(n)]
+        assert ints(got) == want and got.basis == Basis.LAGRANGE
+        # the same through the operators, term by term
+        acc = polys[0] * Scalar(scal[0])
+        for p_, s_ in zip(polys[1:], scal[1:]):
+            acc = acc + p_ * Scalar(s_)
+        assert (acc + Scalar(const)) == got
+        assert ints(Polynomial.linear_combination([(polys[3], Scalar(1))])) == vecs[3]
+        # twenty terms (the limit), repeated operands
+        many = [(polys[k % 6], Scalar(k + 1)) for k in range(20)]
+        assert ints(Polynomial.linear_combination(many)) == [sum((k + 1) * vecs[k % 6][i] for k in range(20)) % R_MOD for i in range(n)]
+        with pytest.raises(AssertionError):
+            Polynomial.linear_combination(many + [(polys[0], Scalar(1))])
+        # evaluations: off the domain, ON the domain (x - w^i = 0 for one i: that term counts 0, as py_ecc's x / 0) and at 0
+        w = Scalar.root_of_unity(n)
+        xs = [Scalar(rand_vec(960 + k, 1)[0]) for k in range(4)] + [w**3, Scalar(0)]
+        assert Polynomial.barycentric_eval_many(list(zip(polys, xs))) == [p_.barycentric_eval(x) for p_, x in zip(polys, xs)]
+        assert Polynomial.barycentric_eval_many([(polys[2], xs[0])] * 16) == [polys[2].barycentric_eval(xs[0])] * 16
+        # views share storage
+        big = P(vecs[0] + vecs[1] + vecs[2])
+        v1 = big.view(n, 2 * n)
+        assert ints(v1) == vecs[1] and len(v1) == n and ints(v1.view(1, 3)) == vecs[1][1:3]
+        assert ints(v1 + P(vecs[2])) == [(a + b) % R_MOD for a, b in zip(vecs[1], vecs[2])]
+        # commitments: consecutive views (read in place) and scattered buffers (gathered), both bases
+        if n <= 64 or n == 2048:
+            trio = [big.view(k * n, (k + 1) * n) for k in range(3)]
+            assert setup.commit_many(trio) == [setup.commit(p_) for p_ in polys[:3]]
+            assert setup.commit_many([polys[4], polys[1]]) == [setup.commit(polys[4]), setup.commit(polys[1])]
+            mono = [P(v, Basis.MONOMIAL) for v in vecs[:2]]
+            assert setup.commit_many(mono) == [setup.commit_coeffs(m) for m in mono]
+            bigm = P(vecs[0] + vecs[1], Basis.MONOMIAL)
+            assert setup.commit_many([bigm.view(0, n), bigm.view(n, 2 * n)]) == [setup.commit_coeffs(m) for m in mono]
 
 
 # ------------------------------------------------------------------------------------------ MSM / commit

@@ -25,6 +25,34 @@ def test_gpus_flag_spawns_that_many_ranks(emu_cdll):
     assert line["scaling"] == "weak" and line["unit"] == "proofs/s" and line["value"] > 0
 
 
+def test_force_comm_runs_the_multi_gpu_code_path_with_one_rank(emu_cdll):
+    """`--gpus 1 --force-comm`: a one-rank communicator, the device-resident gather, the max over ranks and the barrier inside
+    the timed region, and the per-rank block of an N-GPU line (here over the emulation's communicator stub; the same command
+    runs against RCCL on the GPU box: tests/test_gpu_multiprocess.py)."""
+    r = _run(["--gpus", "1", "--force-comm"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    cfg = line["config"]
+    assert cfg["gather_transport"] == "rccl" and cfg["gather_in_timed_region"] and cfg["ranks_in_communicator"] == 1
+    assert cfg["gather_path"].startswith("device buffers") and cfg["results_gathered_per_step"] == 6
+    assert cfg["torch_imported"] is False and "rccl_path" in cfg and "rccl_version" in cfg
+    pr = line["per_rank"]
+    assert len(pr["proofs_per_s"]) == 1 and pr["proofs_per_s_min"] == pr["proofs_per_s_max"] > 0
+    assert len(pr["msm_table_build_s"]) == 1 and len(pr["allgather_us_per_step"]) == 1
+    # the whole-job value is measured over the barrier, a rank's own rate before it: never below it
+    assert pr["proofs_per_s_sum"] >= line["value"] * 0.999
+
+
+def test_two_ranks_report_per_rank_figures(emu_cdll):
+    r = _run(["--gpus", "2", "--dist-backend", "sockets"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    pr = line["per_rank"]
+    assert len(pr["proofs_per_s"]) == 2 and all(x > 0 for x in pr["proofs_per_s"])
+    assert pr["proofs_per_s_min"] <= pr["proofs_per_s_max"] and len(pr["allgather_us_per_step"]) == 2
+    assert pr["proofs_per_s_sum"] >= line["value"] * 0.999
+
+
 def test_more_rccl_ranks_than_devices_is_an_error(emu_cdll):
     r = _run(["--gpus", "3"])  # the emulation reports one device
     assert r.returncode != 0 and "refusing" in r.stderr

@@ -215,3 +215,63 @@ def test_lazy_gather_matches_the_eager_one():
             lazy = D.gather_proofs_lazy(blobs[r], total, Replay(r) if world > 1 else None)
             assert len(lazy) == total and lazy.complete()
             assert [lazy[i] for i in range(total)] == eager
+
+
+def test_rendezvous_survives_stray_connections():
+    """a connection that announces an impossible rank, one that repeats a rank already seen and one that says
+    nothing at all are dropped; the launch goes on and the real rank still gets in.  No field of the star is displaced."""
+    import socket
+    import struct
+    import threading
+    import time
+
+    from plonkathon_amd import distributed as D
+
+    with socket.socket() as s0:
+        s0.bind(("127.0.0.1", 0))
+        port = s0.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", PLONK_RDZV_PORT=str(port))
+    out = {}
+
+    def rank0():
+        star = D._Star(0, 3, timeout=30.0)
+        out["peers"] = sorted(star.peers)
+        out["got"] = star.all_gather(b"zero")
+        star.close()
+
+    t = threading.Thread(target=rank0)
+    t.start()
+
+    def connect():
+        for _ in range(200):
+            try:
+                return socket.create_connection(("127.0.0.1", port), timeout=5.0)
+            except OSError:
+                time.sleep(0.05)
+        raise AssertionError("rank 0 never listened")
+
+    silent = connect()                       # says nothing: dropped after its hello deadline
+    bad = connect()
+    bad.sendall(struct.pack("<I", 99))       # rank 99 of 3
+    results = {}
+
+    def peer(r):
+        star = D._Star(r, 3, timeout=30.0)
+        results[r] = star.all_gather(b"r%d" % r)
+        star.close()
+
+    p1 = threading.Thread(target=peer, args=(1,))
+    p1.start()
+    time.sleep(0.3)
+    dup = connect()
+    dup.sendall(struct.pack("<I", 1))        # rank 1 again: must not displace the first
+    p2 = threading.Thread(target=peer, args=(2,))
+    p2.start()
+    for th in (p1, p2, t):
+        th.join(60)
+        assert not th.is_alive()
+    for c in (silent, bad, dup):
+        c.close()
+    assert out["peers"] == [1, 2]
+    assert out["got"] == [b"zero", b"r1", b"r2"] == results[1] == results[2]
+    os.environ.pop("PLONK_RDZV_PORT")

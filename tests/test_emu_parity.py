@@ -88,6 +88,12 @@ def test_setup_commit_vkeys_lincomb(emu):
     pc.lincomb_fuzz(setup, 12)
 
 
+def test_batched_operators(emu):
+    from plonkathon_amd import Setup
+
+    pc.batched_operators(Setup.from_file(pc.PTAU), sizes=(8, 64))
+
+
 def test_msm_window_configs(emu):
     from plonkathon_amd import Setup, get_context
     from plonkathon_amd._lib import check

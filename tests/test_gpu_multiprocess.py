@@ -42,3 +42,71 @@ def test_eight_processes_share_the_gpu_and_gather_512_proofs(tmp_path):
     raw, status = bp.download_raw()
     assert not any(status)
     assert raw == blob
+
+
+def _bench(extra, timeout=1500, env_extra=None):
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.update(env_extra or {})
+    cmd = [sys.executable, os.path.join(REPO, "bench.py")] + extra
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+
+
+SHORT = ["--no-cpu-baseline", "--no-microbench", "--no-fallbacks", "--no-end-to-end", "--no-configs", "--no-latency"]
+
+
+@pytest.mark.gpu
+def test_one_rank_rccl_in_a_process_that_never_imports_torch():
+    """the process the driver's 8-GPU run starts — bench.py, no PyTorch, the ROCm installation's own librccl,
+    ncclCommInitRank — executed on hardware with one rank: `--force-comm` puts the device-resident gather
+    (plonk_gather_proofs_device -> ncclAllGather), the max over ranks (ncclAllReduce) and the barrier inside the timed region.
+    A fresh subprocess: pytest's own process has torch (and torch's bundled librccl) mapped, this one must not."""
+    line = _bench(["--gpus", "1", "--force-comm", "--steps", "2", "--warmup", "1", "--batch", "64", "--batches-per-step", "4", "--streams", "2",
+                   "--lookup-budget-gb", "4"] + SHORT)
+    cfg = line["config"]
+    assert cfg["gather_transport"] == "rccl" and cfg["gather_in_timed_region"] and cfg["ranks_in_communicator"] == 1
+    assert cfg["gather_path"].startswith("device buffers")
+    assert cfg["torch_imported"] is False
+    assert "torch" not in cfg["rccl_path"] and os.path.basename(cfg["rccl_path"]).startswith("librccl.so"), cfg["rccl_path"]
+    assert cfg["rccl_version"].split(".")[0].isdigit() and cfg["rccl_version"] != "0.0.0"
+    # the RCCL calls really were issued: one all-gather per step (3 with the warm-up), the barriers / max over ranks (all-reduce)
+    # around the timed region and the exchange of the per-rank figures (all-gather through host buffers)
+    assert cfg["rccl_calls_issued"] >= 3 + 3
+    pr = line["per_rank"]
+    assert len(pr["proofs_per_s"]) == 1 and pr["allgather_us_per_step"][0] > 0
+    assert pr["allgather_fraction_of_step"] < 0.05
+    assert cfg["results_gathered_per_step"] == 256 and line["value"] > 0
+    print("rccl:", cfg["rccl_path"], cfg["rccl_version"], "all-gather us/step:", pr["allgather_us_per_step"])
+
+
+@pytest.mark.gpu
+def test_an_explicit_rccl_path_is_honoured_and_a_wrong_one_fails_loudly():
+    line = _bench(["--gpus", "1", "--force-comm", "--steps", "1", "--warmup", "0", "--batch", "8", "--batches-per-step", "1", "--streams", "1",
+                   "--log-n", "6", "--no-lookup"] + SHORT, env_extra={"PLONK_RCCL_LIB": "/opt/rocm/lib/librccl.so.1"})
+    assert os.path.realpath(line["config"]["rccl_path"]) == os.path.realpath("/opt/rocm/lib/librccl.so.1")
+    env = dict(os.environ, PLONK_RCCL_LIB="/nonexistent/librccl.so.1")
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--force-comm", "--steps", "1", "--warmup", "0", "--batch", "8",
+                        "--batches-per-step", "1", "--streams", "1", "--log-n", "6", "--no-lookup"] + SHORT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "librccl could not be loaded" in r.stderr
+
+
+@pytest.mark.gpu
+def test_dress_rehearsal_eight_ranks_at_the_default_batch():
+    """`bench.py --gpus 8` with the bench's DEFAULT step (20 lock-step batches of 512 per rank, 4 streams) as
+    eight processes on the one GPU (sockets transport, the library's 4 GiB table budget per process: 8 x ~25 GB of HBM).  The
+    eight ranks share one chip, so their summed rate is the single-process rate on the same budget: within 10 %."""
+    common = ["--steps", "2", "--warmup", "1", "--lookup-budget-gb", "4"] + SHORT
+    one = _bench(["--gpus", "1"] + common)
+    eight = _bench(["--gpus", "8", "--dist-backend", "sockets"] + common, timeout=2400)
+    cfg = eight["config"]
+    assert eight["n_gpus"] == 8 and cfg["ranks_in_communicator"] == 8 and cfg["lockstep_batch"] == 512 and cfg["batches_per_step"] == 20
+    assert cfg["results_gathered_per_step"] == 8 * 10240 and cfg["msm_table_bits"] == 11
+    pr = eight["per_rank"]
+    assert len(pr["proofs_per_s"]) == 8 and len(pr["msm_table_build_s"]) == 8
+    ratio = eight["value"] / one["value"]
+    print("8 ranks on one GPU: %.0f proofs/s; one process: %.0f; ratio %.3f; per rank min/max %.0f / %.0f"
+          % (eight["value"], one["value"], ratio, pr["proofs_per_s_min"], pr["proofs_per_s_max"]))
+    assert 0.9 <= ratio <= 1.1, ratio

@@ -26,6 +26,10 @@ for step in "$@"; do
     rocprof)
       ( cd /tmp && rocprofv3 --kernel-trace --stats -d "$OLDPWD/$out/rocprof" -o trace -- python "$OLDPWD/bench.py" $arg > "$OLDPWD/$out/bench_under_rocprof.json" 2> "$OLDPWD/$out/rocprof.err" ); echo "rocprof rc=$?"
       find "$out/rocprof" -name "*kernel_stats.csv" | head -1 | xargs -r head -12 ;;
+    ntt_trace)   # rocprofv3 --kernel-trace --stats of the lone transforms of configs[3]: per-pass kernel names and durations
+      ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/$out/ntt_trace" -o t -- python "$OLDPWD/tools/ntt_only.py" ${arg:-16,18,20,22,24} 7 > "$OLDPWD/$out/ntt_trace.log" 2> "$OLDPWD/$out/ntt_trace.err" ); echo "ntt_trace rc=$?"
+      python tools/ntt_trace_summary.py "$out/ntt_trace" "$out/ntt_trace.log" > "$out/ntt_kernel_stats.txt" 2>> "$out/ntt_trace.err"; cat "$out/ntt_kernel_stats.txt"
+      find "$out/ntt_trace" -name "*kernel_stats.csv" | head -1 | xargs -r head -12 ;;
     pmc) bash tools/pmc_collect.sh "$out" $arg ;;
     pmcu) bash tools/pmc_ntt_util.sh "$out/pmcu" ;;
     env_sweep)   # "VAR=VALUE <ntt_sweep args>": the sweep under one environment setting, rows tagged VAR=VALUE

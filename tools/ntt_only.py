@@ -14,7 +14,7 @@ from plonkathon_amd import Context, set_context  # noqa: E402
 from plonkathon_amd._lib import check  # noqa: E402
 
 SHAPES = [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "16,18,20,22,24").split(",")]
-REPS = 3
+REPS = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 ctx = Context(0)
 set_context(ctx)
 L, H = ctx.L, ctx.handle
