@@ -11,8 +11,9 @@ for step in "$@"; do
   echo "=== $name $arg"
   case $name in
     tests)
-      if [ -n "$arg" ]; then timeout 1200 python -m pytest tests -m gpu -x -q -k "$arg" > "$out/pytest_gpu.log" 2>&1
-      else timeout 1500 python -m pytest tests -m gpu -x -q > "$out/pytest_gpu.log" 2>&1; fi
+      # (--timeout-method=thread: a test stuck inside a HIP / RCCL call is ended by os._exit, not left to the session's own limit)
+      if [ -n "$arg" ]; then timeout 1500 python -m pytest tests -m gpu -x -q -s --timeout=900 --timeout-method=thread -k "$arg" > "$out/pytest_gpu.log" 2>&1
+      else timeout 1800 python -m pytest tests -m gpu -x -q --timeout=900 --timeout-method=thread > "$out/pytest_gpu.log" 2>&1; fi
       echo "pytest rc=$?" >> "$out/pytest_gpu.log"; tail -4 "$out/pytest_gpu.log" ;;
     smoke) timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > "$out/smoke.log" 2>&1; echo "smoke rc=$?"; tail -2 "$out/smoke.log" ;;
     ntt_sweep) timeout 600 python tools/ntt_sweep.py $arg >> "$out/ntt_sweep.jsonl" 2>> "$out/ntt_sweep.err"; echo "rc=$?"; tail -3 "$out/ntt_sweep.jsonl" ;;
