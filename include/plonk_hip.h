@@ -236,7 +236,8 @@ int plonk_srs_lookup_info(const plonk_srs* srs, unsigned* out_bits, size_t* out_
  *                         a_eval, b_eval, c_eval, s1_eval, s2_eval, z_shifted_eval canonical LE;
  *                         status[b]: bit 0 = some commitment is the identity (the reference's
  *                         append_point(None) raises), bit 1 = Z does not close to 1 (prover.py:132),
- *                         bit 2 = quotient degree >= 3n, i.e. a gate constraint fails (prover.py:108-116, 205-208),
+ *                         bit 2 = a gate constraint fails on some row (prover.py:108-116; what the quotient-degree assert of
+ *                         prover.py:205-208 detects),
  *                         bit 3 = a value uploaded by plonk_prover_upload_variables_async was not a canonical Fr value.
  *   plonk_prover_challenges  beta, gamma, alpha, fft_cofactor, zeta, v of proof b (tests).          */
 typedef struct plonk_prover plonk_prover;

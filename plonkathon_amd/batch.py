@@ -179,7 +179,7 @@ class BatchProver:
                 raise ProofError("proof %d: an uploaded witness value is not a canonical Fr value (>= r)" % b)
             if st & 4:
                 raise ProofError("proof %d: witness does not satisfy the gate constraints "
-                                 "(prover.py:108-116; quotient degree check prover.py:205-208)" % b)
+                                 "(prover.py:108-116, checked row by row; it is what the quotient-degree assert of prover.py:205-208 detects)" % b)
             if st & 2:
                 raise ProofError("proof %d: permutation accumulator does not close to 1 (prover.py:132)" % b)
             if st & 1:

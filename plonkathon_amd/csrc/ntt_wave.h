@@ -76,7 +76,15 @@ template <class P> struct NttWaveT {
     unsigned has_out_scalar;
     FpLS<P> w8[3];           // w_8, w_8^2 (= w_4), w_8^3 for the transform direction, Shoup pairs: kernel arguments live in SGPRs
     const int32_t* jm;     // fpl_reduce_small's table of j * m
+    // mode 0 only: blockIdx.y = "fan" index f — the same input transformed several times under different scalings (the
+    // prover evaluates one coefficient vector on three cosets) or adjacent slices of one buffer.  Bit 0: in += f N, bit 1:
+    // out += f N, bit 2: in_scale / out_scale += f N (N = this kernel's transform size; one argument instead of three strides:
+    // the 8-element kernels have no scalar registers to spare)
+    unsigned fan;
 };
+#define NTT_FAN_IN 1u
+#define NTT_FAN_OUT 2u
+#define NTT_FAN_SCALE 4u
 
 // entry idx of a limb-form table (Montgomery residue)
 template <class P> PLONK_DEV FpL<P> wavel_ld_tw(const int32_t* tab, unsigned idx) {
@@ -285,9 +293,9 @@ PLONK_DEV void wavel_transform(const NttWaveT<P>& p, unsigned char* smem) {
     u32x4* l_hi = l_lo + 4 * NT;
     uint32_t* l_top = reinterpret_cast<uint32_t*>(l_hi + 4 * NT);
     const unsigned tid0 = threadIdx.x;
-    const unsigned bidx = p.mode ? blockIdx.y : blockIdx.x;
-    const Fp<P>* in = p.in + (size_t)bidx * p.in_bstride;
-    Fp<P>* out = p.out + (size_t)bidx * p.out_bstride;
+    const unsigned bidx = p.mode ? blockIdx.y : blockIdx.x, fan = p.mode ? 0u : (blockIdx.y << LOG_N);  // f N
+    const Fp<P>* in = p.in + (size_t)bidx * p.in_bstride + ((p.fan & NTT_FAN_IN) ? fan : 0u);
+    Fp<P>* out = p.out + (size_t)bidx * p.out_bstride + ((p.fan & NTT_FAN_OUT) ? fan : 0u);
     // column / row of a two-pass transform.  Workgroup b runs on XCD b % 8 (each XCD has its own L2): the remap gives
     // every XCD four ADJACENT columns (rows) per group of 32, so the 32-byte elements it touches share 128-byte lines.
     const unsigned b = blockIdx.x;
@@ -308,10 +316,11 @@ PLONK_DEV void wavel_transform(const NttWaveT<P>& p, unsigned char* smem) {
         x[j] = g < p.in_len ? fpl_from_fp(fp_load(wavel_at(in, g))) : fpl_zero<P>();  // [0, 2m): canonical input, or the column pass's redundant residues
     });
     if (p.in_scale) {
+        const Fp<P>* in_scale = p.in_scale + ((p.fan & NTT_FAN_SCALE) ? fan : 0u);
         wave_for<E>([&](auto J) {
             constexpr unsigned j = decltype(J)::value;
             const unsigned g = ((j * NT + tid0) << in_shift) + in_off;
-            if (g < p.in_len) x[j] = fpl_mul(x[j], fpl_from_fp(fp_load(wavel_at(p.in_scale, g))));
+            if (g < p.in_len) x[j] = fpl_mul(x[j], fpl_from_fp(fp_load(wavel_at(in_scale, g))));
         });
     }
     // stage A: digit = the top LOG_E index bits, low = tid0
@@ -411,9 +420,10 @@ PLONK_DEV void wavel_transform(const NttWaveT<P>& p, unsigned char* smem) {
         });
     }
     if (p.out_scale) {
+        const Fp<P>* out_scale = p.out_scale + ((!p.mode && (p.fan & NTT_FAN_SCALE)) ? (blockIdx.y << LOG_N) : 0u);
         wave_for<E>([&](auto J) {
             constexpr unsigned j = decltype(J)::value;
-            x[j] = fpl_mul(x[j], fpl_from_fp(fp_load(wavel_at(p.out_scale, ((k | (j << shift)) << out_shift) + out_off))));
+            x[j] = fpl_mul(x[j], fpl_from_fp(fp_load(wavel_at(out_scale, ((k | (j << shift)) << out_shift) + out_off))));
         });
     }
     if (p.has_out_scalar) {

@@ -293,13 +293,20 @@ template <class F> static int wave_plan_get(plonk_ctx* ctx, unsigned log_n, bool
     return PLONK_OK;
 }
 
+// the wave kernels take a fan whose strides are 0 or the transform size (ntt_wave.h: NttWaveT::fan)
+static inline bool wave_fan_ok(const NttFan& f, size_t N) {
+    return (f.in_stride == 0 || f.in_stride == N) && (f.out_stride == 0 || f.out_stride == N) && (f.scale_stride == 0 || f.scale_stride == N);
+}
+
 // one transform per batch entry: a single launch for 2^8 .. 2^13, columns then rows through scratch slot 0 for 2^14 .. 2^26
 template <class F>
 static int wave_run(plonk_ctx* ctx, const Fp<typename F::P>* in, Fp<typename F::P>* out, unsigned log_n, bool inverse, size_t batch, size_t in_len,
-                    size_t in_bstride, size_t out_bstride, const Fp<typename F::P>* in_scale, const Fp<typename F::P>* out_scale, bool scale_by_n_inv) {
+                    size_t in_bstride, size_t out_bstride, const Fp<typename F::P>* in_scale, const Fp<typename F::P>* out_scale, bool scale_by_n_inv,
+                    const NttFan* fan = nullptr) {
     typedef typename F::P P;
     typedef Fp<P> E;
     const size_t N = (size_t)1 << log_n;
+    PLONK_REQUIRE(!fan || (log_n <= 13 && wave_fan_ok(*fan, N)), PLONK_ERR_ARG, "a fanned transform needs a single-pass size (2^8 .. 2^13) and strides of 0 or N");
     const bool want_full = log_n >= 16 && (log_n == 16 || ((size_t)batch << log_n) >= ((size_t)1 << 19));
     const WavePlan<P>* plan;
     PLONK_TRY(wave_plan_get<F>(ctx, log_n, inverse, scale_by_n_inv, want_full, &plan));
@@ -312,6 +319,7 @@ static int wave_run(plonk_ctx* ctx, const Fp<typename F::P>* in, Fp<typename F::
         p.in_len = in_len32;
         p.in_scale = in_scale;
         p.out_scale = out_scale;
+        if (fan) p.fan = (fan->in_stride ? NTT_FAN_IN : 0u) | (fan->out_stride ? NTT_FAN_OUT : 0u) | (fan->scale_stride ? NTT_FAN_SCALE : 0u);
         // an in-place transform is safe: every thread has read all of its inputs before any thread stores (the stages
         // in between are separated by barriers for L > 0; for L = 0 the single wave runs in lock step)
         PLONK_TRY(prof_begin(ctx, "ntt_pass", 64.0 * (double)N * (double)batch));
@@ -319,7 +327,7 @@ static int wave_run(plonk_ctx* ctx, const Fp<typename F::P>* in, Fp<typename F::
             const size_t nb = batch - b0 < ((size_t)1 << 30) ? batch - b0 : (size_t)1 << 30;
             p.in = in + b0 * in_bstride;
             p.out = out + b0 * out_bstride;
-            PLONK_TRY(wave_launch<F>(ctx, p, log_n, (unsigned)nb, 1));
+            PLONK_TRY(wave_launch<F>(ctx, p, log_n, (unsigned)nb, fan ? fan->count : 1));
         }
         PLONK_TRY(prof_end(ctx));
         PLONK_CHECK_HIP(hipGetLastError());  // a refused launch (thread-local, no synchronisation)

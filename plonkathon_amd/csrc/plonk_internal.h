@@ -159,8 +159,12 @@ bool le32_below_modulus(const uint8_t* b, bool fq);
 int get_power_table(plonk_ctx*, const Fr& base, const Fr& first, size_t n, const Fr** out);  // first * base^i, cached per context
 // ntt.hip
 Fr host_root_of_unity(unsigned log_n, bool inverse);
+// fan (optional): every batch entry is transformed `count` times — copy f reads in + f in_stride, writes out + f out_stride
+// and takes its scaling vector at in_scale / out_scale + f scale_stride (elements): one launch on the wave kernels' single-pass
+// sizes (the prover: a coefficient vector evaluated on three cosets), a loop of calls elsewhere
+struct NttFan { unsigned count, in_stride, out_stride, scale_stride; };
 int ntt_run(plonk_ctx*, const Fr* in, Fr* out, unsigned log_n, bool inverse, size_t batch, size_t in_len,
-            size_t in_bstride, size_t out_bstride, const Fr* in_scale, const Fr* out_scale, bool scale_by_n_inv);
+            size_t in_bstride, size_t out_bstride, const Fr* in_scale, const Fr* out_scale, bool scale_by_n_inv, const NttFan* fan = nullptr);
 int ntt_get_roots(plonk_ctx*, unsigned log_n, bool inverse, const Fr** table_full);
 int ntt_dist_plan(unsigned log_n, unsigned log_w, unsigned* log_r1, unsigned* log_r2);
 bool ntt_wave_plan(const plonk_ctx* ctx /* null: the default splits */, unsigned log_n, unsigned* log_r1, unsigned* log_r2);

@@ -36,6 +36,7 @@ struct ProofState {
 struct ChallengeConsts { Fr c[8]; };  // c[j] = 2^(256 j) R^2 mod r (transcript_kernel)
 
 enum { FX_QM = 0, FX_QL, FX_QR, FX_QO, FX_QC, FX_S1, FX_S2, FX_S3, FX_COUNT };
+#define QCOSETS 3  // cosets of size n the lock-step prover evaluates the quotient on (deg t < 3n)
 
 struct plonk_prover {
     plonk_ctx* ctx;
@@ -43,15 +44,18 @@ struct plonk_prover {
     unsigned log_n;
     size_t n, n_public;
     Fr g;                // fixed coset offset (Montgomery)
+    // The quotient has degree < 3n, so THREE cosets of the n-th roots of unity determine it: x = g mu^r w^j, r < 3 (mu = the
+    // 4n-th root of unity of prover.py:160), "coset-major" [r][j].  Every coset form below is [3][n] in that order.
     Fr* fixed_lag;       // [8][n]   Lagrange values
     Fr* fixed_coef;      // [8][n]   coefficient forms
-    Fr* fixed_big;       // [8][4n]  coset extensions at offset g
-    Fr* l0_big;          // [4n]
-    Fr* x_big;           // [4n]     g * mu^k
-    Fr* g_pow;           // [n]      g^i
-    Fr* ginv_pow;        // [4n]     g^-k / 4n
+    Fr* fixed_big;       // [8][3][n]  the circuit polynomials on the three cosets
+    Fr* l0_big;          // [3][n]
+    Fr* x_big;           // [3][n]   the points g mu^r w^j
+    Fr* g_pow;           // [3][n]   (g mu^r)^i: the load-side scaling of the size-n transform that evaluates on coset r
+    Fr* ginv_pow;        // [3][n]   (g mu^r)^-i / 2n: the store-side scaling of the inverse transform of coset r (its 1/n folded in)
     const Fr* roots;     // [n]      w^i (owned by ctx)
-    Fr zh_inv[4];        // 1 / (g^n * i^k - 1)
+    Fr zh_inv[QCOSETS];  // 1 / (g^n * i^r - 1): Z_H is constant on a coset
+    Fr comb_i, comb_g1, comb_g2;  // quotient_combine_kernel's constants: i = mu^n, 1 / g^n, 1 / g^2n
     // Public inputs are the only non-zero entries of the PI column (prover.py:57-62): with few of them PI's
     // coefficient and coset forms are cheaper from the Lagrange basis directly than through two transforms.
     bool sparse_pi;      // n_public <= PI_SPARSE_MAX
@@ -63,8 +67,8 @@ struct plonk_prover {
     Fr *wit_lag;   // [4][B][n]  A, B, C, PI   Lagrange
     Fr *z_lag;     // [B][n]
     Fr *coef;      // [5][B][n]  Ac, Bc, Cc, PIc, Zc   (coefficient forms; Z last so rounds 1 and 2 fill it in order)
-    Fr *big;       // [5][B][4n] A, B, C, PI, Z on the coset
-    Fr *quot;      // [B][4n]    quotient evaluations, then its coefficients (in place)
+    Fr *big;       // [5][B][3][n] A, B, C, PI, Z on the three cosets
+    Fr *quot;      // [B][4n]    quotient evaluations on the three cosets, then its 3n coefficients (in place; the last n unused)
     Fr *num, *den; // [B][n] scratch (round 2), reused as W_z numerator
     Fr *wz;        // [2][B][n]  W_z, W_zw coefficient forms
     struct LinWeights* lin_w;  // [B]   round-5 linearisation weights (own allocation: 480 B per proof)
@@ -124,7 +128,7 @@ __global__ void public_gather_kernel(const Fr* vars, const uint32_t* pub_index, 
 
 // Sparse public inputs.  PI = sum_{i < l} (-pub_i) L_i with L_i the Lagrange basis of the n-th roots of unity:
 //   coefficient j of L_i is  w^(-ij) / n            (an inverse DFT of a unit vector)
-//   L_i(x) = (w^i / n) (x^n - 1) / (x - w^i)        (li_big holds it on the 4n coset points)
+//   L_i(x) = (w^i / n) (x^n - 1) / (x - w^i)        (li_big holds it on the coset points: [3][n] coset-major)
 __global__ void pi_coeffs_kernel(const Fr* pub, size_t l, const Fr* roots_inv, size_t n, size_t B, Fr n_inv, Fr* pic) {
     const size_t total = B * n;
     for (size_t gI = (size_t)blockIdx.x * blockDim.x + threadIdx.x; gI < total; gI += (size_t)gridDim.x * blockDim.x) {
@@ -143,14 +147,14 @@ __global__ void pi_coset_kernel(const Fr* pub, size_t l, const Fr* li_big, size_
         fp_store(pi_big + gI, fp_neg(acc));
     }
 }
-// li[i][k] = (w^i / n) zh[k & 3] / (x_k - w^i); one field inversion per entry, once per circuit
+// li[i][k] = (w^i / n) zh[k / n] / (x_k - w^i), k = r n + j (Z_H is constant on coset r); one field inversion per entry, once per circuit
 struct Zh4 { Fr v[4]; };
-__global__ void li_coset_kernel(const Fr* xs, const Fr* roots, size_t n4, size_t l, Zh4 zh, Fr n_inv, Fr* li) {
+__global__ void li_coset_kernel(const Fr* xs, const Fr* roots, size_t n4, size_t n, size_t l, Zh4 zh, Fr n_inv, Fr* li) {
     const size_t total = l * n4;
     for (size_t gI = (size_t)blockIdx.x * blockDim.x + threadIdx.x; gI < total; gI += (size_t)gridDim.x * blockDim.x) {
         const size_t i = gI / n4, k = gI - i * n4;
         const Fr wi = fp_load(roots + i);
-        const Fr num = fp_mul(fp_mul(wi, n_inv), zh.v[k & 3]);
+        const Fr num = fp_mul(fp_mul(wi, n_inv), zh.v[k / n]);
         fp_store(li + gI, fp_mul(num, fp_inv(fp_sub(fp_load(xs + k), wi))));  // x_k is never an n-th root of unity
     }
 }
@@ -473,20 +477,27 @@ __global__ void __launch_bounds__(GP_THREADS) grand_product_kernel(GrandProductI
 }
 
 // ------------------------------------------------------------------------------------------------
-// Round 3 (prover.py:188-203): quotient evaluations on the 4n-point coset, fully fused.
-//   wit = A, B, C, PI, Z on the coset, proof b at + b 4n; fixed = QM, QL, QR, QO, QC, S1, S2, S3 (FX_* order), l0, xs: [4n].
+// Round 3 (prover.py:188-203): quotient evaluations on the coset points, fully fused.
+//   wit = A, B, C, PI, Z on the points, proof b at + b n4; fixed = QM, QL, QR, QO, QC, S1, S2, S3 (FX_* order), l0, xs: [n4].
 //   Challenges from the transcript states (st) or, st == null, from `direct` (plonk_fr_quotient).
+//   coset_log == 0: the reference's layout — n4 = 4n points g mu^k in natural order, Z(w x) four places ahead (prover.py:173),
+//   Z_H by k & 3 (plonk_fr_quotient).  coset_log == log2 n: the lock-step prover's — n4 = 3n points [r][j] = g mu^r w^j, Z(w x)
+//   one place ahead INSIDE the coset, Z_H by r.  The quotient goes to quot[b * out_stride + k].
 struct ZhInv { Fr v[4]; };
 struct QuotientIn { const Fr* wit[5]; const Fr* fixed[FX_COUNT]; const Fr* l0; const Fr* xs; };
-__global__ void quotient_kernel(QuotientIn in, ZhInv zh, const ProofState* st, RoundChallenges direct, size_t n4, size_t B, Fr* quot) {
-    const size_t total = B * n4;
-    for (size_t gI = (size_t)blockIdx.x * blockDim.x + threadIdx.x; gI < total; gI += (size_t)gridDim.x * blockDim.x) {
-        const size_t b = gI / n4, k = gI - b * n4;
+__global__ void quotient_kernel(QuotientIn in, ZhInv zh, const ProofState* st, RoundChallenges direct, unsigned n4, Fr* quot,
+                                unsigned coset_log, unsigned out_stride) {
+    // blockIdx.y = proof, blockIdx.x * blockDim.x + threadIdx.x = point (32-bit indices, no divisions: the kernel sits at 128 VGPRs)
+    const unsigned b = blockIdx.y;
+    for (unsigned k = blockIdx.x * blockDim.x + threadIdx.x; k < n4; k += gridDim.x * blockDim.x) {
+        const unsigned cr = coset_log ? k >> coset_log : 0u, cmask = coset_log ? (1u << coset_log) - 1u : 0u;
         const Fr beta = st ? st[b].beta : direct.beta, gamma = st ? st[b].gamma : direct.gamma, alpha = st ? st[b].alpha : direct.alpha;
-        const Fr a = fp_load(in.wit[0] + b * n4 + k), bb = fp_load(in.wit[1] + b * n4 + k), c = fp_load(in.wit[2] + b * n4 + k),
-                 pi = fp_load(in.wit[3] + b * n4 + k), z = fp_load(in.wit[4] + b * n4 + k);
-        const size_t kw = (k + 4 < n4) ? k + 4 : k + 4 - n4;  // Z(w x) = Z_big.shift(4), prover.py:173
-        const Fr zw = fp_load(in.wit[4] + b * n4 + kw);
+        const size_t row = (size_t)b * n4;
+        const Fr a = fp_load(in.wit[0] + row + k), bb = fp_load(in.wit[1] + row + k), c = fp_load(in.wit[2] + row + k),
+                 pi = fp_load(in.wit[3] + row + k), z = fp_load(in.wit[4] + row + k);
+        const unsigned kw = coset_log ? ((k & ~cmask) | ((k + 1) & cmask))            // the next point of the same coset
+                                      : ((k + 4 < n4) ? k + 4 : k + 4 - n4);          // Z(w x) = Z_big.shift(4), prover.py:173
+        const Fr zw = fp_load(in.wit[4] + row + kw);
         const Fr qm = fp_load(in.fixed[FX_QM] + k), ql = fp_load(in.fixed[FX_QL] + k), qr = fp_load(in.fixed[FX_QR] + k),
                  qo = fp_load(in.fixed[FX_QO] + k), qc = fp_load(in.fixed[FX_QC] + k);
         // gate: A QL + B QR + A B QM + C QO + PI + QC
@@ -503,17 +514,48 @@ __global__ void quotient_kernel(QuotientIn in, ZhInv zh, const ProofState* st, R
                        fp_mul(fp_add(cg, fp_mul(beta, fp_load(in.fixed[FX_S3] + k))), zw));
         Fr first = fp_mul(fp_sub(z, fp_one<FrParams>()), fp_load(in.l0 + k));
         Fr acc = fp_add(gate, fp_mul(alpha, fp_add(fp_sub(p1, p2), fp_mul(alpha, first))));
-        fp_store(quot + gI, fp_mul(acc, zh.v[k & 3]));
+        fp_store(quot + (size_t)b * out_stride + k, fp_mul(acc, zh.v[coset_log ? cr : (k & 3)]));
     }
 }
 
-// prover.py:205-208 — the quotient must have degree < 3n: its top n coefficients are zero exactly
-// when the gate and permutation identities hold on H.  flags[b] |= 1 otherwise.
-__global__ void quotient_degree_check_kernel(const Fr* tcoef, size_t n, size_t B, uint32_t* bad) {
+// The quotient's coefficients from its values on three cosets.  With t = T_0 + X^n T_1 + X^2n T_2 (deg T_q < n) and
+// x^n = g^n i^r on coset r (i = mu^n, a primitive fourth root of unity), the polynomial U_r = T_0 + (g^n i^r) T_1 + (g^n i^r)^2 T_2
+// agrees with t on coset r; the size-n inverse transforms (with their (g mu^r)^-i store-side scaling, which also halves)
+// leave u_r[i] / 2 in slice r of quot.  Per i, with s_1 = g^n t_{n+i}, s_2 = g^2n t_{2n+i}:
+//   u_0 = t_i + s_1 + s_2,   u_1 = t_i + i s_1 - s_2,   u_2 = t_i - s_1 + s_2
+//   =>  s_1 = u_0/2 - u_2/2,   p = t_i + s_2 = u_0/2 + u_2/2,   m = t_i - s_2 = u_1 - i s_1,   t_i = (p + m)/2,  s_2 = (p - m)/2.
+// in place: slice q of quot[b] <- T_q.  Three multiplications per i (by i, 1/g^n, 1/(2 g^2n)) and a halving.
+__global__ void quotient_combine_kernel(Fr* quot, size_t n, size_t stride, size_t B, Fr ci, Fr g1_inv, Fr g2_inv_half, Fr half) {
     const size_t total = B * n;
     for (size_t gI = (size_t)blockIdx.x * blockDim.x + threadIdx.x; gI < total; gI += (size_t)gridDim.x * blockDim.x) {
         const size_t b = gI / n, i = gI - b * n;
-        if (!fp_is_zero(fp_load(tcoef + b * 4 * n + 3 * n + i))) atomicOr(&bad[b], 1u);
+        Fr* q = quot + b * stride + i;
+        const Fr h0 = fp_load(q), h1 = fp_load(q + n), h2 = fp_load(q + 2 * n);  // u_r / 2
+        const Fr s1 = fp_sub(h0, h2), p = fp_add(h0, h2);
+        const Fr m = fp_sub(fp_dbl(h1), fp_mul(ci, s1));
+        fp_store(q, fp_mul(fp_add(p, m), half));
+        fp_store(q + n, fp_mul(s1, g1_inv));
+        fp_store(q + 2 * n, fp_mul(fp_sub(p, m), g2_inv_half));
+    }
+}
+
+// prover.py:108-116 — the gate identity on H, row by row: A QL + B QR + A B QM + C QO + PI + QC = 0.  flags[b] |= 1 otherwise
+// (status bit 2).  Together with "Z closes to 1" (prover.py:132, status bit 1) this is exactly when the quotient's numerator is
+// divisible by Z_H — the condition the reference re-checks on the quotient's top coefficients (prover.py:205-208), which a
+// quotient interpolated from 3n points no longer has.
+__global__ void gate_check_kernel(const Fr* abc, const Fr* pub, size_t l, const Fr* pi_or_null, const Fr* fixed_lag, size_t n, size_t B, uint32_t* bad) {
+    const size_t total = B * n;
+    for (size_t gI = (size_t)blockIdx.x * blockDim.x + threadIdx.x; gI < total; gI += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = gI / n, i = gI - b * n;
+        const Fr a = fp_load(abc + gI), bb = fp_load(abc + total + gI), c = fp_load(abc + 2 * total + gI);
+        Fr pi = fp_zero<FrParams>();
+        if (pi_or_null) pi = fp_load(pi_or_null + gI);
+        else if (i < l) pi = fp_neg(fp_load(pub + b * l + i));
+        Fr gate = fp_add(fp_mul(a, fp_load(fixed_lag + FX_QL * n + i)), fp_mul(bb, fp_load(fixed_lag + FX_QR * n + i)));
+        gate = fp_add(gate, fp_mul(fp_mul(a, bb), fp_load(fixed_lag + FX_QM * n + i)));
+        gate = fp_add(gate, fp_mul(c, fp_load(fixed_lag + FX_QO * n + i)));
+        gate = fp_add(gate, fp_add(pi, fp_load(fixed_lag + FX_QC * n + i)));
+        if (!fp_is_zero(gate)) atomicOr(&bad[b], 1u);
     }
 }
 
@@ -739,7 +781,7 @@ static int ensure_batch(plonk_prover* p, size_t B) {
     PLONK_TRY(dev_alloc((void**)&p->wit_lag, 4 * B * n * e));
     PLONK_TRY(dev_alloc((void**)&p->z_lag, B * n * e));
     PLONK_TRY(dev_alloc((void**)&p->coef, 5 * B * n * e));
-    PLONK_TRY(dev_alloc((void**)&p->big, 5 * B * 4 * n * e));
+    PLONK_TRY(dev_alloc((void**)&p->big, 5 * B * QCOSETS * n * e));
     PLONK_TRY(dev_alloc((void**)&p->quot, B * 4 * n * e));
     PLONK_TRY(dev_alloc((void**)&p->num, B * n * e));
     PLONK_TRY(dev_alloc((void**)&p->den, 2 * B * sizeof(uint32_t) + 64));
@@ -781,7 +823,7 @@ int plonk_prover_create(plonk_ctx* ctx, plonk_srs* srs, unsigned log_n, const ui
 
 static int prover_init(plonk_prover* p, plonk_ctx* ctx, plonk_srs* srs, unsigned log_n, const uint8_t* selectors_le32,
                        size_t n_public) {
-    const size_t n = (size_t)1 << log_n, n4 = 4 * n;
+    const size_t n = (size_t)1 << log_n;
     p->ctx = ctx;
     p->srs = srs;
     p->log_n = log_n;
@@ -799,44 +841,55 @@ static int prover_init(plonk_prover* p, plonk_ctx* ctx, plonk_srs* srs, unsigned
     const size_t e = sizeof(Fr);
     PLONK_TRY(dev_alloc((void**)&p->fixed_lag, 8 * n * e));
     PLONK_TRY(dev_alloc((void**)&p->fixed_coef, 8 * n * e));
-    PLONK_TRY(dev_alloc((void**)&p->fixed_big, 8 * n4 * e));
-    PLONK_TRY(dev_alloc((void**)&p->l0_big, n4 * e));
-    PLONK_TRY(dev_alloc((void**)&p->x_big, n4 * e));
-    PLONK_TRY(dev_alloc((void**)&p->g_pow, n * e));
-    PLONK_TRY(dev_alloc((void**)&p->ginv_pow, n4 * e));
+    const size_t n3 = QCOSETS * n;
+    PLONK_TRY(dev_alloc((void**)&p->fixed_big, 8 * n3 * e));
+    PLONK_TRY(dev_alloc((void**)&p->l0_big, n3 * e));
+    PLONK_TRY(dev_alloc((void**)&p->x_big, n3 * e));
+    PLONK_TRY(dev_alloc((void**)&p->g_pow, n3 * e));
+    PLONK_TRY(dev_alloc((void**)&p->ginv_pow, n3 * e));
     PLONK_TRY(plonk_fr_upload(ctx, p->fixed_lag, selectors_le32, 8 * n));
     PLONK_TRY(ntt_get_roots(ctx, log_n, false, &p->roots));
     const Fr one = fp_one<FrParams>();
-    PLONK_TRY(k_fr_powers(ctx, p->g, one, p->g_pow, n));
-    Fr inv4n = fp_inv(host_fr_u64((uint64_t)n4));
-    PLONK_TRY(k_fr_powers(ctx, fp_inv(p->g), inv4n, p->ginv_pow, n4));
-    PLONK_TRY(k_fr_powers(ctx, host_root_of_unity(log_n + 2, false), p->g, p->x_big, n4));
-    // coefficient forms and coset extensions of the 8 circuit polynomials
+    const Fr half = fp_inv(host_fr_u64(2));
+    const Fr mu = host_root_of_unity(log_n + 2, false), w = host_root_of_unity(log_n, false);
+    Fr base = p->g;  // g mu^r
+    for (unsigned r = 0; r < QCOSETS; r++) {
+        PLONK_TRY(k_fr_powers(ctx, base, one, p->g_pow + r * n, n));
+        PLONK_TRY(k_fr_powers(ctx, fp_inv(base), fp_mul(half, fp_inv(host_fr_u64((uint64_t)n))), p->ginv_pow + r * n, n));
+        PLONK_TRY(k_fr_powers(ctx, w, base, p->x_big + r * n, n));
+        base = fp_mul(base, mu);
+    }
+    // coefficient forms of the 8 circuit polynomials, and their values on the three cosets: P(g mu^r w^j) is the size-n
+    // transform of c_i (g mu^r)^i
     PLONK_TRY(ntt_run(ctx, p->fixed_lag, p->fixed_coef, log_n, true, 8, n, n, n, nullptr, nullptr, true));
-    PLONK_TRY(ntt_run(ctx, p->fixed_coef, p->fixed_big, log_n + 2, false, 8, n, n, n4, p->g_pow, nullptr, false));
+    const NttFan fan{QCOSETS, 0u, (unsigned)n, (unsigned)n};
+    PLONK_TRY(ntt_run(ctx, p->fixed_coef, p->fixed_big, log_n, false, 8, n, n, n3, p->g_pow, nullptr, false, &fan));
     // L0: Lagrange vector e_0 has coefficient form (1/n, 1/n, ...)          prover.py:184-186
     Fr ninv = fp_inv(host_fr_u64((uint64_t)n));
     void* tmpv;
     PLONK_TRY(ctx_scratch(ctx, 2, n * e, &tmpv));  // context-owned scratch: nothing to leak on an error path
     Fr* tmp = (Fr*)tmpv;
     PLONK_TRY(k_fr_powers(ctx, one, ninv, tmp, n));
-    PLONK_TRY(ntt_run(ctx, tmp, p->l0_big, log_n + 2, false, 1, n, n, n4, p->g_pow, nullptr, false));
+    PLONK_TRY(ntt_run(ctx, tmp, p->l0_big, log_n, false, 1, n, n, n3, p->g_pow, nullptr, false, &fan));
     PLONK_CHECK_HIP(hipStreamSynchronize(ctx->stream));
-    // Z_H on the coset takes 4 values: (g mu^k)^n - 1 = g^n i^k - 1, i = mu^n            prover.py:178
+    // Z_H on coset r is the constant (g mu^r)^n - 1 = g^n i^r - 1, i = mu^n            prover.py:178
     Fr gn = p->g;
     for (unsigned i = 0; i < log_n; i++) gn = fp_sqr(gn);
     Fr i4 = host_root_of_unity(2, false), cur = gn;
     Zh4 zh4;
     for (int k = 0; k < 4; k++) {
         zh4.v[k] = fp_sub(cur, one);
-        p->zh_inv[k] = fp_inv(zh4.v[k]);
+        if (k < QCOSETS) p->zh_inv[k] = fp_inv(zh4.v[k]);
         cur = fp_mul(cur, i4);
     }
+    p->comb_i = i4;
+    p->comb_g1 = fp_inv(gn);
+    p->comb_g2 = fp_mul(fp_sqr(p->comb_g1), half);
     p->sparse_pi = n_public <= PI_SPARSE_MAX;
     if (p->sparse_pi && n_public) {
         PLONK_TRY(ntt_get_roots(ctx, log_n, true, &p->roots_inv));
-        PLONK_TRY(dev_alloc((void**)&p->li_big, n_public * n4 * e));
-        PLONK_LAUNCH(li_coset_kernel, grid1(n_public * n4), dim3(256), 0, ctx->stream, (const Fr*)p->x_big, p->roots, n4, n_public,
+        PLONK_TRY(dev_alloc((void**)&p->li_big, n_public * n3 * e));
+        PLONK_LAUNCH(li_coset_kernel, grid1(n_public * n3), dim3(256), 0, ctx->stream, (const Fr*)p->x_big, p->roots, n3, n, n_public,
                      zh4, ninv, p->li_big);
         PLONK_CHECK_HIP(hipGetLastError());
         PLONK_CHECK_HIP(hipStreamSynchronize(ctx->stream));
@@ -996,6 +1049,9 @@ int plonk_prover_run(plonk_prover* p, size_t B) {
     PLONK_LAUNCH(transcript_kernel, dim3(tg), dim3(2 * TC_LANES), 0, s, 0, p->state, B, (const Fq*)cxy, (const uint8_t*)cfl, p->chal);
     // ---- round 1: coefficient forms of A, B, C, PI; commit A, B, C            prover.py:86-119
     const Fr n_inv = fp_inv(host_fr_u64((uint64_t)n));
+    PLONK_CHECK_HIP(hipMemsetAsync(closes + B, 0, B * sizeof(uint32_t), s));
+    PLONK_LAUNCH(gate_check_kernel, grid1(B * n), dim3(256), 0, s, (const Fr*)p->wit_lag, (const Fr*)p->pub, p->n_public,
+                 p->sparse_pi ? (const Fr*)nullptr : (const Fr*)(p->wit_lag + 3 * B * n), (const Fr*)p->fixed_lag, n, B, closes + B);  // prover.py:108-116
     if (p->sparse_pi) {
         PLONK_TRY(ntt_run(ctx, p->wit_lag, p->coef, log_n, true, 3 * B, n, n, n, nullptr, nullptr, true));
         if (p->n_public)
@@ -1022,28 +1078,36 @@ int plonk_prover_run(plonk_prover* p, size_t B) {
     else PLONK_TRY(msm_run_device(ctx, p->srs, p->coef + 4 * B * n, n, B, n, cxy + 2 * 3 * B, cfl + 3 * B));
     PLONK_LAUNCH(transcript_kernel, dim3(tg), dim3(2 * TC_LANES), 0, s, 2, p->state, B, (const Fq*)cxy, (const uint8_t*)cfl, p->chal);
     // ---- round 3: coset extensions, fused quotient, back to coefficients, commit T1..T3   prover.py:154-226
+    // deg t < 3n: three cosets g mu^r H of the n-th roots of unity determine the quotient, so A, B, C, Z are evaluated on 3n
+    // points — per coset a size-n transform of c_i (g mu^r)^i, on the 2^log_n kernel — instead of the reference's 4n, the
+    // fused pass runs over 3n points, and three size-n inverse transforms + quotient_combine_kernel give T1, T2, T3
+    const size_t n3 = QCOSETS * n;
+    const NttFan fan{QCOSETS, 0u, (unsigned)n, (unsigned)n};  // one input, three scalings (g mu^r)^i, outputs [r][n] side by side
     if (p->sparse_pi) {  // A, B, C and Z through the transform, PI from the Lagrange basis on the coset
-        PLONK_TRY(ntt_run(ctx, p->coef, p->big, log_n + 2, false, 3 * B, n, n, n4, p->g_pow, nullptr, false));
-        PLONK_TRY(ntt_run(ctx, p->coef + 4 * B * n, p->big + 4 * B * n4, log_n + 2, false, B, n, n, n4, p->g_pow, nullptr, false));
-        if (p->n_public)
-            PLONK_LAUNCH(pi_coset_kernel, grid1(B * n4), dim3(256), 0, s, (const Fr*)p->pub, p->n_public, (const Fr*)p->li_big, n4, B,
-                         p->big + 3 * B * n4);
-        else
-            PLONK_CHECK_HIP(hipMemsetAsync(p->big + 3 * B * n4, 0, B * n4 * sizeof(Fr), s));
+        PLONK_TRY(ntt_run(ctx, p->coef, p->big, log_n, false, 3 * B, n, n, n3, p->g_pow, nullptr, false, &fan));
+        PLONK_TRY(ntt_run(ctx, p->coef + 4 * B * n, p->big + 4 * B * n3, log_n, false, B, n, n, n3, p->g_pow, nullptr, false, &fan));
     } else {
-        PLONK_TRY(ntt_run(ctx, p->coef, p->big, log_n + 2, false, 5 * B, n, n, n4, p->g_pow, nullptr, false));
+        PLONK_TRY(ntt_run(ctx, p->coef, p->big, log_n, false, 5 * B, n, n, n3, p->g_pow, nullptr, false, &fan));
+    }
+    if (p->sparse_pi) {
+        if (p->n_public)
+            PLONK_LAUNCH(pi_coset_kernel, grid1(B * n3), dim3(256), 0, s, (const Fr*)p->pub, p->n_public, (const Fr*)p->li_big, n3, B,
+                         p->big + 3 * B * n3);
+        else
+            PLONK_CHECK_HIP(hipMemsetAsync(p->big + 3 * B * n3, 0, B * n3 * sizeof(Fr), s));
     }
     ZhInv zh;
-    for (int k = 0; k < 4; k++) zh.v[k] = p->zh_inv[k];
+    for (int k = 0; k < 4; k++) zh.v[k] = p->zh_inv[k < QCOSETS ? k : 0];
     QuotientIn qi;
-    for (int k = 0; k < 5; k++) qi.wit[k] = p->big + (size_t)k * B * n4;
-    for (int k = 0; k < FX_COUNT; k++) qi.fixed[k] = p->fixed_big + (size_t)k * n4;
+    for (int k = 0; k < 5; k++) qi.wit[k] = p->big + (size_t)k * B * n3;
+    for (int k = 0; k < FX_COUNT; k++) qi.fixed[k] = p->fixed_big + (size_t)k * n3;
     qi.l0 = p->l0_big;
     qi.xs = p->x_big;
-    PLONK_LAUNCH(quotient_kernel, grid1(B * n4), dim3(256), 0, s, qi, zh, (const ProofState*)p->state, RoundChallenges{}, n4, B, p->quot);
-    PLONK_TRY(ntt_run(ctx, p->quot, p->quot, log_n + 2, true, B, n4, n4, n4, nullptr, p->ginv_pow, false));
-    PLONK_CHECK_HIP(hipMemsetAsync(closes + B, 0, B * sizeof(uint32_t), s));
-    PLONK_LAUNCH(quotient_degree_check_kernel, grid1(B * n), dim3(256), 0, s, (const Fr*)p->quot, n, B, closes + B);
+    PLONK_LAUNCH(quotient_kernel, dim3((unsigned)((n3 + 255) / 256), (unsigned)B), dim3(256), 0, s, qi, zh, (const ProofState*)p->state, RoundChallenges{},
+                 (unsigned)n3, p->quot, log_n, (unsigned)n4);
+    const NttFan slices{QCOSETS, (unsigned)n, (unsigned)n, (unsigned)n};  // the three coset slices of every quotient row, in place
+    PLONK_TRY(ntt_run(ctx, p->quot, p->quot, log_n, true, B, n, n4, n4, nullptr, p->ginv_pow, false, &slices));
+    PLONK_LAUNCH(quotient_combine_kernel, grid1(B * n), dim3(256), 0, s, p->quot, n, n4, B, p->comb_i, p->comb_g1, p->comb_g2, fp_inv(host_fr_u64(2)));
     // T1..T3 = the three n-coefficient slices of each quotient row, one batched call (MSM k*B + b = slice k of proof b)
     PLONK_TRY(msm_run_device(ctx, p->srs, p->quot, n, 3 * B, n4, cxy + 2 * 4 * B, cfl + 4 * B, B, n));
     PLONK_LAUNCH(transcript_kernel, dim3(tg), dim3(2 * TC_LANES), 0, s, 3, p->state, B, (const Fq*)cxy, (const uint8_t*)cfl, p->chal);
@@ -1069,8 +1133,8 @@ int plonk_prover_run(plonk_prover* p, size_t B) {
 }
 
 // Synchronise and fetch: proofs [B][768], status[B] (0 ok; bit0: identity commitment; bit1: Z does
-// not close to 1, i.e. the witness breaks the copy constraints — prover.py:132; bit2: the quotient has
-// degree >= 3n, i.e. the witness breaks a gate constraint — prover.py:108-116, 205-208).
+// not close to 1, i.e. the witness breaks the copy constraints — prover.py:132; bit2: a gate constraint fails on some row —
+// prover.py:108-116; with bit1 clear that is exactly the condition of the reference's quotient-degree assert, prover.py:205-208).
 static int prover_download(plonk_prover* p, size_t B, uint8_t* out_proofs, uint8_t* out_status, bool compressed);
 int plonk_prover_download(plonk_prover* p, size_t B, uint8_t* out_proofs, uint8_t* out_status) {
     return prover_download(p, B, out_proofs, out_status, false);
@@ -1200,7 +1264,8 @@ int plonk_fr_quotient(plonk_ctx* ctx, unsigned log_n, const void* const d_evals[
     ch.alpha = fr_from_le32(alpha_le32);
     ch.beta = fr_from_le32(beta_le32);
     ch.gamma = fr_from_le32(gamma_le32);
-    PLONK_LAUNCH(quotient_kernel, grid1(n4), dim3(256), 0, ctx->stream, qi, zh, (const ProofState*)nullptr, ch, n4, (size_t)1, (Fr*)d_out);
+    PLONK_LAUNCH(quotient_kernel, dim3((unsigned)((n4 + 255) / 256), 1), dim3(256), 0, ctx->stream, qi, zh, (const ProofState*)nullptr, ch, (unsigned)n4,
+                 (Fr*)d_out, 0u, (unsigned)n4);
     PLONK_CHECK_HIP(hipGetLastError());
     return PLONK_OK;
 }

@@ -165,6 +165,14 @@ def test_batch_prover_vs_oracle(emu):
     pc.batch_prover_rejects_bad_witness(setup)
 
 
+def test_batch_prover_on_the_wave_kernels(emu):
+    """group_order 2^8: the smallest size whose transforms run on the wave kernels — the three coset evaluations of every
+    wire polynomial as ONE fanned launch, the quotient's three inverse transforms likewise (smaller orders loop over calls)."""
+    from plonkathon_amd import Setup
+
+    pc.batch_prover_vs_oracle(Setup.from_file(pc.PTAU), pc.chain_lines(256), 256, [{"x0": 3}, {"x0": 77}])
+
+
 def test_edge_and_error_paths(emu):
     from plonkathon_amd import Setup
 
