@@ -308,9 +308,9 @@ int plonk_ntt_select_kernel(plonk_ctx* ctx, unsigned kind) {
 int plonk_ntt_set_split(plonk_ctx* ctx, unsigned log_n, unsigned log_r1) {
     PLONK_REQUIRE(ctx, PLONK_ERR_ARG, "ctx is NULL");
     PLONK_ENTER(ctx);
-    PLONK_REQUIRE(log_n >= 16 && log_n <= 26, PLONK_ERR_ARG, "two-pass wave transforms cover 2^16 .. 2^26 (got 2^%u)", log_n);
-    PLONK_REQUIRE(log_r1 == 0 || (log_r1 >= 8 && log_r1 <= 13 && log_n - log_r1 >= 8 && log_n - log_r1 <= 13), PLONK_ERR_ARG,
-                  "2^%u = 2^%u x 2^%u: both factors must lie in 2^8 .. 2^13", log_n, log_r1, log_n - log_r1);
+    PLONK_REQUIRE(log_n >= 14 && log_n <= 26, PLONK_ERR_ARG, "two-pass wave transforms cover 2^14 .. 2^26 (got 2^%u)", log_n);
+    PLONK_REQUIRE(log_r1 == 0 || (log_r1 >= 7 && log_r1 <= 13 && log_n - log_r1 >= 7 && log_n - log_r1 <= 13), PLONK_ERR_ARG,
+                  "2^%u = 2^%u x 2^%u: both factors must lie in 2^7 .. 2^13", log_n, log_r1, log_n - log_r1);
     ctx->ntt_split[log_n] = (unsigned char)log_r1;
     ctx->ntt_cfg_epoch++;
     return PLONK_OK;
@@ -319,7 +319,7 @@ int plonk_ntt_set_split(plonk_ctx* ctx, unsigned log_n, unsigned log_r1) {
 int plonk_ntt_get_split(plonk_ctx* ctx, unsigned log_n, unsigned* out_log_r1) {
     PLONK_REQUIRE(out_log_r1, PLONK_ERR_ARG, "bad argument");
     unsigned r1 = 0, r2 = 0;
-    PLONK_REQUIRE(ntt_wave_plan(ctx, log_n, &r1, &r2) && r2 && r1 >= 8, PLONK_ERR_ARG, "2^%u is not a two-pass wave transform (2^16 .. 2^26)", log_n);
+    PLONK_REQUIRE(ntt_wave_plan(ctx, log_n, false, &r1, &r2) && r2, PLONK_ERR_ARG, "2^%u is not a two-pass wave transform (2^14 .. 2^26)", log_n);
     *out_log_r1 = r1;
     return PLONK_OK;
 }

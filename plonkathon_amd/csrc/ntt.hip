@@ -536,27 +536,25 @@ static unsigned plan_passes(const plonk_ctx* ctx, unsigned log_n, unsigned radic
     return P;
 }
 
-// the wave kernels (variant C): N = 2^8 .. 2^13 in one pass (one workgroup of N / 4 or N / 8 threads per transform), and
+// the wave kernels (variant C): N = 2^7 .. 2^13 in one pass (one workgroup of N / 2, N / 4 or N / 8 threads per transform), and
 // N = R1 R2 with R1, R2 from that set in two passes (columns, then rows).  Default splits: the fastest measured on MI355X
 // for a lone transform (profiles/r03_b_ntt_splits.jsonl: the 4-element-per-thread kernels where a size allows them —
 // twice the waves —, and short column transforms for the largest sizes); plonk_ntt_set_split overrides one size.
-bool ntt_wave_plan(const plonk_ctx* ctx, unsigned log_n, unsigned* log_r1, unsigned* log_r2) {
-    if (log_n >= 8 && log_n <= 13) {
+// latency: the call is a small job (<= 2^18 elements in all) — bound by the instruction chain of one wave, not by
+// throughput: 2^16 .. 2^18 then split so that the two-element kernels (2^7, and 2^9 in its two-element form) serve them.
+bool ntt_wave_plan(const plonk_ctx* ctx, unsigned log_n, bool latency, unsigned* log_r1, unsigned* log_r2) {
+    if (log_n >= 7 && log_n <= 13) {
         *log_r1 = log_n;
         *log_r2 = 0;
         return true;
     }
-    if (log_n == 14 || log_n == 15) {  // 4 x 2^12, 4 x 2^13: four-point column transforms (ntt_quad_column_kernel), then the wave kernel's rows
-        *log_r1 = 2;
-        *log_r2 = log_n - 2;
-        return true;
-    }
-    if (log_n < 16 || log_n > 26) return false;
-    //                                   2^16 17  18  19  20  21  22  23  24  25  26
-    static const unsigned char best[] = {8,   8, 10, 10, 10, 11, 11, 10, 11, 12, 13};  // (profiles/r03_r_ntt_splits_final.jsonl: every admissible split, final kernels)
-    unsigned r1 = best[log_n - 16];
+    if (log_n < 14 || log_n > 26) return false;
+    //                                   2^14 15  16 17  18  19  20  21  22  23  24  25  26
+    static const unsigned char best[] = {7,   7,  8,  8, 10, 10, 10, 11, 11, 10, 11, 12, 13};  // (profiles/r03_r_ntt_splits_final.jsonl: every admissible split, final kernels)
+    static const unsigned char lat[] = {7,    7,  7,  8,  9};                                   // (profiles/r04_c_ntt_latency_splits.jsonl)
+    unsigned r1 = (latency && log_n <= 18) ? lat[log_n - 14] : best[log_n - 14];
     if (ctx && log_n < sizeof ctx->ntt_split / sizeof ctx->ntt_split[0] && ctx->ntt_split[log_n]) r1 = ctx->ntt_split[log_n];
-    if (r1 < 8 || r1 > 13 || log_n - r1 < 8 || log_n - r1 > 13) return false;
+    if (r1 < 7 || r1 > 13 || log_n - r1 < 7 || log_n - r1 > 13) return false;
     *log_r1 = r1;
     *log_r2 = log_n - r1;
     return true;
@@ -586,7 +584,7 @@ static int ntt_run_wave(plonk_ctx* ctx, const Fr* in, Fr* out, unsigned log_n, b
 int ntt_dist_plan(unsigned log_n, unsigned log_w, unsigned* log_r1, unsigned* log_r2) {
     unsigned r1 = 0, r2 = 0;
     // the default split (no per-context override: every rank must pick the same one)
-    PLONK_REQUIRE(ntt_wave_plan(nullptr, log_n, &r1, &r2) && r2 && r1 >= 8, PLONK_ERR_ARG,
+    PLONK_REQUIRE(ntt_wave_plan(nullptr, log_n, false, &r1, &r2) && r2 && log_n >= 16, PLONK_ERR_ARG,
                   "distributed NTT supports sizes 2^16 .. 2^26 (got 2^%u)", log_n);
     PLONK_REQUIRE(log_w + 5 <= r2 && log_w + 5 <= r1, PLONK_ERR_ARG, "2^%u ranks are too many for a 2^%u-point transform", log_w, log_n);
     *log_r1 = r1;
@@ -603,7 +601,7 @@ int ntt_dist_columns(plonk_ctx* ctx, const Fr* in, Fr* out, unsigned log_n, unsi
     NttWave a;
     ntt_wave_consts(&a, log_n, inverse);
     PLONK_TRY(wave_lo_hi<Bn254FrField>(ctx, log_n, inverse, false, &a.tw_lo, &a.tw_hi));
-    PLONK_TRY(wave_program_table<Bn254FrField>(ctx, log_r1, inverse, &a.roots));
+    PLONK_TRY(wave_program_table<Bn254FrField>(ctx, log_r1, wavel_log_e(log_r1), inverse, &a.roots));
     a.mode = 1;
     a.log_other = log_cl;
     a.sub_base = rank << log_cl;
@@ -611,7 +609,7 @@ int ntt_dist_columns(plonk_ctx* ctx, const Fr* in, Fr* out, unsigned log_n, unsi
     a.out = out;
     a.in_len = 1u << (log_n - log_w);
     PLONK_TRY(prof_begin(ctx, "ntt_pass", 32.0 * (double)((size_t)1 << (log_n - log_w))));
-    PLONK_TRY(wave_launch<Bn254FrField>(ctx, a, log_r1, 1u << log_cl, 1));
+    PLONK_TRY(wave_launch<Bn254FrField>(ctx, a, log_r1, wavel_log_e(log_r1), 1u << log_cl, 1));
     PLONK_TRY(prof_end(ctx));
     PLONK_CHECK_HIP(hipGetLastError());
     return PLONK_OK;
@@ -624,7 +622,7 @@ int ntt_dist_rows(plonk_ctx* ctx, const Fr* in, Fr* out, unsigned log_n, unsigne
     const unsigned log_cl = log_r2 - log_w, log_kl = log_r1 - log_w;
     NttWave c;
     ntt_wave_consts(&c, log_n, inverse);
-    PLONK_TRY(wave_program_table<Bn254FrField>(ctx, log_r2, inverse, &c.roots));
+    PLONK_TRY(wave_program_table<Bn254FrField>(ctx, log_r2, wavel_log_e(log_r2), inverse, &c.roots));
     c.mode = 2;
     c.log_other = log_kl;  // output stride: frequency k2 of local row kl at out[k2 * R1/W + kl]
     if (log_w) {           // W chunks [source rank][R1/W][R2/W]; one rank: plain contiguous rows
@@ -639,7 +637,7 @@ int ntt_dist_rows(plonk_ctx* ctx, const Fr* in, Fr* out, unsigned log_n, unsigne
         c.has_out_scalar = 1;
     }
     PLONK_TRY(prof_begin(ctx, "ntt_pass", 32.0 * (double)((size_t)1 << (log_n - log_w))));
-    PLONK_TRY(wave_launch<Bn254FrField>(ctx, c, log_r2, 1u << log_kl, 1));
+    PLONK_TRY(wave_launch<Bn254FrField>(ctx, c, log_r2, wavel_log_e(log_r2), 1u << log_kl, 1));
     PLONK_TRY(prof_end(ctx));
     PLONK_CHECK_HIP(hipGetLastError());
     return PLONK_OK;
@@ -652,7 +650,7 @@ int ntt_run(plonk_ctx* ctx, const Fr* in, Fr* out, unsigned log_n, bool inverse,
     const size_t N = (size_t)1 << log_n;
     unsigned wr1, wr2;
     if (fan && fan->count <= 1) fan = nullptr;
-    const bool wave_ok = (ctx->ntt_kind == 0 || ctx->ntt_kind == 5) && ntt_wave_plan(ctx, log_n, &wr1, &wr2) && (!wr2 || wr1 >= 8 || ctx->ntt_kind == 5) &&
+    const bool wave_ok = (ctx->ntt_kind == 0 || ctx->ntt_kind == 5) && ntt_wave_plan(ctx, log_n, false, &wr1, &wr2) &&
                          ((ctx->ntt_single_log >= 11 && ctx->ntt_radix_log >= 10) || ctx->ntt_kind == 5);
     if (fan && !(wave_ok && !wr2 && wave_fan_ok(*fan, N))) {  // no single launch for this size / kernel choice: one call per copy
         for (unsigned f = 0; f < fan->count; f++)

@@ -179,7 +179,7 @@ static bool bls_from_le32(const uint8_t* b, BlsFr* out) {
 
 static bool bls_size_ok(const plonk_ctx* ctx, unsigned log_n) {
     unsigned r1, r2;
-    return ntt_wave_plan(ctx, log_n, &r1, &r2);
+    return ntt_wave_plan(ctx, log_n, false, &r1, &r2);
 }
 
 // poly.py:156-163 over this field: n Lagrange values -> coefficients (ifft) -> c_i offset^i, zero-padded to 4n -> forward transform:
@@ -220,7 +220,7 @@ int plonk_bls_fr_ntt(plonk_ctx* ctx, const void* d_in, void* d_out, unsigned log
     PLONK_ENTER(ctx);
     if (!batch) return PLONK_OK;
     unsigned r1, r2;
-    PLONK_REQUIRE(ntt_wave_plan(ctx, log_n, &r1, &r2), PLONK_ERR_ARG,
+    PLONK_REQUIRE(ntt_wave_plan(ctx, log_n, false, &r1, &r2), PLONK_ERR_ARG,
                   "the BLS12-381 transform covers 2^8 .. 2^26 points (the wave kernels' sizes), not 2^%u", log_n);
     const size_t N = (size_t)1 << log_n;
     return wave_run<BlsFrField>(ctx, (const BlsFr*)d_in, (BlsFr*)d_out, log_n, inverse != 0, batch, N, N, N, nullptr, nullptr, inverse != 0);

@@ -27,6 +27,13 @@ template <unsigned N, class F> PLONK_DEV void wave_for(F f) {
 //   E = 8: N = 2^9, 2^11, 2^13   radix 8, L x radix 4, radix 8, radix 8     (3 waves per SIMD; 4 at 1024 threads)
 //   E = 4: N = 2^8, 2^10, 2^12   radix 4, L x radix 4, 3 x radix 4          (half the registers: 4+ waves per SIMD, and
 //                                 twice the workgroups for a lone transform — round 3)
+//   E = 2: N = 2^7, 2^9          radix 2 throughout (round 4): the LATENCY kernels.  A lone small transform is bound by the
+//                                 dependent instruction chain of ONE wave (a 2^8 transform at E = 4 is ~5 500 instructions per
+//                                 lane: 12-14 us by rocprofv3, with 3 of every 4 SIMDs idle at 2^16); two elements per lane cut
+//                                 the chain to ~2 300 and put four times the waves on the chip.  Same multiplication count
+//                                 per element (radix 2, 4, 8 all pay half a twiddle per element and level), ~10 % more
+//                                 additions / range reductions.  They serve 2^14 = 2^7 x 2^7, 2^15 = 2^7 x 2^8 (sizes no pair
+//                                 of the larger kernels reaches) and lone 2^16 .. 2^18 (2^7 x 2^9, 2^8 x 2^9, 2^9 x 2^9).
 // Decimation in frequency by digits.  The bits of the element index live in three places — the register index (LOG_E
 // bits), the lane (6 bits) and, for L > 0, the wave (2 L bits).  A stage works on the digit currently held in the
 // register index; between stages that digit is swapped with
@@ -126,6 +133,12 @@ template <unsigned E, unsigned RB, unsigned MASK, class P> PLONK_DEV void wavel_
     });
 }
 
+// elements per thread (log2) of the kernel that serves a 2^log_r transform: 2^7 only exists with two; odd sizes take eight,
+// even sizes four; `latency` picks the two-element form of 2^9 (a lone small transform: see the top of this file)
+PLONK_HD constexpr unsigned wavel_log_e(unsigned log_r, bool latency = false) {
+    return (log_r == 7 || (latency && log_r == 9)) ? 1u : ((log_r & 1u) ? 3u : 2u);
+}
+
 // ---- twiddle tables in the order the kernel consumes them ("program order") ----------------------------------------------
 // Stage s of a wave kernel multiplies register f (f = 1 .. count) by w_R^(low f mult), low < nb: the table holds, stage after
 // stage and f after f, one BLOCK of nb Shoup pairs indexed by low — stored as five planes of nb x 16 bytes, so that a load
@@ -134,17 +147,21 @@ template <unsigned E, unsigned RB, unsigned MASK, class P> PLONK_DEV void wavel_
 // use a fifth to a fifteenth of each: at 2^10 .. 2^13, whose tables do not fit the 32 KB L1, that was ~0.5 MB of L2 -> L1
 // traffic per 64 KB transform.  Entries: ~N per kernel size (1020 at 2^10, 2040 at 2^11).
 //   twiddled stages: A (digit in the registers at load), the L wave-bit stages, the lane stages except the last
-PLONK_HD constexpr unsigned wavel_tw_stages(unsigned log_e, unsigned nlds) { return 1 + nlds + (log_e == 3 ? 1 : 2); }
+//   E = 2: every stage but the last is twiddled, stage s on the 2^(6 + 2L - s) values of the thread bits below the one it
+//   will trade next: blocks of NT, NT / 2, .., 2 entries, factor w^(low 2^s)
+PLONK_HD constexpr unsigned wavel_tw_stages(unsigned log_e, unsigned nlds) { return log_e == 1 ? 6 + 2 * nlds : 1 + nlds + (log_e == 3 ? 1 : 2); }
 PLONK_HD constexpr unsigned wavel_tw_nb(unsigned log_e, unsigned nlds, unsigned s) {  // distinct values of `low` in stage s
+    if (log_e == 1) return 1u << (6 + 2 * nlds - s);
     if (s == 0) return 64u << (2 * nlds);
     if (s <= nlds) return 1u << (6 + 2 * (nlds - s));
     return log_e == 3 ? 8u : (s == nlds + 1 ? 16u : 4u);
 }
 PLONK_HD constexpr unsigned wavel_tw_count(unsigned log_e, unsigned nlds, unsigned s) {  // factors f = 1 .. count
-    return (s >= 1 && s <= nlds) ? 3u : (1u << log_e) - 1;
+    return log_e == 1 ? 1u : ((s >= 1 && s <= nlds) ? 3u : (1u << log_e) - 1);
 }
 PLONK_HD constexpr unsigned wavel_tw_mult(unsigned log_e, unsigned nlds, unsigned s) {  // N / S of stage s
     const unsigned log_n = log_e + 6 + 2 * nlds;
+    if (log_e == 1) return 1u << s;
     if (s == 0) return 1;
     if (s <= nlds) return 1u << (log_n - (6 + 2 * (nlds - s) + 2));
     return log_e == 3 ? 1u << (log_n - 6) : (s == nlds + 1 ? 1u << (log_n - 6) : 1u << (log_n - 4));
@@ -186,11 +203,12 @@ PLONK_DEV void wavel_twiddle(FpL<P> (&x)[E], unsigned low, const int32_t* roots,
     constexpr unsigned LOG_N = LOG_E + 6 + 2 * NLDS, NB = wavel_tw_nb(LOG_E, NLDS, STAGE);
     static_assert(COUNT - 1 == wavel_tw_count(LOG_E, NLDS, STAGE), "twiddle layout");
     const int32_t* blocks = roots + (size_t)wavel_tw_offset(LOG_E, NLDS, STAGE) * NTT_SHOUP_STRIDE;
+    constexpr bool TIGHT_MUL = LOG_E == 3 && WAVEL_TIGHT_LOG_N(LOG_N);
     x[BASE] = fpl_reduce_small(x[BASE], jm);
     wave_for<COUNT - 1>([&](auto F) {
         constexpr unsigned f = decltype(F)::value + 1;
-        x[BASE + f] = fpl_mul_shoup<P, WAVEL_TIGHT_LOG_N(LOG_N)>(x[BASE + f], wavel_ld_root_planar<P>(blocks + (f - 1) * NB * NTT_SHOUP_STRIDE, NB, low));
-        if constexpr (WAVEL_TIGHT_LOG_N(LOG_N)) PLONK_SCHED_FENCE();  // 128 VGPRs: keeps the scheduler from holding several twiddles in flight
+        x[BASE + f] = fpl_mul_shoup<P, TIGHT_MUL>(x[BASE + f], wavel_ld_root_planar<P>(blocks + (f - 1) * NB * NTT_SHOUP_STRIDE, NB, low));
+        if constexpr (TIGHT_MUL) PLONK_SCHED_FENCE();  // 128 VGPRs: keeps the scheduler from holding several twiddles in flight
     });
 }
 // inputs N-form, |value| < 2.8.  Outputs: x0 in [0, 2^31) (for fpl_reduce_small), x1..x3 multiplicands; |value| < 11.2
@@ -224,10 +242,17 @@ template <class P> PLONK_DEV void dft8l(FpL<P> (&x)[8], const FpLS<P>& w1, const
     x[3] = fpl_add(f0, f1);                                               // (-2^29, 2^30)
     x[7] = fpl_sub(f0, f1);                                               // (-2^30, 2^29)
 }
-// the digit DFT on the register index: radix 8 (E = 8) or radix 4 (E = 4)
+// inputs N-form, |value| < 2.8.  Outputs: x0 in [0, 2^30) (for fpl_reduce_small), x1 in (-2^29, 2^29) (a multiplicand); |value| < 5.6
+template <class P> PLONK_DEV void dft2l(FpL<P>& x0, FpL<P>& x1) {
+    const FpL<P> a = fpl_add(x0, x1), d = fpl_sub(x0, x1);
+    x0 = a;
+    x1 = d;
+}
+// the digit DFT on the register index: radix 8 (E = 8), radix 4 (E = 4) or radix 2 (E = 2)
 template <unsigned E, class P> PLONK_DEV void wavel_dft(FpL<P> (&x)[E], const FpLS<P>& w1, const FpLS<P>& w2, const FpLS<P>& w3) {
     if constexpr (E == 8) dft8l(x, w1, w2, w3);
-    else dft4l(x[0], x[1], x[2], x[3], w2);
+    else if constexpr (E == 4) dft4l(x[0], x[1], x[2], x[3], w2);
+    else dft2l(x[0], x[1]);
 }
 template <class P> PLONK_DEV void wavel_lds_st(u32x4* lo, u32x4* hi, uint32_t* top, unsigned i, const FpL<P>& a) {
     lo[i] = u32x4{(uint32_t)a.l[0], (uint32_t)a.l[1], (uint32_t)a.l[2], (uint32_t)a.l[3]};
@@ -280,7 +305,7 @@ template <unsigned LOG_E, unsigned NLDS> struct WavelCfg {
 #else
     static constexpr bool TIGHT = NLDS == 2 || LOG_E == 3;
 #endif
-    static constexpr unsigned WAVES = (NLDS == 2 || LOG_E == 2) ? 4 : (TIGHT ? 4 : 3);
+    static constexpr unsigned WAVES = (NLDS == 2 || LOG_E <= 2) ? 4 : (TIGHT ? 4 : 3);
 };
 
 // One transform (or one column / row of a two-pass transform) by one workgroup: the body of both kernels below.
@@ -289,9 +314,10 @@ template <unsigned LOG_E, unsigned NLDS> struct WavelCfg {
 template <class P, unsigned LOG_E, unsigned NLDS, bool FULL = false>
 PLONK_DEV void wavel_transform(const NttWaveT<P>& p, unsigned char* smem) {
     constexpr unsigned E = 1u << LOG_E, LOG_N = LOG_E + 6 + 2 * NLDS, NT = 64u << (2 * NLDS), LOG_T = 6 + 2 * NLDS;
-    u32x4* l_lo = reinterpret_cast<u32x4*>(smem);  // 4 * NT elements as two 16-byte planes and one 4-byte plane
-    u32x4* l_hi = l_lo + 4 * NT;
-    uint32_t* l_top = reinterpret_cast<uint32_t*>(l_hi + 4 * NT);
+    constexpr unsigned LSLOTS = E >= 4 ? 4 : 1;    // elements per thread and exchange round
+    u32x4* l_lo = reinterpret_cast<u32x4*>(smem);  // LSLOTS * NT elements as two 16-byte planes and one 4-byte plane
+    u32x4* l_hi = l_lo + LSLOTS * NT;
+    uint32_t* l_top = reinterpret_cast<uint32_t*>(l_hi + LSLOTS * NT);
     const unsigned tid0 = threadIdx.x;
     const unsigned bidx = p.mode ? blockIdx.y : blockIdx.x, fan = p.mode ? 0u : (blockIdx.y << LOG_N);  // f N
     const Fp<P>* in = p.in + (size_t)bidx * p.in_bstride + ((p.fan & NTT_FAN_IN) ? fan : 0u);
@@ -323,61 +349,96 @@ PLONK_DEV void wavel_transform(const NttWaveT<P>& p, unsigned char* smem) {
             if (g < p.in_len) x[j] = fpl_mul(x[j], fpl_from_fp(fp_load(wavel_at(in_scale, g))));
         });
     }
-    // stage A: digit = the top LOG_E index bits, low = tid0
-    wavel_dft<E>(x, w8_1, w8_2, w8_3);
-    wavel_twiddle<LOG_E, NLDS, 0, 0, E>(x, tid0, p.roots, jm);
-    // L radix-4 stages on the wave bits: swap register bits (1, 0) with thread bits (tb + 1, tb)
-    wave_for<NLDS>([&](auto S) {
-        constexpr unsigned s = decltype(S)::value;
-        constexpr unsigned tb = 6 + 2 * (NLDS - 1 - s);
-        const unsigned tid = wavel_tid<WavelCfg<LOG_E, NLDS>::TIGHT>();
-        const unsigned mine = (tid >> tb) & 3u, rest = tid & ~(3u << tb);
-        wave_for<E / 4>([&](auto R2) {
-            constexpr unsigned r2 = decltype(R2)::value;
-            wave_for<4>([&](auto Q) { wavel_lds_st(l_lo, l_hi, l_top, decltype(Q)::value * NT + tid, x[4 * r2 + decltype(Q)::value]); });
-            __syncthreads();
-            wave_for<4>([&](auto Q) { x[4 * r2 + decltype(Q)::value] = wavel_lds_ld<P>(l_lo, l_hi, l_top, mine * NT + (rest | (decltype(Q)::value << tb))); });
-            __syncthreads();
+    if constexpr (E == 2) {
+        // LOG_T + 1 radix-2 stages.  Stage s works on index bit LOG_T - s (in the register index), multiplies its odd output by
+        // w^(low 2^s), low = the thread bits below, and then trades the register bit for thread bit LOG_T - 1 - s: through LDS
+        // (one element per thread) while that is a wave bit, across lanes for the last six
+        wave_for<LOG_T>([&](auto S) {
+            constexpr unsigned s = decltype(S)::value, tb = LOG_T - 1 - s;
+            dft2l(x[0], x[1]);
+            const unsigned tid = s ? wavel_tid<false>() : tid0;
+            wavel_twiddle<LOG_E, NLDS, s, 0, 2>(x, tid & ((2u << tb) - 1u), p.roots, jm);
+            if constexpr (tb >= 6) {
+                const bool hi = (tid >> tb) & 1u;  // keeps x[1], gives x[0]; the others keep x[0], give x[1]
+                FpL<P> give;
+                wave_for<9>([&](auto W) { give.l[decltype(W)::value] = hi ? x[0].l[decltype(W)::value] : x[1].l[decltype(W)::value]; });
+                wavel_lds_st(l_lo, l_hi, l_top, tid, give);
+                __syncthreads();
+                const FpL<P> got = wavel_lds_ld<P>(l_lo, l_hi, l_top, tid ^ (1u << tb));
+                __syncthreads();
+                wave_for<9>([&](auto W) {
+                    constexpr unsigned i = decltype(W)::value;
+                    x[0].l[i] = hi ? got.l[i] : x[0].l[i];
+                    x[1].l[i] = hi ? x[1].l[i] : got.l[i];
+                });
+            } else {
+                wavel_swap_bit<E, 0, (1u << tb)>(x, tid & 63u);
+            }
         });
-        const unsigned low = tid & ((1u << tb) - 1);
-        wave_for<E / 4>([&](auto R2) {
-            constexpr unsigned r2 = decltype(R2)::value;
-            dft4l(x[4 * r2], x[4 * r2 + 1], x[4 * r2 + 2], x[4 * r2 + 3], w8_2);
-            wavel_twiddle<LOG_E, NLDS, 1 + s, 4 * r2, 4>(x, low, p.roots, jm);
+        dft2l(x[0], x[1]);  // [0, 2^30), (-2^29, 2^29): within the optional multiplications' operand bound
+    }
+    if constexpr (E >= 4) {
+        // stage A: digit = the top LOG_E index bits, low = tid0
+        wavel_dft<E>(x, w8_1, w8_2, w8_3);
+        wavel_twiddle<LOG_E, NLDS, 0, 0, E>(x, tid0, p.roots, jm);
+        // L radix-4 stages on the wave bits: swap register bits (1, 0) with thread bits (tb + 1, tb)
+        wave_for<NLDS>([&](auto S) {
+            constexpr unsigned s = decltype(S)::value;
+            constexpr unsigned tb = 6 + 2 * (NLDS - 1 - s);
+            const unsigned tid = wavel_tid<WavelCfg<LOG_E, NLDS>::TIGHT>();
+            const unsigned mine = (tid >> tb) & 3u, rest = tid & ~(3u << tb);
+            wave_for<E / 4>([&](auto R2) {
+                constexpr unsigned r2 = decltype(R2)::value;
+                wave_for<4>([&](auto Q) { wavel_lds_st(l_lo, l_hi, l_top, decltype(Q)::value * NT + tid, x[4 * r2 + decltype(Q)::value]); });
+                __syncthreads();
+                wave_for<4>([&](auto Q) { x[4 * r2 + decltype(Q)::value] = wavel_lds_ld<P>(l_lo, l_hi, l_top, mine * NT + (rest | (decltype(Q)::value << tb))); });
+                __syncthreads();
+            });
+            const unsigned low = tid & ((1u << tb) - 1);
+            wave_for<E / 4>([&](auto R2) {
+                constexpr unsigned r2 = decltype(R2)::value;
+                dft4l(x[4 * r2], x[4 * r2 + 1], x[4 * r2 + 2], x[4 * r2 + 3], w8_2);
+                wavel_twiddle<LOG_E, NLDS, 1 + s, 4 * r2, 4>(x, low, p.roots, jm);
+            });
         });
-    });
-    const unsigned lane = wavel_tid_after<WavelCfg<LOG_E, NLDS>::TIGHT>(x[E - 1].l[8]) & 63u;
-    if constexpr (E == 8) {
-        // stage on lane bits 5..3
-        wavel_swap_bit<E, 2, 32>(x, lane);
-        wavel_swap_bit<E, 1, 16>(x, lane);
-        wavel_swap_bit<E, 0, 8>(x, lane);
-        dft8l(x, w8_1, w8_2, w8_3);
-        wavel_twiddle<LOG_E, NLDS, NLDS + 1, 0, 8>(x, lane & 7u, p.roots, jm);
-        // stage on lane bits 2..0
-        wavel_swap_bit<E, 2, 4>(x, lane);
-        wavel_swap_bit<E, 1, 2>(x, lane);
-        wavel_swap_bit<E, 0, 1>(x, lane);
-        dft8l(x, w8_1, w8_2, w8_3);
-    } else {
-        // stages on lane bits (5, 4), (3, 2), (1, 0)
-        wavel_swap_bit<E, 1, 32>(x, lane);
-        wavel_swap_bit<E, 0, 16>(x, lane);
-        dft4l(x[0], x[1], x[2], x[3], w8_2);
-        wavel_twiddle<LOG_E, NLDS, NLDS + 1, 0, 4>(x, lane & 15u, p.roots, jm);
-        wavel_swap_bit<E, 1, 8>(x, lane);
-        wavel_swap_bit<E, 0, 4>(x, lane);
-        dft4l(x[0], x[1], x[2], x[3], w8_2);
-        wavel_twiddle<LOG_E, NLDS, NLDS + 2, 0, 4>(x, lane & 3u, p.roots, jm);
-        wavel_swap_bit<E, 1, 2>(x, lane);
-        wavel_swap_bit<E, 0, 1>(x, lane);
-        dft4l(x[0], x[1], x[2], x[3], w8_2);
-        x[0] = fpl_norm(x[0]);  // [0, 2^31) -> N-form: the optional multiplications below take limbs within (-2^30, 2^30]
+        const unsigned lane = wavel_tid_after<WavelCfg<LOG_E, NLDS>::TIGHT>(x[E - 1].l[8]) & 63u;
+        if constexpr (E == 8) {
+            // stage on lane bits 5..3
+            wavel_swap_bit<E, 2, 32>(x, lane);
+            wavel_swap_bit<E, 1, 16>(x, lane);
+            wavel_swap_bit<E, 0, 8>(x, lane);
+            dft8l(x, w8_1, w8_2, w8_3);
+            wavel_twiddle<LOG_E, NLDS, NLDS + 1, 0, 8>(x, lane & 7u, p.roots, jm);
+            // stage on lane bits 2..0
+            wavel_swap_bit<E, 2, 4>(x, lane);
+            wavel_swap_bit<E, 1, 2>(x, lane);
+            wavel_swap_bit<E, 0, 1>(x, lane);
+            dft8l(x, w8_1, w8_2, w8_3);
+        } else {
+            // stages on lane bits (5, 4), (3, 2), (1, 0)
+            wavel_swap_bit<E, 1, 32>(x, lane);
+            wavel_swap_bit<E, 0, 16>(x, lane);
+            dft4l(x[0], x[1], x[2], x[3], w8_2);
+            wavel_twiddle<LOG_E, NLDS, NLDS + 1, 0, 4>(x, lane & 15u, p.roots, jm);
+            wavel_swap_bit<E, 1, 8>(x, lane);
+            wavel_swap_bit<E, 0, 4>(x, lane);
+            dft4l(x[0], x[1], x[2], x[3], w8_2);
+            wavel_twiddle<LOG_E, NLDS, NLDS + 2, 0, 4>(x, lane & 3u, p.roots, jm);
+            wavel_swap_bit<E, 1, 2>(x, lane);
+            wavel_swap_bit<E, 0, 1>(x, lane);
+            dft4l(x[0], x[1], x[2], x[3], w8_2);
+            x[0] = fpl_norm(x[0]);  // [0, 2^31) -> N-form: the optional multiplications below take limbs within (-2^30, 2^30]
+        }
     }
     // frequency of register j: digits in processing order, first digit least significant
     unsigned k, shift;
     const unsigned tid = wavel_tid<WavelCfg<LOG_E, NLDS>::TIGHT>();
-    if constexpr (E == 8) {
+    const unsigned lane = tid & 63u;
+    if constexpr (E == 2) {
+        //   one bit per digit: the thread bits from the top down, then j
+        k = __brev(tid) >> (32 - LOG_T);
+        shift = LOG_T;
+    } else if constexpr (E == 8) {
         //   d_A = (lane bit 5) * 4 + thread bits (top pair);  then the remaining wave pairs;  (lane bits 4, 3);  (lane bits 2..0);  j
         //   (without wave stages the first digit is simply lane bits 5..3)
         shift = 3;
@@ -502,7 +563,10 @@ template <class P> __global__ void ntt_program_block_kernel(const Fp<P>* roots, 
 PLONK_HD unsigned wavel_freq(unsigned log_e, unsigned nlds, unsigned tid, unsigned* shift_out) {
     const unsigned lane = tid & 63u, log_t = 6 + 2 * nlds;
     unsigned k = 0, shift;
-    if (log_e == 3) {
+    if (log_e == 1) {
+        for (unsigned i = 0; i < log_t; i++) k |= ((tid >> (log_t - 1 - i)) & 1u) << i;
+        shift = log_t;
+    } else if (log_e == 3) {
         shift = 3;
         if (nlds) {
             k = (((lane >> 5) & 1u) << 2) | ((tid >> (6 + 2 * (nlds - 1))) & 3u);
@@ -527,10 +591,11 @@ PLONK_HD unsigned wavel_freq(unsigned log_e, unsigned nlds, unsigned tid, unsign
 
 // entry i = (c E + j) NT + tid of that table: the Shoup pair of scale * lo[e & 1023] * hi[e >> 10], e = c * k1(tid, j)
 template <class P>
-__global__ void ntt_interpass_table_kernel(const Fp<P>* lo, const Fp<P>* hi, Fp<P> scale, unsigned log_n, unsigned log_r1, int32_t* out, Ninv261 ninv) {
+__global__ void ntt_interpass_table_kernel(const Fp<P>* lo, const Fp<P>* hi, Fp<P> scale, unsigned log_n, unsigned log_r1, unsigned log_e, int32_t* out,
+                                           Ninv261 ninv) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >> log_n) return;
-    const unsigned log_e = (log_r1 & 1) ? 3 : 2, nlds = (log_r1 - 6 - log_e) / 2, log_t = 6 + 2 * nlds;
+    const unsigned nlds = (log_r1 - 6 - log_e) / 2, log_t = 6 + 2 * nlds;
     const unsigned tid = (unsigned)i & ((1u << log_t) - 1), j = (unsigned)(i >> log_t) & ((1u << log_e) - 1), c = (unsigned)(i >> log_r1);
     unsigned shift;
     const unsigned k1 = wavel_freq(log_e, nlds, tid, &shift) | (j << shift);
@@ -547,50 +612,4 @@ __global__ void ntt_interpass_table_kernel(const Fp<P>* lo, const Fp<P>* hi, Fp<
     int32_t* block = out + (i >> log_t << log_t) * NTT_SHOUP_STRIDE;  // the block of (c, j)
     for (unsigned pl = 0; pl < 5; pl++)
         for (unsigned q = 0; q < NTT_PLANE_WORDS; q++) block[((size_t)pl << log_t | tid) * NTT_PLANE_WORDS + q] = v[pl * NTT_PLANE_WORDS + q];
-}
-
-// ---- 2^14 and 2^15: N = 4 R2 ----------------------------------------------------------------------------------------------
-// Too small for two wave-kernel passes (both factors would have to reach 2^8), too large for one launch: the column pass is
-// four-point transforms, one thread per column on packed residues — x[i1 R2 + c] -> X[k1] w_N^(c k1) at out[k1 R2 + c],
-// coalesced both ways, with zero padding, the coset factors and 1/N where the wave kernels' column pass has them — and the
-// row pass is the 2^12 / 2^13 wave kernel in mode 2 with R1 = 4 (four workgroups per transform).
-template <class P> struct NttQuadT {
-    const Fp<P>* in;
-    Fp<P>* out;
-    size_t in_bstride, out_bstride;
-    unsigned in_len, log_n;
-    const Fp<P>* tw_lo;  // packed: w_N^e = tw_lo[e & 1023] * tw_hi[e >> 10]
-    const Fp<P>* tw_hi;
-    const Fp<P>* in_scale;
-    Fp<P> w4;     // the fourth root of unity of the transform direction
-    Fp<P> scale;  // 1/N (inverse transforms) ...
-    unsigned has_scale;
-};
-template <class P> __global__ void __launch_bounds__(256) ntt_quad_column_kernel(NttQuadT<P> p) {
-    const unsigned log_r2 = p.log_n - 2, c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >> log_r2) return;
-    const Fp<P>* in = p.in + (size_t)blockIdx.y * p.in_bstride;
-    Fp<P>* out = p.out + (size_t)blockIdx.y * p.out_bstride;
-    Fp<P> x[4];  // (compile-time indices only: wave_for, not loops — see the note at wave_for)
-    wave_for<4>([&](auto I) {
-        constexpr unsigned i = decltype(I)::value;
-        const unsigned g = (i << log_r2) + c;
-        x[i] = g < p.in_len ? fp_load(in + g) : fp_zero<P>();
-        if (p.in_scale && g < p.in_len) x[i] = fp_mul(x[i], fp_load(p.in_scale + g));
-    });
-    const Fp<P> a0 = fp_add(x[0], x[2]), a1 = fp_add(x[1], x[3]), d0 = fp_sub(x[0], x[2]), d1 = fp_mul(fp_sub(x[1], x[3]), p.w4);
-    x[0] = fp_add(a0, a1);
-    x[1] = fp_add(d0, d1);
-    x[2] = fp_sub(a0, a1);
-    x[3] = fp_sub(d0, d1);
-    wave_for<4>([&](auto K) {
-        constexpr unsigned k = decltype(K)::value;
-        const unsigned e = c * k;  // < N
-        if (e) {
-            x[k] = fp_mul(x[k], fp_load(p.tw_lo + (e & ((1u << NTT_TW_LO_LOG) - 1))));
-            x[k] = fp_mul(x[k], fp_load(p.tw_hi + (e >> NTT_TW_LO_LOG)));
-        }
-        if (p.has_scale) x[k] = fp_mul(x[k], p.scale);
-        fp_store(out + ((size_t)k << log_r2) + c, x[k]);
-    });
 }

@@ -14,7 +14,7 @@
 #include "ntt_wave.h"
 
 // the two-pass plan of a size (ntt.hip; field independent)
-bool ntt_wave_plan(const plonk_ctx* ctx, unsigned log_n, unsigned* log_r1, unsigned* log_r2);
+bool ntt_wave_plan(const plonk_ctx* ctx, unsigned log_n, bool latency, unsigned* log_r1, unsigned* log_r2);
 
 template <class P> static int wave_limb_table(plonk_ctx* ctx, std::map<unsigned, int32_t*>& cache, unsigned key, const Fp<P>* packed, size_t n,
                                               const int32_t** out) {
@@ -37,15 +37,15 @@ template <class P> static int wave_limb_table(plonk_ctx* ctx, std::map<unsigned,
 }
 
 // the twiddles of the wave kernel serving 2^log_n, in program order (built once per size and direction)
-template <class F> static int wave_program_table(plonk_ctx* ctx, unsigned log_n, bool inverse, const int32_t** out) {
+template <class F> static int wave_program_table(plonk_ctx* ctx, unsigned log_n, unsigned log_e, bool inverse, const int32_t** out) {
     typedef typename F::P P;
     WaveTables& T = F::tables(ctx);
-    const unsigned key = log_n | (inverse ? 256u : 0u);
+    const unsigned key = log_n | (inverse ? 256u : 0u) | (log_e << 12);  // (2^9 exists with eight and with two elements per thread)
     auto it = T.prog.find(key);
     if (it == T.prog.end()) {
         const Fp<P>* packed;
         PLONK_TRY(F::packed_roots(ctx, log_n, inverse, &packed));
-        const unsigned log_e = (log_n & 1) ? 3 : 2, nlds = (log_n - 6 - log_e) / 2, stages = wavel_tw_stages(log_e, nlds);
+        const unsigned nlds = (log_n - 6 - log_e) / 2, stages = wavel_tw_stages(log_e, nlds);
         const size_t entries = wavel_tw_offset(log_e, nlds, stages);
         void* d = nullptr;
         if (hipMalloc(&d, entries * NTT_SHOUP_STRIDE * sizeof(int32_t)) != hipSuccess) {
@@ -99,12 +99,13 @@ template <class F> static int wave_lo_hi(plonk_ctx* ctx, unsigned log_n, bool in
 
 // the column pass's inter-pass twiddles as one table in usage order (ntt_interpass_table_kernel), when the context's
 // table budget allows its N * 80 bytes; *out = null otherwise (the caller falls back to the two small tables)
-template <class F> static int wave_interpass_table(plonk_ctx* ctx, unsigned log_n, unsigned log_r1, bool inverse, bool scaled, const int32_t** out) {
+template <class F>
+static int wave_interpass_table(plonk_ctx* ctx, unsigned log_n, unsigned log_r1, unsigned log_e1, bool inverse, bool scaled, const int32_t** out) {
     typedef typename F::P P;
     WaveTables& T = F::tables(ctx);
     *out = nullptr;
-    if (!ctx->ntt_table_budget || (log_r1 & 1)) return PLONK_OK;  // switched off (tables built earlier stay allocated, unused); E = 4 column kernels only
-    const unsigned key = log_n | (inverse ? 256u : 0u) | (scaled ? 512u : 0u) | (log_r1 << 12);
+    if (!ctx->ntt_table_budget || log_e1 == 3) return PLONK_OK;  // switched off (tables built earlier stay allocated, unused); not for the E = 8 column kernels
+    const unsigned key = log_n | (inverse ? 256u : 0u) | (scaled ? 512u : 0u) | (log_r1 << 12) | (log_e1 << 20);
     auto it = T.interpass.find(key);
     if (it == T.interpass.end()) {
         const size_t bytes = ((size_t)NTT_SHOUP_STRIDE * sizeof(int32_t)) << log_n;
@@ -122,7 +123,7 @@ template <class F> static int wave_interpass_table(plonk_ctx* ctx, unsigned log_
         fpl_ninv261<P>(ninv.l);
         const Fp<P> scale = scaled ? fp_inv(F::from_u64((uint64_t)1 << log_n)) : fp_one<P>();
         PLONK_LAUNCH(ntt_interpass_table_kernel<P>, dim3((unsigned)((((size_t)1 << log_n) + 255) / 256)), dim3(256), 0, ctx->stream, plo, phi, scale, log_n,
-                     log_r1, (int32_t*)d, ninv);
+                     log_r1, log_e1, (int32_t*)d, ninv);
         PLONK_CHECK_HIP(hipGetLastError());
         it = T.interpass.emplace(key, (int32_t*)d).first;
     }
@@ -165,15 +166,15 @@ template <class F> static void wave_params_init(NttWaveT<typename F::P>* p, unsi
 template <class F, unsigned LOG_E, unsigned NLDS> static int wave_launch_as(plonk_ctx* ctx, const NttWaveT<typename F::P>& q, unsigned grid_x, unsigned grid_y) {
     typedef typename F::P P;
     constexpr unsigned nt = 64u << (2 * NLDS);
-    const size_t shmem = NLDS ? (size_t)4 * nt * 36 : 0;  // one round of the wave-bit exchange: 4 elements of 9 words per thread
+    const size_t shmem = NLDS ? (size_t)(LOG_E >= 2 ? 4 : 1) * nt * 36 : 0;  // one round of the wave-bit exchange: 4 elements (E = 2: one) of 9 words per thread
     WaveTables& T = F::tables(ctx);
-    if (NLDS == 2 && !T.attr_set[LOG_E - 2]) {  // 144 KiB: above the default limit; a per-device attribute, tracked per context
+    if (NLDS == 2 && LOG_E >= 2 && !T.attr_set[LOG_E >= 2 ? LOG_E - 2 : 0]) {  // 144 KiB: above the default limit; a per-device attribute, tracked per context
         PLONK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ntt_wavel_kernel<P, LOG_E, NLDS>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)(144 * 1024)));
         T.attr_set[LOG_E - 2] = true;
     }
     void (*kern)(NttWaveT<P>) = ntt_wavel_kernel<P, LOG_E, NLDS>;  // (a template-id's comma would split the macro's arguments)
-    if constexpr (LOG_E == 2) {
+    if constexpr (LOG_E <= 2) {
         if (q.tw_always == 2u) {  // column pass on the full inter-pass table
             kern = ntt_wavel_column_kernel<P, LOG_E, NLDS>;
             if (NLDS == 2 && !T.attr_set[2]) {
@@ -186,19 +187,21 @@ template <class F, unsigned LOG_E, unsigned NLDS> static int wave_launch_as(plon
     return PLONK_OK;
 }
 
-// log_r = 8, 10, 12: 4 elements per thread; 9, 11, 13: 8 elements per thread
-template <class F> static int wave_launch(plonk_ctx* ctx, const NttWaveT<typename F::P>& p, unsigned log_r, unsigned grid_x, unsigned grid_y) {
+// log_r = 8, 10, 12: 4 elements per thread; 9, 11, 13: 8 elements per thread; 7, and 9 in its latency form: 2
+template <class F> static int wave_launch(plonk_ctx* ctx, const NttWaveT<typename F::P>& p, unsigned log_r, unsigned log_e, unsigned grid_x, unsigned grid_y) {
     NttWaveT<typename F::P> q = p;
     if (!q.jm) PLONK_TRY(wave_jm<F>(ctx, &q.jm));  // (wave_run's cached plans carry it)
-    switch (log_r) {
-        case 8: return wave_launch_as<F, 2, 0>(ctx, q, grid_x, grid_y);
-        case 10: return wave_launch_as<F, 2, 1>(ctx, q, grid_x, grid_y);
-        case 12: return wave_launch_as<F, 2, 2>(ctx, q, grid_x, grid_y);
-        case 9: return wave_launch_as<F, 3, 0>(ctx, q, grid_x, grid_y);
-        case 11: return wave_launch_as<F, 3, 1>(ctx, q, grid_x, grid_y);
-        case 13: return wave_launch_as<F, 3, 2>(ctx, q, grid_x, grid_y);
+    switch (log_r | (log_e << 8)) {
+        case 8 | (2 << 8): return wave_launch_as<F, 2, 0>(ctx, q, grid_x, grid_y);
+        case 10 | (2 << 8): return wave_launch_as<F, 2, 1>(ctx, q, grid_x, grid_y);
+        case 12 | (2 << 8): return wave_launch_as<F, 2, 2>(ctx, q, grid_x, grid_y);
+        case 9 | (3 << 8): return wave_launch_as<F, 3, 0>(ctx, q, grid_x, grid_y);
+        case 11 | (3 << 8): return wave_launch_as<F, 3, 1>(ctx, q, grid_x, grid_y);
+        case 13 | (3 << 8): return wave_launch_as<F, 3, 2>(ctx, q, grid_x, grid_y);
+        case 7 | (1 << 8): return wave_launch_as<F, 1, 0>(ctx, q, grid_x, grid_y);
+        case 9 | (1 << 8): return wave_launch_as<F, 1, 1>(ctx, q, grid_x, grid_y);
     }
-    plonk_set_error("no wave kernel for a 2^%u-point transform", log_r);
+    plonk_set_error("no wave kernel for a 2^%u-point transform with 2^%u elements per thread", log_r, log_e);
     return PLONK_ERR_ARG;
 }
 
@@ -209,11 +212,12 @@ template <class F> static int wave_launch(plonk_ctx* ctx, const NttWaveT<typenam
 // call, and a lone 2^16 transform is ~10 us of device time (0.031 ms measured).
 template <class P> struct WavePlan {
     unsigned log_r1 = 0, log_r2 = 0;
+    unsigned log_e1 = 0, log_e2 = 0;  // elements per thread (log2) of the kernels of the two passes (log_e1 alone for a single pass)
     NttWaveT<P> a, c;  // single pass: a;  two passes: a = columns, c = rows
-    NttQuadT<P> q;     // 2^14 / 2^15: the four-point column pass
 };
 
-template <class F> static int wave_plan_get(plonk_ctx* ctx, unsigned log_n, bool inverse, bool scale_by_n_inv, bool want_full, const WavePlan<typename F::P>** out) {
+template <class F>
+static int wave_plan_get(plonk_ctx* ctx, unsigned log_n, bool inverse, bool scale_by_n_inv, bool want_full, bool latency, const WavePlan<typename F::P>** out) {
     typedef typename F::P P;
     typedef Fp<P> E;
     WaveTables& T = F::tables(ctx);
@@ -221,7 +225,7 @@ template <class F> static int wave_plan_get(plonk_ctx* ctx, unsigned log_n, bool
         T.plans.clear();
         T.plan_epoch = ctx->ntt_cfg_epoch;
     }
-    const unsigned key = log_n | (inverse ? 256u : 0u) | (scale_by_n_inv ? 512u : 0u) | (want_full ? 1024u : 0u);
+    const unsigned key = log_n | (inverse ? 256u : 0u) | (scale_by_n_inv ? 512u : 0u) | (want_full ? 1024u : 0u) | (latency ? 2048u : 0u);
     auto it = T.plans.find(key);
     if (it != T.plans.end()) {
         *out = static_cast<const WavePlan<P>*>(it->second.get());
@@ -230,40 +234,25 @@ template <class F> static int wave_plan_get(plonk_ctx* ctx, unsigned log_n, bool
     std::shared_ptr<WavePlan<P>> plan(new WavePlan<P>());
     const size_t N = (size_t)1 << log_n;
     unsigned log_r1 = 0, log_r2 = 0;
-    PLONK_REQUIRE(ntt_wave_plan(ctx, log_n, &log_r1, &log_r2), PLONK_ERR_ARG, "no wave-kernel plan for 2^%u points", log_n);
+    PLONK_REQUIRE(ntt_wave_plan(ctx, log_n, latency, &log_r1, &log_r2), PLONK_ERR_ARG, "no wave-kernel plan for 2^%u points", log_n);
     plan->log_r1 = log_r1;
     plan->log_r2 = log_r2;
+    const unsigned log_e1 = plan->log_e1 = wavel_log_e(log_r1, latency), log_e2 = plan->log_e2 = log_r2 ? wavel_log_e(log_r2, latency) : 0;
     NttWaveT<P> p;
     wave_params_init<F>(&p, log_n, inverse);
     PLONK_TRY(wave_jm<F>(ctx, &p.jm));
     E n_inv = fp_zero<P>();
     if (scale_by_n_inv) n_inv = fp_inv(F::from_u64((uint64_t)N));
     if (!log_r2) {
-        PLONK_TRY(wave_program_table<F>(ctx, log_n, inverse, &p.roots));
+        PLONK_TRY(wave_program_table<F>(ctx, log_n, log_e1, inverse, &p.roots));
         p.out_scalar = n_inv;
         p.has_out_scalar = scale_by_n_inv;
         plan->a = p;
-    } else if (log_r1 == 2) {  // 2^14, 2^15: four-point column transforms on packed residues (ntt_quad_column_kernel), then the wave kernel's row pass
-        NttQuadT<P>& a = plan->q;
-        memset(&a, 0, sizeof a);
-        a.out_bstride = N;
-        a.log_n = log_n;
-        PLONK_TRY(F::packed_lo_hi(ctx, log_n, inverse, &a.tw_lo, &a.tw_hi));
-        a.w4 = F::root_of_unity(2, inverse);
-        a.scale = n_inv;
-        a.has_scale = scale_by_n_inv ? 1u : 0u;
-        NttWaveT<P> c = p;
-        c.mode = 2;
-        c.log_other = log_r1;
-        c.in_bstride = N;
-        c.in_len = (unsigned)N;
-        PLONK_TRY(wave_program_table<F>(ctx, log_r2, inverse, &c.roots));
-        plan->c = c;
     } else {
         // (measured, profiles/r03_m_ntt_sweep.jsonl: the table wins 4-10 % wherever the column pass fills the chip; a lone 2^18 —
         // one workgroup per CU, every load latency exposed — is 5 % faster on the small, L2-resident tables)
         const int32_t* full = nullptr;
-        if (want_full) PLONK_TRY(wave_interpass_table<F>(ctx, log_n, log_r1, inverse, scale_by_n_inv, &full));
+        if (want_full) PLONK_TRY(wave_interpass_table<F>(ctx, log_n, log_r1, log_e1, inverse, scale_by_n_inv, &full));
         if (full) {
             p.tw_lo = full;
             p.tw_always = 2u;
@@ -275,7 +264,7 @@ template <class F> static int wave_plan_get(plonk_ctx* ctx, unsigned log_n, bool
         a.mode = 1;
         a.log_other = log_r2;
         a.out_bstride = N;
-        PLONK_TRY(wave_program_table<F>(ctx, log_r1, inverse, &a.roots));
+        PLONK_TRY(wave_program_table<F>(ctx, log_r1, log_e1, inverse, &a.roots));
         NttWaveT<P> c = p;
         c.mode = 2;
         c.log_other = log_r1;
@@ -283,7 +272,7 @@ template <class F> static int wave_plan_get(plonk_ctx* ctx, unsigned log_n, bool
         c.in_len = (unsigned)N;
         c.has_out_scalar = 0;  // 1/N went into the column pass's inter-pass twiddles (tw_hi)
         c.tw_always = 0;
-        PLONK_TRY(wave_program_table<F>(ctx, log_r2, inverse, &c.roots));
+        PLONK_TRY(wave_program_table<F>(ctx, log_r2, log_e2, inverse, &c.roots));
         plan->a = a;
         plan->c = c;
     }
@@ -307,9 +296,10 @@ static int wave_run(plonk_ctx* ctx, const Fp<typename F::P>* in, Fp<typename F::
     typedef Fp<P> E;
     const size_t N = (size_t)1 << log_n;
     PLONK_REQUIRE(!fan || (log_n <= 13 && wave_fan_ok(*fan, N)), PLONK_ERR_ARG, "a fanned transform needs a single-pass size (2^8 .. 2^13) and strides of 0 or N");
-    const bool want_full = log_n >= 16 && (log_n == 16 || ((size_t)batch << log_n) >= ((size_t)1 << 19));
+    const bool want_full = log_n >= 14 && (log_n <= 16 || ((size_t)batch << log_n) >= ((size_t)1 << 19));
+    const bool latency = ((size_t)batch << log_n) <= ((size_t)1 << 18);  // a small job: one wave's instruction chain is what it waits for
     const WavePlan<P>* plan;
-    PLONK_TRY(wave_plan_get<F>(ctx, log_n, inverse, scale_by_n_inv, want_full, &plan));
+    PLONK_TRY(wave_plan_get<F>(ctx, log_n, inverse, scale_by_n_inv, want_full, latency, &plan));
     const unsigned log_r1 = plan->log_r1, log_r2 = plan->log_r2;
     const unsigned in_len32 = (unsigned)(in_len < N ? in_len : N);
     if (!log_r2) {
@@ -327,7 +317,7 @@ static int wave_run(plonk_ctx* ctx, const Fp<typename F::P>* in, Fp<typename F::
             const size_t nb = batch - b0 < ((size_t)1 << 30) ? batch - b0 : (size_t)1 << 30;
             p.in = in + b0 * in_bstride;
             p.out = out + b0 * out_bstride;
-            PLONK_TRY(wave_launch<F>(ctx, p, log_n, (unsigned)nb, fan ? fan->count : 1));
+            PLONK_TRY(wave_launch<F>(ctx, p, log_n, plan->log_e1, (unsigned)nb, fan ? fan->count : 1));
         }
         PLONK_TRY(prof_end(ctx));
         PLONK_CHECK_HIP(hipGetLastError());  // a refused launch (thread-local, no synchronisation)
@@ -343,29 +333,17 @@ static int wave_run(plonk_ctx* ctx, const Fp<typename F::P>* in, Fp<typename F::
     c.out = out;
     c.out_bstride = out_bstride;
     c.out_scale = out_scale;
-    if (log_r1 == 2) {
-        NttQuadT<P> a = plan->q;
-        a.in = in;
-        a.out = tmp;
-        a.in_bstride = in_bstride;
-        a.in_len = in_len32;
-        a.in_scale = in_scale;
-        PLONK_TRY(prof_begin(ctx, "ntt_pass_columns", 32.0 * (double)N * (double)batch));
-        PLONK_LAUNCH(ntt_quad_column_kernel<P>, dim3((1u << log_r2) / 256, (unsigned)batch), dim3(256), 0, ctx->stream, a);
-        PLONK_TRY(prof_end(ctx));
-    } else {
-        NttWaveT<P> a = plan->a;
-        a.in = in;
-        a.out = tmp;
-        a.in_bstride = in_bstride;
-        a.in_len = in_len32;
-        a.in_scale = in_scale;
-        PLONK_TRY(prof_begin(ctx, "ntt_pass_columns", 32.0 * (double)N * (double)batch));
-        PLONK_TRY(wave_launch<F>(ctx, a, log_r1, 1u << log_r2, (unsigned)batch));
-        PLONK_TRY(prof_end(ctx));
-    }
+    NttWaveT<P> a = plan->a;
+    a.in = in;
+    a.out = tmp;
+    a.in_bstride = in_bstride;
+    a.in_len = in_len32;
+    a.in_scale = in_scale;
+    PLONK_TRY(prof_begin(ctx, "ntt_pass_columns", 32.0 * (double)N * (double)batch));
+    PLONK_TRY(wave_launch<F>(ctx, a, log_r1, plan->log_e1, 1u << log_r2, (unsigned)batch));
+    PLONK_TRY(prof_end(ctx));
     PLONK_TRY(prof_begin(ctx, "ntt_pass_rows", 32.0 * (double)N * (double)batch));
-    PLONK_TRY(wave_launch<F>(ctx, c, log_r2, 1u << log_r1, (unsigned)batch));
+    PLONK_TRY(wave_launch<F>(ctx, c, log_r2, plan->log_e2, 1u << log_r1, (unsigned)batch));
     PLONK_TRY(prof_end(ctx));
     PLONK_CHECK_HIP(hipGetLastError());
     return PLONK_OK;

@@ -167,7 +167,7 @@ int ntt_run(plonk_ctx*, const Fr* in, Fr* out, unsigned log_n, bool inverse, siz
             size_t in_bstride, size_t out_bstride, const Fr* in_scale, const Fr* out_scale, bool scale_by_n_inv, const NttFan* fan = nullptr);
 int ntt_get_roots(plonk_ctx*, unsigned log_n, bool inverse, const Fr** table_full);
 int ntt_dist_plan(unsigned log_n, unsigned log_w, unsigned* log_r1, unsigned* log_r2);
-bool ntt_wave_plan(const plonk_ctx* ctx /* null: the default splits */, unsigned log_n, unsigned* log_r1, unsigned* log_r2);
+bool ntt_wave_plan(const plonk_ctx* ctx /* null: the default splits */, unsigned log_n, bool latency, unsigned* log_r1, unsigned* log_r2);
 int ntt_dist_columns(plonk_ctx*, const Fr* in, Fr* out, unsigned log_n, unsigned log_w, unsigned rank, bool inverse);
 int ntt_dist_rows(plonk_ctx*, const Fr* in, Fr* out, unsigned log_n, unsigned log_w, unsigned rank, bool inverse);
 // msm.hip
