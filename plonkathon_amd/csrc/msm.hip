@@ -27,8 +27,9 @@
 //                             ("piece") per bucket it touches: a bucket boundary costs a 128-byte store,
 //                             never a group operation, so the wave does not serialise on boundaries that
 //                             its lanes cross at different steps.  >= 80 % of this method's time.
-//   3. msm_bucket_reduce_kernel (two waves per MSM) lane l owns K/128 consecutive buckets: walking them top-down,
-//                             run += pieces of bucket k, tot += run; its share is tot + (first bucket - 1) * run;
+//   3. msm_bucket_reduce_kernel (one wave per MSM) lane l owns K/64 consecutive buckets: walking them top-down,
+//                             run += pieces of bucket k, tot += run; its share is tot + (first bucket - 1) * run, the
+//                             second term from a cross-lane suffix scan of the runs (round 4);
 //                             shares are summed across waves through LDS and then inside wave 0 by a cross-lane
 //                             butterfly (wave.h: DPP / ds_swizzle / v_permlane32_swap — the "wave-reduced bucket
 //                             sum"); lane 0 converts the result to the unique affine representative, canonical x||y.
@@ -342,13 +343,24 @@ __global__ void __launch_bounds__(256) msm_bucket_reduce_kernel(const uint32_t* 
         g1_add(tot, run);
         s_hi = s_lo;
     }
-    if (b_lo) {
-        G1Xyzz kr = g1_xyzz_identity();
-        for (int bit = (int)c - 1; bit >= 0; bit--) {
-            g1_dbl(kr);
-            if ((b_lo >> bit) & 1) g1_add(kr, run);
+    // The buckets of lane l weigh b_lo(l) = l pb more than its local walk gave them: sum_l l pb run_l = pb sum_{j >= 1} S_j with
+    // S_j = sum_{l >= j} run_l — a suffix scan over the lanes (six general additions inside a wave, by cross-lane moves; wave
+    // totals through LDS) and log2 pb doublings, where round 3 ran a c-bit double-and-add of (b_lo, run) per lane: c doublings
+    // plus, because a wave executes every branch one of its lanes takes, c - 1 additions.
+    {
+        const unsigned lane = tid & 63u, wave = tid >> 6, nw = nl >> 6;
+        G1Xyzz S = run;
+        g1_wave_suffix_scan(S, lane);
+        if (nw > 1) {
+            if (lane == 0) red[wave] = S;  // lane 0 holds its wave's total
+            __syncthreads();
+            for (unsigned w = nw - 1; w > wave; w--) g1_add(S, red[w]);
+            __syncthreads();
         }
-        g1_add(tot, kr);
+        if (tid) {
+            for (unsigned q = pb; q > 1; q >>= 1) g1_dbl(S);
+            g1_add(tot, S);
+        }
     }
     // shares: across waves through LDS, then the last six levels inside wave 0 by cross-lane moves (wave.h)
     red[tid] = tot;
@@ -962,8 +974,18 @@ int msm_run_device(plonk_ctx* ctx, plonk_srs* srs, const Fr* d_scalars, size_t n
     }
     const size_t max_entries = (size_t)W * n;
     while (G > 1 && (size_t)G * MSM_BLOCK * 4 > max_entries) G /= 2;  // tiny MSMs: one segment is plenty
-    // lanes per MSM in the bucket reduction: measured best of 64 / 128 / 256 (shorter chains vs more idle lanes)
-    const unsigned red_lanes = G >= 8 ? 256 : 128;
+    // lanes per MSM in the bucket reduction (shorter local walks vs more lanes paying the scan and the reduction).  Round 3's
+    // double-and-add weighting measured best at 128 (256 for the largest MSMs); with the suffix scan one wave per MSM does the
+    // least work per MSM.  PLONK_MSM_RED_LANES = 64 / 128 / 256 overrides (A/B runs).
+    unsigned red_lanes = G >= 8 ? 256 : 64;
+    {
+        static const unsigned forced = [] {
+            const char* e = getenv("PLONK_MSM_RED_LANES");
+            const unsigned v = e ? (unsigned)atoi(e) : 0u;
+            return (v == 64 || v == 128 || v == 256) ? v : 0u;
+        }();
+        if (forced) red_lanes = forced;
+    }
     const size_t entry_stride = ((max_entries + 3) & ~(size_t)3) + 4;
     const size_t piece_stride = (size_t)G * MSM_BLOCK + K;
     const size_t ent_bytes = (M * entry_stride * 4 + 255) & ~(size_t)255;

@@ -650,22 +650,19 @@ int ntt_run(plonk_ctx* ctx, const Fr* in, Fr* out, unsigned log_n, bool inverse,
     const size_t N = (size_t)1 << log_n;
     unsigned wr1, wr2;
     if (fan && fan->count <= 1) fan = nullptr;
-    const bool wave_ok = (ctx->ntt_kind == 0 || ctx->ntt_kind == 5) && ntt_wave_plan(ctx, log_n, false, &wr1, &wr2) &&
-                         ((ctx->ntt_single_log >= 11 && ctx->ntt_radix_log >= 10) || ctx->ntt_kind == 5);
-    if (fan && !(wave_ok && !wr2 && wave_fan_ok(*fan, N))) {  // no single launch for this size / kernel choice: one call per copy
+    const bool wave_ok = (ctx->ntt_kind == 0 || ctx->ntt_kind >= 5) && ntt_wave_plan(ctx, log_n, false, &wr1, &wr2) &&
+                         ((ctx->ntt_single_log >= 11 && ctx->ntt_radix_log >= 10) || ctx->ntt_kind >= 5);
+    if (fan && !(wave_ok && !wr2 && wave_fan_ok(*fan, N, out_scale != nullptr))) {  // no single launch for this size / kernel choice: one call per copy
         for (unsigned f = 0; f < fan->count; f++)
             PLONK_TRY(ntt_run(ctx, in + (size_t)f * fan->in_stride, out + (size_t)f * fan->out_stride, log_n, inverse, batch, in_len, in_bstride, out_bstride,
                               in_scale ? in_scale + (size_t)f * fan->scale_stride : nullptr, out_scale ? out_scale + (size_t)f * fan->scale_stride : nullptr,
                               scale_by_n_inv, nullptr));
         return PLONK_OK;
     }
-    // The wave kernels serve every size they cover (2^8 .. 2^13 in one launch, 2^16 .. 2^26 in two): measured on MI355X
-    // they beat the LDS kernels at every such size and batch (profiles/r02_e_ntt_kinds.json, r02_v_ntt_kinds.json,
-    // r03_*).  kind 4 = automatic choice among the LDS kernels only (A/B runs); a plonk_ntt_configure with small tiles
-    // (the multi-pass tests) also keeps a transform on the LDS kernels.
-    // 2^14 / 2^15 (four-point columns + four 1024-thread row workgroups per transform) stay on the LDS kernels unless forced: measured,
-    // a lone 2^15 takes 0.101 ms that way against 0.038, batches are level (profiles/r03_w_ntt_quad_sizes.jsonl) — the plan exists for
-    // the fields that have no LDS kernels (ntt_bls.hip)
+    // The wave kernels serve every size they cover (2^7 .. 2^13 in one launch, 2^14 .. 2^26 in two): measured on MI355X
+    // they beat the LDS kernels at every such size and batch (profiles/r02_e_ntt_kinds.json, r02_v_ntt_kinds.json, r03_*;
+    // 2^14 / 2^15 since round 4's two-element kernels).  kind 4 = automatic choice among the LDS kernels only (A/B runs); a
+    // plonk_ntt_configure with small tiles (the multi-pass tests) also keeps a transform on the LDS kernels.
     if (wave_ok) return ntt_run_wave(ctx, in, out, log_n, inverse, batch, in_len, in_bstride, out_bstride, in_scale, out_scale, scale_by_n_inv, fan);
     PLONK_REQUIRE(batch <= 65535, PLONK_ERR_ARG, "NTT batch %zu exceeds 65535", batch);
     unsigned radices[4];

@@ -481,7 +481,10 @@ PLONK_DEV void wavel_transform(const NttWaveT<P>& p, unsigned char* smem) {
         });
     }
     if (p.out_scale) {
-        const Fp<P>* out_scale = p.out_scale + ((!p.mode && (p.fan & NTT_FAN_SCALE)) ? (blockIdx.y << LOG_N) : 0u);
+        // (the 1024-thread 8-element kernel has no register left for a per-copy out_scale — 12 B of scratch per lane with it:
+        // wave_fan_ok sends such a call down the one-launch-per-copy route)
+        constexpr bool FAN_OUT_SCALE = !(LOG_E == 3 && NLDS == 2);
+        const Fp<P>* out_scale = p.out_scale + ((FAN_OUT_SCALE && !p.mode && (p.fan & NTT_FAN_SCALE)) ? (blockIdx.y << LOG_N) : 0u);
         wave_for<E>([&](auto J) {
             constexpr unsigned j = decltype(J)::value;
             x[j] = fpl_mul(x[j], fpl_from_fp(fp_load(wavel_at(out_scale, ((k | (j << shift)) << out_shift) + out_off))));

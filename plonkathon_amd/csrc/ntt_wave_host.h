@@ -283,8 +283,10 @@ static int wave_plan_get(plonk_ctx* ctx, unsigned log_n, bool inverse, bool scal
 }
 
 // the wave kernels take a fan whose strides are 0 or the transform size (ntt_wave.h: NttWaveT::fan)
-static inline bool wave_fan_ok(const NttFan& f, size_t N) {
-    return (f.in_stride == 0 || f.in_stride == N) && (f.out_stride == 0 || f.out_stride == N) && (f.scale_stride == 0 || f.scale_stride == N);
+// (and the 2^13 kernel takes no per-copy out_scale: ntt_wave.h, FAN_OUT_SCALE)
+static inline bool wave_fan_ok(const NttFan& f, size_t N, bool has_out_scale) {
+    return (f.in_stride == 0 || f.in_stride == N) && (f.out_stride == 0 || f.out_stride == N) && (f.scale_stride == 0 || f.scale_stride == N) &&
+           !(N == ((size_t)1 << 13) && has_out_scale && f.scale_stride);
 }
 
 // one transform per batch entry: a single launch for 2^8 .. 2^13, columns then rows through scratch slot 0 for 2^14 .. 2^26
@@ -295,9 +297,11 @@ static int wave_run(plonk_ctx* ctx, const Fp<typename F::P>* in, Fp<typename F::
     typedef typename F::P P;
     typedef Fp<P> E;
     const size_t N = (size_t)1 << log_n;
-    PLONK_REQUIRE(!fan || (log_n <= 13 && wave_fan_ok(*fan, N)), PLONK_ERR_ARG, "a fanned transform needs a single-pass size (2^8 .. 2^13) and strides of 0 or N");
+    PLONK_REQUIRE(!fan || (log_n <= 13 && wave_fan_ok(*fan, N, out_scale != nullptr)), PLONK_ERR_ARG,
+                  "a fanned transform needs a single-pass size (2^7 .. 2^13) and strides of 0 or N");
     const bool want_full = log_n >= 14 && (log_n <= 16 || ((size_t)batch << log_n) >= ((size_t)1 << 19));
-    const bool latency = ((size_t)batch << log_n) <= ((size_t)1 << 18);  // a small job: one wave's instruction chain is what it waits for
+    // a small job waits for one wave's instruction chain: the two-element forms (plonk_ntt_select_kernel 6 / 7: never / always — tests, A/B runs)
+    const bool latency = ctx->ntt_kind == 6 ? false : (ctx->ntt_kind == 7 || ((size_t)batch << log_n) <= ((size_t)1 << 18));
     const WavePlan<P>* plan;
     PLONK_TRY(wave_plan_get<F>(ctx, log_n, inverse, scale_by_n_inv, want_full, latency, &plan));
     const unsigned log_r1 = plan->log_r1, log_r2 = plan->log_r2;

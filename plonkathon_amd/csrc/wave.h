@@ -6,6 +6,7 @@
 //       MASK 4, 16  ds_swizzle, bit mode   (the LDS crossbar without memory: 17 T/s)
 //       MASK 32     v_permlane32_swap      (the gfx950 half-wave exchange: 8.7 T/s; ds_bpermute manages 6.5 T/s)
 //   wave_swap_words<MASK>(a, b)   swap a register-index bit with a lane bit (the NTT wave kernels' transposes)
+//   g1_wave_suffix_scan(p, lane)  lane l <- p_l + .. + p_63 (the weighting of the bucket reduction)
 //   g1_wave_reduce(p, lane)       butterfly sum of one G1 point per lane: afterwards every lane holds the total
 //                                 ("wave-reduced bucket sum": the last six levels of the MSM reductions)
 // Used by the NTT wave kernels (ntt.hip) for their in-register digit exchanges and by the MSM kernels (msm.hip).
@@ -85,6 +86,23 @@ template <unsigned MASK> PLONK_DEV void g1_wave_reduce_step(G1Xyzz& p, unsigned 
     o.zz = fq_wave_xor<MASK>(p.zz, lane);
     o.zzz = fq_wave_xor<MASK>(p.zzz, lane);
     g1_add(p, o);
+}
+
+// Suffix sums over the lanes of a wave: afterwards lane l holds p_l + p_(l+1) + .. + p_63 (Hillis-Steele; the value of
+// lane + d comes through ds_bpermute — 32 words per step beside a general addition of ~4 000 instructions).
+// All 64 lanes of the wave must call this together.
+PLONK_DEV void g1_wave_suffix_scan(G1Xyzz& p, unsigned lane) {
+    for (unsigned d = 1; d < 64; d <<= 1) {
+        G1Xyzz o;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            o.x.v[i] = (uint32_t)__shfl_down((int)p.x.v[i], d, 64);
+            o.y.v[i] = (uint32_t)__shfl_down((int)p.y.v[i], d, 64);
+            o.zz.v[i] = (uint32_t)__shfl_down((int)p.zz.v[i], d, 64);
+            o.zzz.v[i] = (uint32_t)__shfl_down((int)p.zzz.v[i], d, 64);
+        }
+        if (lane + d < 64) g1_add(p, o);
+    }
 }
 
 // all 64 lanes of the wave must call this together

@@ -45,21 +45,16 @@ def ntt_vs_oracle(log_ns, seed0=0):
 
 
 def ntt_quad_sizes(seed0=60):
-    """2^14 and 2^15 = 4 x 2^12 / 4 x 2^13 (four-point column transforms on packed residues, then the wave kernel's row pass;
-    forced with kernel kind 5 for BN254, the only path of the BLS12-381 transform):
-    plain transforms both ways, in place through the C-ABI, a batch, and the fused forms the prover's sizes would use — zero
-    padding + coset factors on the way in (to_coset_extended_lagrange of 2^12 values -> 2^14) and coset^-1 / N on the way out."""
-    import ctypes
-
+    """2^14 = 2^7 x 2^7 and 2^15 = 2^7 x 2^8 on the wave kernels (the sizes no pair of the 4- / 8-element kernels reaches; until
+    round 4 four-point column transforms + one pass): plain transforms both ways, in place through the C-ABI, a batch, and the
+    fused forms the prover's sizes would use — zero padding + coset factors on the way in (to_coset_extended_lagrange of 2^12
+    values -> 2^14) and coset^-1 / N on the way out.  Once on the default dispatch, once with the wave kernels forced."""
     from plonkathon_amd import get_context
-    from plonkathon_amd._lib import check
 
     ctx = get_context()
-    check(ctx.L.plonk_ntt_select_kernel(ctx.handle, 5))  # BN254's default for these two sizes is the LDS kernels (faster for a lone transform)
-    try:
-        _ntt_quad_sizes_body(ctx, seed0)
-    finally:
-        check(ctx.L.plonk_ntt_select_kernel(ctx.handle, 0))
+    _ntt_quad_sizes_body(ctx, seed0)
+    with ntt_kind(6):
+        _ntt_quad_sizes_body(ctx, seed0 + 1000)
 
 
 def _ntt_quad_sizes_body(ctx, seed0):
@@ -82,6 +77,62 @@ def _ntt_quad_sizes_body(ctx, seed0):
     assert ints(big.coset_extended_lagrange_to_coeffs(Scalar(off))) == want.coset_extended_lagrange_to_coeffs(off).values
 
 
+class ntt_kind:
+    """with ntt_kind(k): the context's transforms run on kernel family k (plonk_ntt_select_kernel), back to automatic afterwards."""
+
+    def __init__(self, kind):
+        self.kind = kind
+
+    def __enter__(self):
+        from plonkathon_amd import get_context
+        from plonkathon_amd._lib import check
+
+        ctx = get_context()
+        check(ctx.L.plonk_ntt_select_kernel(ctx.handle, self.kind))
+
+    def __exit__(self, *exc):
+        from plonkathon_amd import get_context
+        from plonkathon_amd._lib import check
+
+        ctx = get_context()
+        check(ctx.L.plonk_ntt_select_kernel(ctx.handle, 0))
+
+
+def ntt_two_pass_exact(log_ns, seed0=4000, batch=1):
+    """Two-pass sizes exact against the C half of the oracle, forward out of place and inverse in place, `batch` transforms per call."""
+    from oracle import c_oracle
+    from plonkathon_amd import get_context
+    from plonkathon_amd._lib import check
+
+    ctx = get_context()
+    for log_n in log_ns:
+        n = 1 << log_n
+        vs = [rand_vec(seed0 + log_n + 31 * b, n) for b in range(batch)]
+        buf = ctx.upload_ints([x for v in vs for x in v])
+        out = ctx.alloc(batch * n)
+        check(ctx.L.plonk_fr_ntt(ctx.handle, buf.ptr, out.ptr, log_n, 0, batch))
+        got = ctx.download_ints(out)
+        for b in range(batch):
+            assert got[b * n:(b + 1) * n] == c_oracle.fr_ntt(vs[b]), ("fwd", log_n, b)
+        check(ctx.L.plonk_fr_ntt(ctx.handle, buf.ptr, buf.ptr, log_n, 1, batch))
+        got = ctx.download_ints(buf)
+        for b in range(batch):
+            assert got[b * n:(b + 1) * n] == c_oracle.fr_ntt(vs[b], True), ("inv", log_n, b)
+
+
+def ntt_latency_forms(two_pass=(14, 15, 16, 17, 18), batched=(18,)):
+    """Round 4's two-element-per-thread kernels (2^7, and 2^9 in its latency form), forced with kernel kind 7: alone with random
+    and range-driving inputs, and as the passes of 2^14 = 2^7 x 2^7, 2^15 = 2^7 x 2^8, 2^16 = 2^7 x 2^9, 2^17 = 2^8 x 2^9,
+    2^18 = 2^9 x 2^9 (column pass on the full inter-pass table up to 2^16 and for the batched call, on the two small tables
+    otherwise).  Kind 6 keeps a call off them: the same sizes then run on the four- and eight-element kernels."""
+    with ntt_kind(7):
+        ntt_vs_oracle((7, 9), seed0=770)
+        ntt_extreme_inputs((7, 9))
+        ntt_extreme_limbs((7, 9), slots=2)
+        ntt_two_pass_exact(two_pass, seed0=4700)
+        ntt_two_pass_exact(batched, seed0=4800, batch=2)
+
+
 def ntt_extreme_inputs(log_ns):
     """Inputs that drive the limb-form kernel's range bounds: every element at r - 1 (all partial sums at their maximum),
     alternating 0 / r - 1 (differences at their extremes), a lone r - 1, and vectors whose transform is constant."""
@@ -95,7 +146,7 @@ def ntt_extreme_inputs(log_ns):
             assert ints(P(v, Basis.LAGRANGE).ifft()) == fft_ints(v, True), ("ifft", name, log_n)
 
 
-def ntt_extreme_limbs(log_ns):
+def ntt_extreme_limbs(log_ns, slots=0):
     """Inputs whose MONTGOMERY representation (what the kernels hold: x * 2^261 mod r, as 29-bit limbs) has every limb at
     its maximum 2^29 - 1, laid out over the eight register slots of the wave kernels' first butterfly in the patterns
     that maximise its sums and differences.  With the emulator build the range checks of fpl.h run on exactly these."""
@@ -106,11 +157,12 @@ def ntt_extreme_limbs(log_ns):
     hi, lo = max_mont * r_inv % m, 0                    # the canonical values that upload to those representations
     for log_n in log_ns:
         n = 1 << log_n
-        slots_n = 8 if log_n & 1 else 4                 # elements per thread of the wave kernel serving this size
+        slots_n = slots or (8 if log_n & 1 else 4)      # elements per thread of the wave kernel serving this size (2: the latency forms)
         nt = n // slots_n                               # element j * nt + tid sits in register slot j of thread tid
-        for name, slots in (("all", 0xFF), ("low_half", 0x0F if slots_n == 8 else 0x3), ("high_half", 0xF0 if slots_n == 8 else 0xC),
+        half = (1 << (slots_n // 2)) - 1
+        for name, mask in (("all", 0xFF), ("low_half", half), ("high_half", half << (slots_n // 2)),
                             ("even", 0x55), ("odd", 0xAA), ("pairs", 0x33 if slots_n == 8 else 0x9), ("one", 0x01), ("seven", 0xFE)):
-            v = [hi if (slots >> (i // nt)) & 1 else lo for i in range(n)]
+            v = [hi if (mask >> (i // nt)) & 1 else lo for i in range(n)]
             assert ints(P(v, Basis.MONOMIAL).fft()) == fft_ints(v), ("fft", name, log_n)
             assert ints(P(v, Basis.LAGRANGE).ifft()) == fft_ints(v, True), ("ifft", name, log_n)
 
@@ -180,7 +232,7 @@ def bls_ntt_vs_oracle(log_ns, seed0=40, batch=1):
     w = bls.root_of_unity(n)
     assert roots[:3] == [1, w, w * w % m] and roots[n - 1] == pow(w, n - 1, m)
     assert bls.root_of_unity(1 << 32) == 0x16A2A19EDFE81F20D09B681922C813B4B63683508C2280B93829971F439F0D2B
-    for bad in (lambda: bls.upload(le([m])), lambda: bls.ntt(bls.upload(le([1] * 128)), 7), lambda: bls.ntt(bls.upload(bytes(32 << 7)), 27)):
+    for bad in (lambda: bls.upload(le([m])), lambda: bls.ntt(bls.upload(le([1] * 64)), 6), lambda: bls.ntt(bls.upload(bytes(32 << 7)), 27)):
         try:
             bad()
         except AssertionError:

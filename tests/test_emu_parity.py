@@ -32,7 +32,7 @@ def test_ntt_forced_variants(emu):
 
     ctx = get_context()
     try:
-        for kind in (1, 2, 5):
+        for kind in (1, 2, 6, 7):  # (6 / 7: the wave kernels without / with their two-element latency forms)
             check(ctx.L.plonk_ntt_select_kernel(ctx.handle, kind))
             check(ctx.L.plonk_ntt_configure(ctx.handle, 0, 0, 0))
             pc.ntt_vs_oracle([0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13], seed0=10 * kind)
@@ -48,14 +48,22 @@ def test_ntt_properties(emu):
 
 
 def test_ntt_extreme_inputs(emu):
-    pc.ntt_extreme_inputs((8, 9, 10, 11, 12, 13))
-    pc.ntt_extreme_limbs((8, 9, 10, 11, 12))
+    with pc.ntt_kind(6):  # the four- and eight-element kernels (a lone 2^9 would otherwise take its two-element form)
+        pc.ntt_extreme_inputs((8, 9, 10, 11, 12, 13))
+        pc.ntt_extreme_limbs((8, 9, 10, 11, 12))
+
+
+def test_ntt_latency_forms(emu):
+    pc.ntt_latency_forms(two_pass=(14, 15, 16), batched=(18,))
 
 
 def test_bls12_381_ntt(emu):
-    """One size per wave kernel (E = 4 and 8; 0, 1, 2 LDS stages) with the emulator's range checks on the 255-bit modulus."""
-    pc.bls_ntt_vs_oracle((8, 9, 10, 11), batch=3)
-    pc.bls_ntt_vs_oracle((12, 13), seed0=77)
+    """One size per wave kernel (E = 2, 4 and 8; 0, 1, 2 LDS stages) with the emulator's range checks on the 255-bit modulus."""
+    with pc.ntt_kind(6):
+        pc.bls_ntt_vs_oracle((8, 9, 10, 11), batch=3)
+        pc.bls_ntt_vs_oracle((12, 13), seed0=77)
+    with pc.ntt_kind(7):
+        pc.bls_ntt_vs_oracle((7, 9), seed0=177, batch=2)
 
 
 def test_poly_golden(emu):
@@ -218,6 +226,7 @@ def test_ntt_two_pass_wave_kernel(emu):
     from plonkathon_amd._lib import check
 
     ctx = get_context()
+    check(ctx.L.plonk_ntt_select_kernel(ctx.handle, 6))  # (lone transforms of these sizes default to the latency forms: test_ntt_latency_forms)
     for log_n in (16, 17):
         v = pc.rand_vec(4000 + log_n, 1 << log_n)
         assert pc.ints(pc.P(v, Basis.MONOMIAL).fft()) == c_oracle.fr_ntt(v), log_n
@@ -238,9 +247,10 @@ def test_ntt_two_pass_wave_kernel(emu):
         check(ctx.L.plonk_ntt_set_split(ctx.handle, 18, 10))
         v = pc.rand_vec(4018, 1 << 18)
         assert pc.ints(pc.P(v, Basis.MONOMIAL).fft()) == c_oracle.fr_ntt(v)
-        assert ctx.L.plonk_ntt_set_split(ctx.handle, 18, 14) != 0 and ctx.L.plonk_ntt_set_split(ctx.handle, 15, 8) != 0
+        assert ctx.L.plonk_ntt_set_split(ctx.handle, 18, 14) != 0 and ctx.L.plonk_ntt_set_split(ctx.handle, 15, 9) != 0
     finally:
         check(ctx.L.plonk_ntt_set_split(ctx.handle, 18, 0))
+        check(ctx.L.plonk_ntt_select_kernel(ctx.handle, 0))
 
 
 def test_ntt_2_14_and_2_15(emu):

@@ -50,7 +50,7 @@ def test_ntt_forced_variants():
 
     ctx = get_context()
     try:
-        for kind in (1, 2, 4, 5):
+        for kind in (1, 2, 4, 5, 6, 7):  # (6 / 7: the wave kernels without / with their two-element latency forms)
             check(ctx.L.plonk_ntt_select_kernel(ctx.handle, kind))
             check(ctx.L.plonk_ntt_configure(ctx.handle, 0, 0, 0))
             pc.ntt_vs_oracle([0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 16], seed0=10 * kind)
@@ -63,8 +63,21 @@ def test_ntt_forced_variants():
 
 
 def test_ntt_extreme_inputs():
-    pc.ntt_extreme_inputs((8, 9, 10, 11, 12, 13, 16))
-    pc.ntt_extreme_limbs((8, 9, 10, 11, 12, 13))
+    with pc.ntt_kind(6):  # the four- and eight-element kernels (a lone 2^9 or 2^16 would otherwise take the two-element forms)
+        pc.ntt_extreme_inputs((8, 9, 10, 11, 12, 13, 16))
+        pc.ntt_extreme_limbs((8, 9, 10, 11, 12, 13))
+    pc.ntt_extreme_inputs((14, 15, 16))  # ... and the default: latency forms
+
+
+@pytest.mark.gpu
+def test_ntt_latency_forms():
+    """The two-element kernels alone and as both passes of 2^14 .. 2^18, BN254 and BLS12-381, forced and by default."""
+    pc.ntt_latency_forms()
+    with pc.ntt_kind(7):
+        pc.bls_ntt_vs_oracle((7, 9), seed0=177, batch=4)
+        pc.bls_ntt_vs_oracle((14, 15, 16, 17, 18), seed0=470, batch=2)
+    with pc.ntt_kind(6):
+        pc.ntt_two_pass_exact((14, 15, 16, 17, 18), seed0=4900)
 
 
 @pytest.mark.parametrize("log_n", [18, 20, 22, 24])
@@ -321,7 +334,7 @@ def test_ntt_inter_pass_twiddles_from_the_small_tables():
 
 
 def test_ntt_2_14_and_2_15():
-    """4 x 2^12 and 4 x 2^13: the four-point column pass + the wave kernel's row pass, with the fused coset forms."""
+    """2^14 = 2^7 x 2^7 and 2^15 = 2^7 x 2^8 on the wave kernels (two-element column pass), with the fused coset forms."""
     pc.ntt_quad_sizes()
     pc.bls_ntt_vs_oracle((14, 15), seed0=55, batch=3)
 
@@ -335,7 +348,8 @@ def test_bls12_381_coset_transforms():
 def test_bls12_381_ntt_every_wave_kernel():
     """The standalone BLS12-381 Fr transform, one size per wave kernel plus a two-pass size: random and extreme inputs, both
     directions, in place, batched, bad inputs refused — bit-exact against the C oracle's oracle_bls_fr_ntt."""
-    pc.bls_ntt_vs_oracle((8, 9, 10, 11, 12, 13), batch=5)
+    with pc.ntt_kind(6):
+        pc.bls_ntt_vs_oracle((8, 9, 10, 11, 12, 13), batch=5)
     pc.bls_ntt_vs_oracle((16, 17, 19), seed0=300)
 
 

@@ -1,7 +1,7 @@
 #!/bin/bash
 # One GPU session = a list of named steps, run in order on the gpurun box; every step writes under gpurun_out/<tag>/.
 #   /usr/local/graft/bin/gpurun --timeout 1500 -- 'bash tools/gpu_session.sh r03a tests ntt_sweep bench'
-# Steps: tests[:<pytest -k expr>]  ntt_sweep[:<args>]  ntt_ab  bench[:<args>]  rocprof  pmc  ubench  smoke
+# Steps: tests[:<pytest -k expr>]  ntt_sweep[:<args>]  ntt_ab  bench[:<args>]  env_bench:<VAR=VALUE args>  rocprof  ntt_trace  pmc  ubench  smoke  latency
 tag=$1; shift
 out=gpurun_out/$tag
 mkdir -p "$out"
@@ -40,6 +40,9 @@ for step in "$@"; do
       nm=${arg%% *}; rest=${arg#* }
       ( cd /tmp && rocprofv3 --kernel-trace --stats -d "$OLDPWD/$out/rocprof_$nm" -o trace -- python "$OLDPWD/bench.py" $rest > "$OLDPWD/$out/bench_under_rocprof_$nm.json" 2> "$OLDPWD/$out/rocprof_$nm.err" ); echo "rocprof rc=$?"
       find "$out/rocprof_$nm" -name "*kernel_stats.csv" | head -1 | xargs -r head -14 ;;
+    env_bench)   # "VAR=VALUE <bench args>": bench.py under one environment setting -> bench_VAR=VALUE.json
+      kv=${arg%% *}; rest=${arg#* }
+      env "$kv" timeout 600 python bench.py $rest > "$out/bench_$kv.json" 2> "$out/bench_$kv.err"; echo "bench $kv rc=$?"; cut -c1-200 "$out/bench_$kv.json"; echo ;;
     latency) timeout 600 python tools/latency.py $arg > "$out/latency.json" 2> "$out/latency.err"; echo "rc=$?"; cat "$out/latency.json" ;;
     ubench) for b in tools/ubench/*.bin; do timeout 120 "$b" > "$out/$(basename $b .bin).json" 2>&1; done ;;
     *) echo "unknown step $name" ;;
