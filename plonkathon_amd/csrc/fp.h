@@ -270,6 +270,23 @@ template <class P> PLONK_HD Fp<P> fp_inv_fermat(const Fp<P>& a) {
     return fp_pow_limbs(a, e);
 }
 
+// f(0) .. f(N-1) with compile-time arguments: an array of field elements must never be indexed by a run-time value, or it
+// moves from VGPRs to scratch memory — and `#pragma unroll` gives up on loops whose bodies hold two field multiplications
+// (the wave NTT kernels' element arrays, the chunks of the batch inversions)
+template <unsigned J> struct WaveIdx { static constexpr unsigned value = J; };
+template <unsigned N, class F> PLONK_HD void wave_for(F f) {
+    if constexpr (N > 0) {
+        wave_for<N - 1>(f);
+        f(WaveIdx<N - 1>{});
+    }
+}
+template <unsigned N, class F> PLONK_HD void wave_for_down(F f) {  // f(N-1) .. f(0)
+    if constexpr (N > 0) {
+        f(WaveIdx<N - 1>{});
+        wave_for_down<N - 1>(f);
+    }
+}
+
 // ---- inversion by Bernstein-Yang division steps -------------------------------------------------------
 // Values are 9 signed limbs of 30 bits.  Thirty division steps are run on the low limbs of (f, g) only and
 // recorded as a 2x2 integer matrix t with [f'; g'] = t [f; g] / 2^30; the matrix is then applied once to

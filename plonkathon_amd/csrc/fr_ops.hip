@@ -152,30 +152,34 @@ int k_fr_rotate(plonk_ctx* ctx, const Fr* in, Fr* out, size_t n, size_t shift, s
 // Batch inversion (Montgomery's trick) — one field inversion (fp_inv) per lane-chunk of INV_CHUNK elements.
 // Zeros are skipped in the running product and map to zero (py_ecc: x / 0 == 0).
 #define INV_CHUNK 8
-__global__ void fr_batch_inverse_kernel(const Fr* in, Fr* out, size_t n) {
+__global__ void __launch_bounds__(64) fr_batch_inverse_kernel(const Fr* in, Fr* out, size_t n) {
     size_t nchunks = (n + INV_CHUNK - 1) / INV_CHUNK;
     for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < nchunks; c += (size_t)gridDim.x * blockDim.x) {
         size_t base = c * INV_CHUNK;
-        Fr v[INV_CHUNK], pre[INV_CHUNK];
+        // prefix products in registers (compile-time indices); the values themselves are read again on the way back instead of
+        // being held — 64 VGPRs instead of 128, and no scratch (round 3: 528 B per lane).  in == out is fine: element k is
+        // written after its second read and before nothing that still needs it.
+        Fr pre[INV_CHUNK];
         Fr acc = fp_one<FrParams>();
-#pragma unroll
-        for (int k = 0; k < INV_CHUNK; k++) {
-            v[k] = (base + k < n) ? fp_load(in + base + k) : fp_zero<FrParams>();
+        wave_for<INV_CHUNK>([&](auto K) {
+            constexpr unsigned k = decltype(K)::value;
+            const Fr v = (base + k < n) ? fp_load(in + base + k) : fp_zero<FrParams>();
             pre[k] = acc;
-            if (!fp_is_zero(v[k])) acc = fp_mul(acc, v[k]);
-        }
+            if (!fp_is_zero(v)) acc = fp_mul(acc, v);
+        });
         acc = fp_inv(acc);
-#pragma unroll
-        for (int k = INV_CHUNK - 1; k >= 0; k--) {
+        wave_for_down<INV_CHUNK>([&](auto K) {
+            constexpr unsigned k = decltype(K)::value;
             if (base + k < n) {
+                const Fr v = fp_load(in + base + k);
                 Fr r = fp_zero<FrParams>();
-                if (!fp_is_zero(v[k])) {
+                if (!fp_is_zero(v)) {
                     r = fp_mul(acc, pre[k]);
-                    acc = fp_mul(acc, v[k]);
+                    acc = fp_mul(acc, v);
                 }
                 fp_store(out + base + k, r);
             }
-        }
+        });
     }
 }
 
@@ -238,7 +242,7 @@ int k_fr_powers(plonk_ctx* ctx, const Fr& base_mont, const Fr& first_mont, Fr* o
 #define BARY_CHUNK 8
 #define FR_BARY_MANY_MAX 16
 struct FrBaryPtrs { const Fr* p[FR_BARY_MANY_MAX]; };  // vals == null: polynomial b lives at ptrs.p[b] (plonk_fr_barycentric_many)
-__global__ void fr_barycentric_kernel(const Fr* vals, FrBaryPtrs ptrs, const Fr* roots, unsigned log_n, const Fr* xs, size_t x_stride,
+__global__ void __launch_bounds__(256) fr_barycentric_kernel(const Fr* vals, FrBaryPtrs ptrs, const Fr* roots, unsigned log_n, const Fr* xs, size_t x_stride,
                                       Fr n_inv, Fr* out) {
     const size_t n = (size_t)1 << log_n;
     const Fr* v = vals ? vals + (size_t)blockIdx.x * n : ptrs.p[blockIdx.x];
@@ -247,24 +251,26 @@ __global__ void fr_barycentric_kernel(const Fr* vals, FrBaryPtrs ptrs, const Fr*
     size_t nchunks = (n + BARY_CHUNK - 1) / BARY_CHUNK;
     for (size_t c = threadIdx.x; c < nchunks; c += blockDim.x) {
         size_t base = c * BARY_CHUNK;
-        Fr d[BARY_CHUNK], pre[BARY_CHUNK];
+        Fr pre[BARY_CHUNK];  // (as in fr_batch_inverse_kernel: prefix products in registers, d_i formed again on the way back)
         Fr acc = fp_one<FrParams>();
-#pragma unroll
-        for (int k = 0; k < BARY_CHUNK; k++) {
-            d[k] = (base + k < n) ? fp_sub(x, fp_load(roots + base + k)) : fp_zero<FrParams>();
+        wave_for<BARY_CHUNK>([&](auto K) {
+            constexpr unsigned k = decltype(K)::value;
+            const Fr d = (base + k < n) ? fp_sub(x, fp_load(roots + base + k)) : fp_zero<FrParams>();
             pre[k] = acc;
-            if (!fp_is_zero(d[k])) acc = fp_mul(acc, d[k]);
-        }
+            if (!fp_is_zero(d)) acc = fp_mul(acc, d);
+        });
         acc = fp_inv(acc);
-#pragma unroll
-        for (int k = BARY_CHUNK - 1; k >= 0; k--) {
-            if (base + k < n && !fp_is_zero(d[k])) {
-                Fr dinv = fp_mul(acc, pre[k]);
-                acc = fp_mul(acc, d[k]);
-                Fr term = fp_mul(fp_mul(fp_load(v + base + k), fp_load(roots + base + k)), dinv);
-                sum = fp_add(sum, term);
+        wave_for_down<BARY_CHUNK>([&](auto K) {
+            constexpr unsigned k = decltype(K)::value;
+            if (base + k < n) {
+                const Fr w = fp_load(roots + base + k), d = fp_sub(x, w);
+                if (!fp_is_zero(d)) {
+                    const Fr dinv = fp_mul(acc, pre[k]);
+                    acc = fp_mul(acc, d);
+                    sum = fp_add(sum, fp_mul(fp_mul(fp_load(v + base + k), w), dinv));
+                }
             }
-        }
+        });
     }
     __shared__ Fr red[256];
     red[threadIdx.x] = sum;

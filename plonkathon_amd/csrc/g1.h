@@ -73,6 +73,9 @@ PLONK_HD G1Xyzz g1_dbl_affine(const G1Affine& q) {
     return r;
 }
 
+// the rare exits of g1_madd: acc == q (double it) or acc == -q (identity)
+PLONK_HD_NOINLINE G1Xyzz g1_madd_equal_x(const G1Affine q, bool same) { return same ? g1_dbl_affine(q) : g1_xyzz_identity(); }
+
 // acc += affine q   (madd-2008-s)
 PLONK_HD void g1_madd(G1Xyzz& p, const G1Affine& q) {
     if (g1_affine_is_identity(q)) return;
@@ -84,9 +87,8 @@ PLONK_HD void g1_madd(G1Xyzz& p, const G1Affine& q) {
     Fq s2 = fp_mul(q.y, p.zzz);
     Fq pp_ = fp_sub(u2, p.x);
     Fq r = fp_sub(s2, p.y);
-    if (fp_is_zero(pp_)) {
-        if (fp_is_zero(r)) p = g1_dbl_affine(q);   // same point
-        else p = g1_xyzz_identity();               // opposite points
+    if (fp_is_zero(pp_)) {  // same point / opposite points: out of line (inlined, this branch cost every caller 120+ spilled registers)
+        p = g1_madd_equal_x(q, fp_is_zero(r));
         return;
     }
     Fq pp = fp_sqr(pp_);

@@ -27,7 +27,7 @@
 //                             ("piece") per bucket it touches: a bucket boundary costs a 128-byte store,
 //                             never a group operation, so the wave does not serialise on boundaries that
 //                             its lanes cross at different steps.  >= 80 % of this method's time.
-//   3. msm_bucket_reduce_kernel (one wave per MSM) lane l owns K/64 consecutive buckets: walking them top-down,
+//   3. msm_bucket_reduce_kernel (two waves per MSM) lane l owns K/128 consecutive buckets: walking them top-down,
 //                             run += pieces of bucket k, tot += run; its share is tot + (first bucket - 1) * run, the
 //                             second term from a cross-lane suffix scan of the runs (round 4);
 //                             shares are summed across waves through LDS and then inside wave 0 by a cross-lane
@@ -79,36 +79,36 @@ __global__ void msm_table_kernel(const G1Affine* bases, size_t n, unsigned c, un
 
 // XYZZ -> affine for a whole array, Montgomery's trick over chunks of 8 (identity -> (0,0)).
 #define AFF_CHUNK 8
-__global__ void g1_batch_to_affine_kernel(const G1Xyzz* in, G1Affine* out, size_t n) {
+__global__ void __launch_bounds__(64) g1_batch_to_affine_kernel(const G1Xyzz* in, G1Affine* out, size_t n) {
     size_t nchunks = (n + AFF_CHUNK - 1) / AFF_CHUNK;
     for (size_t ch = (size_t)blockIdx.x * blockDim.x + threadIdx.x; ch < nchunks; ch += (size_t)gridDim.x * blockDim.x) {
         size_t base = ch * AFF_CHUNK;
-        Fq den[AFF_CHUNK], pre[AFF_CHUNK];
+        Fq pre[AFF_CHUNK];  // prefix products in registers (compile-time indices); zz zzz is formed again on the way back
         Fq acc = fp_one<FqParams>();
-        for (int k = 0; k < AFF_CHUNK; k++) {
-            den[k] = fp_zero<FqParams>();
+        wave_for<AFF_CHUNK>([&](auto K) {
+            constexpr unsigned k = decltype(K)::value;
+            Fq den = fp_zero<FqParams>();
+            if (base + k < n) den = fp_mul(fp_load(&in[base + k].zz), fp_load(&in[base + k].zzz));  // zero <=> identity
+            pre[k] = acc;
+            if (!fp_is_zero(den)) acc = fp_mul(acc, den);
+        });
+        acc = fp_inv(acc);
+        wave_for_down<AFF_CHUNK>([&](auto K) {
+            constexpr unsigned k = decltype(K)::value;
             if (base + k < n) {
                 const G1Xyzz& p = in[base + k];
-                den[k] = fp_mul(fp_load(&p.zz), fp_load(&p.zzz));  // zero <=> identity
+                const Fq zz = fp_load(&p.zz), zzz = fp_load(&p.zzz), den = fp_mul(zz, zzz);
+                G1Affine r = g1_affine_identity();
+                if (!fp_is_zero(den)) {
+                    const Fq t = fp_mul(acc, pre[k]);  // 1 / (zz * zzz)
+                    acc = fp_mul(acc, den);
+                    r.x = fp_mul(fp_load(&p.x), fp_mul(t, zzz));
+                    r.y = fp_mul(fp_load(&p.y), fp_mul(t, zz));
+                }
+                fp_store(&out[base + k].x, r.x);
+                fp_store(&out[base + k].y, r.y);
             }
-            pre[k] = acc;
-            if (!fp_is_zero(den[k])) acc = fp_mul(acc, den[k]);
-        }
-        acc = fp_inv(acc);
-        for (int k = AFF_CHUNK - 1; k >= 0; k--) {
-            if (base + k >= n) continue;
-            G1Affine r = g1_affine_identity();
-            if (!fp_is_zero(den[k])) {
-                const G1Xyzz& p = in[base + k];
-                Fq t = fp_mul(acc, pre[k]);  // 1 / (zz * zzz)
-                acc = fp_mul(acc, den[k]);
-                Fq zz = fp_load(&p.zz), zzz = fp_load(&p.zzz);
-                r.x = fp_mul(fp_load(&p.x), fp_mul(t, zzz));
-                r.y = fp_mul(fp_load(&p.y), fp_mul(t, zz));
-            }
-            fp_store(&out[base + k].x, r.x);
-            fp_store(&out[base + k].y, r.y);
-        }
+        });
     }
 }
 
@@ -393,7 +393,7 @@ __global__ void __launch_bounds__(256) msm_bucket_reduce_kernel(const uint32_t* 
 // Signed digits as in the bucket method; a lane walks a flat range of (scalar, window) items.
 
 // tmp[i * half + d - 1] = d * wbase[w * n + i] for one window w, XYZZ (converted by g1_batch_to_affine_kernel)
-__global__ void msm_lookup_fill_kernel(const G1Affine* wbase, size_t n, unsigned c, unsigned w, G1Xyzz* tmp) {
+__global__ void __launch_bounds__(64) msm_lookup_fill_kernel(const G1Affine* wbase, size_t n, unsigned c, unsigned w, G1Xyzz* tmp) {
     const size_t half = (size_t)1 << (c - 1);
     const size_t seg_len = half < 256 ? half : 256, nseg = half / seg_len;
     for (size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x; id < n * nseg; id += (size_t)gridDim.x * blockDim.x) {
@@ -402,11 +402,13 @@ __global__ void msm_lookup_fill_kernel(const G1Affine* wbase, size_t n, unsigned
         b.x = fp_load(&wbase[(size_t)w * n + i].x);
         b.y = fp_load(&wbase[(size_t)w * n + i].y);
         G1Xyzz acc = g1_xyzz_identity();
+#pragma unroll 1
         for (int bit = (int)c - 1; bit >= 0; bit--) {  // acc = k * b
             g1_dbl(acc);
             if ((k >> bit) & 1) g1_madd(acc, b);
         }
         G1Xyzz* out = tmp + i * half + k;
+#pragma unroll 1
         for (size_t j = 0; j < seg_len; j++) {
             g1_madd(acc, b);
             out[j] = acc;
@@ -974,10 +976,10 @@ int msm_run_device(plonk_ctx* ctx, plonk_srs* srs, const Fr* d_scalars, size_t n
     }
     const size_t max_entries = (size_t)W * n;
     while (G > 1 && (size_t)G * MSM_BLOCK * 4 > max_entries) G /= 2;  // tiny MSMs: one segment is plenty
-    // lanes per MSM in the bucket reduction (shorter local walks vs more lanes paying the scan and the reduction).  Round 3's
-    // double-and-add weighting measured best at 128 (256 for the largest MSMs); with the suffix scan one wave per MSM does the
-    // least work per MSM.  PLONK_MSM_RED_LANES = 64 / 128 / 256 overrides (A/B runs).
-    unsigned red_lanes = G >= 8 ? 256 : 64;
+    // lanes per MSM in the bucket reduction (shorter local walks vs more lanes paying the scan and the reduction): 128 measured
+    // best again with the suffix-scan weighting (profiles/r04_c_bucket_reduce_lanes_ab.jsonl: 23.3 k proofs/s against 22.5 k at
+    // 64; round 3's double-and-add weighting: 22.8 k at 128).  PLONK_MSM_RED_LANES = 64 / 128 / 256 overrides (A/B runs).
+    unsigned red_lanes = G >= 8 ? 256 : 128;
     {
         static const unsigned forced = [] {
             const char* e = getenv("PLONK_MSM_RED_LANES");

@@ -8,15 +8,7 @@
 
 #define NTT_TW_LO_LOG 10
 
-// f(0) .. f(N-1) with compile-time arguments: the element array must never be indexed by a run-time value, or it moves
-// from VGPRs to scratch memory (clang gives up unrolling loops whose bodies hold two field multiplications)
-template <unsigned J> struct WaveIdx { static constexpr unsigned value = J; };
-template <unsigned N, class F> PLONK_DEV void wave_for(F f) {
-    if constexpr (N > 0) {
-        wave_for<N - 1>(f);
-        f(WaveIdx<N - 1>{});
-    }
-}
+// (wave_for<N>: fp.h — every loop over the element array is expanded at compile time)
 
 // ------------------------------------------------------------------------------------------------
 // Variant C ("wave" kernels): the whole transform in registers, exchanges INSIDE a wave by cross-lane moves.
