@@ -403,7 +403,7 @@ def main():
     ap.add_argument("--dump-proofs", default="", help="rank 0 writes the last step's gathered proofs (768 bytes each, global order) to this file")
     ap.add_argument("--lagrange-commits", action="store_true", help="commit rounds 1-2 from Lagrange values over the Lagrange-basis SRS (a second lookup table)")
     ap.add_argument("--msm-groups", type=int, default=0, help="plonk_msm_configure groups: workgroups per MSM (0 = library default)")
-    ap.add_argument("--ntt-kind", type=int, default=0, help="plonk_ntt_select_kernel: 0 auto, 1 radix-2 stages, 2 Stockham, 4 auto among the LDS kernels (A/B), 5 wave kernels wherever they apply")
+    ap.add_argument("--ntt-kind", type=int, default=0, help="plonk_ntt_select_kernel: 0 auto, 1 / 4 the LDS kernel (radix-2 stages; A/B), 5 wave kernels wherever they apply, 6 / 7 wave kernels without / with the latency forms")
     ap.add_argument("--log-n", type=int, default=11, help="log2(group_order); 11 = the BASELINE workload, smaller values are for functional tests only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-microbench", action="store_true")

@@ -85,11 +85,11 @@ int plonk_fr_coset_to_coeffs(plonk_ctx* ctx, const void* d_in, void* d_out, unsi
 int plonk_ntt_configure(plonk_ctx* ctx, unsigned tile_log, unsigned single_pass_log, unsigned radix_log);
 /* kernel family: 0 = auto (what measures fastest on MI355X: the in-register "wave" kernels — 2, 4 or 8 elements per
  * thread as signed 29-bit limbs, digits exchanged inside a wave by DPP / v_permlane16_swap / v_permlane32_swap, LDS only
- * across waves — for 2^7 .. 2^13 in one launch and 2^14 .. 2^26 as two passes of those; the LDS kernels below 2^7 and
- * above 2^26: Stockham radix-8 for single-pass sizes, radix-2 stages otherwise), 1 = radix-2 stages, 2 = Stockham radix-8,
- * 4 = auto among the LDS kernels only (A/B runs), 5 = the wave kernels wherever they apply, whatever
- * plonk_ntt_configure says; 6 / 7 = as 5, but never / always on the two-element "latency" forms (2^9, and the splits of
- * 2^14 .. 2^18 built on 2^7 and 2^9) that 0 and 5 pick for calls of at most 2^18 elements.  (3 is retired.) */
+ * across waves — for 2^7 .. 2^13 in one launch and 2^14 .. 2^26 as two passes of those; the LDS kernel, radix-2 stages,
+ * below 2^7 and above 2^26), 1 = the LDS kernel at every size, 4 = the same (A/B runs; it used to choose among two LDS
+ * kernels), 5 = the wave kernels wherever they apply, whatever plonk_ntt_configure says; 6 / 7 = as 5, but never / always
+ * on the two-element "latency" forms (2^9, and the splits of 2^14 .. 2^18 built on 2^7 and 2^9) that 0 and 5 pick for
+ * calls of at most 2^18 elements.  (2, the Stockham LDS kernel, and 3 are retired.) */
 int plonk_ntt_select_kernel(plonk_ctx* ctx, unsigned kind);
 /* two-pass wave transforms N = R1 R2 (R1-point column transforms, then R2-point row transforms): log2 R1 for one
  * log2 N in [16, 26]; 0 = the default (as square as possible).  Both factors must lie in 2^8 .. 2^13.  A/B runs, tests. */

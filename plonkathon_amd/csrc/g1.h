@@ -76,8 +76,10 @@ PLONK_HD G1Xyzz g1_dbl_affine(const G1Affine& q) {
 // the rare exits of g1_madd: acc == q (double it) or acc == -q (identity)
 PLONK_HD_NOINLINE G1Xyzz g1_madd_equal_x(const G1Affine q, bool same) { return same ? g1_dbl_affine(q) : g1_xyzz_identity(); }
 
-// acc += affine q   (madd-2008-s)
-PLONK_HD void g1_madd(G1Xyzz& p, const G1Affine& q) {
+// acc += affine q   (madd-2008-s).  OUTLINE_RARE: the acc == +-q exit as a call — inlined, that branch costs a kernel whose
+// loop body is this addition 120 .. 1 000 spilled registers (msm_lookup_fill_kernel: 2 200 B of scratch per lane in round 3);
+// as a call it costs a 144-byte frame that only the rare exit touches.  The kernels that had no scratch keep the inline form.
+template <bool OUTLINE_RARE = false> PLONK_HD void g1_madd(G1Xyzz& p, const G1Affine& q) {
     if (g1_affine_is_identity(q)) return;
     if (g1_is_identity(p)) {
         p.x = q.x; p.y = q.y; p.zz = fp_one<FqParams>(); p.zzz = fp_one<FqParams>();
@@ -87,8 +89,10 @@ PLONK_HD void g1_madd(G1Xyzz& p, const G1Affine& q) {
     Fq s2 = fp_mul(q.y, p.zzz);
     Fq pp_ = fp_sub(u2, p.x);
     Fq r = fp_sub(s2, p.y);
-    if (fp_is_zero(pp_)) {  // same point / opposite points: out of line (inlined, this branch cost every caller 120+ spilled registers)
-        p = g1_madd_equal_x(q, fp_is_zero(r));
+    if (fp_is_zero(pp_)) {
+        if constexpr (OUTLINE_RARE) p = g1_madd_equal_x(q, fp_is_zero(r));
+        else if (fp_is_zero(r)) p = g1_dbl_affine(q);   // same point
+        else p = g1_xyzz_identity();                    // opposite points
         return;
     }
     Fq pp = fp_sqr(pp_);

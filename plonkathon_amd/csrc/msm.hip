@@ -405,12 +405,12 @@ __global__ void __launch_bounds__(64) msm_lookup_fill_kernel(const G1Affine* wba
 #pragma unroll 1
         for (int bit = (int)c - 1; bit >= 0; bit--) {  // acc = k * b
             g1_dbl(acc);
-            if ((k >> bit) & 1) g1_madd(acc, b);
+            if ((k >> bit) & 1) g1_madd<true>(acc, b);
         }
         G1Xyzz* out = tmp + i * half + k;
 #pragma unroll 1
         for (size_t j = 0; j < seg_len; j++) {
-            g1_madd(acc, b);
+            g1_madd<true>(acc, b);
             out[j] = acc;
         }
     }
@@ -572,12 +572,12 @@ __global__ void __launch_bounds__(256) msm_slow_kernel(int kind, const G1Affine*
             pt.y = fp_load(&src->y);
             if (d < 0) pt.y = fp_neg(pt.y);
             if (kind == 0) {
-                g1_madd(acc, pt);
+                g1_madd<true>(acc, pt);
             } else {
                 G1Xyzz t = g1_xyzz_identity();
                 for (int bit = (int)c - 1; bit >= 0; bit--) {
                     g1_dbl(t);
-                    if ((ad >> bit) & 1) g1_madd(t, pt);
+                    if ((ad >> bit) & 1) g1_madd<true>(t, pt);
                 }
                 g1_add(acc, t);
             }
@@ -636,8 +636,10 @@ static MsmLookupTable* lut_find(const plonk_srs* srs, unsigned bits) {  // g_lut
     return best;
 }
 
-// The registry key is a 64-bit FNV-1a of the loaded bytes — not collision resistant — so a candidate is only attached
-// after its d = 1 entries of window 0 (the bases themselves) have been compared with this SRS's bases on the device.
+// The registry key is a 64-bit FNV-1a of the loaded bytes — not collision resistant — so a candidate (same device, key,
+// number of bases and window bits: lut_find) is only attached after its d = 1 entries of window 0 — the bases themselves —
+// have ALL been compared with this SRS's bases on the device.  That is the whole check a table needs: every other entry is a
+// function of (bases, number of bases, window bits) alone, computed by this library when the table was registered.
 __global__ void lut_verify_kernel(const G1Affine* bases, const G1Affine* lookup, size_t n, unsigned c, unsigned* mismatches) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;

@@ -6,15 +6,15 @@
 // coset_extended_lagrange_to_coeffs (poly.py:169-177).  The transform is the plain DFT
 // X[k] = sum_j x[j] w^(jk), w = 5^((r-1)/N) (curve.py:14-16); the inverse uses w^-1 and 1/N.
 //
-// Algorithm: N = R1*R2*..*RP (P <= 3 passes, Ri <= 2^10 when P > 1, <= 2^11 for
-// a single pass).  Pass p runs Rp-point sub-transforms for a tile of C adjacent columns in LDS (tile
-// of up to 4096 elements, stored as two 16-byte planes so unit-stride lanes are bank-conflict-free)
-// as Stockham auto-sort levels of radix-8 register butterflies (3 LDS round trips for 2^11 points),
-// with the Rp/2 twiddles w_Rp^k staged in LDS when they fit beside the tile, then multiplies by the
-// inter-pass twiddle w_N^(H*j*k) (two-level table: one extra multiplication) on the way out.  Global accesses are chunks of C*32 B >= 128 B; the last pass
-// reads whole rows and performs the digit-reversing write that restores natural order, so no
-// separate transpose or bit-reversal kernel exists.  Coset scaling, zero padding, the 1/N factor
-// and the inverse-coset scaling are fused into the first-pass load / last-pass store.
+// Kernels: the in-register wave kernels (ntt_wave.h, driven by ntt_wave_host.h) serve 2^7 .. 2^13 in one launch and
+// 2^14 .. 2^26 in two.  What they do not cover (sizes below 2^7, above 2^26, and the multi-pass plans the tests force with
+// plonk_ntt_configure) runs on ntt_pass_radix2_kernel below: N = R1*R2*..*RP (P <= 4 passes), pass p runs Rp-point
+// sub-transforms for a tile of C adjacent columns in LDS (two 16-byte planes: unit-stride lanes are conflict-free) as
+// radix-2 stages, multiplies by the inter-pass twiddle w_N^(H*j*k) (two-level table) on the way out; the last pass reads
+// whole rows and performs the digit-reversing write that restores natural order.  Coset scaling, zero padding, the 1/N
+// factor and the inverse-coset scaling are fused into the first-pass load / last-pass store of either family.
+// (Round 1's Stockham radix-8 LDS kernel — 198 VGPRs, two waves per SIMD — served only sizes below 2^7 after round 3 and
+// was removed in round 4.)
 #include <string.h>
 
 #include "ntt_wave_host.h"
@@ -35,8 +35,7 @@ struct NttPass {
     unsigned log_s;  // element stride of this pass's digit
     unsigned first, last;
     unsigned in_len;
-    const Fr* small_tw;  // w_R^k, k < R/2 (global; staged into LDS when tw_in_lds)
-    unsigned tw_in_lds;
+    const Fr* small_tw;  // w_R^k, k < R/2 (global; staged into LDS)
     const Fr* tw_lo;
     const Fr* tw_hi;
     const Fr* in_scale;
@@ -45,9 +44,6 @@ struct NttPass {
     unsigned has_out_scalar;
     unsigned nprev;
     unsigned prev_log_r[3];
-    unsigned n_levels;
-    unsigned level_radices;  // log2 radix of each in-LDS level, 2 bits per level: 3, 3, .., then 2 or 1
-    Fr w8_1, w8_2, w8_3;     // w_8, w_8^2 (= w_4), w_8^3 for the transform direction
 };
 
 PLONK_DEV Fr lds_ld(const u32x4* lo, const u32x4* hi, unsigned i) {
@@ -62,188 +58,8 @@ PLONK_DEV void lds_st(u32x4* lo, u32x4* hi, unsigned i, const Fr& a) {
     hi[i] = u32x4{a.v[4], a.v[5], a.v[6], a.v[7]};
 }
 
-// 8/4/2-point DFTs in registers (decimation in frequency), outputs in natural frequency order.
-PLONK_DEV void dft8(Fr x[8], const Fr& w1, const Fr& w2, const Fr& w3) {
-    Fr a0 = fp_add(x[0], x[4]), a1 = fp_add(x[1], x[5]), a2 = fp_add(x[2], x[6]), a3 = fp_add(x[3], x[7]);
-    Fr b0 = fp_sub(x[0], x[4]), b1 = fp_mul(fp_sub(x[1], x[5]), w1), b2 = fp_mul(fp_sub(x[2], x[6]), w2),
-       b3 = fp_mul(fp_sub(x[3], x[7]), w3);
-    Fr c0 = fp_add(a0, a2), c1 = fp_add(a1, a3), d0 = fp_sub(a0, a2), d1 = fp_mul(fp_sub(a1, a3), w2);
-    Fr e0 = fp_add(b0, b2), e1 = fp_add(b1, b3), f0 = fp_sub(b0, b2), f1 = fp_mul(fp_sub(b1, b3), w2);
-    x[0] = fp_add(c0, c1); x[4] = fp_sub(c0, c1); x[2] = fp_add(d0, d1); x[6] = fp_sub(d0, d1);
-    x[1] = fp_add(e0, e1); x[5] = fp_sub(e0, e1); x[3] = fp_add(f0, f1); x[7] = fp_sub(f0, f1);
-}
-PLONK_DEV void dft4(Fr x[4], const Fr& w2) {
-    Fr a0 = fp_add(x[0], x[2]), a1 = fp_add(x[1], x[3]), d0 = fp_sub(x[0], x[2]), d1 = fp_mul(fp_sub(x[1], x[3]), w2);
-    x[0] = fp_add(a0, a1); x[2] = fp_sub(a0, a1); x[1] = fp_add(d0, d1); x[3] = fp_sub(d0, d1);
-}
-PLONK_DEV void dft2(Fr x[2]) {
-    Fr s = fp_add(x[0], x[1]), d = fp_sub(x[0], x[1]);
-    x[0] = s; x[1] = d;
-}
-
-// One pass: each workgroup transforms a tile of C columns x R points held in LDS with the Stockham
-// auto-sort recurrence in radix-8 (then 4 / 2) register butterflies:
-//   level with sub-length n, stride s, radix rho, m = n/rho; group (p, q), p < m, q < s:
-//     inputs   x[q + s (p + j m)]         (= g + j R/rho for the flat group index g = p s + q)
-//     outputs  y[q + s (rho p + j')] = w_n^(p j') * DFT_rho(inputs)[j']
-// The first level reads its inputs straight from HBM, the last level writes straight to HBM, so a
-// 2^11-point transform makes 3 LDS round trips (11 in a radix-2 formulation) and ends in natural order.
-__global__ void __launch_bounds__(512) ntt_pass_stockham_kernel(NttPass p) {
-    PLONK_DYN_SMEM(smem);
-    const unsigned R = 1u << p.log_r, C = 1u << p.log_c;
-    const unsigned T = R * C;
-    // LDS index of tile element (i, c): column-interleaved for strided passes, padded rows for the
-    // row (last) pass so both the i-fastest and the c-fastest phases are conflict-free.
-    const unsigned row_pitch = p.last ? (R + (C > 1 ? 1 : 0)) : 0;
-    const unsigned t_pad = p.last ? row_pitch * C : T;
-    u32x4* d_lo = reinterpret_cast<u32x4*>(smem);
-    u32x4* d_hi = d_lo + t_pad;
-    u32x4* w_lo = d_hi + t_pad;
-    u32x4* w_hi = w_lo + (R / 2 ? R / 2 : 1);
-#define LIDX(i, c) (p.last ? ((c) * row_pitch + (i)) : (((i) << p.log_c) + (c)))
-
-    const unsigned tid = threadIdx.x, nthr = blockDim.x;
-    const Fr* in = p.in + (size_t)blockIdx.y * p.in_bstride;
-    Fr* out = p.out + (size_t)blockIdx.y * p.out_bstride;
-    const unsigned tile = blockIdx.x;
-
-    // tile coordinates
-    unsigned cb = 0, kb = 0, rest = 0, log_r1 = 0;
-    size_t base = 0;
-    if (!p.last) {
-        const unsigned log_tiles_per_hi = p.log_s - p.log_c;
-        const unsigned hi_idx = tile >> log_tiles_per_hi;
-        cb = tile & ((1u << log_tiles_per_hi) - 1);
-        base = ((size_t)hi_idx << (p.log_n - p.log_h)) + ((size_t)cb << p.log_c);
-    } else if (p.nprev) {
-        log_r1 = p.prev_log_r[0];
-        const unsigned log_kb = log_r1 - p.log_c;
-        kb = tile & ((1u << log_kb) - 1);
-        rest = tile >> log_kb;
-    }
-    unsigned rev_rest = 0;
-    if (p.last && p.nprev > 1) {
-        // rest = (k2, .., k_{P-1}) with k_{P-1} least significant; output weight of k_q is R1*..*R_{q-1}
-        unsigned rr = rest, weight = p.prev_log_r[0];
-        unsigned w_of[3] = {0, 0, 0};
-        for (unsigned q = 1; q < p.nprev; q++) { w_of[q] = weight; weight += p.prev_log_r[q]; }
-        for (int q = (int)p.nprev - 1; q >= 1; q--) {
-            unsigned kq = rr & ((1u << p.prev_log_r[q]) - 1);
-            rr >>= p.prev_log_r[q];
-            rev_rest += kq << w_of[q];
-        }
-    }
-
-    if (p.tw_in_lds) {
-        for (unsigned i = tid; i < R / 2; i += nthr) lds_st(w_lo, w_hi, i, fp_load(p.small_tw + i));
-    }
-
-    // global element index of tile position (i, c) on the input side
-    auto in_index = [&](unsigned i, unsigned c) PLONK_LAMBDA_INLINE -> size_t {
-        if (!p.last) return base + ((size_t)i << p.log_s) + c;
-        size_t row = p.nprev ? ((((size_t)(kb << p.log_c) + c) << (p.log_h - log_r1)) + rest) : 0;
-        return (row << p.log_r) + i;
-    };
-    auto load_in = [&](unsigned i, unsigned c) PLONK_LAMBDA_INLINE -> Fr {
-        const size_t g = in_index(i, c);
-        if (p.first && g >= p.in_len) return fp_zero<FrParams>();
-        Fr v = fp_load(in + g);
-        if (p.first && p.in_scale) v = fp_mul(v, fp_load(p.in_scale + g));
-        return v;
-    };
-    auto store_out = [&](unsigned k, unsigned c, Fr v) PLONK_LAMBDA_INLINE {
-        if (!p.last) {
-            const size_t jrest = ((size_t)cb << p.log_c) + c;
-            const size_t ex = (jrest * k) << p.log_h;  // < N
-            if (ex) {
-                Fr tw = fp_load(p.tw_lo + (ex & ((1u << NTT_TW_LO_LOG) - 1)));
-                if (p.log_n > NTT_TW_LO_LOG) tw = fp_mul(tw, fp_load(p.tw_hi + (ex >> NTT_TW_LO_LOG)));
-                v = fp_mul(v, tw);
-            }
-            fp_store(out + base + ((size_t)k << p.log_s) + c, v);
-        } else {
-            size_t o = p.nprev ? (((size_t)(kb << p.log_c) + c) + rev_rest + ((size_t)k << p.log_h)) : k;
-            if (p.out_scale) v = fp_mul(v, fp_load(p.out_scale + o));
-            if (p.has_out_scalar) v = fp_mul(v, p.out_scalar);
-            fp_store(out + o, v);
-        }
-    };
-    // w_R^e for any e (table holds e < R/2; w^(e + R/2) = -w^e)
-    auto twiddle = [&](unsigned e) PLONK_LAMBDA_INLINE -> Fr {
-        e &= R - 1;
-        const unsigned idx = e & (R / 2 - 1);
-        Fr t = p.tw_in_lds ? lds_ld(w_lo, w_hi, idx) : fp_load(p.small_tw + idx);
-        return (e & (R / 2)) ? fp_neg(t) : t;
-    };
-
-    if (p.n_levels == 0) {  // R == 1: a pure (scaled) copy
-        for (unsigned e = tid; e < T; e += nthr) store_out(0, e, load_in(0, e));
-        return;
-    }
-    if (p.tw_in_lds) __syncthreads();
-
-    const Fr w8_1 = p.w8_1, w8_2 = p.w8_2, w8_3 = p.w8_3;
-    unsigned log_nn = p.log_r;  // log2 of the current sub-transform length n
-    unsigned log_ss = 0;        // log2 of the current stride s
-    for (unsigned lev = 0; lev < p.n_levels; lev++) {
-        const unsigned lr = (p.level_radices >> (2 * lev)) & 3u, rho = 1u << lr;
-        const bool from_global = lev == 0, to_global = lev + 1 == p.n_levels;
-        const unsigned groups_per_col = R >> lr, n_groups = T >> lr;
-        const unsigned log_m = log_nn - lr;
-        // column-fastest thread order keeps HBM chunks and LDS rows contiguous; the row (last) pass
-        // walks i-fastest while it reads and c-fastest when it finally writes to HBM
-        const bool c_fastest = !p.last || to_global;
-        Fr x[8];
-        // A thread may own several groups per level (radix < 8, or tiny tiles); when the level reads
-        // LDS and writes LDS, all reads of the level must finish before any write: two sweeps.
-        const unsigned sweeps = (n_groups + nthr - 1) / nthr;
-        // (only the LAST level can have radix < 8, hence several sweeps, and it writes to HBM, so no
-        //  LDS->LDS level ever overwrites inputs another sweep still has to read)
-        for (unsigned sw = 0; sw < sweeps; sw++) {
-            const unsigned gid = sw * nthr + tid;
-            const bool active = gid < n_groups;
-            unsigned c = 0, g = 0;
-            if (active) {
-                if (c_fastest) { c = gid & (C - 1); g = gid >> p.log_c; }
-                else { g = gid & (groups_per_col - 1); c = gid >> (p.log_r - lr); }
-                wave_for<8>([&](auto J) {  // compile-time expansion: `#pragma unroll` gives up on bodies this large and x[] would move to scratch
-                    constexpr unsigned j = decltype(J)::value;
-                    if (j < rho) {
-                        const unsigned i = g + j * groups_per_col;
-                        x[j] = from_global ? load_in(i, c) : lds_ld(d_lo, d_hi, LIDX(i, c));
-                    }
-                });
-            }
-            if (!from_global) __syncthreads();  // every lane has its inputs in registers
-            if (active) {
-                if (lr == 3) dft8(x, w8_1, w8_2, w8_3);
-                else if (lr == 2) dft4(x, w8_2);
-                else dft2(x);
-                const unsigned pp = g >> log_ss, q = g & ((1u << log_ss) - 1);
-                const unsigned tw_scale = p.log_r - log_nn;  // w_n^(p j') = w_R^((p j') << tw_scale)
-                wave_for<8>([&](auto J) {
-                    constexpr unsigned j = decltype(J)::value;
-                    if (j < rho) {
-                        Fr v = x[j];
-                        if (j && pp) v = fp_mul(v, twiddle((pp * j) << tw_scale));
-                        const unsigned o = q + (((pp << lr) + j) << log_ss);
-                        if (to_global) store_out(o, c, v);
-                        else lds_st(d_lo, d_hi, LIDX(o, c), v);
-                    }
-                });
-            }
-            if (!to_global) __syncthreads();  // outputs visible before the next sweep / level reads
-        }
-        (void)log_m;
-        log_nn -= lr;
-        log_ss += lr;
-    }
-#undef LIDX
-}
-
 // ------------------------------------------------------------------------------------------------
-// Variant A: radix-2 Gentleman-Sande stages, one LDS round trip + barrier per stage, bit-reversed read
-// at the end.  Tiny register footprint (40 VGPRs, 8 waves/SIMD).  plonk_ntt_configure(kind = 1).
+// The LDS kernel: radix-2 Gentleman-Sande stages, two levels per LDS round trip, bit-reversed read at the end.
 PLONK_DEV unsigned bitrev(unsigned x, unsigned bits) { return bits ? (__brev(x) >> (32 - bits)) : 0; }
 
 __global__ void __launch_bounds__(1024) ntt_pass_radix2_kernel(NttPass p) {
@@ -722,40 +538,22 @@ int ntt_run(plonk_ctx* ctx, const Fr* in, Fr* out, unsigned log_n, bool inverse,
         for (unsigned q = 0; q < pi && q < 3; q++) p.prev_log_r[q] = radices[q];
 
         const unsigned R = 1u << p.log_r, C = 1u << p.log_c, T = R * C;
-        // in-LDS levels: radix 8 while three bits remain, then 4 or 2
-        p.n_levels = 0;
-        p.level_radices = 0;
-        for (unsigned bits = p.log_r; bits;) {
-            unsigned lr = bits >= 3 ? 3 : bits;
-            p.level_radices |= lr << (2 * p.n_levels++);
-            bits -= lr;
-        }
-        Fr w8 = host_root_of_unity(3, inverse);
-        p.w8_1 = w8;
-        p.w8_2 = fp_sqr(w8);
-        p.w8_3 = fp_mul(p.w8_2, w8);
-        const bool stockham = ctx->ntt_kind == 2 || ((ctx->ntt_kind == 0 || ctx->ntt_kind >= 3) && P == 1);
-        unsigned nthr = stockham ? T / 8 : T / 4;
+        unsigned nthr = T / 4;
         if (nthr < 64) nthr = 64;
-        if (nthr > (stockham ? 512u : 1024u)) nthr = stockham ? 512 : 1024;
+        if (nthr > 1024u) nthr = 1024;
         const unsigned row_pitch = last ? (R + (C > 1 ? 1 : 0)) : 0;
         const size_t t_pad = last ? (size_t)row_pitch * C : T;
         const size_t tw_bytes = 32 * (size_t)(R / 2 ? R / 2 : 1);
-        // keep two workgroups per CU when the tile allows it: twiddles go to LDS only if they fit in 80 KiB
-        p.tw_in_lds = !stockham || ((32 * t_pad + tw_bytes <= 80 * 1024 || 32 * t_pad > 80 * 1024) && (32 * t_pad + tw_bytes <= 160 * 1024));
-        const size_t shmem = 32 * t_pad + (p.tw_in_lds ? tw_bytes : 32);
+        const size_t shmem = 32 * t_pad + tw_bytes;
         const size_t tiles = N / T;
         if (!ctx->ntt_attr_set) {  // a per-device attribute: tracked per context, not per process
-            PLONK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ntt_pass_stockham_kernel),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
             PLONK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ntt_pass_radix2_kernel),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
             ctx->ntt_attr_set = true;
         }
         // algorithmic bytes of a size-N transform: 64 * N (read once, write once), split over its passes
         PLONK_TRY(prof_begin(ctx, "ntt_pass", 64.0 * (double)N * (double)batch / (double)P));
-        if (stockham) PLONK_LAUNCH(ntt_pass_stockham_kernel, dim3((unsigned)tiles, (unsigned)batch), dim3(nthr), shmem, ctx->stream, p);
-        else PLONK_LAUNCH(ntt_pass_radix2_kernel, dim3((unsigned)tiles, (unsigned)batch), dim3(nthr), shmem, ctx->stream, p);
+        PLONK_LAUNCH(ntt_pass_radix2_kernel, dim3((unsigned)tiles, (unsigned)batch), dim3(nthr), shmem, ctx->stream, p);
         PLONK_TRY(prof_end(ctx));
         PLONK_CHECK_HIP(hipGetLastError());
         log_h += p.log_r;

@@ -634,7 +634,7 @@ PLONK_DEV LinWeights linearisation_weights(const ProofState& s, unsigned log_n, 
 }
 
 // one lane per proof: the 15 weights (one field inversion each) are computed once, not once per tile
-__global__ void linearisation_weights_kernel(const ProofState* st, unsigned log_n, Fr n_inv, size_t B, LinWeights* out) {
+__global__ void __launch_bounds__(64) linearisation_weights_kernel(const ProofState* st, unsigned log_n, Fr n_inv, size_t B, LinWeights* out) {
     const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (b < B) out[b] = linearisation_weights(st[b], log_n, n_inv);
 }

@@ -14,7 +14,7 @@ import sys
 sys.path.insert(0, %r); sys.path.insert(0, %r)
 import parity_cases as pc
 from plonkathon_amd.kzg import Setup
-pc.ntt_vs_oracle((5, 9, 11, 12), seed0=41)          # Stockham, wave (limb form) and radix-2 multi-pass kernels
+pc.ntt_vs_oracle((5, 9, 11, 12), seed0=41)          # the LDS kernel (single pass), wave (limb form) and the LDS kernel's multi-pass plans
 pc.ntt_extreme_inputs((9,))
 setup = Setup.from_file(pc.PTAU)
 pc.msm_vs_oracle(setup, 64, seed=7, batch=3)         # lookup-table MSM (tiny table budget) incl. its LDS tree
