@@ -830,8 +830,36 @@ def main():
             line["config"]["poseidon_2^%d_proofs_s" % (n_p.bit_length() - 1)] = round(PB / dt, 1)
             line["config"]["poseidon_2^%d_proof_0_matches_fixture" % (n_p.bit_length() - 1)] = cfg["poseidon_group_order_%d" % n_p]["proof_0_bit_identical_to_fixture"]
             del pr
+            if n_p == 2048 and NS > 1:
+                # the same circuit the way the headline runs: one lock-step batch of distinct witnesses per stream, all streams busy
+                t0 = time.perf_counter()
+                more = [prog.fill_variable_assignments({"L0": 1 + i, "M0": 2 + i}) for i in range(PB, NS * PB)]
+                t_wit += time.perf_counter() - t0
+                allw = wits + more
+                prs = [BatchProver(setup, prog, c) for c in ctxs]
+                for k, q in enumerate(prs):
+                    q.upload(allw[k * PB:(k + 1) * PB])
+
+                def multi():
+                    for q in prs:
+                        q.run()
+                    return [q.download_raw() for q in prs]
+
+                for _ in range(2):
+                    multi()
+                barrier()
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    outs = multi()
+                dtm = (time.perf_counter() - t0) / reps
+                assert not any(any(st) for _, st in outs)
+                cfg["poseidon_group_order_2048_all_streams"] = {"proofs_per_s": NS * PB / dtm, "ms_per_step": 1e3 * dtm, "streams": NS, "proofs_per_step": NS * PB,
+                                                                "witness_generation_ms_per_proof": 1e3 * t_wit / (NS * PB)}
+                line["config"]["poseidon_2^11_proofs_s_%d_streams" % NS] = round(NS * PB / dtm, 1)
+                del prs
         line["configs"] = {"configs[2]": cfg,
-                           "note": "one stream, one lock-step batch resident (the headline runs 20 batches on 4 streams); fixture = "
+                           "note": "one stream, one lock-step batch resident (the headline runs 20 batches on 4 streams), and — "
+                                   "`_all_streams`, group_order 2^11 — one batch per stream of the headline's configuration; fixture = "
                                    "tests/golden/oracle_proofs.json"}
 
     if not args.no_latency and world == 1:
