@@ -44,6 +44,9 @@ for step in "$@"; do
       kv=${arg%% *}; rest=${arg#* }
       env "$kv" timeout 600 python bench.py $rest > "$out/bench_$kv.json" 2> "$out/bench_$kv.err"; echo "bench $kv rc=$?"; cut -c1-200 "$out/bench_$kv.json"; echo ;;
     latency) timeout 600 python tools/latency.py $arg > "$out/latency.json" 2> "$out/latency.err"; echo "rc=$?"; cat "$out/latency.json" ;;
+    lat_trace)   # kernel trace of batches of one through the lock-step prover: where a single proof's 1.9 ms go
+      ( cd /tmp && LATENCY_ONLY=b1 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/$out/lat_trace" -o t -- python "$OLDPWD/tools/latency.py" 11 20 > "$OLDPWD/$out/lat_trace.log" 2> "$OLDPWD/$out/lat_trace.err" ); echo "lat_trace rc=$?"; cat "$out/lat_trace.log"
+      find "$out/lat_trace" -name "*kernel_stats.csv" | head -1 | xargs -r head -40 ;;
     ubench) for b in tools/ubench/*.bin; do timeout 120 "$b" > "$out/$(basename $b .bin).json" 2>&1; done ;;
     *) echo "unknown step $name" ;;
   esac

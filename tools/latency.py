@@ -34,6 +34,10 @@ def timed(fn):
 
 assert n == bench.GROUP_ORDER
 wits = [bench.witness_for(i) for i in range(3)]
+if os.environ.get("LATENCY_ONLY") == "b1":  # for a kernel trace: nothing but batches of one through the lock-step prover
+    bp = BatchProver(setup, program)
+    print(json.dumps(dict(out, batch_prover_b1=timed(lambda: bp.prove(dict(wits[0]))))))
+    sys.exit(0)
 api = Prover(setup, program)
 k = [0]
 
