@@ -89,7 +89,9 @@ int plonk_ntt_configure(plonk_ctx* ctx, unsigned tile_log, unsigned single_pass_
  * below 2^7 and above 2^26), 1 = the LDS kernel at every size, 4 = the same (A/B runs; it used to choose among two LDS
  * kernels), 5 = the wave kernels wherever they apply, whatever plonk_ntt_configure says; 6 / 7 = as 5, but never / always
  * on the two-element "latency" forms (2^9, and the splits of 2^14 .. 2^18 built on 2^7 and 2^9) that 0 and 5 pick for
- * calls of at most 2^18 elements.  (2, the Stockham LDS kernel, and 3 are retired.) */
+ * calls of at most 2^18 elements; 8 = as 5, with 2^12 on its 1024-thread, 4-element form instead of 512 threads x 8
+ * elements (which 0 and 5 use wherever 2^12 is not a column pass on the one-table inter-pass twiddles).
+ * (2, the Stockham LDS kernel, and 3 are retired.) */
 int plonk_ntt_select_kernel(plonk_ctx* ctx, unsigned kind);
 /* two-pass wave transforms N = R1 R2 (R1-point column transforms, then R2-point row transforms): log2 R1 for one
  * log2 N in [16, 26]; 0 = the default (as square as possible).  Both factors must lie in 2^8 .. 2^13.  A/B runs, tests. */

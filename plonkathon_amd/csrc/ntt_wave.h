@@ -19,6 +19,9 @@
 //   E = 8: N = 2^9, 2^11, 2^13   radix 8, L x radix 4, radix 8, radix 8     (3 waves per SIMD; 4 at 1024 threads)
 //   E = 4: N = 2^8, 2^10, 2^12   radix 4, L x radix 4, 3 x radix 4          (half the registers: 4+ waves per SIMD, and
 //                                 twice the workgroups for a lone transform — round 3)
+//   E = 8, 512 threads: N = 2^12  radix 8, ONE radix-8 stage on the three wave bits, radix 8, radix 8 (round 4; template argument
+//                                 NLDS = 3).  The 1024-thread kernels leave one workgroup per CU — nothing fills the ALUs while its
+//                                 sixteen waves exchange through LDS; this form fits two (72 KiB of LDS, 128 registers)
 //   E = 2: N = 2^7, 2^9          radix 2 throughout (round 4): the LATENCY kernels.  A lone small transform is bound by the
 //                                 dependent instruction chain of ONE wave (a 2^8 transform at E = 4 is ~5 500 instructions per
 //                                 lane: 12-14 us by rocprofv3, with 3 of every 4 SIMDs idle at 2^16); two elements per lane cut
@@ -141,17 +144,25 @@ PLONK_HD constexpr unsigned wavel_log_e(unsigned log_r, bool latency = false) {
 //   twiddled stages: A (digit in the registers at load), the L wave-bit stages, the lane stages except the last
 //   E = 2: every stage but the last is twiddled, stage s on the 2^(6 + 2L - s) values of the thread bits below the one it
 //   will trade next: blocks of NT, NT / 2, .., 2 entries, factor w^(low 2^s)
-PLONK_HD constexpr unsigned wavel_tw_stages(unsigned log_e, unsigned nlds) { return log_e == 1 ? 6 + 2 * nlds : 1 + nlds + (log_e == 3 ? 1 : 2); }
+// thread-index bits above the lane: two per radix-4 LDS stage; nlds = 3 names the 512-thread form with ONE radix-8 stage on three
+PLONK_HD constexpr unsigned wavel_log_t(unsigned nlds) { return 6 + (nlds == 3 ? 3u : 2u * nlds); }
+// the nlds of the kernel that serves 2^log_r with 2^log_e elements per thread
+PLONK_HD constexpr unsigned wavel_nlds(unsigned log_r, unsigned log_e) { return (log_r == 12 && log_e == 3) ? 3u : (log_r - 6 - log_e) / 2; }
+PLONK_HD constexpr unsigned wavel_tw_stages(unsigned log_e, unsigned nlds) {
+    return log_e == 1 ? 6 + 2 * nlds : (nlds == 3 ? 3u : 1 + nlds + (log_e == 3 ? 1 : 2));
+}
 PLONK_HD constexpr unsigned wavel_tw_nb(unsigned log_e, unsigned nlds, unsigned s) {  // distinct values of `low` in stage s
+    if (nlds == 3) return s == 0 ? 512u : (s == 1 ? 64u : 8u);
     if (log_e == 1) return 1u << (6 + 2 * nlds - s);
     if (s == 0) return 64u << (2 * nlds);
     if (s <= nlds) return 1u << (6 + 2 * (nlds - s));
     return log_e == 3 ? 8u : (s == nlds + 1 ? 16u : 4u);
 }
 PLONK_HD constexpr unsigned wavel_tw_count(unsigned log_e, unsigned nlds, unsigned s) {  // factors f = 1 .. count
-    return log_e == 1 ? 1u : ((s >= 1 && s <= nlds) ? 3u : (1u << log_e) - 1);
+    return log_e == 1 ? 1u : ((nlds != 3 && s >= 1 && s <= nlds) ? 3u : (1u << log_e) - 1);
 }
 PLONK_HD constexpr unsigned wavel_tw_mult(unsigned log_e, unsigned nlds, unsigned s) {  // N / S of stage s
+    if (nlds == 3) return s == 0 ? 1u : (s == 1 ? 8u : 64u);
     const unsigned log_n = log_e + 6 + 2 * nlds;
     if (log_e == 1) return 1u << s;
     if (s == 0) return 1;
@@ -192,7 +203,7 @@ template <class P> PLONK_DEV FpLS<P> wavel_ld_root_planar(const int32_t* block, 
 // factor) is range-reduced instead
 template <unsigned LOG_E, unsigned NLDS, unsigned STAGE, unsigned BASE, unsigned COUNT, unsigned E, class P>
 PLONK_DEV void wavel_twiddle(FpL<P> (&x)[E], unsigned low, const int32_t* roots, const int32_t* jm) {
-    constexpr unsigned LOG_N = LOG_E + 6 + 2 * NLDS, NB = wavel_tw_nb(LOG_E, NLDS, STAGE);
+    constexpr unsigned LOG_N = LOG_E + wavel_log_t(NLDS), NB = wavel_tw_nb(LOG_E, NLDS, STAGE);
     static_assert(COUNT - 1 == wavel_tw_count(LOG_E, NLDS, STAGE), "twiddle layout");
     const int32_t* blocks = roots + (size_t)wavel_tw_offset(LOG_E, NLDS, STAGE) * NTT_SHOUP_STRIDE;
     constexpr bool TIGHT_MUL = LOG_E == 3 && WAVEL_TIGHT_LOG_N(LOG_N);
@@ -289,7 +300,7 @@ template <class T> PLONK_DEV T* wavel_at(T* base, unsigned g) { return reinterpr
 // waves per SIMD the register allocation aims at: 1024-thread workgroups must fit 128 VGPRs (4); the E = 8 forms run
 // faster without spills at 3 (measured in round 2: 18.1 vs 16.8 G elements/s at 2^11 x 2048); E = 4 fits 4 without spills
 template <unsigned LOG_E, unsigned NLDS> struct WavelCfg {
-    static constexpr unsigned E = 1u << LOG_E, LOG_N = LOG_E + 6 + 2 * NLDS, NT = 64u << (2 * NLDS);
+    static constexpr unsigned E = 1u << LOG_E, LOG_N = LOG_E + wavel_log_t(NLDS), NT = 1u << wavel_log_t(NLDS);
     // TIGHT: the kernel is compiled for 128 VGPRs with the register-saving measures of the 1024-thread kernel (opaque
     // threadIdx re-reads per stage, scheduling fences around the twiddle multiplications)
 #ifdef PLONK_NTT_W11_3  // A/B: the 256-thread E = 8 kernel at 3 waves per SIMD (158 VGPRs), as in round 2
@@ -305,7 +316,7 @@ template <unsigned LOG_E, unsigned NLDS> struct WavelCfg {
 // — a kernel of its own, for E = 4 only: the E = 8 kernels sit at 128 registers and any change to this epilogue spills
 template <class P, unsigned LOG_E, unsigned NLDS, bool FULL = false>
 PLONK_DEV void wavel_transform(const NttWaveT<P>& p, unsigned char* smem) {
-    constexpr unsigned E = 1u << LOG_E, LOG_N = LOG_E + 6 + 2 * NLDS, NT = 64u << (2 * NLDS), LOG_T = 6 + 2 * NLDS;
+    constexpr unsigned E = 1u << LOG_E, LOG_T = wavel_log_t(NLDS), LOG_N = LOG_E + LOG_T, NT = 1u << LOG_T;
     constexpr unsigned LSLOTS = E >= 4 ? 4 : 1;    // elements per thread and exchange round
     u32x4* l_lo = reinterpret_cast<u32x4*>(smem);  // LSLOTS * NT elements as two 16-byte planes and one 4-byte plane
     u32x4* l_hi = l_lo + LSLOTS * NT;
@@ -373,8 +384,42 @@ PLONK_DEV void wavel_transform(const NttWaveT<P>& p, unsigned char* smem) {
         // stage A: digit = the top LOG_E index bits, low = tid0
         wavel_dft<E>(x, w8_1, w8_2, w8_3);
         wavel_twiddle<LOG_E, NLDS, 0, 0, E>(x, tid0, p.roots, jm);
+        if constexpr (NLDS == 3) {
+            // ONE radix-8 stage on the three wave bits: register bits (1, 0) <-> thread bits (7, 6) in two rounds of four elements
+            // (the radix-4 stages' exchange), then register bit 2 <-> thread bit 8 in a third: a thread keeps four elements and
+            // trades four with thread tid ^ 256
+            const unsigned tid = wavel_tid<true>();
+            const unsigned mine = (tid >> 6) & 3u, rest = tid & ~(3u << 6);
+            wave_for<2>([&](auto R2) {
+                constexpr unsigned r2 = decltype(R2)::value;
+                wave_for<4>([&](auto Q) { wavel_lds_st(l_lo, l_hi, l_top, decltype(Q)::value * NT + tid, x[4 * r2 + decltype(Q)::value]); });
+                __syncthreads();
+                wave_for<4>([&](auto Q) { x[4 * r2 + decltype(Q)::value] = wavel_lds_ld<P>(l_lo, l_hi, l_top, mine * NT + (rest | (decltype(Q)::value << 6))); });
+                __syncthreads();
+            });
+            const bool hi = (tid >> 8) & 1u;  // keeps x[4 .. 7], gives x[0 .. 3]; the others keep x[0 .. 3], give x[4 .. 7]
+            wave_for<4>([&](auto Q) {
+                constexpr unsigned q = decltype(Q)::value;
+                FpL<P> give;
+                wave_for<9>([&](auto W) { give.l[decltype(W)::value] = hi ? x[q].l[decltype(W)::value] : x[q + 4].l[decltype(W)::value]; });
+                wavel_lds_st(l_lo, l_hi, l_top, q * NT + tid, give);
+            });
+            __syncthreads();
+            wave_for<4>([&](auto Q) {
+                constexpr unsigned q = decltype(Q)::value;
+                const FpL<P> got = wavel_lds_ld<P>(l_lo, l_hi, l_top, q * NT + (tid ^ 256u));
+                wave_for<9>([&](auto W) {
+                    constexpr unsigned i = decltype(W)::value;
+                    x[q].l[i] = hi ? got.l[i] : x[q].l[i];
+                    x[q + 4].l[i] = hi ? x[q + 4].l[i] : got.l[i];
+                });
+            });
+            __syncthreads();
+            dft8l(x, w8_1, w8_2, w8_3);
+            wavel_twiddle<LOG_E, NLDS, 1, 0, 8>(x, tid & 63u, p.roots, jm);
+        }
         // L radix-4 stages on the wave bits: swap register bits (1, 0) with thread bits (tb + 1, tb)
-        wave_for<NLDS>([&](auto S) {
+        wave_for<(NLDS == 3 ? 0u : NLDS)>([&](auto S) {
             constexpr unsigned s = decltype(S)::value;
             constexpr unsigned tb = 6 + 2 * (NLDS - 1 - s);
             const unsigned tid = wavel_tid<WavelCfg<LOG_E, NLDS>::TIGHT>();
@@ -400,7 +445,7 @@ PLONK_DEV void wavel_transform(const NttWaveT<P>& p, unsigned char* smem) {
             wavel_swap_bit<E, 1, 16>(x, lane);
             wavel_swap_bit<E, 0, 8>(x, lane);
             dft8l(x, w8_1, w8_2, w8_3);
-            wavel_twiddle<LOG_E, NLDS, NLDS + 1, 0, 8>(x, lane & 7u, p.roots, jm);
+            wavel_twiddle<LOG_E, NLDS, (NLDS == 3 ? 2u : NLDS + 1), 0, 8>(x, lane & 7u, p.roots, jm);
             // stage on lane bits 2..0
             wavel_swap_bit<E, 2, 4>(x, lane);
             wavel_swap_bit<E, 1, 2>(x, lane);
@@ -434,7 +479,10 @@ PLONK_DEV void wavel_transform(const NttWaveT<P>& p, unsigned char* smem) {
         //   d_A = (lane bit 5) * 4 + thread bits (top pair);  then the remaining wave pairs;  (lane bits 4, 3);  (lane bits 2..0);  j
         //   (without wave stages the first digit is simply lane bits 5..3)
         shift = 3;
-        if (NLDS) {
+        if (NLDS == 3) {  // d_A = thread bits (8, 7, 6); then (lane bits 5..3); (lane bits 2..0); j
+            k = ((tid >> 6) & 7u) | (((lane >> 3) & 7u) << 3);
+            shift = 6;
+        } else if (NLDS) {
             k = (((lane >> 5) & 1u) << 2) | ((tid >> (6 + 2 * (NLDS > 0 ? NLDS - 1 : 0))) & 3u);
             for (unsigned s = 1; s < NLDS; s++) {
                 k |= ((tid >> (6 + 2 * (NLDS - 1 - s))) & 3u) << shift;
@@ -467,7 +515,9 @@ PLONK_DEV void wavel_transform(const NttWaveT<P>& p, unsigned char* smem) {
             constexpr unsigned j = decltype(J)::value;
             const unsigned e = (sub + p.sub_base) * (k | (j << shift));  // < N
             if (e || p.tw_always) {  // two multiplications by table constants (380 instructions) instead of forming their product first (434)
-                x[j] = fpl_mul_shoup(x[j], wavel_ld_root<P>(p.tw_lo, e & ((1u << NTT_TW_LO_LOG) - 1)));
+                // (the 512-thread kernel is never a column pass — wave_launch_as refuses — and keeps only the second factor here: with
+                // both it spills 7 registers, without the section 35; the allocation it gets this way has none)
+                if constexpr (NLDS != 3) x[j] = fpl_mul_shoup(x[j], wavel_ld_root<P>(p.tw_lo, e & ((1u << NTT_TW_LO_LOG) - 1)));
                 if (p.log_n > NTT_TW_LO_LOG) x[j] = fpl_mul_shoup(x[j], wavel_ld_root<P>(p.tw_hi, e >> NTT_TW_LO_LOG));
             }
         });
@@ -493,7 +543,7 @@ PLONK_DEV void wavel_transform(const NttWaveT<P>& p, unsigned char* smem) {
 }
 
 template <class P, unsigned LOG_E, unsigned NLDS>
-__global__ void __launch_bounds__(64u << (2 * NLDS), (WavelCfg<LOG_E, NLDS>::WAVES)) ntt_wavel_kernel(NttWaveT<P> p) {
+__global__ void __launch_bounds__(1u << wavel_log_t(NLDS), (WavelCfg<LOG_E, NLDS>::WAVES)) ntt_wavel_kernel(NttWaveT<P> p) {
     PLONK_DYN_SMEM(smem);
     wavel_transform<P, LOG_E, NLDS>(p, smem);
 }
@@ -501,7 +551,7 @@ __global__ void __launch_bounds__(64u << (2 * NLDS), (WavelCfg<LOG_E, NLDS>::WAV
 // SIMD — 132-135 registers, no scratch — they were measured: batches gain 4-5 %, but a lone 2^21 loses 8 % and a lone 2^24
 // 8 %, profiles/r03_q_ntt_e8_column_table_ab.jsonl)
 template <class P, unsigned LOG_E, unsigned NLDS>
-__global__ void __launch_bounds__(64u << (2 * NLDS), (WavelCfg<LOG_E, NLDS>::WAVES)) ntt_wavel_column_kernel(NttWaveT<P> p) {
+__global__ void __launch_bounds__(1u << wavel_log_t(NLDS), (WavelCfg<LOG_E, NLDS>::WAVES)) ntt_wavel_column_kernel(NttWaveT<P> p) {
     PLONK_DYN_SMEM(smem);
     wavel_transform<P, LOG_E, NLDS, true>(p, smem);
 }
@@ -556,14 +606,17 @@ template <class P> __global__ void ntt_program_block_kernel(const Fp<P>* roots, 
 // frequency (without the register digit) of thread tid's outputs and the bit position of the register digit: the
 // run-time restatement of the index arithmetic at the end of wavel_transform (the parity tests compare both paths)
 PLONK_HD unsigned wavel_freq(unsigned log_e, unsigned nlds, unsigned tid, unsigned* shift_out) {
-    const unsigned lane = tid & 63u, log_t = 6 + 2 * nlds;
+    const unsigned lane = tid & 63u, log_t = wavel_log_t(nlds);
     unsigned k = 0, shift;
     if (log_e == 1) {
         for (unsigned i = 0; i < log_t; i++) k |= ((tid >> (log_t - 1 - i)) & 1u) << i;
         shift = log_t;
     } else if (log_e == 3) {
         shift = 3;
-        if (nlds) {
+        if (nlds == 3) {
+            k = ((tid >> 6) & 7u) | (((lane >> 3) & 7u) << 3);
+            shift = 6;
+        } else if (nlds) {
             k = (((lane >> 5) & 1u) << 2) | ((tid >> (6 + 2 * (nlds - 1))) & 3u);
             for (unsigned s = 1; s < nlds; s++) {
                 k |= ((tid >> (6 + 2 * (nlds - 1 - s))) & 3u) << shift;
@@ -590,7 +643,7 @@ __global__ void ntt_interpass_table_kernel(const Fp<P>* lo, const Fp<P>* hi, Fp<
                                            Ninv261 ninv) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >> log_n) return;
-    const unsigned nlds = (log_r1 - 6 - log_e) / 2, log_t = 6 + 2 * nlds;
+    const unsigned nlds = wavel_nlds(log_r1, log_e), log_t = wavel_log_t(nlds);
     const unsigned tid = (unsigned)i & ((1u << log_t) - 1), j = (unsigned)(i >> log_t) & ((1u << log_e) - 1), c = (unsigned)(i >> log_r1);
     unsigned shift;
     const unsigned k1 = wavel_freq(log_e, nlds, tid, &shift) | (j << shift);

@@ -9,6 +9,7 @@
 //   static WaveTables& tables(plonk_ctx*)                     this field's table cache of the context
 // ntt.hip instantiates it for BN254 Fr (the prover's field), ntt_bls.hip for BLS12-381 Fr (standalone transform).
 #pragma once
+#include <stdlib.h>
 #include <string.h>
 
 #include "ntt_wave.h"
@@ -45,7 +46,7 @@ template <class F> static int wave_program_table(plonk_ctx* ctx, unsigned log_n,
     if (it == T.prog.end()) {
         const Fp<P>* packed;
         PLONK_TRY(F::packed_roots(ctx, log_n, inverse, &packed));
-        const unsigned nlds = (log_n - 6 - log_e) / 2, stages = wavel_tw_stages(log_e, nlds);
+        const unsigned nlds = wavel_nlds(log_n, log_e), stages = wavel_tw_stages(log_e, nlds);
         const size_t entries = wavel_tw_offset(log_e, nlds, stages);
         void* d = nullptr;
         if (hipMalloc(&d, entries * NTT_SHOUP_STRIDE * sizeof(int32_t)) != hipSuccess) {
@@ -165,13 +166,19 @@ template <class F> static void wave_params_init(NttWaveT<typename F::P>* p, unsi
 
 template <class F, unsigned LOG_E, unsigned NLDS> static int wave_launch_as(plonk_ctx* ctx, const NttWaveT<typename F::P>& q, unsigned grid_x, unsigned grid_y) {
     typedef typename F::P P;
-    constexpr unsigned nt = 64u << (2 * NLDS);
+    constexpr unsigned nt = 1u << wavel_log_t(NLDS);
     const size_t shmem = NLDS ? (size_t)(LOG_E >= 2 ? 4 : 1) * nt * 36 : 0;  // one round of the wave-bit exchange: 4 elements (E = 2: one) of 9 words per thread
     WaveTables& T = F::tables(ctx);
     if (NLDS == 2 && LOG_E >= 2 && !T.attr_set[LOG_E >= 2 ? LOG_E - 2 : 0]) {  // 144 KiB: above the default limit; a per-device attribute, tracked per context
         PLONK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ntt_wavel_kernel<P, LOG_E, NLDS>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)(144 * 1024)));
         T.attr_set[LOG_E - 2] = true;
+    }
+    PLONK_REQUIRE(NLDS != 3 || q.mode != 1, PLONK_ERR_STATE, "the 512-thread 2^12 kernel cannot run a column pass");
+    if (NLDS == 3 && !T.attr_set[3]) {  // the 512-thread 2^12 kernel: 72 KiB
+        PLONK_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ntt_wavel_kernel<P, LOG_E, NLDS>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)(72 * 1024)));
+        T.attr_set[3] = true;
     }
     void (*kern)(NttWaveT<P>) = ntt_wavel_kernel<P, LOG_E, NLDS>;  // (a template-id's comma would split the macro's arguments)
     if constexpr (LOG_E <= 2) {
@@ -187,7 +194,7 @@ template <class F, unsigned LOG_E, unsigned NLDS> static int wave_launch_as(plon
     return PLONK_OK;
 }
 
-// log_r = 8, 10, 12: 4 elements per thread; 9, 11, 13: 8 elements per thread; 7, and 9 in its latency form: 2
+// log_r = 8, 10, 12: 4 elements per thread; 9, 11, 13 (and 12 in its 512-thread form): 8; 7, and 9 in its latency form: 2
 template <class F> static int wave_launch(plonk_ctx* ctx, const NttWaveT<typename F::P>& p, unsigned log_r, unsigned log_e, unsigned grid_x, unsigned grid_y) {
     NttWaveT<typename F::P> q = p;
     if (!q.jm) PLONK_TRY(wave_jm<F>(ctx, &q.jm));  // (wave_run's cached plans carry it)
@@ -198,6 +205,7 @@ template <class F> static int wave_launch(plonk_ctx* ctx, const NttWaveT<typenam
         case 9 | (3 << 8): return wave_launch_as<F, 3, 0>(ctx, q, grid_x, grid_y);
         case 11 | (3 << 8): return wave_launch_as<F, 3, 1>(ctx, q, grid_x, grid_y);
         case 13 | (3 << 8): return wave_launch_as<F, 3, 2>(ctx, q, grid_x, grid_y);
+        case 12 | (3 << 8): return wave_launch_as<F, 3, 3>(ctx, q, grid_x, grid_y);  // 512 threads x 8 elements
         case 7 | (1 << 8): return wave_launch_as<F, 1, 0>(ctx, q, grid_x, grid_y);
         case 9 | (1 << 8): return wave_launch_as<F, 1, 1>(ctx, q, grid_x, grid_y);
     }
@@ -210,6 +218,15 @@ template <class F> static int wave_launch(plonk_ctx* ctx, const NttWaveT<typenam
 // call of a (size, direction, scaling, table choice) and cached per context and field: the host-side field arithmetic —
 // a root of unity by repeated squaring, a 261-bit Hensel lift, a modular inversion, ~20 us in all — used to run on EVERY
 // call, and a lone 2^16 transform is ~10 us of device time (0.031 ms measured).
+// PLONK_NTT_W12 = 4: keep 2^12 on the 1024-thread 4-element kernel everywhere (A/B runs)
+static inline bool wave_w12_as_512x8() {
+    static const bool on = [] {
+        const char* e = getenv("PLONK_NTT_W12");
+        return !(e && atoi(e) == 4);
+    }();
+    return on;
+}
+
 template <class P> struct WavePlan {
     unsigned log_r1 = 0, log_r2 = 0;
     unsigned log_e1 = 0, log_e2 = 0;  // elements per thread (log2) of the kernels of the two passes (log_e1 alone for a single pass)
@@ -237,7 +254,11 @@ static int wave_plan_get(plonk_ctx* ctx, unsigned log_n, bool inverse, bool scal
     PLONK_REQUIRE(ntt_wave_plan(ctx, log_n, latency, &log_r1, &log_r2), PLONK_ERR_ARG, "no wave-kernel plan for 2^%u points", log_n);
     plan->log_r1 = log_r1;
     plan->log_r2 = log_r2;
-    const unsigned log_e1 = plan->log_e1 = wavel_log_e(log_r1, latency), log_e2 = plan->log_e2 = log_r2 ? wavel_log_e(log_r2, latency) : 0;
+    // 2^12 runs as 512 threads x 8 elements (two workgroups per CU) as a single pass and as a row pass; a column pass stays on the
+    // 1024-thread 4-element kernel (the one-table inter-pass twiddles need its register room; ntt_wave.h)
+    const bool w12 = wave_w12_as_512x8() && ctx->ntt_kind != 8;  // (kind 8: 2^12 on the 1024-thread form everywhere — tests, A/B)
+    const unsigned log_e1 = plan->log_e1 = (log_r1 == 12 && w12 && !log_r2) ? 3u : wavel_log_e(log_r1, latency);
+    const unsigned log_e2 = plan->log_e2 = !log_r2 ? 0u : ((log_r2 == 12 && w12) ? 3u : wavel_log_e(log_r2, latency));
     NttWaveT<P> p;
     wave_params_init<F>(&p, log_n, inverse);
     PLONK_TRY(wave_jm<F>(ctx, &p.jm));

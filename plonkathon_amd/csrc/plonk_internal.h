@@ -51,7 +51,7 @@ struct WaveTables {
     std::map<unsigned, int32_t*> prog, lo, hi;  // keys: log2(size) | inverse << 8 (| 512: hi scaled by 1/N)
     std::map<unsigned, int32_t*> interpass;     // full inter-pass tables: log2 N | inverse << 8 | scaled << 9 | log2 R1 << 12
     const int32_t* jm = nullptr;                // fpl_reduce_small's multiples of the modulus
-    bool attr_set[3] = {false, false, false};   // hipFuncSetAttribute is per device: tracked per context (E = 4, E = 8, E = 4 column kernel)
+    bool attr_set[4] = {false, false, false, false};   // hipFuncSetAttribute is per device: tracked per context (E = 4, E = 8, E = 4 column kernel, the 512-thread 2^12 kernel)
     std::map<unsigned, void*> packed[3];        // packed source tables (full, lo, hi) of a field that has no cache of its own (BLS12-381 Fr)
     std::map<unsigned, std::shared_ptr<void>> plans;  // WavePlan<P> per (log2 N | inverse << 8 | 1/N << 9 | full table << 10): ntt_wave_host.h
     unsigned plan_epoch = 0;                    // plonk_ctx::ntt_cfg_epoch the plans were built under
@@ -127,7 +127,7 @@ struct plonk_ctx {
     size_t ntt_table_budget = (size_t)4 << 30, ntt_tables_bytes = 0;  // full inter-pass twiddle tables (80 B per point and direction): plonk_ntt_set_table_budget
     unsigned char ntt_split[32] = {0};  // plonk_ntt_set_split: log2 R1 of the two-pass wave plan per log2 N (0 = default)
     unsigned ntt_cfg_epoch = 0;  // bumped by every plonk_ntt_* setter: cached launch plans are rebuilt
-    unsigned ntt_kind = 0;  // 0 = auto (wave kernels where they apply, else the LDS kernel), 1 / 4 = the LDS kernel, 5 = force wave, 6 / 7 = force wave without / with the two-element latency forms
+    unsigned ntt_kind = 0;  // 0 = auto (wave kernels where they apply, else the LDS kernel), 1 / 4 = the LDS kernel, 5 = force wave, 6 / 7 = force wave without / with the two-element latency forms, 8 = force wave with 2^12 on 1024 threads
 };
 
 // scratch slot use: 0 = NTT inter-pass buffer, 1 = MSM digits/partials, 2-3 = API-level temporaries

@@ -32,10 +32,12 @@ def test_ntt_forced_variants(emu):
 
     ctx = get_context()
     try:
-        for kind in (1, 6, 7):  # (6 / 7: the wave kernels without / with their two-element latency forms)
+        for kind in (1, 6, 7, 8):  # (6 / 7: the wave kernels without / with their two-element latency forms; 8: 2^12 on 1024 threads)
             check(ctx.L.plonk_ntt_select_kernel(ctx.handle, kind))
             check(ctx.L.plonk_ntt_configure(ctx.handle, 0, 0, 0))
-            pc.ntt_vs_oracle([0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13], seed0=10 * kind)
+            pc.ntt_vs_oracle([0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13] if kind != 8 else [12], seed0=10 * kind)
+            if kind == 8:
+                continue
             check(ctx.L.plonk_ntt_configure(ctx.handle, 6, 4, 4))
             pc.ntt_vs_oracle((9, 11, 12), seed0=600 + kind)
     finally:
@@ -50,7 +52,11 @@ def test_ntt_properties(emu):
 def test_ntt_extreme_inputs(emu):
     with pc.ntt_kind(6):  # the four- and eight-element kernels (a lone 2^9 would otherwise take its two-element form)
         pc.ntt_extreme_inputs((8, 9, 10, 11, 12, 13))
-        pc.ntt_extreme_limbs((8, 9, 10, 11, 12))
+        pc.ntt_extreme_limbs((8, 9, 10, 11))
+        pc.ntt_extreme_limbs((12,), slots=8)  # 2^12 = 512 threads x 8 elements
+    with pc.ntt_kind(8):  # ... and its 1024-thread, 4-element form (the column-pass kernel of 2^24 = 2^12 x 2^12)
+        pc.ntt_extreme_inputs((12,))
+        pc.ntt_extreme_limbs((12,))
 
 
 def test_ntt_latency_forms(emu):
@@ -64,6 +70,8 @@ def test_bls12_381_ntt(emu):
         pc.bls_ntt_vs_oracle((12, 13), seed0=77)
     with pc.ntt_kind(7):
         pc.bls_ntt_vs_oracle((7, 9), seed0=177, batch=2)
+    with pc.ntt_kind(8):
+        pc.bls_ntt_vs_oracle((12,), seed0=277)
 
 
 def test_poly_golden(emu):
@@ -248,8 +256,12 @@ def test_ntt_two_pass_wave_kernel(emu):
         v = pc.rand_vec(4018, 1 << 18)
         assert pc.ints(pc.P(v, Basis.MONOMIAL).fft()) == c_oracle.fr_ntt(v)
         assert ctx.L.plonk_ntt_set_split(ctx.handle, 18, 14) != 0 and ctx.L.plonk_ntt_set_split(ctx.handle, 15, 9) != 0
+        # 2^12 as a ROW pass: the 512-thread, 8-element kernel (2^19 = 2^7 x 2^12)
+        check(ctx.L.plonk_ntt_set_split(ctx.handle, 19, 7))
+        pc.ntt_two_pass_exact((19,), seed0=4190)
     finally:
         check(ctx.L.plonk_ntt_set_split(ctx.handle, 18, 0))
+        check(ctx.L.plonk_ntt_set_split(ctx.handle, 19, 0))
         check(ctx.L.plonk_ntt_select_kernel(ctx.handle, 0))
 
 

@@ -50,7 +50,7 @@ def test_ntt_forced_variants():
 
     ctx = get_context()
     try:
-        for kind in (1, 4, 5, 6, 7):  # (6 / 7: the wave kernels without / with their two-element latency forms)
+        for kind in (1, 4, 5, 6, 7, 8):  # (6 / 7: the wave kernels without / with their two-element latency forms; 8: 2^12 on 1024 threads)
             check(ctx.L.plonk_ntt_select_kernel(ctx.handle, kind))
             check(ctx.L.plonk_ntt_configure(ctx.handle, 0, 0, 0))
             pc.ntt_vs_oracle([0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 16], seed0=10 * kind)
@@ -65,7 +65,12 @@ def test_ntt_forced_variants():
 def test_ntt_extreme_inputs():
     with pc.ntt_kind(6):  # the four- and eight-element kernels (a lone 2^9 or 2^16 would otherwise take the two-element forms)
         pc.ntt_extreme_inputs((8, 9, 10, 11, 12, 13, 16))
-        pc.ntt_extreme_limbs((8, 9, 10, 11, 12, 13))
+        pc.ntt_extreme_limbs((8, 9, 10, 11, 13))
+        pc.ntt_extreme_limbs((12,), slots=8)  # 2^12 = 512 threads x 8 elements
+    with pc.ntt_kind(8):  # ... and its 1024-thread, 4-element form
+        pc.ntt_extreme_inputs((12,))
+        pc.ntt_extreme_limbs((12,))
+        pc.bls_ntt_vs_oracle((12,), seed0=277, batch=5)
     pc.ntt_extreme_inputs((14, 15, 16))  # ... and the default: latency forms
 
 
