@@ -233,8 +233,10 @@ template <class P> struct WavePlan {
     NttWaveT<P> a, c;  // single pass: a;  two passes: a = columns, c = rows
 };
 
+// big: the call has at least 2^20 elements (the 512-thread form of 2^12 pays from there: profiles/r04_f_ntt_2e12_forms_ab.jsonl)
 template <class F>
-static int wave_plan_get(plonk_ctx* ctx, unsigned log_n, bool inverse, bool scale_by_n_inv, bool want_full, bool latency, const WavePlan<typename F::P>** out) {
+static int wave_plan_get(plonk_ctx* ctx, unsigned log_n, bool inverse, bool scale_by_n_inv, bool want_full, bool latency, bool big,
+                         const WavePlan<typename F::P>** out) {
     typedef typename F::P P;
     typedef Fp<P> E;
     WaveTables& T = F::tables(ctx);
@@ -242,7 +244,7 @@ static int wave_plan_get(plonk_ctx* ctx, unsigned log_n, bool inverse, bool scal
         T.plans.clear();
         T.plan_epoch = ctx->ntt_cfg_epoch;
     }
-    const unsigned key = log_n | (inverse ? 256u : 0u) | (scale_by_n_inv ? 512u : 0u) | (want_full ? 1024u : 0u) | (latency ? 2048u : 0u);
+    const unsigned key = log_n | (inverse ? 256u : 0u) | (scale_by_n_inv ? 512u : 0u) | (want_full ? 1024u : 0u) | (latency ? 2048u : 0u) | (big ? 4096u : 0u);
     auto it = T.plans.find(key);
     if (it != T.plans.end()) {
         *out = static_cast<const WavePlan<P>*>(it->second.get());
@@ -254,9 +256,11 @@ static int wave_plan_get(plonk_ctx* ctx, unsigned log_n, bool inverse, bool scal
     PLONK_REQUIRE(ntt_wave_plan(ctx, log_n, latency, &log_r1, &log_r2), PLONK_ERR_ARG, "no wave-kernel plan for 2^%u points", log_n);
     plan->log_r1 = log_r1;
     plan->log_r2 = log_r2;
-    // 2^12 runs as 512 threads x 8 elements (two workgroups per CU) as a single pass and as a row pass; a column pass stays on the
-    // 1024-thread 4-element kernel (the one-table inter-pass twiddles need its register room; ntt_wave.h)
-    const bool w12 = wave_w12_as_512x8() && ctx->ntt_kind != 8;  // (kind 8: 2^12 on the 1024-thread form everywhere — tests, A/B)
+    // 2^12 runs as 512 threads x 8 elements (two workgroups per CU) as a single pass and as a row pass of calls with at least 2^20
+    // elements: 18.0 -> 19.2 G elements/s at 512 transforms, 17.7 -> 20.7 at 4096, row passes +2 .. 5 %; a small call is faster on
+    // the 1024-thread kernel's shorter chain (a lone 2^12: 0.043 against 0.048 ms).  A column pass stays on the 1024-thread
+    // 4-element kernel (the one-table inter-pass twiddles need its register room; ntt_wave.h)
+    const bool w12 = big && wave_w12_as_512x8() && ctx->ntt_kind != 8;  // (kind 8: 2^12 on the 1024-thread form everywhere — tests, A/B)
     const unsigned log_e1 = plan->log_e1 = (log_r1 == 12 && w12 && !log_r2) ? 3u : wavel_log_e(log_r1, latency);
     const unsigned log_e2 = plan->log_e2 = !log_r2 ? 0u : ((log_r2 == 12 && w12) ? 3u : wavel_log_e(log_r2, latency));
     NttWaveT<P> p;
@@ -324,7 +328,8 @@ static int wave_run(plonk_ctx* ctx, const Fp<typename F::P>* in, Fp<typename F::
     // a small job waits for one wave's instruction chain: the two-element forms (plonk_ntt_select_kernel 6 / 7: never / always — tests, A/B runs)
     const bool latency = ctx->ntt_kind == 6 ? false : (ctx->ntt_kind == 7 || ((size_t)batch << log_n) <= ((size_t)1 << 18));
     const WavePlan<P>* plan;
-    PLONK_TRY(wave_plan_get<F>(ctx, log_n, inverse, scale_by_n_inv, want_full, latency, &plan));
+    const bool big = ctx->ntt_kind == 6 || ((size_t)batch << log_n) >= ((size_t)1 << 20);
+    PLONK_TRY(wave_plan_get<F>(ctx, log_n, inverse, scale_by_n_inv, want_full, latency, big, &plan));
     const unsigned log_r1 = plan->log_r1, log_r2 = plan->log_r2;
     const unsigned in_len32 = (unsigned)(in_len < N ? in_len : N);
     if (!log_r2) {

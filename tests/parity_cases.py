@@ -48,13 +48,10 @@ def ntt_quad_sizes(seed0=60):
     """2^14 = 2^7 x 2^7 and 2^15 = 2^7 x 2^8 on the wave kernels (the sizes no pair of the 4- / 8-element kernels reaches; until
     round 4 four-point column transforms + one pass): plain transforms both ways, in place through the C-ABI, a batch, and the
     fused forms the prover's sizes would use — zero padding + coset factors on the way in (to_coset_extended_lagrange of 2^12
-    values -> 2^14) and coset^-1 / N on the way out.  Once on the default dispatch, once with the wave kernels forced."""
+    values -> 2^14) and coset^-1 / N on the way out."""
     from plonkathon_amd import get_context
 
-    ctx = get_context()
-    _ntt_quad_sizes_body(ctx, seed0)
-    with ntt_kind(6):
-        _ntt_quad_sizes_body(ctx, seed0 + 1000)
+    _ntt_quad_sizes_body(get_context(), seed0)  # (kernel kinds 5 .. 7 pick the same two kernels for these sizes)
 
 
 def _ntt_quad_sizes_body(ctx, seed0):
@@ -120,7 +117,7 @@ def ntt_two_pass_exact(log_ns, seed0=4000, batch=1):
             assert got[b * n:(b + 1) * n] == c_oracle.fr_ntt(vs[b], True), ("inv", log_n, b)
 
 
-def ntt_latency_forms(two_pass=(14, 15, 16, 17, 18), batched=(18,)):
+def ntt_latency_forms(two_pass=(14, 15, 16, 17, 18), batched=(18,), forced=((16, 9),)):
     """Round 4's two-element-per-thread kernels (2^7, and 2^9 in its latency form), forced with kernel kind 7: alone with random
     and range-driving inputs, and as the passes of 2^14 = 2^7 x 2^7, 2^15 = 2^7 x 2^8, 2^16 = 2^7 x 2^9, 2^17 = 2^8 x 2^9,
     2^18 = 2^9 x 2^9 (column pass on the full inter-pass table up to 2^16 and for the batched call, on the two small tables
@@ -131,6 +128,16 @@ def ntt_latency_forms(two_pass=(14, 15, 16, 17, 18), batched=(18,)):
         ntt_extreme_limbs((7, 9), slots=2)
         ntt_two_pass_exact(two_pass, seed0=4700)
         ntt_two_pass_exact(batched, seed0=4800, batch=2)
+        from plonkathon_amd import get_context
+        from plonkathon_amd._lib import check
+
+        ctx = get_context()
+        for log_n, r1 in forced:  # e.g. 2^16 = 2^9 x 2^7: the 256-thread two-element kernel as a column pass on the one-table twiddles
+            try:
+                check(ctx.L.plonk_ntt_set_split(ctx.handle, log_n, r1))
+                ntt_two_pass_exact((log_n,), seed0=4900 + r1)
+            finally:
+                check(ctx.L.plonk_ntt_set_split(ctx.handle, log_n, 0))
 
 
 def ntt_extreme_inputs(log_ns):

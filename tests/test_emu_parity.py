@@ -60,7 +60,7 @@ def test_ntt_extreme_inputs(emu):
 
 
 def test_ntt_latency_forms(emu):
-    pc.ntt_latency_forms(two_pass=(14, 15, 16), batched=(18,))
+    pc.ntt_latency_forms(two_pass=(14, 15, 16), batched=())  # (2^17, 2^18 and the batched calls: the GPU suite)
 
 
 def test_bls12_381_ntt(emu):
@@ -228,7 +228,8 @@ def test_lagrange_srs_paths(emu):
 def test_ntt_two_pass_wave_kernel(emu):
     """Two-pass transforms through the wave kernels' column and row passes, exact against the C oracle: 2^16 = 2^8 x 2^8
     (4 elements per thread in both passes), 2^17 = 2^8 x 2^9 (4, then 8) and forced to 2^9 x 2^8 (8, then 4: the column pass
-    of the 8-element kernels takes its inter-pass twiddles from the two small tables), 2^18 forced to 2^10 x 2^8."""
+    of the 8-element kernels takes its inter-pass twiddles from the two small tables), 2^19 forced to 2^7 x 2^12 (the 512-thread
+    kernel as a row pass).  Kernel kind 6: the throughput forms whatever the size of the call."""
     from oracle import c_oracle
     from plonkathon_amd import Basis, get_context
     from plonkathon_amd._lib import check
@@ -252,13 +253,11 @@ def test_ntt_two_pass_wave_kernel(emu):
         check(ctx.L.plonk_ntt_set_table_budget(ctx.handle, 4 << 30))
     assert pc.ints(pc.P(v, Basis.LAGRANGE).ifft()) == c_oracle.fr_ntt(v, True)  # ... and from the full table (1/N folded in)
     try:
-        check(ctx.L.plonk_ntt_set_split(ctx.handle, 18, 10))
-        v = pc.rand_vec(4018, 1 << 18)
-        assert pc.ints(pc.P(v, Basis.MONOMIAL).fft()) == c_oracle.fr_ntt(v)
         assert ctx.L.plonk_ntt_set_split(ctx.handle, 18, 14) != 0 and ctx.L.plonk_ntt_set_split(ctx.handle, 15, 9) != 0
-        # 2^12 as a ROW pass: the 512-thread, 8-element kernel (2^19 = 2^7 x 2^12)
+        # 2^12 as a ROW pass: the 512-thread, 8-element kernel (2^19 = 2^7 x 2^12; kind 6 = the configuration of a large call)
         check(ctx.L.plonk_ntt_set_split(ctx.handle, 19, 7))
-        pc.ntt_two_pass_exact((19,), seed0=4190)
+        v = pc.rand_vec(4190, 1 << 19)
+        assert pc.ints(pc.P(v, Basis.MONOMIAL).fft()) == c_oracle.fr_ntt(v)
     finally:
         check(ctx.L.plonk_ntt_set_split(ctx.handle, 18, 0))
         check(ctx.L.plonk_ntt_set_split(ctx.handle, 19, 0))
