@@ -51,6 +51,9 @@ import time
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
+# RCCL between processes needs dmabuf IPC on this driver (hipIpcGetMemHandle fails otherwise); the GPU boxes export this already —
+# set before the HIP runtime is loaded in case a launcher scrubbed the environment
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s measured copy)
 # chip-wide rate of the MSM loop's unit of work — the lazy mixed addition on register-resident operands —
