@@ -65,7 +65,7 @@ template <class P> struct NttWaveT {
     // Distributed (multi-GPU) transforms run the same two passes on a slice: rank g of W owns R2 / W columns for the
     // column pass (twiddle column = sub + sub_base) and R1 / W rows for the row pass, whose input arrives from the
     // all-to-all as W chunks [source rank][local row][source's columns]: position c of a row sits at
-    // (c >> chunk_log) * chunk_stride + row * 2^chunk_log + (c & (2^chunk_log - 1)).  chunk_log = 0 means contiguous rows.
+    // (c >> chunk_log) * chunk_stride + row * 2^chunk_log + (c & (2^chunk_log - 1)).  chunk_stride = 0 means contiguous rows.
     unsigned sub_base, chunk_log, chunk_stride;
     const int32_t* tw_lo;  // inter-pass twiddles w_N^e = tw_lo[e & 1023] * tw_hi[e >> 10], Shoup pairs: applied one after the other (mode 1)
     const int32_t* tw_hi;  //   (for an inverse transform tw_hi carries the factor 1/N as well: tw_always)
@@ -87,6 +87,7 @@ template <class P> struct NttWaveT {
 #define NTT_FAN_IN 1u
 #define NTT_FAN_OUT 2u
 #define NTT_FAN_SCALE 4u
+#define NTT_TMP_TRANSPOSED 8u  // modes 1 and 2: see wavel_transform
 
 // entry idx of a limb-form table (Montgomery residue)
 template <class P> PLONK_DEV FpL<P> wavel_ld_tw(const int32_t* tab, unsigned idx) {
@@ -330,9 +331,15 @@ PLONK_DEV void wavel_transform(const NttWaveT<P>& p, unsigned char* smem) {
     const unsigned b = blockIdx.x;
     const unsigned sub = !p.mode ? 0 : ((gridDim.x & 31u) ? b : ((b & ~31u) | ((b & 7u) << 2) | ((b >> 3) & 3u)));
     // global index of sub-transform position pos on the input side, of frequency o on the output side
-    const unsigned in_shift = p.mode == 1 ? p.log_other : 0, out_shift = p.mode ? p.log_other : 0;
-    const unsigned in_off = p.mode == 1 ? sub : (p.mode == 2 ? (p.chunk_log ? sub << p.chunk_log : sub << LOG_N) : 0);
-    const unsigned out_off = p.mode ? sub : 0;
+    // The intermediate buffer of a two-pass transform is kept TRANSPOSED (NTT_TMP_TRANSPOSED in `fan`, which modes 1 and 2 do not
+    // otherwise use): the column pass stores column c as one contiguous run tmp[c R1 + k1], the row pass gathers row k1 with stride
+    // R1 (chunk_log = 0, chunk_stride = R1).  The strided access moves from the stores — which write partial 128-byte lines back
+    // once the L2 of an XCD cannot hold every column in flight: 1.3 - 1.4 x the bytes at 2^22 / 2^24 — to the loads, which do not care.
+    // (not in the 1024-thread 8-element kernel — with this selection it spills two registers: a 2^13 column pass stores as before)
+    const bool tmp_t = !(LOG_E == 3 && NLDS == 2) && p.mode == 1 && (p.fan & NTT_TMP_TRANSPOSED);
+    const unsigned in_shift = p.mode == 1 ? p.log_other : 0, out_shift = (p.mode && !tmp_t) ? p.log_other : 0;
+    const unsigned in_off = p.mode == 1 ? sub : (p.mode == 2 ? (p.chunk_stride ? sub << p.chunk_log : sub << LOG_N) : 0);
+    const unsigned out_off = p.mode ? (tmp_t ? sub << LOG_N : sub) : 0;
     const unsigned chunk_mask = (1u << p.chunk_log) - 1;
     const int32_t* jm = p.jm;
     const FpLS<P> &w8_1 = p.w8[0], &w8_2 = p.w8[1], &w8_3 = p.w8[2];  // kernel arguments: scalar registers
@@ -341,7 +348,7 @@ PLONK_DEV void wavel_transform(const NttWaveT<P>& p, unsigned char* smem) {
     wave_for<E>([&](auto J) {  // position j * NT + tid: consecutive lanes read consecutive positions
         constexpr unsigned j = decltype(J)::value;
         const unsigned pos = j * NT + tid0;
-        const unsigned g = p.chunk_log ? (pos >> p.chunk_log) * p.chunk_stride + (pos & chunk_mask) + in_off : (pos << in_shift) + in_off;
+        const unsigned g = p.chunk_stride ? (pos >> p.chunk_log) * p.chunk_stride + (pos & chunk_mask) + in_off : (pos << in_shift) + in_off;
         x[j] = g < p.in_len ? fpl_from_fp(fp_load(wavel_at(in, g))) : fpl_zero<P>();  // [0, 2m): canonical input, or the column pass's redundant residues
     });
     if (p.in_scale) {

@@ -227,6 +227,14 @@ static inline bool wave_w12_as_512x8() {
     return on;
 }
 
+static inline bool wave_tmp_transposed() {
+    static const bool on = [] {
+        const char* e = getenv("PLONK_NTT_TMP_TRANSPOSED");
+        return !(e && atoi(e) == 0);
+    }();
+    return on;
+}
+
 template <class P> struct WavePlan {
     unsigned log_r1 = 0, log_r2 = 0;
     unsigned log_e1 = 0, log_e2 = 0;  // elements per thread (log2) of the kernels of the two passes (log_e1 alone for a single pass)
@@ -286,13 +294,21 @@ static int wave_plan_get(plonk_ctx* ctx, unsigned log_n, bool inverse, bool scal
             p.tw_always = scale_by_n_inv ? 1u : 0u;
         }
         NttWaveT<P> a = p;
+        // the intermediate buffer is this library's own scratch: kept transposed (PLONK_NTT_TMP_TRANSPOSED=0: as [k1][c], A/B runs)
+        // Measured (profiles/r04_g_ntt_tmp_transposed_ab.jsonl): lone transforms level, batches 3 - 9 % faster, the column pass's
+        // WRITE_SIZE 1.28 - 1.38 x -> 1.02 x its bytes at 2^22 / 2^24; 2^25 = 2^12 x 2^13 is 5 % slower (its 1024-thread row kernel
+        // gathers eight elements per thread 128 KiB apart) and keeps the [k1][c] form, like 2^26 (the 2^13 kernel cannot store
+        // transposed: ntt_wave.h)
+        const bool tr = wave_tmp_transposed() && log_r1 != 13 && log_n <= 24;
         a.mode = 1;
+        a.fan = tr ? NTT_TMP_TRANSPOSED : 0u;
         a.log_other = log_r2;
         a.out_bstride = N;
         PLONK_TRY(wave_program_table<F>(ctx, log_r1, log_e1, inverse, &a.roots));
         NttWaveT<P> c = p;
         c.mode = 2;
         c.log_other = log_r1;
+        c.chunk_stride = tr ? 1u << log_r1 : 0u;  // (chunk_log = 0: position c of row k1 at c R1 + k1)
         c.in_bstride = N;
         c.in_len = (unsigned)N;
         c.has_out_scalar = 0;  // 1/N went into the column pass's inter-pass twiddles (tw_hi)
