@@ -449,11 +449,7 @@ __global__ void __launch_bounds__(MSM_BLOCK, MSM_ACC_WAVES) msm_lookup_kernel(
         const int d = (int)((uint32_t)(two >> sh) & mask) - (int)half;
         if (d) {
             const uint32_t ad = d < 0 ? (uint32_t)-d : (uint32_t)d;
-#ifdef MSM_PROBE_REGION_MASK  // timing probe only (wrong results): the gathers stay random but span fewer 4 MB regions
-            const G1Affine* src = lookup + (((((size_t)w * table_n + i) & MSM_PROBE_REGION_MASK) << (c - 1)) + (ad - 1));
-#else
             const G1Affine* src = lookup + ((((size_t)w * table_n + i) << (c - 1)) + (ad - 1));
-#endif
             const Fq x = fp_load(&src->x), y = fp_load(&src->y);
             if (!g1l_madd_fast(run, x, y, d < 0) && !(fp_is_zero(x) && fp_is_zero(y))) {  // see msm_accumulate_kernel
                 const uint32_t slot = atomicAdd(n_deferred + m, 1u);

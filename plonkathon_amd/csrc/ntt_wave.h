@@ -39,7 +39,7 @@
 //     through ds_swizzle — no LDS memory, no barrier for the last six levels of every transform.
 // After a stage on a digit of a sub-transform of size S (remaining points indexed by `low`), output f is multiplied by
 // w_S^(low f) = roots[(N / S) low f]  (the Cooley-Tukey twiddle between the digit DFT and the remaining sub-transforms);
-// the root table is stored AS LIMBS (12 words per entry: no unpacking in the loop).  Outputs appear at frequency
+// the root table is stored as Shoup pairs of limbs (no unpacking in the loop).  Outputs appear at frequency
 // k = d_A + r_A d_B + ... (first digit least significant), which the final store turns into a natural-order write.
 // Coset scaling, zero padding n -> 4n, 1/N and the inverse-coset scaling are fused into the first load / last store.
 //
@@ -50,7 +50,6 @@
 // |value| < 0.51 m).  Inside a radix-8 butterfly five carry sweeps keep every limb inside int32 and every multiplicand
 // inside the multiplications' operand bound (|limb| < 1.27 * 2^30): the bounds are written on each line of dft8l / dft4l.
 // |value| never exceeds 22.4 m (a sum of eight inputs): fpl_reduce_small's table reaches 23 m, the multiplications 128 m.
-#define NTT_LIMB_STRIDE 12   // int32 words per entry of a limb-form table (9 used): Montgomery residues (inter-pass twiddles)
 #define NTT_SHOUP_STRIDE 20  // int32 words per entry of a root table: w (9), floor(w 2^261 / m) (9), 2 unused
 template <class P> struct NttWaveT {
     const Fp<P>* in;
@@ -89,19 +88,6 @@ template <class P> struct NttWaveT {
 #define NTT_FAN_SCALE 4u
 #define NTT_TMP_TRANSPOSED 8u  // modes 1 and 2: see wavel_transform
 
-// entry idx of a limb-form table (Montgomery residue)
-template <class P> PLONK_DEV FpL<P> wavel_ld_tw(const int32_t* tab, unsigned idx) {
-    // (a 32-bit byte offset from a uniform base: SGPR-base addressing, one VGPR per address instead of two)
-    const int32_t* t = reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(tab) + idx * (unsigned)(NTT_LIMB_STRIDE * sizeof(int32_t)));
-    const u32x4 a = *reinterpret_cast<const u32x4*>(t), b = *reinterpret_cast<const u32x4*>(t + 4);
-    FpL<P> r;
-    r.l[0] = (int32_t)a.x; r.l[1] = (int32_t)a.y; r.l[2] = (int32_t)a.z; r.l[3] = (int32_t)a.w;
-    r.l[4] = (int32_t)b.x; r.l[5] = (int32_t)b.y; r.l[6] = (int32_t)b.z; r.l[7] = (int32_t)b.w;
-    r.l[8] = t[8];
-#pragma unroll
-    for (int i = 0; i < 9; i++) FPL_ANY_SIGN(r.l[i]);
-    return r;
-}
 // entry idx of a root table: the Shoup pair of w^idx, 80 bytes as five 16-byte loads
 template <class P> PLONK_DEV FpLS<P> wavel_ld_root(const int32_t* tab, unsigned idx) {
     const u32x4* t = reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(tab) + idx * (unsigned)(NTT_SHOUP_STRIDE * sizeof(int32_t)));
@@ -195,11 +181,7 @@ template <class P> PLONK_DEV FpLS<P> wavel_ld_root_planar(const int32_t* block, 
 }
 
 // the kernels compiled for 128 VGPRs with 8 elements per thread (WavelCfg::TIGHT): 2^13 and 2^11
-#ifdef PLONK_NTT_W11_3
-#define WAVEL_TIGHT_LOG_N(log_n) ((log_n) == 13)
-#else
 #define WAVEL_TIGHT_LOG_N(log_n) ((log_n) == 13 || (log_n) == 11 || (log_n) == 9)
-#endif
 // x[BASE + f] *= w^(low f mult), f = 1 .. COUNT-1, from stage STAGE's blocks of the program-order table;  x[BASE] (no
 // factor) is range-reduced instead
 template <unsigned LOG_E, unsigned NLDS, unsigned STAGE, unsigned BASE, unsigned COUNT, unsigned E, class P>
@@ -304,11 +286,7 @@ template <unsigned LOG_E, unsigned NLDS> struct WavelCfg {
     static constexpr unsigned E = 1u << LOG_E, LOG_N = LOG_E + wavel_log_t(NLDS), NT = 1u << wavel_log_t(NLDS);
     // TIGHT: the kernel is compiled for 128 VGPRs with the register-saving measures of the 1024-thread kernel (opaque
     // threadIdx re-reads per stage, scheduling fences around the twiddle multiplications)
-#ifdef PLONK_NTT_W11_3  // A/B: the 256-thread E = 8 kernel at 3 waves per SIMD (158 VGPRs), as in round 2
-    static constexpr bool TIGHT = NLDS == 2;
-#else
     static constexpr bool TIGHT = NLDS == 2 || LOG_E == 3;
-#endif
     static constexpr unsigned WAVES = (NLDS == 2 || LOG_E <= 2) ? 4 : (TIGHT ? 4 : 3);
 };
 
@@ -565,27 +543,18 @@ __global__ void __launch_bounds__(1u << wavel_log_t(NLDS), (WavelCfg<LOG_E, NLDS
 
 
 
-// limb form of a packed table: NTT_LIMB_STRIDE words per entry (what wavel_ld_tw reads); with shoup != 0 the Shoup pair of
-// every entry, NTT_SHOUP_STRIDE words (what wavel_ld_root reads)
+// the Shoup pair of every entry of a packed table, NTT_SHOUP_STRIDE words per entry (what wavel_ld_root reads)
 struct Ninv261 { uint32_t l[9]; };
-template <class P> __global__ void ntt_limb_table_kernel(const Fp<P>* in, int32_t* out, size_t n, int shoup, Ninv261 ninv) {
+template <class P> __global__ void ntt_limb_table_kernel(const Fp<P>* in, int32_t* out, size_t n, Ninv261 ninv) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const Fp<P> v = fp_load(in + i);
-    if (shoup) {
-        const FpLS<P> a = fpl_shoup_from_mont(v, ninv.l);
-        int32_t* o = out + i * NTT_SHOUP_STRIDE;
-        for (int w = 0; w < 9; w++) {
-            o[w] = a.w[w];
-            o[9 + w] = a.wp[w];
-        }
-        o[18] = o[19] = 0;
-    } else {
-        const FpL<P> a = fpl_from_fp(v);
-        int32_t* o = out + i * NTT_LIMB_STRIDE;
-        for (int w = 0; w < 9; w++) o[w] = a.l[w];
-        o[9] = o[10] = o[11] = 0;
+    const FpLS<P> a = fpl_shoup_from_mont(fp_load(in + i), ninv.l);
+    int32_t* o = out + i * NTT_SHOUP_STRIDE;
+    for (int w = 0; w < 9; w++) {
+        o[w] = a.w[w];
+        o[9 + w] = a.wp[w];
     }
+    o[18] = o[19] = 0;
 }
 
 

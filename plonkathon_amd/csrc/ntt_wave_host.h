@@ -29,7 +29,7 @@ template <class P> static int wave_limb_table(plonk_ctx* ctx, std::map<unsigned,
             return PLONK_ERR_NOMEM;
         }
         ctx->owned.push_back(d);
-        PLONK_LAUNCH(ntt_limb_table_kernel<P>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, packed, (int32_t*)d, n, 1, ninv);
+        PLONK_LAUNCH(ntt_limb_table_kernel<P>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, packed, (int32_t*)d, n, ninv);
         PLONK_CHECK_HIP(hipGetLastError());
         it = cache.emplace(key, (int32_t*)d).first;
     }

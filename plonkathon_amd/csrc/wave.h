@@ -31,10 +31,7 @@ template <unsigned MASK> PLONK_DEV uint32_t wave_lane_xor(uint32_t v, unsigned l
 //   MASK 8, 4    two DPP moves whose bank_mask writes only the receiving lanes (row_ror:8; row_shr:4 / row_shl:4): the
 //                select is part of the move
 //   MASK 2, 1    a quad_perm DPP move and a select per direction (bank_mask cannot split a quad)
-// PLONK_SWAP_VIA_SELECT (A/B switch): the round-2 form for every mask — select the word to send, one cross-lane move,
-// two selects.
 template <unsigned MASK> PLONK_DEV void wave_swap_words(int32_t& a, int32_t& b, bool hi, unsigned lane) {
-#if !defined(PLONK_SWAP_VIA_SELECT)
     if constexpr (MASK == 32) {
         auto r = __builtin_amdgcn_permlane32_swap((uint32_t)a, (uint32_t)b, false, false);
         a = (int32_t)r[0];
@@ -64,12 +61,6 @@ template <unsigned MASK> PLONK_DEV void wave_swap_words(int32_t& a, int32_t& b, 
         b = nb;
         return;
     }
-#else
-    const uint32_t send = (uint32_t)(hi ? a : b);
-    const uint32_t recv = wave_lane_xor<MASK>(send, lane);
-    if (hi) a = (int32_t)recv;
-    else b = (int32_t)recv;
-#endif
 }
 
 template <unsigned MASK> PLONK_DEV Fq fq_wave_xor(const Fq& a, unsigned lane) {
