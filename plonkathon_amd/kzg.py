@@ -379,3 +379,45 @@ def ec_lincomb(pairs):
     bases = _DeviceBases(ctx, h, len(pairs))
     scalars = ctx.upload_ints([int(n) % R_MOD for _, n in pairs])  # curve.py:41
     return _msm(bases, scalars.ptr, len(pairs), 1, len(pairs))[0]
+
+
+def _is_g1(x):
+    return x is None or (isinstance(x, tuple) and len(x) == 2)
+
+
+def multisubset(numbers, subsets, adder=None, zero=0):
+    """curve.py:59-87's generic entry: for every subset (an iterable of indices) the sum of numbers[i] under `adder`, from `zero`.
+    G1 points under the curve's own addition (adder None) are summed on the GPU, one MSM with 0 / 1 coefficients per subset; any
+    other group — the reference's self-test runs this on plain integers (test.py's K8 vector) — is folded on the host."""
+    numbers = list(numbers)
+    if adder is None and numbers and all(_is_g1(x) for x in numbers):
+        return [ec_lincomb([(numbers[i], 1) for i in sub]) if sub else None for sub in subsets]
+    add = adder if adder is not None else (lambda x, y: x + y)
+    out = []
+    for sub in subsets:
+        acc = zero
+        for i in sorted(sub):
+            acc = add(acc, numbers[i])
+        out.append(acc)
+    return out
+
+
+def lincomb(numbers, factors, adder=None, zero=0):
+    """curve.py:91-111's generic entry: numbers[0] * factors[0] + numbers[1] * factors[1] + ... under `adder`, from `zero`.
+    G1 points under the curve's own addition go to the GPU (`ec_lincomb`); for any other group the sum is formed on the host by a
+    left-to-right binary method written for this file: per bit of the longest factor one doubling of the running sum and one
+    addition per number whose factor has that bit set (the reference partitions the numbers into power-set tables instead;
+    both compute the same group element, which is all its K8 self-test compares)."""
+    numbers, factors = list(numbers), [int(f) for f in factors]
+    if adder is None and numbers and all(_is_g1(x) for x in numbers):
+        return ec_lincomb(zip(numbers, factors))
+    add = adder if adder is not None else (lambda x, y: x + y)
+    assert all(f >= 0 for f in factors)
+    acc = zero
+    for bit in range(max(f.bit_length() for f in factors) - 1, -1, -1):  # (an empty list raises ValueError, as curve.py:93 does)
+        acc = add(acc, acc)
+        for x, f in zip(numbers, factors):
+            if (f >> bit) & 1:
+                acc = add(acc, x)
+    return acc
+

@@ -662,6 +662,13 @@ def lincomb_golden(setup, full_size=True):
     assert affine(pa.ec_lincomb(mixed)) == og1.ec_lincomb([(None if p is None else affine(p), k) for p, k in mixed])
     assert pa.ec_mul(Pts[3], 0) is None
     assert affine(pa.ec_mul(Pts[3], Scalar(7))) == og1.multiply(affine(Pts[3]), 7)
+    # the generic entry points (curve.py:59-111) on G1 points: the same sums through the MSM
+    some = [Pts[1], Pts[4], None, Pts[6]]
+    assert affine(pa.lincomb(some, [5, 2**200 + 3, 9, 1])) == og1.ec_lincomb([(None if p is None else affine(p), k) for p, k in zip(some, [5, 2**200 + 3, 9, 1])])
+    subs = pa.multisubset(some, [[0, 1], [], [2], [0, 1, 3]])
+    assert subs[1] is None and subs[2] is None
+    assert affine(subs[0]) == og1.ec_lincomb([(affine(Pts[1]), 1), (affine(Pts[4]), 1)])
+    assert affine(subs[3]) == og1.ec_lincomb([(affine(Pts[1]), 1), (affine(Pts[4]), 1), (affine(Pts[6]), 1)])
 
 
 def msm_vs_oracle(setup, n, seed, batch=1):

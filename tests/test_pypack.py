@@ -75,3 +75,29 @@ def test_pack_dicts_le32_walk_shortcut_never_changes_the_result():
         _pypack.pack_dicts_le32([{k: 1 for k in keys[1:]}, dict(same[0])], keys, R_MOD)
     # a key listed twice is served by the general path
     assert _pypack.pack_dicts_le32(same, keys + keys[:3], R_MOD) == b"".join(want(w[k]) for w in same for k in keys + keys[:3])
+
+
+def test_generic_lincomb_and_multisubset_on_integers():
+    """The product's `lincomb` / `multisubset` with the reference's generic signature (curve.py:59-111) on the group the reference's
+    own self-test uses — plain integers (its K8 vector, test.py via tools/gen_golden.py) — and on a custom adder.  Host only: G1
+    points go to the GPU (tests/test_gpu_parity.py::test_lincomb_golden)."""
+    import json
+    import os
+
+    from plonkathon_amd import lincomb, multisubset
+
+    k8 = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "lincomb_vectors.json")))["k8_int"]
+    numbers, factors = [int(x) for x in k8["numbers"]], [int(x) for x in k8["factors"]]
+    assert [str(x) for x in multisubset(numbers, [set(s) for s in k8["subsets"]])] == k8["multisubset"]
+    assert str(lincomb(numbers, factors)) == k8["lincomb"]
+    assert lincomb(numbers, factors) == sum(n * f for n, f in zip(numbers, factors))  # curve.py:139
+    m = 2**61 - 1
+    assert lincomb([3, 5, 7], [10, 0, 2**70 + 1], adder=lambda x, y: (x + y) % m, zero=0) == (30 + 7 * (2**70 + 1)) % m
+    assert multisubset(["a", "b", "c"], [[0, 2], [], [1]], adder=lambda x, y: x + y, zero="") == ["ac", "", "b"]
+    try:
+        lincomb([], [])
+    except ValueError:
+        pass
+    else:
+        raise AssertionError("an empty linear combination must raise, as curve.py:93 does")
+
