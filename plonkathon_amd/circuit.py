@@ -11,6 +11,8 @@ spaces; `+`/`-` tokens split terms, `*` tokens split factors; a `-` sign applies
 the term it precedes (so `- 45 * x` contributes +45*x, `- 45 * x * y` contributes -45*x*y); a leading
 `-` glued to a token flips that factor only.
 """
+import enum
+import functools
 from dataclasses import dataclass
 from typing import Optional
 
@@ -18,6 +20,49 @@ from .field import R_MOD, Scalar
 from .polynomial import Basis, Polynomial
 
 OUTPUT_COEFF, PUBLIC_FLAG = "$output_coeff", "$public"
+
+
+class Column(enum.IntEnum):
+    """compiler/utils.py:6-19: the three wire columns.  An IntEnum, so `S[Column.LEFT]` and `S[1]` name the same entry of
+    `Program.make_s_polynomials()` and the members order as the reference's `__lt__` does."""
+
+    LEFT = 1
+    RIGHT = 2
+    OUTPUT = 3
+
+    @staticmethod
+    def variants():
+        return [Column.LEFT, Column.RIGHT, Column.OUTPUT]
+
+
+@functools.total_ordering
+class Cell:
+    """compiler/utils.py:22-51: one cell of the wire table; ordered by (row, column), labelled w^row * column — the value the
+    permutation argument stores for it (`Program.permutation_columns` computes the same labels for all cells at once)."""
+
+    __slots__ = ("column", "row")
+
+    def __init__(self, column, row: int):
+        self.column, self.row = Column(column), int(row)
+
+    def _key(self):
+        return (self.row, int(self.column))
+
+    def __eq__(self, other):
+        return isinstance(other, Cell) and self._key() == other._key()
+
+    def __lt__(self, other):
+        return self._key() < other._key() if isinstance(other, Cell) else NotImplemented
+
+    def __hash__(self):
+        return hash(self._key())
+
+    def __repr__(self):
+        return "(%d, %d)" % self._key()
+
+    def label(self, group_order: int) -> Scalar:
+        assert self.row < group_order
+        return Scalar(pow(Scalar.root_of_unity(group_order).n, self.row, R_MOD) * int(self.column) % R_MOD)
 
 
 def is_valid_variable_name(name: str) -> bool:  # compiler/utils.py:59-60
@@ -236,7 +281,7 @@ class Program:
 
     def make_s_polynomials(self):
         sigma = self.permutation_columns()
-        return {k: Polynomial.from_ints(v, Basis.LAGRANGE) for k, v in sigma.items()}
+        return {Column(k): Polynomial.from_ints(v, Basis.LAGRANGE) for k, v in sigma.items()}
 
     def gate_columns(self):
         """(L, R, M, O, C) selector columns as int lists (compiler/program.py:134-155)."""

@@ -101,3 +101,23 @@ def test_generic_lincomb_and_multisubset_on_integers():
     else:
         raise AssertionError("an empty linear combination must raise, as curve.py:93 does")
 
+
+def test_column_and_cell_helpers():
+    """compiler/utils.py:6-51 in the product namespace: ordering, labels w^row * column, and `Column` keys that also answer to 1, 2, 3."""
+    from plonkathon_amd import Cell, Column, Program
+    from plonkathon_amd.field import R_MOD, Scalar
+
+    assert Column.LEFT < Column.RIGHT < Column.OUTPUT and Column.variants() == [Column.LEFT, Column.RIGHT, Column.OUTPUT]
+    c = Cell(Column.RIGHT, 3)
+    assert repr(c) == "(3, 2)" and c < Cell(Column.LEFT, 4) and c == Cell(2, 3) and len({c, Cell(2, 3)}) == 1
+    assert sorted([Cell(3, 1), Cell(1, 2), Cell(2, 1)]) == [Cell(2, 1), Cell(3, 1), Cell(1, 2)]
+    w = Scalar.root_of_unity(8).n
+    assert c.label(8).n == pow(w, 3, R_MOD) * 2 % R_MOD
+    try:
+        Cell(Column.LEFT, 8).label(8)
+    except AssertionError:
+        pass
+    else:
+        raise AssertionError("row >= group_order must be refused")
+    assert set(Program(["c <== a * b"], 8).permutation_columns()) == {1, 2, 3} == {int(k) for k in Column.variants()}
+
