@@ -13,7 +13,7 @@ Transports (all expose `rank`, `world`, `all_gather(bytes) -> [bytes] * world`, 
   * `SocketComm` — plain TCP through rank 0, for CPU tests and for several ranks sharing one GPU (RCCL refuses
                    two ranks on one device).  Never selected implicitly on a multi-GPU run.
 Environment (the torchrun convention): RANK, WORLD_SIZE, LOCAL_RANK, MASTER_ADDR, MASTER_PORT; the rendezvous
-socket listens on PLONK_RDZV_PORT (default MASTER_PORT + 1: torchrun's own store owns MASTER_PORT).
+socket listens on the first free port from PLONK_RDZV_PORT (default MASTER_PORT + 1: torchrun's own store owns MASTER_PORT).
 """
 import ctypes
 import os
@@ -64,8 +64,19 @@ def _recv_msg(sock):
     return _recv_exact(sock, n)
 
 
+_MAGIC = b"PLNK"
+_PORT_SPAN = 16  # rank 0 listens on the first free port of [port, port + 16); the others probe the same range
+
+
+def _job_token():
+    """What tells this job's rendezvous from another job's on the same host: its MASTER_PORT (torchrun gives every job its own)."""
+    return int(os.environ.get("MASTER_PORT", "29500")) & 0xFFFFFFFF
+
+
 class _Star:
-    """Rank 0 listens, ranks 1..W-1 connect and introduce themselves; the sockets stay open."""
+    """Rank 0 listens, ranks 1..W-1 connect and introduce themselves; the sockets stay open.
+    Hello = magic, rank, job token; rank 0 answers magic, world; the rank confirms.  A port that is taken (rank 0) or that answers anything else
+    (the others) is skipped, so a foreign service on MASTER_PORT + 1 delays the launch instead of breaking it."""
 
     def __init__(self, rank, world, timeout=120.0):
         self.rank, self.world = rank, world
@@ -73,11 +84,21 @@ class _Star:
         self.peers = {}
         if world == 1:
             return
+        token = _job_token()
         if rank == 0:
-            srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
-            srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
-            srv.bind((host, port))
-            srv.listen(world)
+            srv = None
+            for off in range(_PORT_SPAN):
+                cand = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+                cand.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+                try:
+                    cand.bind((host, port + off))
+                    cand.listen(world)
+                    srv = cand
+                    break
+                except OSError:
+                    cand.close()
+            if srv is None:
+                raise OSError("rendezvous: no free port in %d .. %d on %s" % (port, port + _PORT_SPAN - 1, host))
             deadline = time.time() + timeout
             while len(self.peers) < world - 1:
                 left = deadline - time.time()
@@ -90,15 +111,22 @@ class _Star:
                     conn, _ = srv.accept()
                 except socket.timeout:
                     continue
-                # a stray connection (a port scanner, a retried worker) must neither displace a rank, nor abort the launch,
-                # nor hold the accept loop for long: two seconds for its 4-byte hello, then it is dropped and the loop goes on
+                # a stray connection (a port scanner, a retried worker, another job probing the range) must neither displace a
+                # rank, nor abort the launch, nor hold the accept loop for long: two seconds for its hello, then it is dropped
                 try:
                     conn.settimeout(min(2.0, max(left, 0.1)))
-                    (r,) = struct.unpack("<I", _recv_exact(conn, 4))
+                    magic, r, tok = struct.unpack("<4sII", _recv_exact(conn, 12))
                 except (OSError, ConnectionError, struct.error):
                     conn.close()
                     continue
-                if not 0 < r < world or r in self.peers:
+                if magic != _MAGIC or tok != token or not 0 < r < world or r in self.peers:
+                    conn.close()
+                    continue
+                try:  # answer, and hear the rank confirm it: one that gave up waiting and reconnected must not be registered twice
+                    conn.sendall(struct.pack("<4sI", _MAGIC, world))
+                    if _recv_exact(conn, 1) != b"K":
+                        raise ConnectionError("bad confirmation")
+                except (OSError, ConnectionError):
                     conn.close()
                     continue
                 conn.settimeout(timeout)
@@ -107,17 +135,31 @@ class _Star:
             srv.close()
         else:
             deadline = time.time() + timeout
-            while True:
-                try:
-                    s = socket.create_connection((host, port), timeout=5.0)
-                    break
-                except OSError:
+            s = None
+            while s is None:
+                for off in range(_PORT_SPAN):
+                    try:
+                        c = socket.create_connection((host, port + off), timeout=1.0)
+                    except OSError:
+                        continue
+                    try:  # rank 0 may be busy dropping strays (two seconds each): wait for its answer well beyond that
+                        c.settimeout(max(1.0, min(30.0, deadline - time.time())))
+                        c.sendall(struct.pack("<4sII", _MAGIC, rank, token))
+                        magic, w = struct.unpack("<4sI", _recv_exact(c, 8))
+                        if magic == _MAGIC and w == world:
+                            c.sendall(b"K")
+                            s = c
+                            break
+                    except (OSError, ConnectionError, struct.error):
+                        pass
+                    c.close()
+                if s is None:
                     if time.time() > deadline:
-                        raise
+                        raise TimeoutError("rendezvous: rank %d found no rank 0 of this job on %s:%d .. %d within %.0f s"
+                                           % (rank, host, port, port + _PORT_SPAN - 1, timeout))
                     time.sleep(0.05)
             s.settimeout(timeout)
             s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-            s.sendall(struct.pack("<I", rank))
             self.peers[0] = s
 
     def broadcast(self, payload):

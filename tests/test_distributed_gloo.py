@@ -252,7 +252,7 @@ def test_rendezvous_survives_stray_connections():
 
     silent = connect()                       # says nothing: dropped after its hello deadline
     bad = connect()
-    bad.sendall(struct.pack("<I", 99))       # rank 99 of 3
+    bad.sendall(struct.pack("<4sII", b"PLNK", 99, D._job_token()))       # rank 99 of 3
     results = {}
 
     def peer(r):
@@ -264,7 +264,7 @@ def test_rendezvous_survives_stray_connections():
     p1.start()
     time.sleep(0.3)
     dup = connect()
-    dup.sendall(struct.pack("<I", 1))        # rank 1 again: must not displace the first
+    dup.sendall(struct.pack("<4sII", b"PLNK", 1, D._job_token()))        # rank 1 again: must not displace the first
     p2 = threading.Thread(target=peer, args=(2,))
     p2.start()
     for th in (p1, p2, t):
@@ -275,3 +275,53 @@ def test_rendezvous_survives_stray_connections():
     assert out["peers"] == [1, 2]
     assert out["got"] == [b"zero", b"r1", b"r2"] == results[1] == results[2]
     os.environ.pop("PLONK_RDZV_PORT")
+
+
+def test_rendezvous_moves_past_a_port_that_is_taken():
+    """The default rendezvous port (MASTER_PORT + 1) may belong to someone else on the node: rank 0 then listens on the next free
+    port of its range and the other ranks find it there — a foreign listener that hangs up on them costs a retry, not the launch."""
+    import socket
+    import threading
+
+    from plonkathon_amd import distributed as D
+
+    foreign = socket.socket()
+    foreign.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+    foreign.bind(("127.0.0.1", 0))
+    foreign.listen(8)
+    port = foreign.getsockname()[1]
+    stop = threading.Event()
+
+    def hang_up():
+        foreign.settimeout(0.2)
+        while not stop.is_set():
+            try:
+                c, _ = foreign.accept()
+                c.close()
+            except OSError:
+                pass
+
+    th = threading.Thread(target=hang_up)
+    th.start()
+    os.environ.update(MASTER_ADDR="127.0.0.1", PLONK_RDZV_PORT=str(port))
+    got = {}
+
+    def run(r):
+        star = D._Star(r, 2, timeout=30.0)
+        got[r] = star.all_gather(b"rank%d" % r)
+        star.close()
+
+    try:
+        ts = [threading.Thread(target=run, args=(r,)) for r in (0, 1)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join(60)
+            assert not t.is_alive()
+        assert got[0] == got[1] == [b"rank0", b"rank1"]
+    finally:
+        stop.set()
+        th.join(5)
+        foreign.close()
+        os.environ.pop("PLONK_RDZV_PORT")
+
