@@ -393,7 +393,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=512, help="proofs per lock-step batch (BASELINE configs[4]: 512)")
     ap.add_argument("--batches-per-step", type=int, default=20, help="lock-step batches per GPU per step (all witnesses distinct)")
-    ap.add_argument("--streams", type=int, default=4, help="HIP streams per GPU: the lock-step batches of a step are dealt round-robin to this many contexts, so one batch's latency-bound kernels (transcript, inversions, scans) overlap another's MSMs (measured 1 / 2 / 4 / 8 streams: 34.1 / 36.3 / 38.3 / 38.4 k proofs/s, profiles/r02_s_streams.txt)")
+    ap.add_argument("--hw-queues", type=int, default=0,
+                    help="GPU_MAX_HW_QUEUES for this process (the HIP runtime maps its streams onto 4 hardware queues by default: eight compute "
+                         "streams then share them in pairs and lose the overlap they exist for); 0 = 2 x --streams (a compute and a copy "
+                         "stream per context), unless the environment already sets it")
+    ap.add_argument("--streams", type=int, default=8, help="HIP streams per GPU: the lock-step batches of a step are dealt round-robin to this many contexts, so one batch's latency-bound kernels (transcript, inversions, scans) overlap another's MSMs (measured 1 / 2 / 4 / 8 streams: 34.1 / 36.3 / 38.3 / 38.4 k proofs/s, profiles/r02_s_streams.txt)")
     ap.add_argument("--dist-backend", default="rccl", choices=["rccl", "sockets"],
                     help="transport of the final gather for N > 1: rccl = RCCL over xGMI through the C-ABI (default); sockets = TCP, lets ranks share one GPU")
     ap.add_argument("--lookup-budget-gb", type=float, default=DEFAULT_TABLE_GB,
@@ -425,6 +429,10 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+
+    # before the HIP runtime initialises (measured, same box: 4 streams on the default 4 queues 40.1 - 40.3 k proofs/s, 8 streams on
+    # 8 or 16 queues 41.1 k, 12 on 24 41.4 k — profiles/r04_j_streams_hw_queues.jsonl)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(args.hw_queues or 2 * max(1, args.streams)))
 
     from plonkathon_amd import BatchProver, Context, Program, Setup, set_context
     from plonkathon_amd import distributed as D
@@ -594,6 +602,7 @@ def main():
             "batches_per_step": S,
             "prover": "BatchProver (lock-step, GPU-resident transcript)",
             "streams_per_gpu": NS,
+            "hip_hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
             "results_gathered_per_step": n_results,
             "parallelism": "proof-sharded x%d" % world,
             "ranks_in_communicator": comm.world if comm is not None else 1,
@@ -861,7 +870,7 @@ def main():
                 line["config"]["poseidon_2^11_proofs_s_%d_streams" % NS] = round(NS * PB / dtm, 1)
                 del prs
         line["configs"] = {"configs[2]": cfg,
-                           "note": "one stream, one lock-step batch resident (the headline runs 20 batches on 4 streams), and — "
+                           "note": "one stream, one lock-step batch resident (the headline runs 20 batches on all its streams), and — "
                                    "`_all_streams`, group_order 2^11 — one batch per stream of the headline's configuration; fixture = "
                                    "tests/golden/oracle_proofs.json"}
 
