@@ -397,7 +397,7 @@ def main():
                     help="GPU_MAX_HW_QUEUES for this process (the HIP runtime maps its streams onto 4 hardware queues by default: eight compute "
                          "streams then share them in pairs and lose the overlap they exist for); 0 = 2 x --streams (a compute and a copy "
                          "stream per context), unless the environment already sets it")
-    ap.add_argument("--streams", type=int, default=8, help="HIP streams per GPU: the lock-step batches of a step are dealt round-robin to this many contexts, so one batch's latency-bound kernels (transcript, inversions, scans) overlap another's MSMs (measured 1 / 2 / 4 / 8 streams: 34.1 / 36.3 / 38.3 / 38.4 k proofs/s, profiles/r02_s_streams.txt)")
+    ap.add_argument("--streams", type=int, default=0, help="HIP streams per GPU (0 = one per lock-step batch of a step: --batches-per-step): the lock-step batches of a step are dealt round-robin to this many contexts, so one batch's latency-bound kernels (transcript, inversions, scans) overlap another's MSMs (measured 1 / 2 / 4 / 8 streams: 34.1 / 36.3 / 38.3 / 38.4 k proofs/s, profiles/r02_s_streams.txt)")
     ap.add_argument("--dist-backend", default="rccl", choices=["rccl", "sockets"],
                     help="transport of the final gather for N > 1: rccl = RCCL over xGMI through the C-ABI (default); sockets = TCP, lets ranks share one GPU")
     ap.add_argument("--lookup-budget-gb", type=float, default=DEFAULT_TABLE_GB,
@@ -430,9 +430,10 @@ def main():
     if world != args.gpus:
         sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
 
-    # before the HIP runtime initialises (measured, same box: 4 streams on the default 4 queues 40.1 - 40.3 k proofs/s, 8 streams on
-    # 8 or 16 queues 41.1 k, 12 on 24 41.4 k — profiles/r04_j_streams_hw_queues.jsonl)
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(args.hw_queues or 2 * max(1, args.streams)))
+    # before the HIP runtime initialises.  Measured (profiles/r04_j_streams_hw_queues.jsonl; same box within a session): 4 streams on
+    # the runtime's default 4 queues 40.1 - 40.3 k proofs/s, 8 streams on 16 queues 41.1 k, 12 on 24 41.4 k; another box: 8 on 16
+    # 42.0 k, 16 on 32 42.4 k, 20 on 40 — one lock-step batch per stream — 43.1 k
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(args.hw_queues or 2 * max(1, args.streams or args.batches_per_step)))
 
     from plonkathon_amd import BatchProver, Context, Program, Setup, set_context
     from plonkathon_amd import distributed as D
@@ -445,7 +446,8 @@ def main():
     if comm is not None and comm.world != world:
         sys.exit("bench.py: communicator has %d ranks, expected %d" % (comm.world, world))
     budget = 0 if args.no_lookup else int(args.lookup_budget_gb * 1e9)
-    B, S, NS = args.batch, args.batches_per_step, max(1, args.streams)
+    B, S = args.batch, args.batches_per_step
+    NS = max(1, args.streams or S)
     ctxs = [ctx] + [Context(local_rank) for _ in range(NS - 1)]
     for c in ctxs:
         c.msm_lookup(1 if args.no_lookup else 0, 0, budget)
@@ -571,7 +573,7 @@ def main():
         barrier()
         ctx.profile_reset()
         ctx.profile(True)
-        for _ in range(3):
+        for _ in range(max(3, -(-12 // len(provers[0::NS])))):  # (at least 48 launches of the kernel, however few batches stream 0 holds)
             for pr in provers[0::NS]:
                 pr.run()
                 pr.download_raw()
