@@ -394,9 +394,9 @@ def main():
     ap.add_argument("--batch", type=int, default=512, help="proofs per lock-step batch (BASELINE configs[4]: 512)")
     ap.add_argument("--batches-per-step", type=int, default=20, help="lock-step batches per GPU per step (all witnesses distinct)")
     ap.add_argument("--hw-queues", type=int, default=0,
-                    help="GPU_MAX_HW_QUEUES for this process (the HIP runtime maps its streams onto 4 hardware queues by default: eight compute "
-                         "streams then share them in pairs and lose the overlap they exist for); 0 = 2 x --streams (a compute and a copy "
-                         "stream per context), unless the environment already sets it")
+                    help="GPU_MAX_HW_QUEUES for this process (the HIP runtime maps its streams onto 4 hardware queues by default: more "
+                         "compute streams then share them and lose the overlap they exist for); 0 = one per stream, at most 20, unless "
+                         "the environment already sets it")
     ap.add_argument("--streams", type=int, default=0, help="HIP streams per GPU (0 = one per lock-step batch of a step: --batches-per-step): the lock-step batches of a step are dealt round-robin to this many contexts, so one batch's latency-bound kernels (transcript, inversions, scans) overlap another's MSMs (measured 1 / 2 / 4 / 8 streams: 34.1 / 36.3 / 38.3 / 38.4 k proofs/s, profiles/r02_s_streams.txt)")
     ap.add_argument("--dist-backend", default="rccl", choices=["rccl", "sockets"],
                     help="transport of the final gather for N > 1: rccl = RCCL over xGMI through the C-ABI (default); sockets = TCP, lets ranks share one GPU")
@@ -430,10 +430,12 @@ def main():
     if world != args.gpus:
         sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
 
-    # before the HIP runtime initialises.  Measured (profiles/r04_j_streams_hw_queues.jsonl; same box within a session): 4 streams on
-    # the runtime's default 4 queues 40.1 - 40.3 k proofs/s, 8 streams on 16 queues 41.1 k, 12 on 24 41.4 k; another box: 8 on 16
-    # 42.0 k, 16 on 32 42.4 k, 20 on 40 — one lock-step batch per stream — 43.1 k
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(args.hw_queues or 2 * max(1, args.streams or args.batches_per_step)))
+    # Before the HIP runtime initialises: one hardware queue per compute stream, at most 20.  The runtime's default of 4 makes
+    # streams share queues (and serialise); more queues than the device schedules at once cost every latency-bound path.  Measured
+    # (profiles/r04_j_streams_hw_queues.jsonl, same box within a session): 4 streams / 4 queues 40.1 - 40.3 k proofs/s, 8 / 16 41.1 k,
+    # 12 / 24 41.4 k; another box: 8 / 16 42.0 k, 20 / 20 42.9 k, 20 / 40 43.1 k — but from 24 queues up the one-stream legs lose up to
+    # half (Poseidon at 2^11 36.7 k -> 29.4 k at 24 queues, 17.7 k at 40; fresh uploads 0.98 -> 0.86 -> 0.78 of the headline)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(args.hw_queues or min(20, max(4, args.streams or args.batches_per_step))))
 
     from plonkathon_amd import BatchProver, Context, Program, Setup, set_context
     from plonkathon_amd import distributed as D
