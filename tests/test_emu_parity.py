@@ -55,7 +55,6 @@ def test_ntt_extreme_inputs(emu):
         pc.ntt_extreme_limbs((8, 9, 10, 11))
         pc.ntt_extreme_limbs((12,), slots=8)  # 2^12 = 512 threads x 8 elements
     with pc.ntt_kind(8):  # ... and its 1024-thread, 4-element form (the column-pass kernel of 2^24 = 2^12 x 2^12)
-        pc.ntt_extreme_inputs((12,))
         pc.ntt_extreme_limbs((12,))
 
 
@@ -66,12 +65,11 @@ def test_ntt_latency_forms(emu):
 def test_bls12_381_ntt(emu):
     """One size per wave kernel (E = 2, 4 and 8; 0, 1, 2 LDS stages) with the emulator's range checks on the 255-bit modulus."""
     with pc.ntt_kind(6):
-        pc.bls_ntt_vs_oracle((8, 9, 10, 11), batch=3)
+        pc.bls_ntt_vs_oracle((8, 9, 10, 11), batch=2)
         pc.bls_ntt_vs_oracle((12, 13), seed0=77)
     with pc.ntt_kind(7):
         pc.bls_ntt_vs_oracle((7, 9), seed0=177, batch=2)
-    with pc.ntt_kind(8):
-        pc.bls_ntt_vs_oracle((12,), seed0=277)
+
 
 
 def test_poly_golden(emu):
@@ -228,8 +226,9 @@ def test_lagrange_srs_paths(emu):
 def test_ntt_two_pass_wave_kernel(emu):
     """Two-pass transforms through the wave kernels' column and row passes, exact against the C oracle: 2^16 = 2^8 x 2^8
     (4 elements per thread in both passes), 2^17 = 2^8 x 2^9 (4, then 8) and forced to 2^9 x 2^8 (8, then 4: the column pass
-    of the 8-element kernels takes its inter-pass twiddles from the two small tables), 2^19 forced to 2^7 x 2^12 (the 512-thread
-    kernel as a row pass).  Kernel kind 6: the throughput forms whatever the size of the call."""
+    of the 8-element kernels takes its inter-pass twiddles from the two small tables).  Kernel kind 6: the throughput forms whatever
+    the size of the call.  (The 512-thread 2^12 kernel as a ROW pass needs 2^19 points — a minute on the emulator: the GPU suite's
+    2^24 = 2^12 x 2^12 case; as a single pass it is in test_ntt_forced_variants and test_ntt_extreme_inputs.)"""
     from oracle import c_oracle
     from plonkathon_amd import Basis, get_context
     from plonkathon_amd._lib import check
@@ -254,13 +253,8 @@ def test_ntt_two_pass_wave_kernel(emu):
     assert pc.ints(pc.P(v, Basis.LAGRANGE).ifft()) == c_oracle.fr_ntt(v, True)  # ... and from the full table (1/N folded in)
     try:
         assert ctx.L.plonk_ntt_set_split(ctx.handle, 18, 14) != 0 and ctx.L.plonk_ntt_set_split(ctx.handle, 15, 9) != 0
-        # 2^12 as a ROW pass: the 512-thread, 8-element kernel (2^19 = 2^7 x 2^12; kind 6 = the configuration of a large call)
-        check(ctx.L.plonk_ntt_set_split(ctx.handle, 19, 7))
-        v = pc.rand_vec(4190, 1 << 19)
-        assert pc.ints(pc.P(v, Basis.MONOMIAL).fft()) == c_oracle.fr_ntt(v)
     finally:
         check(ctx.L.plonk_ntt_set_split(ctx.handle, 18, 0))
-        check(ctx.L.plonk_ntt_set_split(ctx.handle, 19, 0))
         check(ctx.L.plonk_ntt_select_kernel(ctx.handle, 0))
 
 
