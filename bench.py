@@ -442,9 +442,28 @@ def main():
 
     ctx = Context(local_rank)
     set_context(ctx)
-    comm = D.init_from_env(ctx, args.dist_backend) if world > 1 else None
-    if comm is None and args.force_comm:
-        comm = D.RcclComm(ctx, 0, 1) if args.dist_backend == "rccl" else D.SocketComm(0, 1)
+    # librccl announces itself on C stdout ("RCCL version : ..", five lines, flushed whenever libc pleases — after this script's JSON
+    # line when stdout is a pipe): while the communicator is created, file descriptor 1 points at stderr, and libc's buffer is flushed
+    # before it is restored, so that stdout carries the one JSON line and nothing else
+    import ctypes
+
+    sys.stdout.flush()
+    saved_fd = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        comm = D.init_from_env(ctx, args.dist_backend) if world > 1 else None
+        if comm is None and args.force_comm:
+            comm = D.RcclComm(ctx, 0, 1) if args.dist_backend == "rccl" else D.SocketComm(0, 1)
+        if comm is not None and comm.kind == "rccl":
+            comm.barrier()  # (the first collective: whatever the library prints lazily, it prints now)
+            ctx.sync()
+    finally:
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        os.dup2(saved_fd, 1)
+        os.close(saved_fd)
     if comm is not None and comm.world != world:
         sys.exit("bench.py: communicator has %d ranks, expected %d" % (comm.world, world))
     budget = 0 if args.no_lookup else int(args.lookup_budget_gb * 1e9)

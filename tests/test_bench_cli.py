@@ -19,6 +19,7 @@ def _run(extra, timeout=600):
 def test_gpus_flag_spawns_that_many_ranks(emu_cdll):
     r = _run(["--gpus", "2", "--dist-backend", "sockets"])
     assert r.returncode == 0, r.stderr[-2000:]
+    assert len(r.stdout.strip().splitlines()) == 1, r.stdout  # ONE JSON line and nothing else
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and line["config"]["ranks_in_communicator"] == 2
     assert line["config"]["results_gathered_per_step"] == 2 * 3 * 2 and line["config"]["gather_in_timed_region"]
@@ -31,6 +32,7 @@ def test_force_comm_runs_the_multi_gpu_code_path_with_one_rank(emu_cdll):
     runs against RCCL on the GPU box: tests/test_gpu_multiprocess.py)."""
     r = _run(["--gpus", "1", "--force-comm"])
     assert r.returncode == 0, r.stderr[-2000:]
+    assert len(r.stdout.strip().splitlines()) == 1, r.stdout  # ONE JSON line and nothing else
     line = json.loads(r.stdout.strip().splitlines()[-1])
     cfg = line["config"]
     assert cfg["gather_transport"] == "rccl" and cfg["gather_in_timed_region"] and cfg["ranks_in_communicator"] == 1
@@ -46,6 +48,7 @@ def test_force_comm_runs_the_multi_gpu_code_path_with_one_rank(emu_cdll):
 def test_two_ranks_report_per_rank_figures(emu_cdll):
     r = _run(["--gpus", "2", "--dist-backend", "sockets"])
     assert r.returncode == 0, r.stderr[-2000:]
+    assert len(r.stdout.strip().splitlines()) == 1, r.stdout  # ONE JSON line and nothing else
     line = json.loads(r.stdout.strip().splitlines()[-1])
     pr = line["per_rank"]
     assert len(pr["proofs_per_s"]) == 2 and all(x > 0 for x in pr["proofs_per_s"])

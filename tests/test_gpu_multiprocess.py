@@ -51,7 +51,11 @@ def _bench(extra, timeout=1500, env_extra=None):
     cmd = [sys.executable, os.path.join(REPO, "bench.py")] + extra
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
     assert r.returncode == 0, r.stderr[-3000:]
-    return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    # the contract: ONE JSON line on stdout and nothing else (librccl's own banner goes to stderr: bench.py points fd 1 there while
+    # the communicator is created)
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[-2000:]
+    return json.loads(lines[0])
 
 
 SHORT = ["--no-cpu-baseline", "--no-microbench", "--no-fallbacks", "--no-end-to-end", "--no-configs", "--no-latency"]
