@@ -99,13 +99,15 @@ def test_an_explicit_rccl_path_is_honoured_and_a_wrong_one_fails_loudly():
 
 @pytest.mark.gpu
 def test_dress_rehearsal_eight_ranks_at_the_default_batch():
-    """`bench.py --gpus 8` with the bench's DEFAULT step (20 lock-step batches of 512 per rank, 4 streams) as
+    """`bench.py --gpus 8` with the bench's DEFAULT step (20 lock-step batches of 512 per rank; 4 streams) as
     eight processes on the one GPU (sockets transport, the library's 4 GiB table budget per process: 8 x ~25 GB of HBM).  The
     eight ranks share one chip, so their summed rate is bounded by the single-process rate on the same budget; what the
     driver's time-slicing of eight processes' queues costs on top was measured at 21 % (22.5 k against 28.5 k proofs/s, every
     rank within 2.5 % of the others: profiles/r04_b_pytest_gpu.log) — the bound below is what a per-rank defect (a rank that
     stalls, serialised table builds, a gather that scales with the rank count) would break, not a performance target."""
-    common = ["--steps", "2", "--warmup", "1", "--lookup-budget-gb", "4"] + SHORT
+    # (four streams on four hardware queues per process, as in round 3: eight processes with the bench's default of twenty queues
+    # each would put 160 queues on the one GPU, and what is measured then is the queue scheduler — 0.69 in session q)
+    common = ["--steps", "2", "--warmup", "1", "--lookup-budget-gb", "4", "--streams", "4", "--hw-queues", "4"] + SHORT
     one = _bench(["--gpus", "1"] + common)
     eight = _bench(["--gpus", "8", "--dist-backend", "sockets"] + common, timeout=2400)
     cfg = eight["config"]
