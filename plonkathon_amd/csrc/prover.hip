@@ -485,36 +485,54 @@ __global__ void __launch_bounds__(GP_THREADS) grand_product_kernel(GrandProductI
 //   one place ahead INSIDE the coset, Z_H by r.  The quotient goes to quot[b * out_stride + k].
 struct ZhInv { Fr v[4]; };
 struct QuotientIn { const Fr* wit[5]; const Fr* fixed[FX_COUNT]; const Fr* l0; const Fr* xs; };
-__global__ void quotient_kernel(QuotientIn in, ZhInv zh, const ProofState* st, RoundChallenges direct, unsigned n4, Fr* quot,
-                                unsigned coset_log, unsigned out_stride) {
-    // blockIdx.y = proof, blockIdx.x * blockDim.x + threadIdx.x = point (32-bit indices, no divisions: the kernel sits at 128 VGPRs)
+// Round 4: the arithmetic runs on lazy limbs (fpl.h) — operands stay unpacked between the 19 products of a point, the gate's
+// four products share two reductions (fpl_mul_add), sums of two are multiplied as they stand and only the seven sums of three
+// or more are carry-swept: ~4 800 instructions per point against ~5 800 on packed residues.  Bounds, in units of m, beside
+// each line ("n" = normalised: limbs 0..7 in [0, 2^29)); the emulator build asserts them on every operand.
+__global__ void __launch_bounds__(256) quotient_kernel(QuotientIn in, ZhInv zh, const ProofState* st, RoundChallenges direct, unsigned n4, Fr* quot,
+                                                       unsigned coset_log, unsigned out_stride) {
+    typedef FpL<FrParams> L;
+    // blockIdx.y = proof, blockIdx.x * blockDim.x + threadIdx.x = point (32-bit indices, no divisions)
     const unsigned b = blockIdx.y;
+    // the challenges are the same for every lane of the block: limbs in scalar registers
+    const L beta = fpl_from_fp_uniform(st ? st[b].beta : direct.beta), gamma = fpl_from_fp_uniform(st ? st[b].gamma : direct.gamma),
+            alpha = fpl_from_fp_uniform(st ? st[b].alpha : direct.alpha);                                   // n, [0, 1)
+    const L one = fpl_one<FrParams>();
+    const size_t row = (size_t)b * n4;
     for (unsigned k = blockIdx.x * blockDim.x + threadIdx.x; k < n4; k += gridDim.x * blockDim.x) {
         const unsigned cr = coset_log ? k >> coset_log : 0u, cmask = coset_log ? (1u << coset_log) - 1u : 0u;
-        const Fr beta = st ? st[b].beta : direct.beta, gamma = st ? st[b].gamma : direct.gamma, alpha = st ? st[b].alpha : direct.alpha;
-        const size_t row = (size_t)b * n4;
-        const Fr a = fp_load(in.wit[0] + row + k), bb = fp_load(in.wit[1] + row + k), c = fp_load(in.wit[2] + row + k),
-                 pi = fp_load(in.wit[3] + row + k), z = fp_load(in.wit[4] + row + k);
         const unsigned kw = coset_log ? ((k & ~cmask) | ((k + 1) & cmask))            // the next point of the same coset
                                       : ((k + 4 < n4) ? k + 4 : k + 4 - n4);          // Z(w x) = Z_big.shift(4), prover.py:173
-        const Fr zw = fp_load(in.wit[4] + row + kw);
-        const Fr qm = fp_load(in.fixed[FX_QM] + k), ql = fp_load(in.fixed[FX_QL] + k), qr = fp_load(in.fixed[FX_QR] + k),
-                 qo = fp_load(in.fixed[FX_QO] + k), qc = fp_load(in.fixed[FX_QC] + k);
+        const auto ld = [&](const Fr* p) PLONK_LAMBDA_INLINE { return fpl_from_fp(fp_load(p)); };          // n, [0, 1)
+        const L a = ld(in.wit[0] + row + k), bb = ld(in.wit[1] + row + k), c = ld(in.wit[2] + row + k);
         // gate: A QL + B QR + A B QM + C QO + PI + QC
-        Fr gate = fp_add(fp_mul(a, ql), fp_mul(bb, qr));
-        gate = fp_add(gate, fp_mul(fp_mul(a, bb), qm));
-        gate = fp_add(gate, fp_mul(c, qo));
-        gate = fp_add(gate, fp_add(pi, qc));
-        // permutation
-        const Fr ag = fp_add(a, gamma), bg = fp_add(bb, gamma), cg = fp_add(c, gamma);
-        const Fr bx = fp_mul(beta, fp_load(in.xs + k));
-        Fr p1 = fp_mul(fp_mul(fp_add(ag, bx), fp_add(bg, fp_dbl(bx))), fp_mul(fp_add(cg, fp_mul3(bx)), z));
-        Fr p2 = fp_mul(fp_mul(fp_add(ag, fp_mul(beta, fp_load(in.fixed[FX_S1] + k))),
-                              fp_add(bg, fp_mul(beta, fp_load(in.fixed[FX_S2] + k)))),
-                       fp_mul(fp_add(cg, fp_mul(beta, fp_load(in.fixed[FX_S3] + k))), zw));
-        Fr first = fp_mul(fp_sub(z, fp_one<FrParams>()), fp_load(in.l0 + k));
-        Fr acc = fp_add(gate, fp_mul(alpha, fp_add(fp_sub(p1, p2), fp_mul(alpha, first))));
-        fp_store(quot + (size_t)b * out_stride + k, fp_mul(acc, zh.v[coset_log ? cr : (k & 3)]));
+        const L t1 = fpl_mul_add(a, ld(in.fixed[FX_QL] + k), bb, ld(in.fixed[FX_QR] + k));               // n, (-1, 2)
+        const L ab = fpl_mul(a, bb);                                                                       // n, (-1, 2)
+        const L t2 = fpl_mul_add(ab, ld(in.fixed[FX_QM] + k), c, ld(in.fixed[FX_QO] + k));               // n, (-1, 2)
+        const L gate = fpl_norm(fpl_add(fpl_add(t1, t2), fpl_add(ld(in.wit[3] + row + k), ld(in.fixed[FX_QC] + k))));  // four terms: limbs < 2^31; n, (-2, 6)
+        // permutation: (A + g + b x)(B + g + 2 b x)(C + g + 3 b x) Z - (A + g + b S1)(B + g + b S2)(C + g + b S3) Z(w x)
+        const L bx = fpl_mul(beta, ld(in.xs + k));                                                         // n, (-1, 2)
+        const L u1 = fpl_norm(fpl_add(gamma, bx));                                                         // n, (-1, 3)
+        const L u2 = fpl_norm(fpl_add(u1, bx));                                                            // n, (-2, 5)
+        const L u3 = fpl_norm(fpl_add(u2, bx));                                                            // n, (-3, 7)
+        const L z = ld(in.wit[4] + row + k);
+        L p1 = fpl_mul(fpl_add(a, u1), z);                                                                 // (two terms) x n: |.| < 4;  n, (-1, 2)
+        p1 = fpl_mul(fpl_add(bb, u2), p1);                                                                 // < 6 x 2
+        p1 = fpl_mul(fpl_add(c, u3), p1);                                                                  // < 8 x 2
+        const L v1 = fpl_norm(fpl_add(gamma, fpl_mul(beta, ld(in.fixed[FX_S1] + k))));                     // n, (-1, 3)
+        L p2 = fpl_mul(fpl_add(a, v1), ld(in.wit[4] + row + kw));                                          // < 4 x 1
+        const L v2 = fpl_norm(fpl_add(gamma, fpl_mul(beta, ld(in.fixed[FX_S2] + k))));
+        p2 = fpl_mul(fpl_add(bb, v2), p2);                                                                 // < 4 x 2
+        const L v3 = fpl_norm(fpl_add(gamma, fpl_mul(beta, ld(in.fixed[FX_S3] + k))));
+        p2 = fpl_mul(fpl_add(c, v3), p2);
+        // (Z - 1) L0, and the sum under alpha
+        const L first = fpl_mul(fpl_sub(z, one), ld(in.l0 + k));                     // difference x n;  n, (-1, 2)
+        const L inner = fpl_add(fpl_sub(p1, p2), fpl_mul(alpha, first));                                   // limbs within (-2^29, 2^30); (-4, 5)
+        const L acc = fpl_add(gate, fpl_mul(alpha, inner));                                                // two n terms; (-3, 8)
+        L zhi;
+        if (coset_log >= 6) zhi = fpl_from_fp_uniform(zh.v[cr]);  // a wave's 64 points lie in one coset (64 | n): scalar registers
+        else zhi = fpl_from_fp(zh.v[coset_log ? cr : (k & 3)]);
+        fp_store(quot + (size_t)b * out_stride + k, fpl_pack_canonical(fpl_mul(acc, zhi)));
     }
 }
 
