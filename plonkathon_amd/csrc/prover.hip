@@ -657,23 +657,51 @@ __global__ void __launch_bounds__(64) linearisation_weights_kernel(const ProofSt
     if (b < B) out[b] = linearisation_weights(st[b], log_n, n_inv);
 }
 
-__global__ void __launch_bounds__(256) linearisation_kernel(const Fr* coef, const Fr* fixed_coef, const Fr* tcoef,
-                                                           const LinWeights* weights, unsigned log_n, size_t B,
-                                                           Fr* out) {
-    __shared__ LinWeights W;
+// (lazy limbs, round 4: the 15 products of a coefficient pair up under 8 reductions — fpl_mul_add — with the weights unpacked
+// once per block into LDS; the sum of the first seven results rides as "1 x sum" in the eighth, which leaves it reduced)
+__global__ void __launch_bounds__(256, 4) linearisation_kernel(const Fr* coef, const Fr* fixed_coef, const Fr* tcoef,
+                                                              const LinWeights* weights, unsigned log_n, size_t B,
+                                                              Fr* out) {
+    typedef FpL<FrParams> L;
+    __shared__ int32_t WL[16][12];  // the weights as limbs (9 of 12 words used); [15] = R mod m, the Montgomery form of 1
     const size_t n = (size_t)1 << log_n;
     const size_t b = blockIdx.y;
-    if (threadIdx.x < 15) W.w[threadIdx.x] = fp_load(&weights[b].w[threadIdx.x]);
+    if (threadIdx.x < 16) {
+        const L w = threadIdx.x < 15 ? fpl_from_fp(fp_load(&weights[b].w[threadIdx.x])) : fpl_one<FrParams>();
+#pragma unroll
+        for (int q = 0; q < 9; q++) WL[threadIdx.x][q] = w.l[q];
+    }
     __syncthreads();
     const Fr* vec[15] = {fixed_coef + FX_QM * n, fixed_coef + FX_QL * n, fixed_coef + FX_QR * n, fixed_coef + FX_QO * n,
                          fixed_coef + FX_QC * n, coef + (4 * B + b) * n, fixed_coef + FX_S3 * n, tcoef + b * 4 * n,
                          tcoef + b * 4 * n + n,   tcoef + b * 4 * n + 2 * n, coef + (0 * B + b) * n,
                          coef + (1 * B + b) * n,  coef + (2 * B + b) * n,    fixed_coef + FX_S1 * n, fixed_coef + FX_S2 * n};
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        Fr acc = fp_zero<FrParams>();
+    const auto weight = [&](unsigned j) PLONK_LAMBDA_INLINE {
+        L w;
 #pragma unroll
-        for (int j = 0; j < 15; j++) acc = fp_add(acc, fp_mul(W.w[j], fp_load(vec[j] + i)));
-        fp_store(out + b * n + i, acc);
+        for (int q = 0; q < 9; q++) {
+            w.l[q] = WL[j][q];
+            FPL_ANY_SIGN(w.l[q]);
+        }
+        return w;  // normalised, [0, m)
+    };
+    const auto value = [&](unsigned j, size_t i) PLONK_LAMBDA_INLINE { return fpl_from_fp(fp_load(vec[j] + i)); };
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        L s = fpl_zero<FrParams>();
+        wave_for<4>([&](auto Q) {  // four results, each normalised in (-m, 2m): limbs of the sum < 2^31
+            constexpr unsigned j = 2 * decltype(Q)::value;
+            s = fpl_add(s, fpl_mul_add(weight(j), value(j, i), weight(j + 1), value(j + 1, i)));
+            PLONK_SCHED_FENCE();
+        });
+        s = fpl_norm(s);  // (-4 m, 8 m)
+        L t = fpl_zero<FrParams>();
+        wave_for<3>([&](auto Q) {
+            constexpr unsigned j = 8 + 2 * decltype(Q)::value;
+            t = fpl_add(t, fpl_mul_add(weight(j), value(j, i), weight(j + 1), value(j + 1, i)));
+            PLONK_SCHED_FENCE();
+        });
+        const L u = fpl_norm(fpl_add(s, fpl_norm(t)));  // (-7 m, 14 m), normalised
+        fp_store(out + b * n + i, fpl_pack_canonical(fpl_mul_add(weight(14), value(14, i), weight(15), u)));  // |.| < 1 + 14
     }
 }
 
