@@ -595,14 +595,23 @@ __global__ void __launch_bounds__(EV_THREADS) eval_kernel(const Fr* coef, const 
     const size_t lo = tid * per, hi = (lo + per < n) ? lo + per : n;
     // x^(chunk start) once per evaluation point, not once per polynomial
     const Fr shift_z = fp_pow_u64(zeta, (uint64_t)lo), shift_zw = fp_pow_u64(zeta_w, (uint64_t)lo);
+    // Horner on lazy limbs (round 4), the seven chains side by side: acc x is normalised in (-m, 2m), plus a coefficient it is a
+    // sum of two — a valid multiplicand as it stands; the evaluation points sit in scalar registers
+    typedef FpL<FrParams> L;
+    const L zl = fpl_from_fp_uniform(zeta), zwl = fpl_from_fp_uniform(zeta_w);
+    L acc[NEVAL];
+    wave_for<NEVAL>([&](auto P_) { acc[decltype(P_)::value] = fpl_zero<FrParams>(); });
 #pragma unroll 1
-    for (int p = 0; p < NEVAL; p++) {
-        const Fr x = (p == 5) ? zeta_w : zeta;
-        Fr acc = fp_zero<FrParams>();
-        for (size_t i = hi; i-- > lo;) acc = fp_add(fp_mul(acc, x), fp_load(polys[p] + i));
-        if (lo < hi) acc = fp_mul(acc, (p == 5) ? shift_zw : shift_z);
-        red[p][tid] = acc;
-    }
+    for (size_t i = hi; i-- > lo;)
+        wave_for<NEVAL>([&](auto P_) {
+            constexpr unsigned p = decltype(P_)::value;
+            acc[p] = fpl_add(fpl_mul(acc[p], p == 5 ? zwl : zl), fpl_from_fp(fp_load(polys[p] + i)));  // (-m, 3m), limbs < 2^30
+        });
+    const L sh_z = fpl_from_fp(shift_z), sh_zw = fpl_from_fp(shift_zw);
+    wave_for<NEVAL>([&](auto P_) {
+        constexpr unsigned p = decltype(P_)::value;
+        red[p][tid] = lo < hi ? fpl_pack_canonical(fpl_mul(acc[p], p == 5 ? sh_zw : sh_z)) : fp_zero<FrParams>();
+    });
     __syncthreads();
     for (unsigned s = EV_THREADS / 2; s > 0; s >>= 1) {  // the seven sums share the barriers
         if (tid < s)
