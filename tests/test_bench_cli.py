@@ -12,12 +12,12 @@ def _run(extra, timeout=600):
     env = dict(os.environ, PLONK_HIP_LIB=EMU_LIB, PLONK_MSM_TABLE_GB="0.0001")
     env.pop("WORLD_SIZE", None)
     cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--log-n", "4", "--batch", "3", "--batches-per-step", "2", "--steps", "2",
-           "--warmup", "1", "--no-cpu-baseline", "--no-microbench", "--no-fallbacks", "--no-lookup"] + extra
+           "--warmup", "1", "--no-cpu-baseline", "--no-microbench", "--no-fallbacks", "--no-lookup", "--no-latency"] + extra
     return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
 
 
 def test_gpus_flag_spawns_that_many_ranks(emu_cdll):
-    r = _run(["--gpus", "2", "--dist-backend", "sockets"])
+    r = _run(["--gpus", "2", "--dist-backend", "sockets", "--no-end-to-end"])
     assert r.returncode == 0, r.stderr[-2000:]
     assert len(r.stdout.strip().splitlines()) == 1, r.stdout  # ONE JSON line and nothing else
     line = json.loads(r.stdout.strip().splitlines()[-1])
@@ -46,7 +46,7 @@ def test_force_comm_runs_the_multi_gpu_code_path_with_one_rank(emu_cdll):
 
 
 def test_two_ranks_report_per_rank_figures(emu_cdll):
-    r = _run(["--gpus", "2", "--dist-backend", "sockets"])
+    r = _run(["--gpus", "2", "--dist-backend", "sockets", "--no-end-to-end"])
     assert r.returncode == 0, r.stderr[-2000:]
     assert len(r.stdout.strip().splitlines()) == 1, r.stdout  # ONE JSON line and nothing else
     line = json.loads(r.stdout.strip().splitlines()[-1])
@@ -77,7 +77,7 @@ def test_launched_by_torch_distributed_run(emu_cdll):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(REPO, "bench.py"), "--gpus", "2", "--dist-backend", "sockets", "--log-n", "4",
            "--batch", "3", "--batches-per-step", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-microbench",
-           "--no-fallbacks", "--no-lookup"]
+           "--no-fallbacks", "--no-lookup", "--no-latency", "--no-end-to-end"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
