@@ -8,41 +8,67 @@ import sys
 from conftest import EMU_LIB, REPO
 
 
-def _run(extra, timeout=600):
+def _run(extra, timeout=600, detail=None):
     env = dict(os.environ, PLONK_HIP_LIB=EMU_LIB, PLONK_MSM_TABLE_GB="0.0001")
     env.pop("WORLD_SIZE", None)
     cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--log-n", "4", "--batch", "3", "--batches-per-step", "2", "--steps", "2",
            "--warmup", "1", "--no-cpu-baseline", "--no-microbench", "--no-fallbacks", "--no-lookup", "--no-latency"] + extra
+    if detail is not None:
+        cmd += ["--detail", str(detail)]
     return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
 
 
-def test_gpus_flag_spawns_that_many_ranks(emu_cdll):
-    r = _run(["--gpus", "2", "--dist-backend", "sockets", "--no-end-to-end"])
+CONTRACT_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                 "dtype", "data", "config")
+
+
+def _one_short_line(stdout):
+    """The driver's record keeps the tail of stdout: ONE JSON line, under 4 KB, with every contract field (round 4's line had
+    grown to 20 KB and the driver could not parse it)."""
+    lines = stdout.strip().splitlines()
+    assert len(lines) == 1, stdout
+    assert len(lines[0]) < 4096, len(lines[0])
+    line = json.loads(lines[0])
+    assert all(k in line for k in CONTRACT_KEYS), sorted(line)
+    assert "workload" in line["config"] and len(line["config"]) <= 13
+    assert all(not isinstance(v, (dict, list)) for v in line["config"].values())  # scalars only
+    return line
+
+
+def test_gpus_flag_spawns_that_many_ranks(emu_cdll, tmp_path):
+    r = _run(["--gpus", "2", "--dist-backend", "sockets", "--no-end-to-end"], detail=tmp_path / "d.json")
     assert r.returncode == 0, r.stderr[-2000:]
-    assert len(r.stdout.strip().splitlines()) == 1, r.stdout  # ONE JSON line and nothing else
-    line = json.loads(r.stdout.strip().splitlines()[-1])
+    line = _one_short_line(r.stdout)  # ONE short JSON line and nothing else
+    detail = json.load(open(tmp_path / "d.json"))  # everything else the run measured
+    assert detail["line"] == line
     assert line["n_gpus"] == 2 and line["config"]["ranks_in_communicator"] == 2
-    assert line["config"]["results_gathered_per_step"] == 2 * 3 * 2 and line["config"]["gather_in_timed_region"]
+    assert detail["config"]["results_gathered_per_step"] == 2 * 3 * 2 and detail["config"]["gather_in_timed_region"]
     assert line["scaling"] == "weak" and line["unit"] == "proofs/s" and line["value"] > 0
-    pr = line["per_rank"]  # every rank's own figures, so that a scaling record explains itself
+    assert line["config"]["sampled_proofs_verify"] is True and len(detail["sampled_verify"]["indices"]) == 4
+    pr = detail["per_rank"]  # every rank's own figures, so that a scaling record explains itself
     assert len(pr["proofs_per_s"]) == 2 and all(x > 0 for x in pr["proofs_per_s"])
     assert pr["proofs_per_s_min"] <= pr["proofs_per_s_max"] and len(pr["allgather_us_per_step"]) == 2
     assert pr["proofs_per_s_sum"] >= line["value"] * 0.999
+    assert len(line["per_rank"]["proofs_per_s"]) == 2  # the short form travels in the line
+    # the detail also went to stderr as one line
+    assert any(l.startswith("bench_detail: {") for l in r.stderr.splitlines())
 
 
-def test_force_comm_runs_the_multi_gpu_code_path_with_one_rank(emu_cdll):
+def test_force_comm_runs_the_multi_gpu_code_path_with_one_rank(emu_cdll, tmp_path):
     """`--gpus 1 --force-comm`: a one-rank communicator, the device-resident gather, the max over ranks and the barrier inside
     the timed region, and the per-rank block of an N-GPU line (here over the emulation's communicator stub; the same command
     runs against RCCL on the GPU box: tests/test_gpu_multiprocess.py)."""
-    r = _run(["--gpus", "1", "--force-comm"])
+    r = _run(["--gpus", "1", "--force-comm"], detail=tmp_path / "d.json")
     assert r.returncode == 0, r.stderr[-2000:]
-    assert len(r.stdout.strip().splitlines()) == 1, r.stdout  # ONE JSON line and nothing else
-    line = json.loads(r.stdout.strip().splitlines()[-1])
-    cfg = line["config"]
+    line = _one_short_line(r.stdout)
+    detail = json.load(open(tmp_path / "d.json"))
+    cfg = detail["config"]
+    assert line["config"]["gather_transport"] == "rccl" and line["config"]["ranks_in_communicator"] == 1
     assert cfg["gather_transport"] == "rccl" and cfg["gather_in_timed_region"] and cfg["ranks_in_communicator"] == 1
     assert cfg["gather_path"].startswith("device buffers") and cfg["results_gathered_per_step"] == 6
     assert cfg["torch_imported"] is False and "rccl_path" in cfg and "rccl_version" in cfg
-    pr = line["per_rank"]
+    assert "end_to_end" in detail and detail["end_to_end"]["fraction_of_value"] > 0
+    pr = detail["per_rank"]
     assert len(pr["proofs_per_s"]) == 1 and pr["proofs_per_s_min"] == pr["proofs_per_s_max"] > 0
     assert len(pr["msm_table_build_s"]) == 1 and len(pr["allgather_us_per_step"]) == 1
     # the whole-job value is measured over the barrier, a rank's own rate before it: never below it
@@ -73,8 +99,8 @@ def test_launched_by_torch_distributed_run(emu_cdll):
            "--no-fallbacks", "--no-lookup", "--no-latency", "--no-end-to-end"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
-    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-    assert line["n_gpus"] == 2 and line["config"]["ranks_in_communicator"] == 2 and line["config"]["gather_in_timed_region"]
+    line = _one_short_line(r.stdout)
+    assert line["n_gpus"] == 2 and line["config"]["ranks_in_communicator"] == 2 and line["config"]["gather_transport"] == "sockets"
 
 
 def test_clock_sampler_parses_rocm_smi_text():

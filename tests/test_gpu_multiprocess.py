@@ -20,13 +20,16 @@ def test_eight_processes_share_the_gpu_and_gather_512_proofs(tmp_path):
     env.pop("WORLD_SIZE", None)
     cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "8", "--dist-backend", "sockets", "--steps", "1", "--warmup", "0",
            "--batch", "64", "--batches-per-step", "1", "--streams", "1", "--lookup-budget-gb", "4", "--no-cpu-baseline",
-           "--no-microbench", "--no-fallbacks", "--no-end-to-end", "--no-configs", "--no-latency", "--dump-proofs", str(dump)]
+           "--no-microbench", "--no-fallbacks", "--no-end-to-end", "--no-configs", "--no-latency", "--dump-proofs", str(dump),
+           "--detail", str(tmp_path / "detail.json")]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    cfg = json.load(open(tmp_path / "detail.json"))["config"]
     assert line["n_gpus"] == 8 and line["config"]["ranks_in_communicator"] == 8
-    assert line["config"]["results_gathered_per_step"] == 512 and line["config"]["gather_in_timed_region"]
-    assert line["config"]["msm_table_bits"] == 11  # the 4 GiB budget: 3.2 GB table per process
+    assert line["config"]["sampled_proofs_verify"] is True  # four random proofs of the 512 under the pairing check
+    assert cfg["results_gathered_per_step"] == 512 and cfg["gather_in_timed_region"]
+    assert cfg["msm_table_bits"] == 11  # the 4 GiB budget: 3.2 GB table per process
     blob = dump.read_bytes()
     assert len(blob) == 512 * 768
 
@@ -45,17 +48,23 @@ def test_eight_processes_share_the_gpu_and_gather_512_proofs(tmp_path):
 
 
 def _bench(extra, timeout=1500, env_extra=None):
+    """-> (the stdout line, the detail record): the line is the short contract form, everything else is in the detail."""
+    import tempfile
+
     env = dict(os.environ)
     env.pop("WORLD_SIZE", None)
     env.update(env_extra or {})
-    cmd = [sys.executable, os.path.join(REPO, "bench.py")] + extra
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
-    assert r.returncode == 0, r.stderr[-3000:]
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "detail.json")
+        cmd = [sys.executable, os.path.join(REPO, "bench.py")] + extra + ["--detail", path]
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+        assert r.returncode == 0, r.stderr[-3000:]
+        detail = json.load(open(path))
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     # the contract: ONE JSON line on stdout and nothing else (librccl's own banner goes to stderr: bench.py points fd 1 there while
-    # the communicator is created)
-    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[-2000:]
-    return json.loads(lines[0])
+    # the communicator is created), short enough for the driver's record to keep all of it
+    assert len(lines) == 1 and lines[0].startswith("{") and len(lines[0]) < 4096, r.stdout[-2000:]
+    return json.loads(lines[0]), detail
 
 
 SHORT = ["--no-cpu-baseline", "--no-microbench", "--no-fallbacks", "--no-end-to-end", "--no-configs", "--no-latency"]
@@ -67,9 +76,9 @@ def test_one_rank_rccl_in_a_process_that_never_imports_torch():
     ncclCommInitRank — executed on hardware with one rank: `--force-comm` puts the device-resident gather
     (plonk_gather_proofs_device -> ncclAllGather), the max over ranks (ncclAllReduce) and the barrier inside the timed region.
     A fresh subprocess: pytest's own process has torch (and torch's bundled librccl) mapped, this one must not."""
-    line = _bench(["--gpus", "1", "--force-comm", "--steps", "2", "--warmup", "1", "--batch", "64", "--batches-per-step", "4", "--streams", "2",
-                   "--lookup-budget-gb", "4"] + SHORT)
-    cfg = line["config"]
+    line, detail = _bench(["--gpus", "1", "--force-comm", "--steps", "2", "--warmup", "1", "--batch", "64", "--batches-per-step", "4", "--streams", "2",
+                           "--lookup-budget-gb", "4"] + SHORT)
+    cfg = detail["config"]
     assert cfg["gather_transport"] == "rccl" and cfg["gather_in_timed_region"] and cfg["ranks_in_communicator"] == 1
     assert cfg["gather_path"].startswith("device buffers")
     assert cfg["torch_imported"] is False
@@ -78,7 +87,7 @@ def test_one_rank_rccl_in_a_process_that_never_imports_torch():
     # the RCCL calls really were issued: one all-gather per step (3 with the warm-up), the barriers / max over ranks (all-reduce)
     # around the timed region and the exchange of the per-rank figures (all-gather through host buffers)
     assert cfg["rccl_calls_issued"] >= 3 + 3
-    pr = line["per_rank"]
+    pr = detail["per_rank"]
     assert len(pr["proofs_per_s"]) == 1 and pr["allgather_us_per_step"][0] > 0
     assert pr["allgather_fraction_of_step"] < 0.05
     assert cfg["results_gathered_per_step"] == 256 and line["value"] > 0
@@ -87,9 +96,9 @@ def test_one_rank_rccl_in_a_process_that_never_imports_torch():
 
 @pytest.mark.gpu
 def test_an_explicit_rccl_path_is_honoured_and_a_wrong_one_fails_loudly():
-    line = _bench(["--gpus", "1", "--force-comm", "--steps", "1", "--warmup", "0", "--batch", "8", "--batches-per-step", "1", "--streams", "1",
-                   "--log-n", "6", "--no-lookup"] + SHORT, env_extra={"PLONK_RCCL_LIB": "/opt/rocm/lib/librccl.so.1"})
-    assert os.path.realpath(line["config"]["rccl_path"]) == os.path.realpath("/opt/rocm/lib/librccl.so.1")
+    _, detail = _bench(["--gpus", "1", "--force-comm", "--steps", "1", "--warmup", "0", "--batch", "8", "--batches-per-step", "1", "--streams", "1",
+                        "--log-n", "6", "--no-lookup"] + SHORT, env_extra={"PLONK_RCCL_LIB": "/opt/rocm/lib/librccl.so.1"})
+    assert os.path.realpath(detail["config"]["rccl_path"]) == os.path.realpath("/opt/rocm/lib/librccl.so.1")
     env = dict(os.environ, PLONK_RCCL_LIB="/nonexistent/librccl.so.1")
     env.pop("WORLD_SIZE", None)
     r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--force-comm", "--steps", "1", "--warmup", "0", "--batch", "8",
@@ -107,14 +116,14 @@ def test_dress_rehearsal_eight_ranks_at_the_default_batch():
     stalls, serialised table builds, a gather that scales with the rank count) would break, not a performance target."""
     # (four streams on four hardware queues per process, as in round 3: eight processes with the bench's default of twenty queues
     # each would put 160 queues on the one GPU, and what is measured then is the queue scheduler — 0.69 in session q)
-    common = ["--steps", "2", "--warmup", "1", "--lookup-budget-gb", "4", "--streams", "4", "--hw-queues", "4"] + SHORT
-    one = _bench(["--gpus", "1"] + common)
-    eight = _bench(["--gpus", "8", "--dist-backend", "sockets"] + common, timeout=2400)
-    cfg = eight["config"]
+    common = ["--steps", "2", "--warmup", "1", "--lookup-budget-gb", "4", "--streams", "4", "--hw-queues", "4", "--verify-samples", "0"] + SHORT
+    one, _ = _bench(["--gpus", "1"] + common)
+    eight, detail = _bench(["--gpus", "8", "--dist-backend", "sockets"] + common, timeout=2400)
+    cfg = detail["config"]
     assert eight["n_gpus"] == 8 and cfg["ranks_in_communicator"] == 8 and cfg["lockstep_batch"] == 512 and cfg["batches_per_step"] == 20
     assert cfg["results_gathered_per_step"] == 8 * 10240 and cfg["msm_table_bits"] == 11
-    pr = eight["per_rank"]
-    assert len(pr["proofs_per_s"]) == 8 and len(pr["msm_table_build_s"]) == 8
+    pr = detail["per_rank"]
+    assert len(pr["proofs_per_s"]) == 8 and len(pr["msm_table_build_s"]) == 8 and len(eight["per_rank"]["proofs_per_s"]) == 8
     ratio = eight["value"] / one["value"]
     print("8 ranks on one GPU: %.0f proofs/s; one process: %.0f; ratio %.3f; per rank min/max %.0f / %.0f"
           % (eight["value"], one["value"], ratio, pr["proofs_per_s_min"], pr["proofs_per_s_max"]))
