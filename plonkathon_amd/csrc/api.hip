@@ -34,7 +34,7 @@ int ctx_scratch(plonk_ctx* ctx, int slot, size_t bytes, void** out) {
         }
         size_t want = bytes + bytes / 4;
         void* p = nullptr;
-        if (hipMalloc(&p, want) != hipSuccess) {
+        if (!plonk_dev_malloc(&p, want)) {
             plonk_set_error("hipMalloc of %zu scratch bytes failed", want);
             return PLONK_ERR_NOMEM;
         }
@@ -181,7 +181,7 @@ int plonk_host_alloc(plonk_ctx* ctx, size_t bytes, void** out_hptr) {
     PLONK_REQUIRE(ctx && out_hptr, PLONK_ERR_ARG, "bad argument");
     PLONK_ENTER(ctx);
     void* p = nullptr;
-    if (hipHostMalloc(&p, bytes ? bytes : 1) != hipSuccess) {
+    if (!plonk_host_malloc(&p, bytes ? bytes : 1)) {
         plonk_set_error("hipHostMalloc of %zu bytes failed", bytes);
         return PLONK_ERR_NOMEM;
     }
@@ -199,7 +199,7 @@ int plonk_mem_alloc(plonk_ctx* ctx, size_t bytes, void** out_dptr) {
     PLONK_REQUIRE(ctx && out_dptr, PLONK_ERR_ARG, "bad argument");
     PLONK_ENTER(ctx);
     void* p = nullptr;
-    if (hipMalloc(&p, bytes ? bytes : 32) != hipSuccess) {
+    if (!plonk_dev_malloc(&p, bytes ? bytes : 32)) {
         plonk_set_error("hipMalloc(%zu) failed", bytes);
         return PLONK_ERR_NOMEM;
     }
@@ -365,7 +365,7 @@ extern "C++" int get_power_table(plonk_ctx* ctx, const Fr& base, const Fr& first
             ctx->power_tables.clear();
         }
         void* p = nullptr;
-        if (hipMalloc(&p, n * sizeof(Fr)) != hipSuccess) {
+        if (!plonk_dev_malloc(&p, n * sizeof(Fr))) {
             plonk_set_error("hipMalloc of a %zu-entry power table failed", n);
             return PLONK_ERR_NOMEM;
         }
@@ -560,7 +560,7 @@ static int srs_alloc(plonk_ctx* ctx, size_t n_points, plonk_srs** out) {
     s->n_points = n_points;
     s->device = ctx->device;
     void* p = nullptr;
-    if (hipMalloc(&p, n_points * sizeof(G1Affine)) != hipSuccess) {
+    if (!plonk_dev_malloc(&p, n_points * sizeof(G1Affine))) {
         delete s;
         plonk_set_error("hipMalloc of %zu G1 bases failed", n_points);
         return PLONK_ERR_NOMEM;
@@ -569,6 +569,14 @@ static int srs_alloc(plonk_ctx* ctx, size_t n_points, plonk_srs** out) {
     *out = s;
     (void)ctx;
     return PLONK_OK;
+}
+
+// Registry key of a base set: FNV-1a of the loaded bytes (a 64-bit hash is NOT an identity: the lookup-table registry compares
+// the bases themselves before it shares a table, msm.hip: lut_verified).  PLONK_TEST_SRS_KEY forces a constant key so that the
+// tests can file two different base sets under ONE key and watch the registry tell them apart.
+static uint64_t srs_content_key(const void* bytes, size_t n, uint64_t salt) {
+    if (const char* e = getenv("PLONK_TEST_SRS_KEY")) return strtoull(e, nullptr, 0);
+    return plonk_fnv1a64(bytes, n) ^ salt;
 }
 
 int plonk_srs_load_ptau(plonk_ctx* ctx, const uint8_t* g1_mont_le, size_t n_points, plonk_srs** out_srs) {
@@ -589,7 +597,7 @@ int plonk_srs_load_ptau(plonk_ctx* ctx, const uint8_t* g1_mont_le, size_t n_poin
     }
     PLONK_CHECK_HIP(hipStreamSynchronize(ctx->stream));
     s->fixed = true;
-    s->content_key = plonk_fnv1a64(g1_mont_le, n_points * 64);
+    s->content_key = srs_content_key(g1_mont_le, n_points * 64, 0);
     *out_srs = s;
     return PLONK_OK;
 }
@@ -609,7 +617,7 @@ int plonk_srs_load_affine(plonk_ctx* ctx, const uint8_t* xy_le, size_t n_points,
     PLONK_TRY(srs_alloc(ctx, n_points, &s));
     PLONK_CHECK_HIP(hipMemcpyAsync(s->bases, host.data(), n_points * 64, hipMemcpyHostToDevice, ctx->stream));
     PLONK_CHECK_HIP(hipStreamSynchronize(ctx->stream));
-    s->content_key = plonk_fnv1a64(xy_le, n_points * 64) ^ 0x9e3779b97f4a7c15ull;  // canonical bytes: a different key space
+    s->content_key = srs_content_key(xy_le, n_points * 64, 0x9e3779b97f4a7c15ull);  // canonical bytes: a different key space
     *out_srs = s;
     return PLONK_OK;
 }

@@ -110,7 +110,7 @@ static int comm_staging(plonk_comm* c, size_t bytes) {
         c->cap = 0;
     }
     void* p = nullptr;
-    if (hipMalloc(&p, bytes) != hipSuccess) {
+    if (!plonk_dev_malloc(&p, bytes)) {
         plonk_set_error("hipMalloc of %zu gather-staging bytes failed", bytes);
         return PLONK_ERR_NOMEM;
     }

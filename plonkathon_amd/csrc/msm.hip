@@ -603,6 +603,7 @@ __global__ void __launch_bounds__(256) msm_slow_kernel(int kind, const G1Affine*
 // ------------------------------------------------------------------------------------------------
 // Registry of lookup tables: one per (process, device, base set, window bits), shared by every plonk_srs that
 // was loaded from the same bytes — several contexts / streams / BatchProvers of one GPU use ONE table.
+#include <algorithm>
 #include <mutex>
 static std::mutex g_lut_mu;
 static std::vector<MsmLookupTable*> g_luts;
@@ -622,36 +623,74 @@ static void lut_attach(plonk_srs* srs, MsmLookupTable* t) {  // g_lut_mu held
     if (t) t->refs++;
 }
 
-// the registered table of this base set with `bits` window bits (0: the one with the most)
-static MsmLookupTable* lut_find(const plonk_srs* srs, unsigned bits) {  // g_lut_mu held
-    MsmLookupTable* best = nullptr;
-    for (MsmLookupTable* t : g_luts) {
-        if (t->device != srs->device || t->key != srs->content_key || t->n_points != srs->n_points) continue;
-        if (bits ? t->bits == bits : (!best || t->bits > best->bits)) best = t;
-    }
-    return best;
-}
-
 // The registry key is a 64-bit FNV-1a of the loaded bytes — not collision resistant — so a candidate (same device, key,
-// number of bases and window bits: lut_find) is only attached after its d = 1 entries of window 0 — the bases themselves —
-// have ALL been compared with this SRS's bases on the device.  That is the whole check a table needs: every other entry is a
-// function of (bases, number of bases, window bits) alone, computed by this library when the table was registered.
+// number of bases and window bits: lut_find_verified) is only attached after it was compared with THIS SRS on the device:
+//   1. its d = 1 entries of window 0 — the bases themselves — ALL equal this SRS's bases (lut_verify_kernel);
+//   2. for LUT_VERIFY_SAMPLES bases spread over the set and EVERY window w, its d = 1 entry equals 2^(c w) P_i and its last
+//      entry (d = 2^(c-1)) equals 2^(c w + c - 1) P_i, both recomputed here by doublings from this SRS's own base
+//      (lut_verify_windows_kernel) — a table of another window size or window count filed under the same key, or one whose
+//      higher windows belong to other bases, fails here;
+//   3. the registered n_points / bits / windows match what this call would build.
+// Every other entry is a function of (bases, number of bases, window bits) alone, computed by this library when the table
+// was registered.
+#define LUT_VERIFY_SAMPLES 8
 __global__ void lut_verify_kernel(const G1Affine* bases, const G1Affine* lookup, size_t n, unsigned c, unsigned* mismatches) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const G1Affine* e = lookup + (i << (c - 1));
     if (!fp_eq(fp_load(&bases[i].x), fp_load(&e->x)) || !fp_eq(fp_load(&bases[i].y), fp_load(&e->y))) atomicAdd(mismatches, 1u);
 }
+// lane = (sample s, window w): P = 2^(c w) bases[i_s] by doublings; compare with entries d = 1 and d = 2^(c-1) of (w, i_s)
+__global__ void __launch_bounds__(64) lut_verify_windows_kernel(const G1Affine* bases, const G1Affine* lookup, size_t n, unsigned c, unsigned W,
+                                                                unsigned* mismatches) {
+    const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= LUT_VERIFY_SAMPLES * W) return;
+    const unsigned s = t / W, w = t - s * W;
+    const size_t i = n <= LUT_VERIFY_SAMPLES ? (s < n ? s : n - 1) : (size_t)s * (n - 1) / (LUT_VERIFY_SAMPLES - 1);
+    G1Affine b;
+    b.x = fp_load(&bases[i].x);
+    b.y = fp_load(&bases[i].y);
+    if (g1_affine_is_identity(b)) return;  // (0, 0) stays (0, 0) in every window: covered by check 1
+    G1Xyzz p = g1_xyzz_from_affine(b);
+#pragma unroll 1
+    for (unsigned k = 0; k < c * w; k++) g1_dbl(p);
+    const G1Affine* e = lookup + ((((size_t)w * n + i) << (c - 1)));
+    G1Affine a = g1_to_affine(p);
+    bool ok = fp_eq(a.x, fp_load(&e[0].x)) && fp_eq(a.y, fp_load(&e[0].y));
+#pragma unroll 1
+    for (unsigned k = 0; k + 1 < c; k++) g1_dbl(p);
+    a = g1_to_affine(p);
+    const size_t last = ((size_t)1 << (c - 1)) - 1;
+    ok = ok && fp_eq(a.x, fp_load(&e[last].x)) && fp_eq(a.y, fp_load(&e[last].y));
+    if (!ok) atomicAdd(mismatches, 1u);
+}
+static unsigned windows_for(unsigned c);
 static MsmLookupTable* lut_verified(plonk_ctx* ctx, const plonk_srs* srs, MsmLookupTable* t) {  // g_lut_mu held
     if (!t) return nullptr;
+    if (t->n_points != srs->n_points || t->windows != windows_for(t->bits) ||
+        t->bytes != t->n_points * t->windows * ((size_t)1 << (t->bits - 1)) * sizeof(G1Affine))
+        return nullptr;
     void* flag;
     if (ctx_scratch(ctx, 3, 64, &flag) != PLONK_OK) return nullptr;
     unsigned bad = 1;
     if (hipMemsetAsync(flag, 0, 4, ctx->stream) != hipSuccess) return nullptr;
     PLONK_LAUNCH(lut_verify_kernel, dim3((unsigned)((srs->n_points + 255) / 256)), dim3(256), 0, ctx->stream, (const G1Affine*)srs->bases,
                  (const G1Affine*)t->data, srs->n_points, t->bits, (unsigned*)flag);
+    PLONK_LAUNCH(lut_verify_windows_kernel, dim3((LUT_VERIFY_SAMPLES * t->windows + 63) / 64), dim3(64), 0, ctx->stream,
+                 (const G1Affine*)srs->bases, (const G1Affine*)t->data, srs->n_points, t->bits, t->windows, (unsigned*)flag);
     if (hipMemcpyAsync(&bad, flag, 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) return nullptr;
     return bad ? nullptr : t;
+}
+// the registered table of this base set with `bits` window bits (0: the one with the most) that passes the comparison above;
+// several tables may sit under one key (a collision, or several window sizes): every candidate is tried, widest first
+static MsmLookupTable* lut_find_verified(plonk_ctx* ctx, const plonk_srs* srs, unsigned bits) {  // g_lut_mu held
+    std::vector<MsmLookupTable*> cand;
+    for (MsmLookupTable* t : g_luts)
+        if (t->device == srs->device && t->key == srs->content_key && t->n_points == srs->n_points && (!bits || t->bits == bits)) cand.push_back(t);
+    std::sort(cand.begin(), cand.end(), [](const MsmLookupTable* a, const MsmLookupTable* b) { return a->bits > b->bits; });
+    for (MsmLookupTable* t : cand)
+        if (lut_verified(ctx, srs, t)) return t;
+    return nullptr;
 }
 // A Lagrange-basis view is a base set of its own with a table of its own: the automatic choice charges the tables of its
 // parent SRS and of the parent's other views against the same budget, so that what the caller granted is not spent twice.
@@ -695,7 +734,7 @@ int msm_build_table(plonk_ctx* ctx, plonk_srs* srs, unsigned c) {
     const unsigned W = windows_for(c);
     const size_t n = srs->n_points, total = n * W;
     void *tmp = nullptr, *tab = nullptr;
-    if (hipMalloc(&tmp, total * sizeof(G1Xyzz)) != hipSuccess || hipMalloc(&tab, total * sizeof(G1Affine)) != hipSuccess) {
+    if (!plonk_dev_malloc(&tmp, total * sizeof(G1Xyzz)) || !plonk_dev_malloc(&tab, total * sizeof(G1Affine))) {
         if (tmp) hipFree(tmp);
         plonk_set_error("hipMalloc of the %zu-point window table failed", total);
         return PLONK_ERR_NOMEM;
@@ -744,10 +783,10 @@ static int msm_lookup_build(plonk_ctx* ctx, plonk_srs* srs, unsigned c) {  // g_
         plonk_set_error("the %u-bit lookup table (%zu MiB) does not fit in device memory", c, msm_lookup_bytes(n, c) >> 20);
         return PLONK_ERR_NOMEM;
     };
-    if (hipMalloc(&tab, n * W * half * sizeof(G1Affine)) != hipSuccess) return fail();
-    if (hipMalloc(&tmp, n * half * sizeof(G1Xyzz)) != hipSuccess) return fail();
-    if (hipMalloc(&wx, n * W * sizeof(G1Xyzz)) != hipSuccess) return fail();
-    if (hipMalloc(&wb, n * W * sizeof(G1Affine)) != hipSuccess) return fail();
+    if (!plonk_dev_malloc(&tab, n * W * half * sizeof(G1Affine))) return fail();
+    if (!plonk_dev_malloc(&tmp, n * half * sizeof(G1Xyzz))) return fail();
+    if (!plonk_dev_malloc(&wx, n * W * sizeof(G1Xyzz))) return fail();
+    if (!plonk_dev_malloc(&wb, n * W * sizeof(G1Affine))) return fail();
     // window bases 2^(c w) P_i, affine
     unsigned grid = (unsigned)((n + 63) / 64);
     if (grid > 2048) grid = 2048;
@@ -800,7 +839,7 @@ static bool msm_lookup_prepare(plonk_ctx* ctx, plonk_srs* srs) {
     std::lock_guard<std::mutex> lk(g_lut_mu);
     if (ctx->msm_lookup_mode == 2) {  // forced window size, any base set
         if (srs->shared && srs->lookup_bits == want) return true;
-        if (MsmLookupTable* t = lut_verified(ctx, srs, lut_find(srs, want))) {
+        if (MsmLookupTable* t = lut_find_verified(ctx, srs, want)) {
             lut_attach(srs, t);
             return true;
         }
@@ -809,7 +848,7 @@ static bool msm_lookup_prepare(plonk_ctx* ctx, plonk_srs* srs) {
     if (!srs->fixed) return false;
     if (srs->shared && (!want || want == srs->lookup_bits)) return true;
     if (want) {
-        if (MsmLookupTable* t = lut_verified(ctx, srs, lut_find(srs, want))) {
+        if (MsmLookupTable* t = lut_find_verified(ctx, srs, want)) {
             lut_attach(srs, t);
             return true;
         }
@@ -818,7 +857,7 @@ static bool msm_lookup_prepare(plonk_ctx* ctx, plonk_srs* srs) {
     const size_t budget = ctx->msm_lookup_budget ? ctx->msm_lookup_budget : msm_default_lookup_budget();
     // A table another context of this device already built for these bases is taken as it is — unless this context's
     // budget affords a bigger one (more window bits = fewer additions), which is then built and shared in its turn.
-    MsmLookupTable* have = want ? nullptr : lut_verified(ctx, srs, lut_find(srs, 0));
+    MsmLookupTable* have = want ? nullptr : lut_find_verified(ctx, srs, 0);
     // The automatic choice charges the tables of the same SRS family (an SRS and its Lagrange-basis views) against one
     // budget.  An explicit window size (`want`) is an explicit request and only has to fit the budget by itself.
     const size_t used = want ? 0 : lut_bytes_of_family(srs);
@@ -913,8 +952,8 @@ int msm_lagrange_srs(plonk_ctx* ctx, plonk_srs* srs, unsigned log_n, plonk_srs**
         if (mat) hipFree(mat);
         if (res) hipFree(res);
     };
-    if (hipMalloc(&mat, rows * n * sizeof(Fr)) != hipSuccess || hipMalloc(&res, rows * (2 * sizeof(Fq) + 1) + 64) != hipSuccess ||
-        hipMalloc(&bases, n * sizeof(G1Affine)) != hipSuccess) {
+    if (!plonk_dev_malloc(&mat, rows * n * sizeof(Fr)) || !plonk_dev_malloc(&res, rows * (2 * sizeof(Fq) + 1) + 64) ||
+        !plonk_dev_malloc(&bases, n * sizeof(G1Affine))) {
         cleanup();
         if (bases) hipFree(bases);
         plonk_set_error("hipMalloc failed while building the Lagrange-basis SRS of size %zu", n);
@@ -974,9 +1013,10 @@ int msm_run_device(plonk_ctx* ctx, plonk_srs* srs, const Fr* d_scalars, size_t n
     }
     const size_t max_entries = (size_t)W * n;
     while (G > 1 && (size_t)G * MSM_BLOCK * 4 > max_entries) G /= 2;  // tiny MSMs: one segment is plenty
-    // lanes per MSM in the bucket reduction (shorter local walks vs more lanes paying the scan and the reduction): 128 measured
-    // best again with the suffix-scan weighting (profiles/r04_c_bucket_reduce_lanes_ab.jsonl: 23.3 k proofs/s against 22.5 k at
-    // 64; round 3's double-and-add weighting: 22.8 k at 128).  PLONK_MSM_RED_LANES = 64 / 128 / 256 overrides (A/B runs).
+    // lanes per MSM in the bucket reduction (shorter local walks vs more lanes paying the scan and the reduction): batches (G < 8)
+    // take 128 — measured best with the suffix-scan weighting (profiles/r04_c_bucket_reduce_lanes_ab.jsonl: 23.3 k proofs/s against
+    // 22.5 k at 64; round 3's double-and-add weighting: 22.8 k at 128) — a lone MSM cut into many workgroups (G >= 8) is latency
+    // bound and takes 256.  PLONK_MSM_RED_LANES = 64 / 128 / 256 overrides (A/B runs).
     unsigned red_lanes = G >= 8 ? 256 : 128;
     {
         static const unsigned forced = [] {
@@ -986,6 +1026,9 @@ int msm_run_device(plonk_ctx* ctx, plonk_srs* srs, const Fr* d_scalars, size_t n
         }();
         if (forced) red_lanes = forced;
     }
+    // msm_bucket_reduce_kernel weighs a lane's run by pb = K / red_lanes through log2(pb) doublings: both must be powers of two
+    PLONK_REQUIRE((red_lanes & (red_lanes - 1)) == 0 && red_lanes >= 64 && (K % red_lanes == 0 || K < red_lanes), PLONK_ERR_ARG,
+                  "bucket reduction needs a power-of-two lane count dividing the %u buckets (got %u)", K, red_lanes);
     const size_t entry_stride = ((max_entries + 3) & ~(size_t)3) + 4;
     const size_t piece_stride = (size_t)G * MSM_BLOCK + K;
     const size_t ent_bytes = (M * entry_stride * 4 + 255) & ~(size_t)255;

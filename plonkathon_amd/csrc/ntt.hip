@@ -279,7 +279,7 @@ Fr host_root_of_unity(unsigned log_n, bool inverse) {
 
 static int alloc_table(plonk_ctx* ctx, size_t n, Fr** out) {
     void* p = nullptr;
-    if (hipMalloc(&p, (n ? n : 1) * sizeof(Fr)) != hipSuccess) {
+    if (!plonk_dev_malloc(&p, (n ? n : 1) * sizeof(Fr))) {
         plonk_set_error("hipMalloc of %zu-entry twiddle table failed", n);
         return PLONK_ERR_NOMEM;
     }

@@ -70,7 +70,7 @@ static int bls_power_table(plonk_ctx* ctx, std::map<unsigned, void*>& cache, uns
     auto it = cache.find(key);
     if (it == cache.end()) {
         void* d = nullptr;
-        if (hipMalloc(&d, n * sizeof(BlsFr)) != hipSuccess) {
+        if (!plonk_dev_malloc(&d, n * sizeof(BlsFr))) {
             plonk_set_error("hipMalloc of a %zu-entry twiddle table failed", n);
             return PLONK_ERR_NOMEM;
         }
@@ -148,7 +148,7 @@ static int bls_power_table(plonk_ctx* ctx, const BlsFr& base, const BlsFr& first
     auto it = ctx->power_tables.find(key);
     if (it == ctx->power_tables.end()) {
         void* p = nullptr;
-        if (hipMalloc(&p, n * sizeof(BlsFr)) != hipSuccess) {
+        if (!plonk_dev_malloc(&p, n * sizeof(BlsFr))) {
             plonk_set_error("hipMalloc of a %zu-entry power table failed", n);
             return PLONK_ERR_NOMEM;
         }

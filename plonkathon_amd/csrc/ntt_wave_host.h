@@ -24,7 +24,7 @@ template <class P> static int wave_limb_table(plonk_ctx* ctx, std::map<unsigned,
         void* d = nullptr;
         Ninv261 ninv;
         fpl_ninv261<P>(ninv.l);
-        if (hipMalloc(&d, n * NTT_SHOUP_STRIDE * sizeof(int32_t)) != hipSuccess) {
+        if (!plonk_dev_malloc(&d, n * NTT_SHOUP_STRIDE * sizeof(int32_t))) {
             plonk_set_error("hipMalloc of a %zu-entry twiddle table failed", n);
             return PLONK_ERR_NOMEM;
         }
@@ -49,7 +49,7 @@ template <class F> static int wave_program_table(plonk_ctx* ctx, unsigned log_n,
         const unsigned nlds = wavel_nlds(log_n, log_e), stages = wavel_tw_stages(log_e, nlds);
         const size_t entries = wavel_tw_offset(log_e, nlds, stages);
         void* d = nullptr;
-        if (hipMalloc(&d, entries * NTT_SHOUP_STRIDE * sizeof(int32_t)) != hipSuccess) {
+        if (!plonk_dev_malloc(&d, entries * NTT_SHOUP_STRIDE * sizeof(int32_t))) {
             plonk_set_error("hipMalloc of a %zu-entry twiddle table failed", entries);
             return PLONK_ERR_NOMEM;
         }
@@ -85,7 +85,7 @@ template <class F> static int wave_lo_hi(plonk_ctx* ctx, unsigned log_n, bool in
         Fp<P> whi = F::root_of_unity(log_n, inverse);
         for (unsigned i = 0; i < NTT_TW_LO_LOG; i++) whi = fp_sqr(whi);
         void* tmp = nullptr;  // (not a scratch slot: callers hold those across this call)
-        if (hipMalloc(&tmp, nhi * sizeof(Fp<P>)) != hipSuccess) {
+        if (!plonk_dev_malloc(&tmp, nhi * sizeof(Fp<P>))) {
             plonk_set_error("hipMalloc of a %zu-entry twiddle table failed", nhi);
             return PLONK_ERR_NOMEM;
         }
@@ -114,7 +114,7 @@ static int wave_interpass_table(plonk_ctx* ctx, unsigned log_n, unsigned log_r1,
         const Fp<P>*plo, *phi;
         PLONK_TRY(F::packed_lo_hi(ctx, log_n, inverse, &plo, &phi));
         void* d = nullptr;
-        if (hipMalloc(&d, bytes) != hipSuccess) {
+        if (!plonk_dev_malloc(&d, bytes)) {
             (void)hipGetLastError();  // not an error of the transform: the two small tables serve it
             return PLONK_OK;
         }
@@ -139,7 +139,7 @@ template <class F> static int wave_jm(plonk_ctx* ctx, const int32_t** out) {
         int32_t host[(2 * FPL_RS_J + 1) * 12];
         for (int j = -FPL_RS_J; j <= FPL_RS_J; j++) fpl_jm_entry<typename F::P>(j, host + (j + FPL_RS_J) * 12);
         void* d = nullptr;
-        if (hipMalloc(&d, sizeof host) != hipSuccess) {
+        if (!plonk_dev_malloc(&d, sizeof host)) {
             plonk_set_error("hipMalloc of the NTT range-reduction table failed");
             return PLONK_ERR_NOMEM;
         }

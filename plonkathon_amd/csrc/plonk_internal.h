@@ -23,6 +23,22 @@ void plonk_set_error(const char* fmt, ...);
         }                                                                                         \
     } while (0)
 
+// Allocation that may fail and be recovered from (the caller frees something and retries, or falls back to a smaller table):
+// HIP parks the failure in its thread-local last-error slot, where the next `PLONK_CHECK_HIP(hipGetLastError())` after a kernel
+// launch would find it and report a stale out-of-memory as PLONK_ERR_HIP.  The slot is emptied here, at the failing call.
+template <class T> static inline bool plonk_dev_malloc(T** p, size_t bytes) {
+    if (hipMalloc((void**)p, bytes) == hipSuccess) return true;
+    (void)hipGetLastError();
+    *p = nullptr;
+    return false;
+}
+template <class T> static inline bool plonk_host_malloc(T** p, size_t bytes) {
+    if (hipHostMalloc((void**)p, bytes) == hipSuccess) return true;
+    (void)hipGetLastError();
+    *p = nullptr;
+    return false;
+}
+
 #define PLONK_REQUIRE(cond, code, ...)    \
     do {                                  \
         if (!(cond)) {                    \

@@ -797,7 +797,7 @@ __global__ void pack_status_kernel(const ProofState* st, const uint32_t* closes,
 // ================================================================================================
 // host side
 static int dev_alloc(void** p, size_t bytes) {
-    if (hipMalloc(p, bytes ? bytes : 32) != hipSuccess) {
+    if (!plonk_dev_malloc(p, bytes ? bytes : 32)) {
         plonk_set_error("hipMalloc(%zu) failed in the batched prover", bytes);
         return PLONK_ERR_NOMEM;
     }

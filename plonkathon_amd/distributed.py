@@ -69,14 +69,24 @@ _PORT_SPAN = 16  # rank 0 listens on the first free port of [port, port + 16); t
 
 
 def _job_token():
-    """What tells this job's rendezvous from another job's on the same host: its MASTER_PORT (torchrun gives every job its own)."""
-    return int(os.environ.get("MASTER_PORT", "29500")) & 0xFFFFFFFF
+    """What tells this job's rendezvous from another job's on the same host: its MASTER_PORT (torchrun gives every job its own)
+    mixed with the launcher's job id when there is one (TORCHELASTIC_RUN_ID, or PLONK_JOB_ID — bench.py's own launcher sets it), so
+    that two jobs started without MASTER_PORT on the same port range and world size do not register each other's ranks."""
+    import zlib
+
+    tok = int(os.environ.get("MASTER_PORT", "29500")) & 0xFFFFFFFF
+    job = os.environ.get("PLONK_JOB_ID") or os.environ.get("TORCHELASTIC_RUN_ID") or ""
+    if job and job != "none":  # (torchrun's default run id is the literal "none")
+        tok ^= zlib.crc32(job.encode())
+    return tok & 0xFFFFFFFF
 
 
 class _Star:
     """Rank 0 listens, ranks 1..W-1 connect and introduce themselves; the sockets stay open.
-    Hello = magic, rank, job token; rank 0 answers magic, world; the rank confirms.  A port that is taken (rank 0) or that answers anything else
-    (the others) is skipped, so a foreign service on MASTER_PORT + 1 delays the launch instead of breaking it."""
+    Hello = magic, rank, job token; rank 0 answers magic, world; the rank confirms ("K"); rank 0 stores it and acknowledges ("A").
+    A rank that does not hear the acknowledgement goes back to probing, so neither side ever believes in a registration the other
+    dropped.  A port that is taken (rank 0) or that answers anything else (the others) is skipped, so a foreign service on
+    MASTER_PORT + 1 delays the launch instead of breaking it."""
 
     def __init__(self, rank, world, timeout=120.0):
         self.rank, self.world = rank, world
@@ -122,15 +132,18 @@ class _Star:
                 if magic != _MAGIC or tok != token or not 0 < r < world or r in self.peers:
                     conn.close()
                     continue
-                try:  # answer, and hear the rank confirm it: one that gave up waiting and reconnected must not be registered twice
+                try:  # answer, and hear the rank confirm it: one that gave up waiting and reconnected must not be registered twice.
+                    # The hello identified a rank of THIS job: its confirmation gets more patience than a stray's hello did
                     conn.sendall(struct.pack("<4sI", _MAGIC, world))
+                    conn.settimeout(min(10.0, max(left, 0.1)))
                     if _recv_exact(conn, 1) != b"K":
                         raise ConnectionError("bad confirmation")
+                    conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                    conn.sendall(b"A")  # registered: without this the rank returns to its probe loop
                 except (OSError, ConnectionError):
                     conn.close()
                     continue
                 conn.settimeout(timeout)
-                conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
                 self.peers[r] = conn
             srv.close()
         else:
@@ -148,8 +161,9 @@ class _Star:
                         magic, w = struct.unpack("<4sI", _recv_exact(c, 8))
                         if magic == _MAGIC and w == world:
                             c.sendall(b"K")
-                            s = c
-                            break
+                            if _recv_exact(c, 1) == b"A":  # rank 0 stored this connection
+                                s = c
+                                break
                     except (OSError, ConnectionError, struct.error):
                         pass
                     c.close()

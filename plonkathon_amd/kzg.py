@@ -382,7 +382,9 @@ def ec_lincomb(pairs):
 
 
 def _is_g1(x):
-    return x is None or (isinstance(x, tuple) and len(x) == 2)
+    """A BN254 G1 point as this package (and py_ecc) represents it: None or a pair of Fq — a generic 2-tuple is NOT one, so that
+    `lincomb` / `multisubset` over any other group take the host fold the reference performs (curve.py:59-111)."""
+    return x is None or (isinstance(x, tuple) and len(x) == 2 and isinstance(x[0], Fq) and isinstance(x[1], Fq))
 
 
 def multisubset(numbers, subsets, adder=None, zero=0):

@@ -1041,6 +1041,43 @@ def lookup_table_is_shared_across_contexts():
         b.msm_lookup(0)
 
 
+def lookup_table_colliding_key():
+    """ADVICE r03 / VERDICT r04 #7: the registry key is a 64-bit hash, so two DIFFERENT base sets may share it.  With the key
+    forced to one value (PLONK_TEST_SRS_KEY) a second SRS with other bases must not attach to the first one's table — it builds
+    its own and commits correctly — while a third with the first one's bases still shares it."""
+    import os
+
+    from plonkathon_amd import Context, Setup
+    from plonkathon_amd.kzg import _msm
+
+    a, b, c = Context(0), Context(0), Context(0)
+    sa = Setup.from_file(PTAU)
+    pts = sa.powers_of_x[:64]
+    other = Setup(list(reversed(pts)))           # the same 64 points in another order: same size, other base set
+    same = Setup(list(pts))
+    first = Setup(list(pts))
+    coeffs = list(range(3, 3 + 64))
+    os.environ["PLONK_TEST_SRS_KEY"] = "0x1234"
+    try:
+        for ctx in (a, b, c):
+            ctx.msm_lookup(2, 4)
+        d1, d2, d3 = first.device_bases(a), other.device_bases(b), same.device_bases(c)
+        bufs = [ctx.upload_ints(coeffs) for ctx in (a, b, c)]
+        r1 = _msm(d1, bufs[0].ptr, 64, 1, 64)[0]
+        r2 = _msm(d2, bufs[1].ptr, 64, 1, 64)[0]   # same key, other bases: its own table
+        r3 = _msm(d3, bufs[2].ptr, 64, 1, 64)[0]   # same key, same bases: shares the first table
+        assert affine(r1) == og1.ec_lincomb([(affine(p), k) for p, k in zip(pts, coeffs)])
+        assert affine(r2) == og1.ec_lincomb([(affine(p), k) for p, k in zip(reversed(pts), coeffs)])
+        assert affine(r3) == affine(r1) and affine(r2) != affine(r1)
+        i1, i2, i3 = d1.lookup_info(), d2.lookup_info(), d3.lookup_info()
+        assert i1["bits"] == i2["bits"] == i3["bits"] == 4
+        assert i1["sharers"] == 2 and i3["sharers"] == 2 and i2["sharers"] == 1, (i1, i2, i3)
+    finally:
+        del os.environ["PLONK_TEST_SRS_KEY"]
+        for ctx in (a, b, c):
+            ctx.msm_lookup(0)
+
+
 # ------------------------------------------------------------------------------------------ product-side verifier
 def verifier_cases(setup, full_size=False):
     """The reference's own verifier tests on the product's `VerificationKey` (plonk_pairing_check on the host):

@@ -215,6 +215,7 @@ def test_msm_deferred_overflow_is_recomputed(emu):
 
 def test_lookup_table_is_shared_across_contexts(emu):
     pc.lookup_table_is_shared_across_contexts()
+    pc.lookup_table_colliding_key()
 
 
 def test_lagrange_srs_paths(emu):

@@ -446,12 +446,14 @@ def test_msm_deferred_overflow_is_recomputed():
 @pytest.mark.gpu
 def test_lookup_table_is_shared_across_contexts():
     pc.lookup_table_is_shared_across_contexts()
+    pc.lookup_table_colliding_key()
 
 
 @pytest.mark.gpu
 def test_configs4_batch_of_512_distinct_proofs_sharded_and_gathered(setup):
     """BASELINE configs[4]: 512 independent group_order = 2^11 proofs.  One lock-step batch of 512 distinct witnesses:
-    proofs 0 and 1 equal the fixtures, every status is 0, and the batch is byte-identical to the same 512 proofs
+    proofs 0 and 1 equal the fixtures, every status is 0, 16 random ones pass the pairing check (a corrupted one does not),
+    2 random ones equal the oracle prover's, and the batch is byte-identical to the same 512 proofs
     proved as 8 shards of 64 (the 8-GPU sharding, rank r owning indices r, r+8, ...) and reassembled by
     distributed.gather_proofs."""
     import json
@@ -475,6 +477,39 @@ def test_configs4_batch_of_512_distinct_proofs_sharded_and_gathered(setup):
         for k, v in fx[name]["proof"].items():
             assert got[k] == (pc.pt(v) if isinstance(v, list) else int(v)), (name, k)
     assert len({blob[768 * i : 768 * (i + 1)] for i in range(total)}) == total  # all distinct
+
+    # Independent acceptance of the bulk (the reference verifies what it proves: test.py:103-133).  16 random indices under the
+    # pairing check of VerificationKey.verify_proof, 2 random indices byte for byte against the oracle's prover (a CPU proof
+    # each), and a proof corrupted at a random index must be rejected.
+    import random
+
+    from oracle.circuit import Program as OProgram
+    from oracle.plonk_prover import Prover as OProver
+    from oracle.srs import Setup as OSetup
+
+    rng = random.Random(20260928)
+    vk = setup.verification_key(program.common_preprocessed_input())
+    picked = rng.sample(range(2, total), 16)
+    for i in picked:
+        assert vk.verify_proof(n, BatchProver.decode(blob[768 * i : 768 * (i + 1)]), [wits[i]["x0"]]), i
+    i = picked[0]
+    bad = bytearray(blob[768 * i : 768 * (i + 1)])
+    bad[rng.randrange(768 - 6 * 32, 768)] ^= 0x01          # one bit of one of the six evaluations
+    assert not vk.verify_proof(n, BatchProver.decode(bytes(bad)), [wits[i]["x0"]])
+    bad = bytearray(blob[768 * i : 768 * (i + 1)])
+    bad[64 * rng.randrange(9) + 1] ^= 0x80                  # a commitment pushed off its value (and the curve)
+    try:
+        accepted = vk.verify_proof(n, BatchProver.decode(bytes(bad)), [wits[i]["x0"]])
+    except Exception:  # (the library may refuse a point that is not on the curve outright)
+        accepted = False
+    assert not accepted
+    assert not vk.verify_proof(n, BatchProver.decode(blob[768 * i : 768 * (i + 1)]), [wits[i]["x0"] + 1])  # wrong public input
+    oprover = OProver(OSetup.from_file(os.path.join(pc.GOLDEN, "srs_2048.ptau")), OProgram(pc.chain_lines(n), n))
+    for i in rng.sample(range(2, total), 2):
+        want = oprover.prove(dict(wits[i])).flatten()
+        got = pc.flat(BatchProver.decode(blob[768 * i : 768 * (i + 1)]))
+        for k, v in want.items():
+            assert got[k] == v, (i, k)
 
     shards = []
     sp = BatchProver(setup, program)

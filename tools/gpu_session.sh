@@ -23,7 +23,7 @@ for step in "$@"; do
         PLONK_HIP_LIB=$so timeout 300 python tools/ntt_sweep.py --tag "$t" $arg >> "$out/ntt_ab.jsonl" 2>> "$out/ntt_ab.err"
       done
       timeout 300 python tools/ntt_sweep.py --tag default $arg >> "$out/ntt_ab.jsonl" 2>> "$out/ntt_ab.err"; echo "rc=$?" ;;
-    bench) timeout 900 python bench.py $arg > "$out/bench.json" 2> "$out/bench.err"; echo "bench rc=$?"; cut -c1-400 "$out/bench.json"; echo ;;
+    bench) timeout 900 python bench.py --detail "$out/bench_detail.json" $arg > "$out/bench.json" 2> "$out/bench.err"; echo "bench rc=$?"; wc -c "$out/bench.json"; cat "$out/bench.json"; echo ;;
     rocprof)
       ( cd /tmp && rocprofv3 --kernel-trace --stats -d "$OLDPWD/$out/rocprof" -o trace -- python "$OLDPWD/bench.py" $arg > "$OLDPWD/$out/bench_under_rocprof.json" 2> "$OLDPWD/$out/rocprof.err" ); echo "rocprof rc=$?"
       find "$out/rocprof" -name "*kernel_stats.csv" | head -1 | xargs -r head -12 ;;
@@ -33,6 +33,7 @@ for step in "$@"; do
       find "$out/ntt_trace" -name "*kernel_stats.csv" | head -1 | xargs -r head -12 ;;
     pmc) bash tools/pmc_collect.sh "$out" $arg ;;
     pmcu) bash tools/pmc_ntt_util.sh "$out/pmcu" ;;
+    valu) bash tools/pmc_valu.sh "$out/valu" ;;
     env_sweep)   # "VAR=VALUE <ntt_sweep args>": the sweep under one environment setting, rows tagged VAR=VALUE
       kv=${arg%% *}; rest=${arg#* }
       env "$kv" timeout 300 python tools/ntt_sweep.py --tag "$kv" $rest >> "$out/ntt_sweep.jsonl" 2>> "$out/ntt_sweep.err"; echo "rc=$?" ;;

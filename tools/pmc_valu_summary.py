@@ -1,0 +1,136 @@
+#!/usr/bin/env python3
+"""Summarises the SQ / TCP counter passes of tools/pmc_valu.sh into profiles/rNN_valu_summary.json — the file bench.py reads
+`roofline.valu` and `roofline.secondary.valu` from.     usage: python tools/pmc_valu_summary.py <dir of the passes> <out.json>
+
+Units (MI355X_MICROARCH.md): SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count QUAD-cycles, summed over all waves of the
+launch; SQ_INSTS_* count wave-level instructions; GRBM_GUI_ACTIVE counts shader cycles, summed over the XCDs that report
+it.  Derived per kernel (per launch, mean over the launches of the pass):
+  cycles                 = GRBM_GUI_ACTIVE / xcd_factor  (xcd_factor in {1, 8}: the one that puts cycles / duration in 1.2 .. 2.6 GHz)
+  effective_clock_ghz    = cycles / duration from the trace's own timestamps
+  valu_busy              = 4 * SQ_ACTIVE_INST_VALU / (SIMDS * cycles)           [rocprofiler's VALUBusy; SIMDS = 1024]
+  cycles_per_valu_inst   = 4 * SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU
+  waves_per_simd         = 4 * SQ_WAVE_CYCLES / (SIMDS * cycles)                [average resident waves]
+  wave_time_split        = VALU-active / waiting (s_waitcnt, barrier) / issue-stalled fractions of a wave's resident time
+  valu_insts_per_addition (MSM: launch = 1152 MSMs x 30720 additions / 64 lanes) and valu_insts_per_element (NTT)."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+src, out = sys.argv[1], sys.argv[2]
+SIMDS = 1024.0
+
+
+def launches(tag):
+    """{kernel: [ {counter: value, 'dur_ns': ..}, ... per dispatch ]}"""
+    paths = glob.glob(os.path.join(src, tag, "**", "*counter_collection.csv"), recursive=True)
+    per = collections.OrderedDict()
+    for p in paths:
+        for r in csv.DictReader(open(p)):
+            key = (int(r["Dispatch_Id"]), r["Kernel_Name"].split("(")[0].replace("void ", ""), int(r["Grid_Size"]), int(r["Workgroup_Size"]))
+            d = per.setdefault(key, {"dur_ns": float(r["End_Timestamp"]) - float(r["Start_Timestamp"])})
+            d[r["Counter_Name"]] = d.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+    by = collections.OrderedDict()
+    for (did, name, grid, wg), d in sorted(per.items()):
+        by.setdefault((name, grid, wg), []).append(d)
+    return by
+
+
+def mean(ds, skip_first=0):
+    ds = ds[skip_first:] if len(ds) > skip_first else ds
+    keys = set().union(*[set(d) for d in ds])
+    return {k: sum(d.get(k, 0.0) for d in ds) / len(ds) for k in keys}, len(ds)
+
+
+def derive(m):
+    o = {k: m[k] for k in sorted(m)}
+    gui, dur = m.get("GRBM_GUI_ACTIVE"), m.get("dur_ns")
+    if gui and dur:
+        fac = next((f for f in (1.0, 8.0, 32.0) if 1.2 <= gui / f / dur <= 2.6), None)
+        if fac:
+            cyc = gui / fac
+            o.update({"xcd_factor": fac, "cycles": cyc, "effective_clock_ghz": cyc / dur})
+            if "SQ_ACTIVE_INST_VALU" in m:
+                o["valu_busy"] = 4.0 * m["SQ_ACTIVE_INST_VALU"] / (SIMDS * cyc)
+            if "SQ_WAVE_CYCLES" in m:
+                o["waves_per_simd"] = 4.0 * m["SQ_WAVE_CYCLES"] / (SIMDS * cyc)
+    if m.get("SQ_INSTS_VALU") and "SQ_ACTIVE_INST_VALU" in m:
+        o["cycles_per_valu_inst"] = 4.0 * m["SQ_ACTIVE_INST_VALU"] / m["SQ_INSTS_VALU"]
+    wc = m.get("SQ_WAVE_CYCLES")
+    if wc:
+        o["wave_time_split"] = {k: m[c] / wc for k, c in (("valu_active", "SQ_ACTIVE_INST_VALU"), ("waiting", "SQ_WAIT_ANY"),
+                                                          ("issue_stalled", "SQ_WAIT_INST_ANY"), ("lds_active", "SQ_ACTIVE_INST_LDS")) if c in m}
+    if m.get("TCP_UTCL1_REQUEST_sum"):
+        o["utcl1_miss_per_request"] = m.get("TCP_UTCL1_TRANSLATION_MISS_sum", 0.0) / m["TCP_UTCL1_REQUEST_sum"]
+        o["utcl1_hit_per_request"] = m.get("TCP_UTCL1_TRANSLATION_HIT_sum", 0.0) / m["TCP_UTCL1_REQUEST_sum"]
+    return o
+
+
+res = {"units": __doc__.split("Units")[1].strip()[:1200]}
+
+# ---- msm_lookup_kernel of one lock-step batch (4 launches per prover run; the first run is the warm-up)
+b = {}
+for tag in ("bench_issue", "bench_mem", "bench_utcl"):
+    for (name, grid, wg), ds in launches(tag).items():
+        if name == "msm_lookup_kernel":
+            m, n = mean(ds)
+            b.setdefault("launches", n)
+            b.update({k: v for k, v in derive(m).items() if k not in b or k in ("dur_ns",)})
+            b["grid_threads"], b["workgroup"] = grid, wg
+if b:
+    # one launch of the batch prover = 1152 MSMs (round 1: 3 x 512 minus ... -> read from the grid: G workgroups per MSM)
+    msms = 1152.0
+    adds = msms * 15 * 2048
+    if "SQ_INSTS_VALU" in b:
+        b["valu_insts_per_addition"] = b["SQ_INSTS_VALU"] / (adds / 64.0)
+        b["assumes"] = "1152 MSMs of 2^11 scalars x 15 windows per launch (the mean over the 4 launch shapes of a batch: 1536 / 512 / 1536 / 1024 MSMs)"
+    if "SQ_INSTS_VMEM_RD" in b:
+        b["vmem_rd_insts_per_addition"] = b["SQ_INSTS_VMEM_RD"] / (adds / 64.0)
+    if "TCP_UTCL1_REQUEST_sum" in b:
+        b["utcl1_requests_per_addition"] = b["TCP_UTCL1_REQUEST_sum"] / adds
+    res["msm_lookup_kernel"] = b
+
+# ---- the two passes of a lone 2^20 transform
+ntt = {}
+for tag in ("ntt_issue", "ntt_mem"):
+    for (name, grid, wg), ds in launches(tag).items():
+        if "ntt_wavel" not in name:
+            continue
+        m, n = mean(ds, skip_first=1)
+        e = ntt.setdefault(name, {"launches": n, "grid_threads": grid, "workgroup": wg})
+        e.update({k: v for k, v in derive(m).items() if k not in e})
+if ntt:
+    tot_insts = sum(e.get("SQ_INSTS_VALU", 0.0) for e in ntt.values())
+    tot_dur = sum(e.get("dur_ns", 0.0) for e in ntt.values())
+    busy = sum(e.get("valu_busy", 0.0) * e.get("dur_ns", 0.0) for e in ntt.values()) / tot_dur if tot_dur else None
+    res["ntt_2^20"] = {"passes": ntt, "valu_insts_per_element": tot_insts * 64.0 / (1 << 20), "valu_busy": busy,
+                       "sum_of_pass_durations_us": tot_dur / 1e3}
+
+# ---- random 64-byte reads against the table size
+g = launches("gather_utcl")
+rates = {}
+try:
+    rates = json.load(open(os.path.join(src, "gather_rates.json")))
+except Exception:
+    pass
+sizes = [k for k in rates if k.endswith("_GiB")]
+gl = [d for (name, grid, wg), ds in g.items() if "k_gather" in name for d in ds]
+if sizes:
+    rows = {}
+    for i, k in enumerate(sizes):
+        ds = gl[3 * i:3 * i + 3]  # three launches per table size, in the order gather.bin runs them
+        row = dict(rates[k])
+        if ds:
+            m, _ = mean(ds)
+            d = derive(m)
+            row.update({kk: d[kk] for kk in ("utcl1_miss_per_request", "utcl1_hit_per_request", "TCP_UTCL1_REQUEST_sum", "GRBM_UTCL2_BUSY", "cycles") if kk in d})
+            if "GRBM_UTCL2_BUSY" in d and d.get("GRBM_GUI_ACTIVE"):
+                row["utcl2_busy_frac"] = d["GRBM_UTCL2_BUSY"] / d["GRBM_GUI_ACTIVE"]
+        rows[k] = row
+    res["gather_random_64B"] = rows
+json.dump(res, open(out, "w"), indent=1)
+for k, v in res.items():
+    if k != "units":
+        print(k, json.dumps(v)[:1800])

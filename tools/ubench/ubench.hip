@@ -71,6 +71,25 @@ __global__ void __launch_bounds__(256) k_fplmul(uint32_t* out, uint32_t seed, in
     for (int i = 0; i < 9; i++) s ^= a.l[i] ^ b.l[i];
     out[tid] = s;
 }
+// the NTT's unit: multiplication by a constant held as a Shoup pair (w, floor(w 2^261 / r)), operand and result on lazy limbs
+__global__ void __launch_bounds__(256) k_fplshoup(uint32_t* out, uint32_t seed, int iters) {
+    uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    FpL<FrParams> a, b;
+    FpLS<FrParams> c, d;
+    for (int i = 0; i < 9; i++) {
+        a.l[i] = (tid * 2654435761u + i * 40503u + seed) & FP29_MASK;
+        b.l[i] = (tid * 40503u + i * 2654435761u + 7u) & FP29_MASK;
+        c.w[i] = (int32_t)((tid * 97u + i * 7919u + seed) & FP29_MASK);
+        c.wp[i] = (int32_t)((tid * 31u + i * 104729u + 3u) & FP29_MASK);
+        d.w[i] = c.wp[i] ^ 0x5555;
+        d.wp[i] = c.w[i] ^ 0x3333;
+    }
+    a.l[8] &= 0xfffff; b.l[8] &= 0xfffff; c.w[8] &= 0xfffff; d.w[8] &= 0xfffff;
+    for (int i = 0; i < iters; i++) { a = fpl_mul_shoup(a, c); b = fpl_mul_shoup(b, d); }
+    uint32_t s = 0;
+    for (int i = 0; i < 9; i++) s ^= a.l[i] ^ b.l[i];
+    out[tid] = s;
+}
 __global__ void __launch_bounds__(256, 4) k_g1lmadd(uint32_t* out, uint32_t seed, int iters) {
     uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
     // not curve points: the formulas do not care, and the exceptional-case filter almost never fires on random data
@@ -129,6 +148,8 @@ int main() {
     double m4 = time_ms([&] { hipLaunchKernelGGL(k_fplmul, dim3(blocks), dim3(threads), 0, 0, out, 1u, it); });
     double m5 = time_ms([&] { hipLaunchKernelGGL(k_g1lmadd, dim3(blocks), dim3(threads), 0, 0, out, 1u, it); });
     printf(", \"fq_lazy_mul_Gops\": %.2f, \"g1_lazy_madd_Gops\": %.3f", lanes * it * 2 / (m4 * 1e-3) / 1e9, lanes * it / (m5 * 1e-3) / 1e9);
+    double m6 = time_ms([&] { hipLaunchKernelGGL(k_fplshoup, dim3(blocks), dim3(threads), 0, 0, out, 1u, it); });
+    printf(", \"fr_shoup_mul_Gops\": %.2f", lanes * it * 2 / (m6 * 1e-3) / 1e9);
     // occupancy sweep for fr_mul: 1,2,4 blocks per CU
     for (int bpc : {1, 2, 4, 8, 16, 32}) {
         int bl = prop.multiProcessorCount * bpc;
