@@ -112,6 +112,14 @@ __global__ void __launch_bounds__(64) g1_batch_to_affine_kernel(const G1Xyzz* in
     }
 }
 
+void g1_batch_to_affine(plonk_ctx* ctx, const G1Xyzz* in, G1Affine* out, size_t n) {
+    const size_t chunks = (n + AFF_CHUNK - 1) / AFF_CHUNK;
+    unsigned g = (unsigned)((chunks + 63) / 64);
+    if (g > 65536) g = 65536;
+    if (!g) return;
+    PLONK_LAUNCH(g1_batch_to_affine_kernel, dim3(g), dim3(64), 0, ctx->stream, in, out, n);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Sorting.  Entry encoding: bits 0..14 base index, bit 15 sign, bits 16.. window.
 struct MsmRecode { uint32_t k[9]; };
@@ -416,27 +424,47 @@ __global__ void __launch_bounds__(64) msm_lookup_fill_kernel(const G1Affine* wba
     }
 }
 
-// item = i * W + w; lane t of the MSM's 256 * G lanes adds items [t * per, (t + 1) * per)
+// item = i * W + w.  Which items a lane adds (`strided`, chosen by the host):
+//   strided (n >= lanes: every batch of the prover)  lane t of the MSM's 256 * G lanes takes the scalars i = t, t + lanes, ..,
+//       all W windows of one scalar before the next.  At any moment the lanes of a workgroup — and, because every workgroup
+//       of a launch walks the same sequence at the same pace, the lanes of the whole chip — read the table slabs of ONE
+//       window and `lanes` CONSECUTIVE bases: a contiguous 1 - 2 GB of the 128.8 GB table.  The table look-ups are random
+//       64-byte reads; what they cost is address translation, not bandwidth (round 5, profiles/r05_valu_summary.json: random
+//       64-byte reads run at 40 G/s over a span of <= 2 GiB and at 20 G/s from 8 GiB up, where 88 - 94 % of the UTCL1 requests
+//       miss and the UTCL2 is busy 99.5 % of the time; this kernel with round 4's order — each lane 8 consecutive scalars, the
+//       chip spread over the whole table — had 92.5 % UTCL1 misses and the UTCL2 busy 92.6 % of its duration).
+//   flat (a lone MSM cut into more lanes than it has scalars)  lane t adds items [t * per, (t + 1) * per).
 __global__ void __launch_bounds__(MSM_BLOCK, MSM_ACC_WAVES) msm_lookup_kernel(
     const G1Affine* lookup, size_t table_n, unsigned c, unsigned W, const Fr* scalars, size_t n, size_t stride, size_t inner,
     size_t outer_stride, MsmRecode rc, unsigned G, G1Xyzz* partial, MsmDeferred* deferred, size_t deferred_stride,
-    uint32_t* n_deferred) {
+    uint32_t* n_deferred, unsigned strided) {
     PLONK_DYN_SMEM(smem);  // MSM_BLOCK x 128 B: first each lane's recoded scalar (10 words), then the tree reduction
     const unsigned m = blockIdx.x / G, g = blockIdx.x % G, tid = threadIdx.x;
     uint32_t* row = reinterpret_cast<uint32_t*>(smem) + tid * 10;
     G1Xyzz* red = reinterpret_cast<G1Xyzz*>(smem);
     const Fr* sc = scalars + (m % inner) * stride + (m / inner) * outer_stride;
-    const uint32_t items = (uint32_t)(n * W), lanes = G * MSM_BLOCK;
-    const uint32_t per = (items + lanes - 1) / lanes;
-    const uint64_t lo64 = (uint64_t)(g * MSM_BLOCK + tid) * per;
-    const uint32_t lo = lo64 < items ? (uint32_t)lo64 : items;
-    const uint32_t hi = lo64 + per < items ? (uint32_t)(lo64 + per) : items;
+    const uint32_t items = (uint32_t)(n * W), lanes = G * MSM_BLOCK, t = g * MSM_BLOCK + tid;
     const uint32_t mask = (1u << c) - 1, half = 1u << (c - 1);
+    uint32_t i, w, count, step;
+    if (strided) {
+        i = t;
+        w = 0;
+        count = t < n ? (((uint32_t)n - 1 - t) / lanes + 1) * W : 0;
+        step = lanes;
+    } else {
+        const uint32_t per = (items + lanes - 1) / lanes;
+        const uint64_t lo64 = (uint64_t)t * per;
+        const uint32_t lo = lo64 < items ? (uint32_t)lo64 : items;
+        const uint32_t hi = lo64 + per < items ? (uint32_t)(lo64 + per) : items;
+        i = lo / W;
+        w = lo - i * W;
+        count = hi - lo;
+        step = 1;
+    }
 
     G1XyzzL run = g1l_identity();
-    uint32_t i = lo / W, w = lo - i * W;
     bool fresh = true;
-    for (uint32_t item = lo; item < hi; item++) {
+    for (uint32_t k = 0; k < count; k++) {
         if (fresh) {  // new scalar: canonical value + recoding constant, parked in this lane's LDS row
             uint32_t limb[10];
             msm_recode(sc, i, rc, limb);
@@ -453,12 +481,12 @@ __global__ void __launch_bounds__(MSM_BLOCK, MSM_ACC_WAVES) msm_lookup_kernel(
             const Fq x = fp_load(&src->x), y = fp_load(&src->y);
             if (!g1l_madd_fast(run, x, y, d < 0) && !(fp_is_zero(x) && fp_is_zero(y))) {  // see msm_accumulate_kernel
                 const uint32_t slot = atomicAdd(n_deferred + m, 1u);
-                if (slot < MSM_DEFER_CAP) deferred[(size_t)m * deferred_stride + slot] = MsmDeferred{item, (uint32_t)d};
+                if (slot < MSM_DEFER_CAP) deferred[(size_t)m * deferred_stride + slot] = MsmDeferred{i * W + w, (uint32_t)d};
             }
         }
         if (++w == W) {
             w = 0;
-            i++;
+            i += step;
             fresh = true;
         }
     }
@@ -897,11 +925,16 @@ static int msm_run_lookup(plonk_ctx* ctx, plonk_srs* srs, const Fr* d_scalars, s
     MsmDeferred* deferred = (MsmDeferred*)((uint8_t*)s + part_bytes + cnt_bytes);
     MsmRecode rc;
     msm_recode_constant(c, W, &rc);
+    // lanes walk scalars t, t + lanes, .. (window after window) whenever every lane gets a scalar: the chip then reads one
+    // contiguous 1 - 2 GB of the table at a time, which the translation caches hold (see msm_lookup_kernel).  PLONK_MSM_ORDER=flat
+    // restores round 4's order (each lane 8 consecutive scalars) for A/B runs.
+    static const bool force_flat = [] { const char* e = getenv("PLONK_MSM_ORDER"); return e && !strcmp(e, "flat"); }();
+    const unsigned strided = (!force_flat && n >= (size_t)G * MSM_BLOCK) ? 1u : 0u;
     PLONK_CHECK_HIP(hipMemsetAsync(n_deferred, 0, M * 4, ctx->stream));
     PLONK_TRY(prof_begin(ctx, "msm_lookup", (double)M * (96.0 * (double)n + 64.0)));
     PLONK_LAUNCH(msm_lookup_kernel, dim3((unsigned)(M * G)), dim3(MSM_BLOCK), (size_t)MSM_BLOCK * sizeof(G1Xyzz), ctx->stream,
                  (const G1Affine*)srs->lookup, srs->n_points, c, W, d_scalars, n, stride, inner, outer_stride, rc, G, partial,
-                 deferred, (size_t)MSM_DEFER_CAP, n_deferred);
+                 deferred, (size_t)MSM_DEFER_CAP, n_deferred, strided);
     PLONK_TRY(prof_end(ctx));
     if (G >= 8)  // few MSMs in many pieces: a wave per MSM sums the pieces in parallel
         PLONK_LAUNCH(msm_lookup_finalize_wave_kernel, dim3((unsigned)M), dim3(64), 0, ctx->stream, (const G1Xyzz*)partial, M, G,
@@ -946,6 +979,36 @@ int msm_lagrange_srs(plonk_ctx* ctx, plonk_srs* srs, unsigned log_n, plonk_srs**
     const size_t n = (size_t)1 << log_n;
     PLONK_REQUIRE(n <= srs->n_points, PLONK_ERR_ARG, "Lagrange basis of size %zu needs %zu powers, the SRS has %zu", n, n, srs->n_points);
     PLONK_REQUIRE(log_n <= PLONK_FR_TWO_ADICITY, PLONK_ERR_ARG, "size 2^%u exceeds the 2-adicity of Fr", log_n);
+    // Two routes to the same points (bit-identical: both end in the unique affine representative).  Up to 2^12: n MSMs over the
+    // monomial bases (below) — a few milliseconds once the lookup table exists, but quadratic.  Above: the inverse DFT over the
+    // group (g1_ntt.hip), n log n group operations.  PLONK_LAGRANGE_SRS = msm / ntt forces one (tests, A/B).
+    {
+        const char* e = getenv("PLONK_LAGRANGE_SRS");
+        const bool by_ntt = e ? !strcmp(e, "ntt") : log_n > 12;
+        if (by_ntt) {
+            G1Affine* nb = nullptr;
+            if (!plonk_dev_malloc(&nb, n * sizeof(G1Affine))) {
+                plonk_set_error("hipMalloc failed while building the Lagrange-basis SRS of size %zu", n);
+                return PLONK_ERR_NOMEM;
+            }
+            const int rcn = g1_lagrange_by_ntt(ctx, srs, log_n, nb);
+            if (rcn != PLONK_OK) {
+                hipFree(nb);
+                return rcn;
+            }
+            plonk_srs* child = new plonk_srs();
+            child->device = srs->device;
+            child->n_points = n;
+            child->bases = nb;
+            child->fixed = srs->fixed;
+            child->parent = srs;
+            const uint64_t tag[2] = {srs->content_key, 0x4c61677200000000ull | log_n};  // "Lagr" | log_n
+            child->content_key = plonk_fnv1a64(tag, sizeof tag);
+            srs->lagrange[log_n] = child;
+            *out = child;
+            return PLONK_OK;
+        }
+    }
     const size_t rows = n < 1024 ? n : 1024;  // rows per round: bounds the scalar matrix at 1024 * n elements
     void *mat = nullptr, *res = nullptr, *bases = nullptr;
     auto cleanup = [&]() {

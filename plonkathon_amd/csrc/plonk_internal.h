@@ -189,6 +189,9 @@ int ntt_dist_rows(plonk_ctx*, const Fr* in, Fr* out, unsigned log_n, unsigned lo
 // msm.hip
 int msm_build_table(plonk_ctx*, plonk_srs*, unsigned c);
 int msm_lagrange_srs(plonk_ctx*, plonk_srs*, unsigned log_n, plonk_srs** out);  // owned by (and freed with) the parent
+void g1_batch_to_affine(plonk_ctx*, const G1Xyzz* in, G1Affine* out, size_t n);  // enqueue: XYZZ -> affine (Montgomery), identity -> (0, 0)
+// g1_ntt.hip: the same Lagrange-basis points by an inverse DFT over the group (n log n group operations)
+int g1_lagrange_by_ntt(plonk_ctx*, const plonk_srs*, unsigned log_n, G1Affine* d_bases_out);
 void msm_srs_release(plonk_srs*);  // drops the reference on the shared lookup table
 int msm_lookup_info(const plonk_srs*, unsigned* bits, size_t* bytes, double* build_s, int* sharers);
 uint64_t plonk_fnv1a64(const void* data, size_t n);

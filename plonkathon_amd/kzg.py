@@ -222,7 +222,10 @@ def _g1_neg(pt):
 G2 = (Fq2(_G2_COORDS[0]), Fq2(_G2_COORDS[1]))
 
 
-LAGRANGE_SRS_MAX_LOG = 12  # largest 2^k for which Setup.commit builds the Lagrange-basis SRS on first use
+# Largest 2^k for which Setup.commit builds the Lagrange-basis SRS on first use.  Up to 2^12 the view is n MSMs of size n (a few
+# milliseconds at the prover's sizes); above, an inverse DFT over the group (csrc/g1_ntt.hip: n log n group operations, tens of
+# milliseconds at 2^16) — round 4 stopped at 2^12 because only the quadratic route existed.
+LAGRANGE_SRS_MAX_LOG = 28
 
 
 class Setup:
@@ -286,8 +289,8 @@ class Setup:
         n = len(values)
         assert n <= self._n  # setup.py:70
         bases, log_n = self.device_bases(), _log2_exact(n)
-        # Building the view is n MSMs of size n (and an n x n scalar matrix): worth it once per circuit size at the
-        # prover's sizes, quadratic beyond them — larger polynomials take the reference's route, ifft then one MSM.
+        # Building the view is a one-off per size (n MSMs of size n up to 2^12, an EC inverse NTT above); beyond
+        # LAGRANGE_SRS_MAX_LOG polynomials take the reference's route, ifft then one MSM.
         if log_n > LAGRANGE_SRS_MAX_LOG and log_n not in bases._views:
             return self.commit_coeffs(values.ifft())
         lag = bases.lagrange(log_n)

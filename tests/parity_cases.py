@@ -983,8 +983,17 @@ def msm_deferred_overflow(setup_unused=None):
         # cancelling pairs: the sum is the identity
         pairs2 = [((Fq(1), Fq(2)), 5)] * 300 + [((Fq(1), Fq(Q_MOD - 2)), 5)] * 300
         assert pa.ec_lincomb(pairs2) is None
+        # the same with ONE workgroup per MSM: 256 lanes <= 700 scalars, so the lookup kernel walks scalars t, t + 256, ..
+        # (the batch order of round 5) and the deferred list / the recomputation are reached from that order too
+        ctx.msm_configure(0, 1)
+        assert affine(pa.ec_lincomb(pairs)) == want
+        assert pa.ec_lincomb(pairs2) is None
+        Pts = [affine(p) for p in Setup.from_file(PTAU).powers_of_x[:300]]
+        mixed = [(p, 7 + 3 * i) for i, p in enumerate(Pts)] + [(Pts[5], 11), (Pts[5], R_MOD - 11), (Pts[17], 1)] * 3  # ragged: 309 scalars
+        assert affine(pa.ec_lincomb([((Fq(p[0]), Fq(p[1])), k) for p, k in mixed])) == og1.ec_lincomb(mixed)
     finally:
         ctx.msm_lookup(0)
+        ctx.msm_configure(0, 0)
 
 
 def lagrange_srs_paths(setup):
@@ -1007,6 +1016,64 @@ def lagrange_srs_paths(setup):
     ref = [flat(p) for p in pa.BatchProver(setup, Program(lines, n)).prove_batch(wits)]
     got = [flat(p) for p in pa.BatchProver(setup, Program(lines, n), lagrange_commits=True).prove_batch(wits)]
     assert got == ref
+
+
+def lagrange_srs_by_ntt(log_ns):
+    """the Lagrange-basis SRS by an inverse DFT over the group (g1_ntt.hip: n log n group operations) must be
+    the SAME points the n-MSM route gives (both end in the unique affine representative), and commitments over it must equal
+    ifft + coefficient-basis MSM (setup.py:66-72) and the oracle."""
+    import os
+    import random
+
+    rng = random.Random(88)
+    osetup = OSetup.from_file(PTAU)
+    for log_n in log_ns:
+        n = 1 << log_n
+        vals = [rng.randrange(R_MOD) for _ in range(n)]
+        unit = [[1 if j == i else 0 for j in range(n)] for i in sorted({0, 1 % n, n // 2, n - 1})]
+        got = {}
+        for route in ("ntt", "msm"):
+            os.environ["PLONK_LAGRANGE_SRS"] = route
+            try:
+                s = Setup.from_file(PTAU)  # a fresh Setup: the view is cached per device copy of the SRS
+                got[route] = [affine(s.commit(P(v))) for v in [vals] + unit]
+            finally:
+                del os.environ["PLONK_LAGRANGE_SRS"]
+        assert got["ntt"] == got["msm"], log_n
+        if n <= 64:
+            coeffs = OPoly(vals, OBasis.LAGRANGE).ifft().values
+            assert got["ntt"][0] == og1.ec_lincomb(list(zip(osetup.powers_of_x[:n], coeffs))), log_n
+
+
+def lagrange_srs_beyond_2e12(log_n=13):
+    """Above 2^12 only the group NTT builds the view (round 4 fell back to ifft + MSM there).  The .ptau slice holds 2^11 points, so
+    the base set is synthetic — s_j G for random s_j, made by one batched MSM of size 1 — which is all the transform needs: it is
+    linear in the points.  commit(values) over the view == commit_coeffs(ifft(values)), and the first view point is checked
+    against the oracle: L_0 = (1/n) sum_j P_j."""
+    import ctypes
+    import random
+
+    from plonkathon_amd import get_context
+    from plonkathon_amd._lib import check
+    from plonkathon_amd.kzg import _DeviceBases, _msm
+
+    n = 1 << log_n
+    ctx = get_context()
+    rng = random.Random(13)
+    sc = [rng.randrange(1, R_MOD) for _ in range(n)]
+    h = ctypes.c_void_p()
+    check(ctx.L.plonk_srs_load_affine(ctx.handle, (1).to_bytes(32, "little") + (2).to_bytes(32, "little"), 1, ctypes.byref(h)))
+    gen = _DeviceBases(ctx, h, 1)
+    buf = ctx.upload_ints(sc)
+    pts = _msm(gen, buf.ptr, 1, n, 1)
+    s = Setup(pts)
+    vals = [rng.randrange(R_MOD) for _ in range(n)]
+    a = s.commit(P(vals))
+    assert log_n in s.device_bases()._views  # the view was built (by the group NTT: log_n > 12)
+    b = s.commit_coeffs(P(vals).ifft())
+    assert affine(a) == affine(b)
+    first = affine(s.commit(P([1] + [0] * (n - 1))))
+    assert first == og1.multiply((1, 2), sum(sc) * pow(n, -1, R_MOD) % R_MOD)
 
 
 def lookup_table_is_shared_across_contexts():

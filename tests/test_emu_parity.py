@@ -138,6 +138,14 @@ def test_msm_lookup_tables(emu):
             if c == 5:
                 pc.lincomb_golden(setup, full_size=False)
                 pc.lincomb_fuzz(setup, 8, seed=77)
+        # 256 lanes per MSM and at least as many scalars: the lookup kernel's batch order (lane t takes scalars t, t + 256, ..),
+        # with a ragged tail (300) and an exact multiple (512), two MSMs per call
+        ctx.msm_lookup(2, 5)
+        ctx.msm_configure(0, 1)
+        setup = Setup.from_file(pc.PTAU)
+        pc.msm_vs_oracle(setup, 300, seed=91)
+        pc.msm_vs_oracle(setup, 512, seed=92)
+        ctx.msm_configure(0, 0)
         ctx.msm_lookup(2, 4)
         pc.prover_k6(Setup.from_file(pc.PTAU))
         pc.batch_prover_k6(Setup.from_file(pc.PTAU))
@@ -211,6 +219,17 @@ def test_batch_prover_tiny_group_orders_and_resident_batch(emu):
 
 def test_msm_deferred_overflow_is_recomputed(emu):
     pc.msm_deferred_overflow()
+
+
+def test_lagrange_srs_by_group_ntt(emu):
+    pc.lagrange_srs_by_ntt((0, 1, 2, 5))
+    import os
+
+    os.environ["PLONK_LAGRANGE_SRS"] = "ntt"   # (the emulator cannot afford 2^13: the same path at 2^6 through the forced route)
+    try:
+        pc.lagrange_srs_beyond_2e12(6)
+    finally:
+        del os.environ["PLONK_LAGRANGE_SRS"]
 
 
 def test_lookup_table_is_shared_across_contexts(emu):

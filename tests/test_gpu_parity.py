@@ -444,6 +444,12 @@ def test_msm_deferred_overflow_is_recomputed():
 
 
 @pytest.mark.gpu
+def test_lagrange_srs_by_group_ntt_equals_the_msm_route():
+    pc.lagrange_srs_by_ntt((0, 3, 8, 11))
+    pc.lagrange_srs_beyond_2e12(13)
+
+
+@pytest.mark.gpu
 def test_lookup_table_is_shared_across_contexts():
     pc.lookup_table_is_shared_across_contexts()
     pc.lookup_table_colliding_key()

@@ -70,27 +70,63 @@ def derive(m):
 
 res = {"units": __doc__.split("Units")[1].strip()[:1200]}
 
-# ---- msm_lookup_kernel of one lock-step batch (4 launches per prover run; the first run is the warm-up)
+# ---- msm_lookup_kernel: every launch of the pass (2 prover runs x 4 launches: 1536 / 512 / 1536 / 1024 MSMs), counters SUMMED over
+# the launches of a pass and set against the summed cycles / additions of the same launches (one run = 9 x 512 MSMs of 2^11
+# scalars x 15 windows of 17 bits = 4608 x 30720 mixed additions; 64 lanes per wave instruction)
+ADDS_PER_RUN = 4608.0 * 15 * 2048
 b = {}
 for tag in ("bench_issue", "bench_mem", "bench_utcl"):
-    for (name, grid, wg), ds in launches(tag).items():
-        if name == "msm_lookup_kernel":
-            m, n = mean(ds)
-            b.setdefault("launches", n)
-            b.update({k: v for k, v in derive(m).items() if k not in b or k in ("dur_ns",)})
-            b["grid_threads"], b["workgroup"] = grid, wg
+    ls = [d for (name, grid, wg), ds in launches(tag).items() if name == "msm_lookup_kernel" for d in ds]
+    if not ls:
+        continue
+    tot = collections.defaultdict(float)
+    for d in ls:
+        for k, v in d.items():
+            tot[k] += v
+    runs = len(ls) / 4.0
+    adds = ADDS_PER_RUN * runs
+    e = {"launches": len(ls), "prover_runs": runs, "sum": dict(tot)}
+    fac = next((f for f in (1.0, 8.0, 32.0) if tot.get("GRBM_GUI_ACTIVE") and 1.2 <= tot["GRBM_GUI_ACTIVE"] / f / tot["dur_ns"] <= 2.6), None)
+    if fac:
+        cyc = tot["GRBM_GUI_ACTIVE"] / fac
+        e.update({"xcd_factor": fac, "cycles": cyc, "effective_clock_ghz": cyc / tot["dur_ns"]})
+        if "SQ_ACTIVE_INST_VALU" in tot:
+            e["valu_busy"] = 4.0 * tot["SQ_ACTIVE_INST_VALU"] / (SIMDS * cyc)
+            e["valu_busy_per_launch"] = [round(4.0 * d["SQ_ACTIVE_INST_VALU"] / (SIMDS * d["GRBM_GUI_ACTIVE"] / fac), 4) for d in ls]
+        if "SQ_WAVE_CYCLES" in tot:
+            e["waves_per_simd"] = 4.0 * tot["SQ_WAVE_CYCLES"] / (SIMDS * cyc)
+    if tot.get("SQ_INSTS_VALU"):
+        e["valu_insts_per_addition"] = tot["SQ_INSTS_VALU"] / (adds / 64.0)
+        e["cycles_per_valu_inst"] = 4.0 * tot["SQ_ACTIVE_INST_VALU"] / tot["SQ_INSTS_VALU"]
+        # what the same instruction stream would do at one VALU instruction per SIMD every cycles_per_valu_inst cycles
+        e["additions_per_s_at_full_issue_per_ghz"] = SIMDS * 1e9 / e["cycles_per_valu_inst"] * 64.0 / e["valu_insts_per_addition"]
+    wc = tot.get("SQ_WAVE_CYCLES")
+    if wc:
+        e["wave_time_split"] = {k: tot[c] / wc for k, c in (("valu_active", "SQ_ACTIVE_INST_VALU"), ("waiting", "SQ_WAIT_ANY"),
+                                                            ("issue_stalled", "SQ_WAIT_INST_ANY"), ("lds_active", "SQ_ACTIVE_INST_LDS")) if c in tot}
+    for k, c in (("vmem_rd_insts_per_addition", "SQ_INSTS_VMEM_RD"), ("salu_insts_per_addition", "SQ_INSTS_SALU"), ("lds_insts_per_addition", "SQ_INSTS_LDS")):
+        if c in tot:
+            e[k] = tot[c] / (adds / 64.0)
+    if tot.get("TCP_UTCL1_REQUEST_sum"):
+        e["utcl1_requests_per_addition"] = tot["TCP_UTCL1_REQUEST_sum"] / adds
+        e["utcl1_miss_per_request"] = tot.get("TCP_UTCL1_TRANSLATION_MISS_sum", 0.0) / tot["TCP_UTCL1_REQUEST_sum"]
+        e["utcl1_hit_per_request"] = tot.get("TCP_UTCL1_TRANSLATION_HIT_sum", 0.0) / tot["TCP_UTCL1_REQUEST_sum"]
+        if tot.get("GRBM_UTCL2_BUSY") and tot.get("GRBM_GUI_ACTIVE"):
+            e["utcl2_busy_frac"] = tot["GRBM_UTCL2_BUSY"] / tot["GRBM_GUI_ACTIVE"]
+    b[tag] = e
 if b:
-    # one launch of the batch prover = 1152 MSMs (round 1: 3 x 512 minus ... -> read from the grid: G workgroups per MSM)
-    msms = 1152.0
-    adds = msms * 15 * 2048
-    if "SQ_INSTS_VALU" in b:
-        b["valu_insts_per_addition"] = b["SQ_INSTS_VALU"] / (adds / 64.0)
-        b["assumes"] = "1152 MSMs of 2^11 scalars x 15 windows per launch (the mean over the 4 launch shapes of a batch: 1536 / 512 / 1536 / 1024 MSMs)"
-    if "SQ_INSTS_VMEM_RD" in b:
-        b["vmem_rd_insts_per_addition"] = b["SQ_INSTS_VMEM_RD"] / (adds / 64.0)
-    if "TCP_UTCL1_REQUEST_sum" in b:
-        b["utcl1_requests_per_addition"] = b["TCP_UTCL1_REQUEST_sum"] / adds
-    res["msm_lookup_kernel"] = b
+    top = {"passes": b, "note": "profiled launches run longer than unprofiled ones (counter collection serialises dispatches): compare ratios, not durations"}
+    for k in ("valu_busy", "valu_busy_per_launch", "valu_insts_per_addition", "cycles_per_valu_inst", "waves_per_simd", "wave_time_split", "effective_clock_ghz",
+              "additions_per_s_at_full_issue_per_ghz"):
+        if k in b.get("bench_issue", {}):
+            top[k] = b["bench_issue"][k]
+    for k in ("utcl1_miss_per_request", "utcl1_requests_per_addition", "utcl2_busy_frac"):
+        if k in b.get("bench_utcl", {}):
+            top[k] = b["bench_utcl"][k]
+    for k in ("vmem_rd_insts_per_addition", "salu_insts_per_addition"):
+        if k in b.get("bench_mem", {}):
+            top[k] = b["bench_mem"][k]
+    res["msm_lookup_kernel"] = top
 
 # ---- the two passes of a lone 2^20 transform
 ntt = {}
