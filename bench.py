@@ -178,7 +178,7 @@ def main():
     ap.add_argument("--dist-backend", default="rccl", choices=["rccl", "sockets"],
                     help="transport of the final gather for N > 1: rccl = RCCL over xGMI through the C-ABI (default); sockets = TCP, lets ranks share one GPU")
     ap.add_argument("--lookup-budget-gb", type=float, default=DEFAULT_TABLE_GB,
-                    help="HBM budget for the MSM lookup table (the library's own default is 4 GiB; the c = 17 table of 2^11 bases is 128.8 GB)")
+                    help="HBM budget for the MSM lookup table (the library's own default is 1/16 of the device's memory; the c = 17 table of 2^11 bases is 128.8 GB)")
     ap.add_argument("--force-comm", action="store_true",
                     help="with --gpus 1: still create a ONE-rank RCCL communicator and run the gather (plonk_gather_proofs_device), the "
                          "max over ranks and the barrier inside the timed region — the code path of an N-GPU run, exercised on one GPU")
@@ -553,10 +553,10 @@ def main():
         if "roofline" in line:  # the kernel north_star puts a number on, inside the block the driver's record keeps
             sec = {k: roof_ntt[k] for k in ("kernel", "frac", "ms_lone", "traffic_over_algorithmic")}
             sec["per_pass_us"] = [roof_ntt["per_pass_us"]["columns_us"], roof_ntt["per_pass_us"]["rows_us"]]
-            if "alu" in roof_ntt:
+            if "frac_of_alu_floor" in roof_ntt.get("alu", {}):
                 sec["alu_frac"] = roof_ntt["alu"]["frac_of_alu_floor"]
             if "valu" in roof_ntt:
-                sec["valu"] = {k: roof_ntt["valu"].get(k) for k in ("valu_busy", "valu_insts_per_element")}
+                sec["valu"] = roof_ntt["valu"]
             line["roofline"]["secondary"] = sec
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         dt, oproof, prim = legs.cpu_baseline(PTAU, chain_program_lines(GROUP_ORDER), GROUP_ORDER)

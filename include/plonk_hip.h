@@ -204,11 +204,12 @@ int plonk_g1_msm(plonk_ctx* ctx, plonk_srs* srs, const void* d_scalars, size_t n
 /* tuning knobs (0 = library default): window bits c and window-groups per MSM (bucket method) */
 int plonk_msm_configure(plonk_ctx* ctx, unsigned window_bits, unsigned groups);
 /* Lookup MSM: for a reusable SRS (plonk_srs_load_ptau) every multiple d * 2^(c w) * P_i, d <= 2^(c-1), is
- * precomputed once into HBM (2^11 points: 128.8 GB at c = 17, 68.7 GB at c = 16, 3.2 GB at c = 11), after which
- * an MSM is N * ceil(255/c) mixed additions of looked-up points: no sorting, no buckets, no doublings.  mode 0
+ * precomputed once into HBM (2^11 points: 128.8 GB at c = 17, 68.7 GB at c = 16, 10.7 GB at c = 13, 3.2 GB at c = 11), after
+ * which an MSM is N * ceil(255/c) mixed additions of looked-up points: no sorting, no buckets, no doublings.  mode 0
  * (default): automatic — the largest c (<= 17) whose table and its one-window staging buffer fit `budget_bytes`;
- * budget 0 = the library default of 4 GiB (or PLONK_MSM_TABLE_GB gigabytes if that variable is set): the big tables
- * are a memory-for-time trade the caller opts into explicitly.  Bucket method when nothing fits or for
+ * budget 0 = the library default of 1/16 of the device's memory (18 GB on an MI355X: c = 13 for 2^11 points), or
+ * PLONK_MSM_TABLE_GB gigabytes if that variable is set: the big tables are a memory-for-time trade the caller opts into
+ * explicitly.  Bucket method when nothing fits or for
  * plonk_srs_load_affine bases; mode 1: never; mode 2: use `window_bits` for every base set (tests).  Same results
  * as the bucket method (curve.py:38-111), bit for bit.                                                          */
 int plonk_msm_lookup_configure(plonk_ctx* ctx, int mode, unsigned window_bits, size_t budget_bytes);

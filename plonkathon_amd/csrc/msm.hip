@@ -852,11 +852,18 @@ static int msm_lookup_build(plonk_ctx* ctx, plonk_srs* srs, unsigned c) {  // g_
 }
 
 static size_t msm_default_lookup_budget() {
-    // The table is a memory-for-time trade the CALLER must opt into: 4 GiB by default (c = 11 for 2^11 bases), more
-    // only through plonk_msm_lookup_configure(budget) or PLONK_MSM_TABLE_GB (bench.py asks for the 129 GB c = 17 table).
+    // The table is a memory-for-time trade the CALLER opts into beyond a modest default: 1/16 of the device's memory (18 GB of an
+    // MI355X's 288: c = 13 for 2^11 bases, 10.7 GB + 1.1 GB while it is built; round 4's fixed 4 GiB — c = 11 — was a figure for
+    // 16 GB cards), more only through plonk_msm_lookup_configure(budget) or PLONK_MSM_TABLE_GB (bench.py asks for the 129 GB
+    // c = 17 table).  Measured (profiles/r05_d_msm_sweep.jsonl, 1152 MSMs of 2^11 per call): c = 11 4.50 ms, 12 4.11, 13 3.86, 14 3.65.
     const char* e = getenv("PLONK_MSM_TABLE_GB");
     if (e && atof(e) > 0) return (size_t)(atof(e) * 1e9);
-    return (size_t)4 << 30;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || !total_b) {
+        (void)hipGetLastError();
+        return (size_t)4 << 30;
+    }
+    return total_b / 16;
 }
 
 // Decides whether this call runs on a lookup table: attaches the table another context of this device already
@@ -904,6 +911,36 @@ static bool msm_lookup_prepare(plonk_ctx* ctx, plonk_srs* srs) {
     return false;
 }
 
+// Workgroups per MSM.  `g0` is what fills the chip; a launch, however, runs in ROUNDS of (CUs x 4) resident 256-thread
+// workgroups, and a last round that is half empty leaves half the SIMD slots without a wave for the time of a whole round
+// (M = 1536 MSMs at one workgroup each: 1.5 rounds on 1024 slots — two of the four MSM launches of a lock-step batch of 512 proofs).
+// Cutting every MSM into twice the workgroups halves the length of a round for `overhead` more work per workgroup (its tree
+// reduction / its extra pieces): taken when the model  rounds x (1 / G + overhead)  says it pays by more than 3 %.
+// PLONK_MSM_ROUNDS=0 keeps g0 (A/B runs).  Measured (profiles/r05_f_msm_rounds_stagger_ab.json, r05_d_msm_sweep.jsonl): 1152 MSMs on the
+// bucket method 5.59 -> 5.14 ms per call; the prover's own launch shapes gain under 1 % on either method.
+static unsigned msm_round_aware_groups(int device, size_t M, unsigned g0, unsigned g_max, double overhead) {
+    static const bool off = [] { const char* e = getenv("PLONK_MSM_ROUNDS"); return e && !strcmp(e, "0"); }();
+    if (off || g0 >= g_max) return g0;
+    static int cus[16] = {0};
+    int& n_cu = cus[device & 15];
+    if (!n_cu) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount;
+        else {
+            (void)hipGetLastError();
+            n_cu = 256;
+        }
+    }
+    const double slots = 4.0 * (double)n_cu;
+    auto cost = [&](unsigned G) {
+        const double wgs = (double)M * G;
+        double rounds = wgs / slots;
+        rounds = rounds <= 1.0 ? 1.0 : (double)(size_t)(rounds + 0.999999);
+        return rounds * (1.0 / G + overhead);
+    };
+    return cost(2 * g0) < 0.97 * cost(g0) ? 2 * g0 : g0;
+}
+
 static int msm_run_lookup(plonk_ctx* ctx, plonk_srs* srs, const Fr* d_scalars, size_t n, size_t M, size_t stride, Fq* d_out_xy,
                           uint8_t* d_flags, size_t inner, size_t outer_stride) {
     const unsigned c = srs->lookup_bits, W = srs->lookup_windows;
@@ -914,6 +951,7 @@ static int msm_run_lookup(plonk_ctx* ctx, plonk_srs* srs, const Fr* d_scalars, s
         G = 1;
         while (G < 64 && M * G * (MSM_BLOCK / 64) < 3072) G *= 2;
     }
+    if (!ctx->msm_groups) G = msm_round_aware_groups(ctx->device, M, G, 64, 0.027);
     while (G > 1 && (size_t)G * MSM_BLOCK * 2 > items) G /= 2;  // at least two additions per lane
     const size_t part_bytes = (M * G * sizeof(G1Xyzz) + 255) & ~(size_t)255;
     const size_t cnt_bytes = (M * 4 + 255) & ~(size_t)255;
@@ -1075,6 +1113,7 @@ int msm_run_device(plonk_ctx* ctx, plonk_srs* srs, const Fr* d_scalars, size_t n
         while (G < 16 && M * G < 1024) G *= 2;
     }
     const size_t max_entries = (size_t)W * n;
+    if (!ctx->msm_groups) G = msm_round_aware_groups(ctx->device, M, G, 16, 0.03);
     while (G > 1 && (size_t)G * MSM_BLOCK * 4 > max_entries) G /= 2;  // tiny MSMs: one segment is plenty
     // lanes per MSM in the bucket reduction (shorter local walks vs more lanes paying the scan and the reduction): batches (G < 8)
     // take 128 — measured best with the suffix-scan weighting (profiles/r04_c_bucket_reduce_lanes_ab.jsonl: 23.3 k proofs/s against

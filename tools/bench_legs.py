@@ -278,13 +278,22 @@ def ntt_legs(run, pmc, pmc_src, valu):
                             "multiplication per element instead of two, a deliberate bytes-for-instructions trade; "
                             "plonk_ntt_set_table_budget(0) gives 2.07 x the algorithmic 64 N instead of 3.3 x and a 6 % slower transform)"}
     ub = ubench_rates()
+    alu = {}
+    if valu and valu.get("ntt_2^20") and valu["ntt_2^20"].get("valu_insts_per_element"):
+        # every VALU instruction of the two passes (rocprofv3 --pmc SQ_INSTS_VALU) at the measured issue cost, on 1024 SIMDs at the nominal clock
+        v = valu["ntt_2^20"]
+        cpi = [e.get("cycles_per_valu_inst") for e in v.get("passes", {}).values() if e.get("cycles_per_valu_inst")]
+        cpi = sum(cpi) / len(cpi) if cpi else 4.0
+        floor_us = (1 << 20) * v["valu_insts_per_element"] / 64.0 * cpi / 1024.0 / NOMINAL_SCLK_MHZ
+        alu.update({"valu_insts_per_element": v["valu_insts_per_element"], "cycles_per_valu_inst": cpi, "floor_us_at_nominal_clock": floor_us,
+                    "frac_of_alu_floor": floor_us / (ms20 * 1e3), "valu_busy_lone_profiled": v.get("valu_busy"), "source": valu.get("source")})
+        roof["valu"] = {"valu_busy": v.get("valu_busy"), "valu_insts_per_element": v["valu_insts_per_element"]}
     if ub and ub.get("fr_shoup_mul_G"):
-        # ~9.5 N twiddle multiplications per transform (two passes + the inter-pass factor) at the measured Shoup rate
-        floor_us = 9.5 * (1 << 20) / (ub["fr_shoup_mul_G"] * 1e9) * 1e6
-        roof["alu"] = {"shoup_mul_G_per_s": ub["fr_shoup_mul_G"], "mults_per_element": 9.5, "floor_us_at_burst_clock": floor_us,
-                       "frac_of_alu_floor": floor_us / (ms20 * 1e3), "source": ub["source"]}
-    if valu and valu.get("ntt_2^20"):
-        roof["valu"] = valu["ntt_2^20"]
+        # the twiddle multiplications alone: ~9.5 N (two passes + the inter-pass factor) at the bare-loop Shoup rate of tools/ubench
+        alu.update({"shoup_mul_G_per_s": ub["fr_shoup_mul_G"], "mults_per_element": 9.5,
+                    "multiplications_only_floor_us": 9.5 * (1 << 20) / (ub["fr_shoup_mul_G"] * 1e9) * 1e6, "ubench_source": ub["source"]})
+    if alu:
+        roof["alu"] = alu
     detail["roofline_ntt"] = roof
     detail["ntt"].update({"ms_2^11_x512": small["2^11_x512"]["ms"], "ms_2^16": sweep["2^16"]["fwd"]["ms"], "ms_2^20": ms20,
                           "ms_2^24": sweep["2^24"]["fwd"]["ms"], "gf_elems_per_s_2^11_x2048": small["2^11_x2048"]["gf_elems_per_s"],
@@ -294,20 +303,20 @@ def ntt_legs(run, pmc, pmc_src, valu):
 
 # ----------------------------------------------------------------------------------------------------------------------
 def fallbacks(run):
-    """The same prover when the HBM for the big table is not available (library default 4 GiB, 40 GB, 80 GB budgets), on the
+    """The same prover when the HBM for the big table is not available (the library's default budget — 1/16 of the device's memory —,
+    4 GiB, 40 GB, 80 GB), on the
     bucket method (what `north_star` names: Pippenger, no table), and ec_lincomb on ARBITRARY bases (curve.py:38-44: no SRS,
     no table — `plonk_srs_load_affine` + the bucket method)."""
     from plonkathon_amd import BatchProver, Context
 
     B, n = run.B, run.group_order
     fb = {}
-    c75 = max(c for c in range(8, 18) if lookup_table_bytes(n, c) <= 80e9)
-    c40 = max(c for c in range(8, 18) if lookup_table_bytes(n, c) <= 40e9)
-    c4 = max(c for c in range(8, 18) if lookup_table_bytes(n, c) <= 4 << 30)
     hbm_total = run.ctx.mem_info()[1]
+    fit = lambda budget: max(c for c in range(8, 18) if lookup_table_bytes(n, c) <= budget)
     wits = [run.witness_for(idx) for idx in run.mine[:B]]
-    for name, conf in (("library_default_4GiB", (0, c4, 4 << 30)), ("table_budget_40GB", (0, c40, int(40e9))),
-                       ("table_budget_80GB", (0, c75, int(80e9))), ("bucket_method", (1, 0, 0))):
+    # (explicit window sizes: with an automatic choice a context would simply attach to the big table the headline built)
+    for name, conf in (("library_default_budget", (0, fit(hbm_total // 16), hbm_total // 16)), ("table_budget_4GiB", (0, fit(4 << 30), 4 << 30)),
+                       ("table_budget_40GB", (0, fit(40e9), int(40e9))), ("table_budget_80GB", (0, fit(80e9), int(80e9))), ("bucket_method", (1, 0, 0))):
         c2 = Context(run.local_rank)
         c2.msm_lookup(*conf)
         pr = BatchProver(run.setup, run.program, c2)

@@ -23,8 +23,9 @@ set_context(ctx)
 L, H = ctx.L, ctx.handle
 rng = random.Random(1)
 src = ctx.upload_ints([rng.randrange(1 << 253) for _ in range(4096)])
-sc = ctx.alloc((n + 1) * M + 4096)
-for off in range(0, (n + 1) * M + 4096, 4096):
+total = ((n + 1) * M + 4095) // 4096 * 4096
+sc = ctx.alloc(total)
+for off in range(0, total, 4096):
     check(L.plonk_mem_d2d(H, sc.at(off), src.ptr, 32 * 4096))
 xy, fl = ctypes.create_string_buffer(64 * M), ctypes.create_string_buffer(M)
 PTAU = os.path.join(REPO, "tests", "golden", "srs_2048.ptau")

@@ -24,6 +24,7 @@ pass bench_mem python $BENCH -- $MEMI
 pass bench_utcl python $BENCH -- $UTCL
 pass ntt_issue python "$root/tools/ntt_only.py" 20 5 -- $ISSUE
 pass ntt_mem python "$root/tools/ntt_only.py" 20 5 -- $MEMI
+pass nttb_issue python "$root/tools/ntt_util.py" -- $ISSUE
 pass gather_utcl "$root/tools/ubench/gather.bin" 160 -- $UTCL
 timeout 300 "$root/tools/ubench/gather.bin" 160 > "$root/$out/gather_rates.json" 2> "$root/$out/gather_rates.err"
 echo "gather rates rc=$?"

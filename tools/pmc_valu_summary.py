@@ -144,6 +144,19 @@ if ntt:
     res["ntt_2^20"] = {"passes": ntt, "valu_insts_per_element": tot_insts * 64.0 / (1 << 20), "valu_busy": busy,
                        "sum_of_pass_durations_us": tot_dur / 1e3}
 
+# ---- the same kernels in steady state: batches of 2^8 .. 2^13 (the prover's shapes) and 16 x 2^20 (tools/ntt_util.py)
+nb = {}
+for (name, grid, wg), ds in launches("nttb_issue").items():
+    if "ntt_wavel" not in name:
+        continue
+    m, n = mean(ds, skip_first=1)
+    d = derive(m)
+    elems = grid * {64: None, 256: None, 512: None, 1024: None}.get(wg, None) if False else None
+    nb["%s grid=%d wg=%d" % (name, grid, wg)] = {k: d.get(k) for k in ("valu_busy", "waves_per_simd", "cycles_per_valu_inst", "effective_clock_ghz", "dur_ns", "wave_time_split")}
+    nb["%s grid=%d wg=%d" % (name, grid, wg)]["launches"] = n
+if nb:
+    res["ntt_batched"] = nb
+
 # ---- random 64-byte reads against the table size
 g = launches("gather_utcl")
 rates = {}
