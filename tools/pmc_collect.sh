@@ -10,7 +10,7 @@ mkdir -p "$root/$out"
 export TMPDIR=/tmp
 cd /tmp
 for ctr in FETCH_SIZE WRITE_SIZE; do
-  timeout 600 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d "$root/$out/bench_$ctr" -o p -- python "$root/bench.py" --steps 1 --warmup 1 --batch 512 --batches-per-step 1 --streams 1 --no-cpu-baseline --no-microbench --no-fallbacks --no-end-to-end --no-configs --no-latency > "$root/$out/bench_$ctr.log" 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d "$root/$out/bench_$ctr" -o p -- python "$root/bench.py" --steps 1 --warmup 1 --batch 512 --batches-per-step 1 --streams 1 --verify-samples 0 --detail /tmp/pmc_detail.json --no-cpu-baseline --no-microbench --no-fallbacks --no-end-to-end --no-configs --no-latency > "$root/$out/bench_$ctr.log" 2>&1
   echo "bench $ctr rc=$?"
   timeout 600 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d "$root/$out/ntt_$ctr" -o p -- python "$root/tools/ntt_only.py" > "$root/$out/ntt_$ctr.log" 2>&1
   echo "ntt $ctr rc=$?"
