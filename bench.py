@@ -44,7 +44,7 @@ from bench_legs import HBM_PEAK_GBS, NOMINAL_SCLK_MHZ, R_MOD, ClockSampler  # no
 MSM_WINDOW_BITS = 10      # bucket-method default (csrc/msm.hip); 26 windows of signed 10-bit digits
 GROUP_ORDER = 2048
 PTAU = os.path.join(REPO, "tests", "golden", "srs_2048.ptau")
-DEFAULT_TABLE_GB = 150.0  # opt-in budget for the MSM lookup table: the c = 17 table of 2^11 bases is 128.8 GB + 17.2 GB of build staging
+DEFAULT_TABLE_GB = 100.0  # opt-in budget for the MSM table: the comb of 20 teeth over 2^11 bases is 68.7 GB + 17.2 GB of build staging
 LINE_LIMIT = 4096         # bytes of the stdout line (the driver's record keeps the last 8 KB of stdout)
 
 
@@ -178,7 +178,7 @@ def main():
     ap.add_argument("--dist-backend", default="rccl", choices=["rccl", "sockets"],
                     help="transport of the final gather for N > 1: rccl = RCCL over xGMI through the C-ABI (default); sockets = TCP, lets ranks share one GPU")
     ap.add_argument("--lookup-budget-gb", type=float, default=DEFAULT_TABLE_GB,
-                    help="HBM budget for the MSM lookup table (the library's own default is 1/16 of the device's memory; the c = 17 table of 2^11 bases is 128.8 GB)")
+                    help="HBM budget for the MSM table (the library's own default is 1/16 of the device's memory; the 20-tooth comb of 2^11 bases is 68.7 GB)")
     ap.add_argument("--force-comm", action="store_true",
                     help="with --gpus 1: still create a ONE-rank RCCL communicator and run the gather (plonk_gather_proofs_device), the "
                          "max over ranks and the barrier inside the timed region — the code path of an N-GPU run, exercised on one GPU")
@@ -363,7 +363,7 @@ def main():
     # the dominant kernel: the lookup MSM when the table fits in HBM (default), else the bucket method's accumulate
     info = setup.device_bases(ctx).lookup_info()
     lookup_bits = info["bits"]
-    msm_kernel = "msm_lookup" if lookup_bits else "msm_accumulate"
+    msm_kernel = {"comb": "msm_comb", "windows": "msm_lookup"}.get(info["layout"], "msm_accumulate")
     msm_ms, msm_launches, msm_bytes = profile_sum(msm_kernel)
     # The same kernel with the chip to itself: with several streams a launch's event-to-event duration includes the time
     # it shares the CUs with the other streams' kernels, so the per-launch figures of the timed region understate the
@@ -399,7 +399,9 @@ def main():
         "parallelism": "proof-sharded x%d" % world,
         "ranks_in_communicator": comm.world if comm is not None else 1,
         "gather_transport": comm.kind if comm is not None else "none (single rank)",
-        "msm_method": ("lookup table, %d-bit windows" % lookup_bits) if lookup_bits else "bucket method, %d-bit windows" % MSM_WINDOW_BITS,
+        "msm_method": ("comb table, %d teeth: %d additions per base" % (lookup_bits, info["additions_per_base"]) if info["layout"] == "comb" else
+                       "window table, %d-bit windows: %d additions per base" % (lookup_bits, info["additions_per_base"]) if lookup_bits else
+                       "bucket method, %d-bit windows" % MSM_WINDOW_BITS),
         "msm_table_bytes": info["bytes"],
         "msm_table_fraction_of_hbm": info["bytes"] / hbm_total,
         "timed_region_s": elapsed,
@@ -483,8 +485,7 @@ def main():
         avg_s = msm_ms * 1e-3 / msm_launches
         bytes_per_launch = msm_bytes / msm_launches
         traffic = pmc["bench"].get(msm_kernel + "_kernel") if B == 512 else None
-        wbits = lookup_bits or MSM_WINDOW_BITS
-        windows = (255 + wbits - 1) // wbits
+        windows = info["additions_per_base"] or (255 + MSM_WINDOW_BITS - 1) // MSM_WINDOW_BITS
         msms_per_launch = bytes_per_launch / (96.0 * GROUP_ORDER + 64.0)
         adds_per_launch = msms_per_launch * windows * GROUP_ORDER
         sclk = clocks["sclk_mhz_median"] if clocks else None

@@ -203,23 +203,29 @@ int plonk_g1_msm(plonk_ctx* ctx, plonk_srs* srs, const void* d_scalars, size_t n
                  size_t scalar_stride, uint8_t* h_out_xy_le, uint8_t* h_out_is_identity);
 /* tuning knobs (0 = library default): window bits c and window-groups per MSM (bucket method) */
 int plonk_msm_configure(plonk_ctx* ctx, unsigned window_bits, unsigned groups);
-/* Lookup MSM: for a reusable SRS (plonk_srs_load_ptau) every multiple d * 2^(c w) * P_i, d <= 2^(c-1), is
- * precomputed once into HBM (2^11 points: 128.8 GB at c = 17, 68.7 GB at c = 16, 10.7 GB at c = 13, 3.2 GB at c = 11), after
- * which an MSM is N * ceil(255/c) mixed additions of looked-up points: no sorting, no buckets, no doublings.  mode 0
- * (default): automatic — the largest c (<= 17) whose table and its one-window staging buffer fit `budget_bytes`;
- * budget 0 = the library default of 1/16 of the device's memory (18 GB on an MI355X: c = 13 for 2^11 points), or
+/* Table MSM: for a reusable SRS (plonk_srs_load_ptau) a table per base is precomputed once into HBM, after which an MSM is
+ * N * a mixed additions of looked-up points: no sorting, no buckets.  Two layouts, same results as the bucket method
+ * (curve.py:38-111), bit for bit:
+ *   comb tables (default; csrc/msm_comb.h)   h teeth spaced a = ceil(254 / h) bits apart: 2^(h-1) entries per base, a additions
+ *       per base and a - 1 doublings per MSM (shared by its bases).  2^11 points: 68.7 GB at h = 20 (13 additions per base),
+ *       8.6 GB at h = 17 (15), 67 MB at h = 10 (26).
+ *   window tables (mode | 16; rounds 2 - 5)  every multiple d * 2^(c w) * P_i, d <= 2^(c-1): ceil(255 / c) windows of 2^(c-1)
+ *       entries per base and as many additions, no doublings.  128.8 GB at c = 17 (15 additions), 10.7 GB at c = 13 (20).
+ * mode 0 (default): automatic — the table with the fewest additions per base that, with its build staging, fits `budget_bytes`;
+ * budget 0 = the library default of 1/16 of the device's memory (18 GB on an MI355X: h = 17 for 2^11 points), or
  * PLONK_MSM_TABLE_GB gigabytes if that variable is set: the big tables are a memory-for-time trade the caller opts into
- * explicitly.  Bucket method when nothing fits or for
- * plonk_srs_load_affine bases; mode 1: never; mode 2: use `window_bits` for every base set (tests).  Same results
- * as the bucket method (curve.py:38-111), bit for bit.                                                          */
-int plonk_msm_lookup_configure(plonk_ctx* ctx, int mode, unsigned window_bits, size_t budget_bytes);
-/* window bits of the lookup table currently attached to `srs` (0 = none: its MSMs use the bucket method) */
+ * explicitly.  Bucket method when nothing fits or for plonk_srs_load_affine bases; mode 1: never; mode 2: use `bits`
+ * (h, or c with | 16) for every base set (tests).                                                                      */
+int plonk_msm_lookup_configure(plonk_ctx* ctx, int mode, unsigned bits, size_t budget_bytes);
+/* bits (teeth h / window bits c) of the table currently attached to `srs` (0 = none: its MSMs use the bucket method) */
 int plonk_srs_lookup_bits(const plonk_srs* srs, unsigned* out_bits);
 /* the same plus the table's size in bytes, the wall time its build took, and how many plonk_srs objects of this
- * process share it: there is ONE table per (device, base set, window bits) whatever the number of contexts /
+ * process share it: there is ONE table per (device, base set, layout, bits) whatever the number of contexts /
  * streams / provers using that SRS on the device; it is freed with the last plonk_srs that references it.      */
 int plonk_srs_lookup_info(const plonk_srs* srs, unsigned* out_bits, size_t* out_bytes, double* out_build_s,
                           int* out_sharers);
+/* its layout: kind 1 = comb, 2 = windows (0 = no table), and the mixed additions an MSM performs per base on it */
+int plonk_srs_lookup_layout(const plonk_srs* srs, unsigned* out_kind, unsigned* out_additions_per_base);
 
 /* ---- batched GPU-resident prover ---------------------------------------------------------------------
  * Replaces Prover.__init__ / Prover.prove / round_1..round_5 (prover.py:45-306) for `batch`

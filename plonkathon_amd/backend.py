@@ -99,9 +99,10 @@ class Context:
         """Bucket-method tuning knobs (0 = library default)."""
         check(self.L.plonk_msm_configure(self.handle, window_bits, groups))
 
-    def msm_lookup(self, mode=0, window_bits=0, budget_bytes=0):
-        """Lookup-MSM policy (include/plonk_hip.h): mode 0 auto, 1 off, 2 force `window_bits` for every base set."""
-        check(self.L.plonk_msm_lookup_configure(self.handle, mode, window_bits, budget_bytes))
+    def msm_lookup(self, mode=0, bits=0, budget_bytes=0, windows=False):
+        """Table-MSM policy (include/plonk_hip.h): mode 0 auto, 1 off, 2 force `bits` for every base set; comb tables (bits =
+        teeth) unless `windows` (bits = window bits: the layout of rounds 2 - 5, kept for comparison)."""
+        check(self.L.plonk_msm_lookup_configure(self.handle, mode | (16 if windows else 0), bits, budget_bytes))
 
     def profile(self, on):
         check(self.L.plonk_profile_enable(self.handle, 1 if on else 0))

@@ -668,15 +668,23 @@ int plonk_srs_lookup_info(const plonk_srs* srs, unsigned* out_bits, size_t* out_
     return msm_lookup_info(srs, out_bits, out_bytes, out_build_s, out_sharers);
 }
 
-int plonk_msm_lookup_configure(plonk_ctx* ctx, int mode, unsigned window_bits, size_t budget_bytes) {
+int plonk_srs_lookup_layout(const plonk_srs* srs, unsigned* out_kind, unsigned* out_additions_per_base) {
+    PLONK_REQUIRE(srs && out_kind && out_additions_per_base, PLONK_ERR_ARG, "bad argument");
+    return msm_lookup_layout(srs, out_kind, out_additions_per_base);
+}
+
+int plonk_msm_lookup_configure(plonk_ctx* ctx, int mode, unsigned bits, size_t budget_bytes) {
     PLONK_REQUIRE(ctx, PLONK_ERR_ARG, "ctx is NULL");
     PLONK_ENTER(ctx);
-    PLONK_REQUIRE(mode >= 0 && mode <= 2, PLONK_ERR_ARG, "mode must be 0 (auto), 1 (off) or 2 (force)");
-    PLONK_REQUIRE(window_bits == 0 || (window_bits >= 2 && window_bits <= 17), PLONK_ERR_ARG,
-                  "window_bits must be 0 (auto) or in [2, 17]");
-    PLONK_REQUIRE(mode != 2 || window_bits, PLONK_ERR_ARG, "mode 2 needs an explicit window_bits");
+    const bool windows = (mode & 16) != 0;
+    mode &= ~16;
+    PLONK_REQUIRE(mode >= 0 && mode <= 2, PLONK_ERR_ARG, "mode must be 0 (auto), 1 (off) or 2 (force), optionally + 16 (window tables)");
+    const unsigned max_bits = windows ? 17u : 24u;
+    PLONK_REQUIRE(bits == 0 || (bits >= 2 && bits <= max_bits), PLONK_ERR_ARG, "bits must be 0 (auto) or in [2, %u]", max_bits);
+    PLONK_REQUIRE(mode != 2 || bits, PLONK_ERR_ARG, "mode 2 needs an explicit number of bits");
     ctx->msm_lookup_mode = mode;
-    ctx->msm_lookup_bits = window_bits;
+    ctx->msm_lookup_kind = windows ? MSM_TABLE_WINDOWS : MSM_TABLE_COMB;
+    ctx->msm_lookup_bits = bits;
     ctx->msm_lookup_budget = budget_bytes;
     return PLONK_OK;
 }

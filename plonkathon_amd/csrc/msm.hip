@@ -44,6 +44,7 @@
 #include <string.h>
 
 #include <chrono>
+#include <utility>
 
 #include "plonk_internal.h"
 #include "wave.h"
@@ -628,8 +629,11 @@ __global__ void __launch_bounds__(256) msm_slow_kernel(int kind, const G1Affine*
     }
 }
 
+#define LUT_VERIFY_SAMPLES 8
+#include "msm_comb.h"
+
 // ------------------------------------------------------------------------------------------------
-// Registry of lookup tables: one per (process, device, base set, window bits), shared by every plonk_srs that
+// Registry of lookup tables: one per (process, device, base set, layout, bits), shared by every plonk_srs that
 // was loaded from the same bytes — several contexts / streams / BatchProvers of one GPU use ONE table.
 #include <algorithm>
 #include <mutex>
@@ -648,6 +652,7 @@ static void lut_attach(plonk_srs* srs, MsmLookupTable* t) {  // g_lut_mu held
     srs->lookup = t ? t->data : nullptr;
     srs->lookup_bits = t ? t->bits : 0;
     srs->lookup_windows = t ? t->windows : 0;
+    srs->lookup_kind = t ? t->kind : 0;
     if (t) t->refs++;
 }
 
@@ -661,7 +666,6 @@ static void lut_attach(plonk_srs* srs, MsmLookupTable* t) {  // g_lut_mu held
 //   3. the registered n_points / bits / windows match what this call would build.
 // Every other entry is a function of (bases, number of bases, window bits) alone, computed by this library when the table
 // was registered.
-#define LUT_VERIFY_SAMPLES 8
 __global__ void lut_verify_kernel(const G1Affine* bases, const G1Affine* lookup, size_t n, unsigned c, unsigned* mismatches) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -693,28 +697,41 @@ __global__ void __launch_bounds__(64) lut_verify_windows_kernel(const G1Affine* 
     if (!ok) atomicAdd(mismatches, 1u);
 }
 static unsigned windows_for(unsigned c);
+static size_t msm_comb_stage_entries(size_t n, unsigned h);
 static MsmLookupTable* lut_verified(plonk_ctx* ctx, const plonk_srs* srs, MsmLookupTable* t) {  // g_lut_mu held
     if (!t) return nullptr;
-    if (t->n_points != srs->n_points || t->windows != windows_for(t->bits) ||
-        t->bytes != t->n_points * t->windows * ((size_t)1 << (t->bits - 1)) * sizeof(G1Affine))
+    if (t->n_points != srs->n_points) return nullptr;
+    if (t->kind == MSM_TABLE_COMB) {
+        if (t->bits < 2 || t->bits > MSM_COMB_MAX_TEETH || t->windows != msm_comb_columns(t->bits) ||
+            t->bytes != (t->n_points << (t->bits - 1)) * sizeof(G1Affine))
+            return nullptr;
+    } else if (t->windows != windows_for(t->bits) || t->bytes != t->n_points * t->windows * ((size_t)1 << (t->bits - 1)) * sizeof(G1Affine)) {
         return nullptr;
+    }
     void* flag;
     if (ctx_scratch(ctx, 3, 64, &flag) != PLONK_OK) return nullptr;
     unsigned bad = 1;
     if (hipMemsetAsync(flag, 0, 4, ctx->stream) != hipSuccess) return nullptr;
-    PLONK_LAUNCH(lut_verify_kernel, dim3((unsigned)((srs->n_points + 255) / 256)), dim3(256), 0, ctx->stream, (const G1Affine*)srs->bases,
-                 (const G1Affine*)t->data, srs->n_points, t->bits, (unsigned*)flag);
-    PLONK_LAUNCH(lut_verify_windows_kernel, dim3((LUT_VERIFY_SAMPLES * t->windows + 63) / 64), dim3(64), 0, ctx->stream,
-                 (const G1Affine*)srs->bases, (const G1Affine*)t->data, srs->n_points, t->bits, t->windows, (unsigned*)flag);
+    if (t->kind == MSM_TABLE_COMB) {
+        const size_t lanes = srs->n_points + 2 * LUT_VERIFY_SAMPLES;
+        PLONK_LAUNCH(msm_comb_verify_kernel, dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0, ctx->stream, (const G1Affine*)srs->bases,
+                     (const G1Affine*)t->data, srs->n_points, t->windows, t->bits, (unsigned)LUT_VERIFY_SAMPLES, (unsigned*)flag);
+    } else {
+        PLONK_LAUNCH(lut_verify_kernel, dim3((unsigned)((srs->n_points + 255) / 256)), dim3(256), 0, ctx->stream, (const G1Affine*)srs->bases,
+                     (const G1Affine*)t->data, srs->n_points, t->bits, (unsigned*)flag);
+        PLONK_LAUNCH(lut_verify_windows_kernel, dim3((LUT_VERIFY_SAMPLES * t->windows + 63) / 64), dim3(64), 0, ctx->stream,
+                     (const G1Affine*)srs->bases, (const G1Affine*)t->data, srs->n_points, t->bits, t->windows, (unsigned*)flag);
+    }
     if (hipMemcpyAsync(&bad, flag, 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) return nullptr;
     return bad ? nullptr : t;
 }
 // the registered table of this base set with `bits` window bits (0: the one with the most) that passes the comparison above;
 // several tables may sit under one key (a collision, or several window sizes): every candidate is tried, widest first
-static MsmLookupTable* lut_find_verified(plonk_ctx* ctx, const plonk_srs* srs, unsigned bits) {  // g_lut_mu held
+static MsmLookupTable* lut_find_verified(plonk_ctx* ctx, const plonk_srs* srs, unsigned kind, unsigned bits) {  // g_lut_mu held
     std::vector<MsmLookupTable*> cand;
     for (MsmLookupTable* t : g_luts)
-        if (t->device == srs->device && t->key == srs->content_key && t->n_points == srs->n_points && (!bits || t->bits == bits)) cand.push_back(t);
+        if (t->device == srs->device && t->key == srs->content_key && t->n_points == srs->n_points && t->kind == kind && (!bits || t->bits == bits))
+            cand.push_back(t);
     std::sort(cand.begin(), cand.end(), [](const MsmLookupTable* a, const MsmLookupTable* b) { return a->bits > b->bits; });
     for (MsmLookupTable* t : cand)
         if (lut_verified(ctx, srs, t)) return t;
@@ -743,6 +760,14 @@ int msm_lookup_info(const plonk_srs* srs, unsigned* bits, size_t* bytes, double*
     *bytes = t ? t->bytes : 0;
     *build_s = t ? t->build_s : 0;
     *sharers = t ? t->refs : 0;
+    return PLONK_OK;
+}
+
+int msm_lookup_layout(const plonk_srs* srs, unsigned* kind, unsigned* additions_per_base) {
+    std::lock_guard<std::mutex> lk(g_lut_mu);
+    const MsmLookupTable* t = srs->shared;
+    *kind = t ? t->kind : 0;
+    *additions_per_base = t ? t->windows : 0;
     return PLONK_OK;
 }
 
@@ -841,6 +866,7 @@ static int msm_lookup_build(plonk_ctx* ctx, plonk_srs* srs, unsigned c) {  // g_
     t->device = srs->device;
     t->key = srs->content_key;
     t->n_points = n;
+    t->kind = MSM_TABLE_WINDOWS;
     t->bits = c;
     t->windows = W;
     t->data = (G1Affine*)tab;
@@ -851,11 +877,83 @@ static int msm_lookup_build(plonk_ctx* ctx, plonk_srs* srs, unsigned c) {  // g_
     return PLONK_OK;
 }
 
+// ---- comb tables (msm_comb.h) -------------------------------------------------------------------
+// XYZZ staging of the build: an eighth of the table's entries at a time (whole bases), at most 2^27 of them (17 GB)
+static size_t msm_comb_stage_entries(size_t n, unsigned h) {
+    const size_t half = (size_t)1 << (h - 1);
+    size_t bases = n / 8 ? n / 8 : 1;
+    while (bases > 1 && bases * half > ((size_t)1 << 27)) bases /= 2;
+    return bases * half;
+}
+static size_t msm_comb_bytes(size_t n, unsigned h) {  // table + staging
+    return (n << (h - 1)) * sizeof(G1Affine) + msm_comb_stage_entries(n, h) * sizeof(G1Xyzz);
+}
+
+// Builds the comb table of h teeth.  PLONK_ERR_NOMEM (nothing allocated, nothing changed) if it does not fit.
+static int msm_comb_build(plonk_ctx* ctx, plonk_srs* srs, unsigned h) {  // g_lut_mu held
+    const auto t0 = std::chrono::steady_clock::now();
+    const unsigned a = msm_comb_columns(h), sb = h - 1 < MSM_COMB_SEG_BITS ? h - 1 : MSM_COMB_SEG_BITS;
+    const size_t n = srs->n_points, half = (size_t)1 << (h - 1), stage = msm_comb_stage_entries(n, h), chunk_bases = stage / half;
+    void *gx = nullptr, *gb = nullptr, *dx = nullptr, *db = nullptr, *tmp = nullptr, *tab = nullptr;
+    auto fail = [&]() {
+        for (void* q : {gx, gb, dx, db, tmp, tab})
+            if (q) hipFree(q);
+        (void)hipGetLastError();
+        plonk_set_error("the %u-tooth comb table (%zu MiB) does not fit in device memory", h, msm_comb_bytes(n, h) >> 20);
+        return PLONK_ERR_NOMEM;
+    };
+    if (!plonk_dev_malloc(&tab, n * half * sizeof(G1Affine))) return fail();
+    if (!plonk_dev_malloc(&tmp, stage * sizeof(G1Xyzz))) return fail();
+    if (!plonk_dev_malloc(&gx, n * h * sizeof(G1Xyzz))) return fail();
+    if (!plonk_dev_malloc(&gb, n * h * sizeof(G1Affine))) return fail();
+    if (!plonk_dev_malloc(&dx, n * (sb ? sb : 1) * sizeof(G1Xyzz))) return fail();
+    if (!plonk_dev_malloc(&db, n * (sb ? sb : 1) * sizeof(G1Affine))) return fail();
+    // tooth points G_k = 2^(a k) P_i (k < h) and the Gray-code steps 2 G_k (k < sb), affine
+    unsigned grid = (unsigned)((n + 63) / 64);
+    if (grid > 2048) grid = 2048;
+    PLONK_LAUNCH(msm_table_kernel, dim3(grid), dim3(64), 0, ctx->stream, srs->bases, n, a, h, (G1Xyzz*)gx);
+    g1_batch_to_affine(ctx, (const G1Xyzz*)gx, (G1Affine*)gb, n * h);
+    if (sb) {
+        unsigned gd = (unsigned)((n * sb + 255) / 256);
+        PLONK_LAUNCH(msm_comb_delta_kernel, dim3(gd > 4096 ? 4096 : gd), dim3(256), 0, ctx->stream, (const G1Affine*)gb, n * sb, (G1Xyzz*)dx);
+        g1_batch_to_affine(ctx, (const G1Xyzz*)dx, (G1Affine*)db, n * sb);
+    }
+    for (size_t i0 = 0; i0 < n; i0 += chunk_bases) {
+        const size_t nb = n - i0 < chunk_bases ? n - i0 : chunk_bases, lanes = nb << (h - 1 - sb);
+        unsigned gf = (unsigned)((lanes + 63) / 64 > 65536 ? 65536 : (lanes + 63) / 64);
+        PLONK_LAUNCH(msm_comb_fill_kernel, dim3(gf), dim3(64), 0, ctx->stream, (const G1Affine*)gb, (const G1Affine*)db, n, i0, nb, h, sb,
+                     (G1Xyzz*)tmp);
+        g1_batch_to_affine(ctx, (const G1Xyzz*)tmp, (G1Affine*)tab + i0 * half, nb * half);
+    }
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) return fail();
+    for (void* q : {gx, gb, dx, db, tmp}) hipFree(q);
+    MsmLookupTable* t = new MsmLookupTable();
+    t->device = srs->device;
+    t->key = srs->content_key;
+    t->n_points = n;
+    t->kind = MSM_TABLE_COMB;
+    t->bits = h;
+    t->windows = a;
+    t->data = (G1Affine*)tab;
+    t->bytes = n * half * sizeof(G1Affine);
+    t->build_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    g_luts.push_back(t);
+    lut_attach(srs, t);
+    return PLONK_OK;
+}
+
+static size_t msm_table_bytes(size_t n, unsigned kind, unsigned bits) {
+    return kind == MSM_TABLE_COMB ? msm_comb_bytes(n, bits) : msm_lookup_bytes(n, bits);
+}
+static int msm_table_build(plonk_ctx* ctx, plonk_srs* srs, unsigned kind, unsigned bits) {
+    return kind == MSM_TABLE_COMB ? msm_comb_build(ctx, srs, bits) : msm_lookup_build(ctx, srs, bits);
+}
+
 static size_t msm_default_lookup_budget() {
     // The table is a memory-for-time trade the CALLER opts into beyond a modest default: 1/16 of the device's memory (18 GB of an
-    // MI355X's 288: c = 13 for 2^11 bases, 10.7 GB + 1.1 GB while it is built; round 4's fixed 4 GiB — c = 11 — was a figure for
-    // 16 GB cards), more only through plonk_msm_lookup_configure(budget) or PLONK_MSM_TABLE_GB (bench.py asks for the 129 GB
-    // c = 17 table).  Measured (profiles/r05_d_msm_sweep.jsonl, 1152 MSMs of 2^11 per call): c = 11 4.50 ms, 12 4.11, 13 3.86, 14 3.65.
+    // MI355X's 288: the comb of 17 teeth for 2^11 bases, 8.6 GB + 1.1 GB while it is built, 15 additions per base), more only
+    // through plonk_msm_lookup_configure(budget) or PLONK_MSM_TABLE_GB (bench.py asks for the 68.7 GB comb of 20 teeth: 13 additions).
+    // Window tables, measured (profiles/r05_d_msm_sweep.jsonl, 1152 MSMs of 2^11 per call): c = 11 4.50 ms, 12 4.11, 13 3.86, 14 3.65.
     const char* e = getenv("PLONK_MSM_TABLE_GB");
     if (e && atof(e) > 0) return (size_t)(atof(e) * 1e9);
     size_t free_b = 0, total_b = 0;
@@ -870,20 +968,20 @@ static size_t msm_default_lookup_budget() {
 // built for the same bases, or builds one on first use.
 static bool msm_lookup_prepare(plonk_ctx* ctx, plonk_srs* srs) {
     if (ctx->msm_lookup_mode == 1) return false;
-    const unsigned want = ctx->msm_lookup_bits;
+    const unsigned want = ctx->msm_lookup_bits, kind = ctx->msm_lookup_kind;
     std::lock_guard<std::mutex> lk(g_lut_mu);
-    if (ctx->msm_lookup_mode == 2) {  // forced window size, any base set
-        if (srs->shared && srs->lookup_bits == want) return true;
-        if (MsmLookupTable* t = lut_find_verified(ctx, srs, want)) {
+    if (ctx->msm_lookup_mode == 2) {  // forced size, any base set
+        if (srs->shared && srs->lookup_kind == kind && srs->lookup_bits == want) return true;
+        if (MsmLookupTable* t = lut_find_verified(ctx, srs, kind, want)) {
             lut_attach(srs, t);
             return true;
         }
-        return msm_lookup_build(ctx, srs, want) == PLONK_OK;
+        return msm_table_build(ctx, srs, kind, want) == PLONK_OK;
     }
     if (!srs->fixed) return false;
-    if (srs->shared && (!want || want == srs->lookup_bits)) return true;
+    if (srs->shared && srs->lookup_kind == kind && (!want || want == srs->lookup_bits)) return true;
     if (want) {
-        if (MsmLookupTable* t = lut_find_verified(ctx, srs, want)) {
+        if (MsmLookupTable* t = lut_find_verified(ctx, srs, kind, want)) {
             lut_attach(srs, t);
             return true;
         }
@@ -891,17 +989,20 @@ static bool msm_lookup_prepare(plonk_ctx* ctx, plonk_srs* srs) {
     if (srs->lookup_failed) return false;
     const size_t budget = ctx->msm_lookup_budget ? ctx->msm_lookup_budget : msm_default_lookup_budget();
     // A table another context of this device already built for these bases is taken as it is — unless this context's
-    // budget affords a bigger one (more window bits = fewer additions), which is then built and shared in its turn.
-    MsmLookupTable* have = want ? nullptr : lut_find_verified(ctx, srs, 0);
+    // budget affords a bigger one (more bits = fewer additions), which is then built and shared in its turn.
+    MsmLookupTable* have = want ? nullptr : lut_find_verified(ctx, srs, kind, 0);
     // The automatic choice charges the tables of the same SRS family (an SRS and its Lagrange-basis views) against one
-    // budget.  An explicit window size (`want`) is an explicit request and only has to fit the budget by itself.
+    // budget.  An explicit size (`want`) is an explicit request and only has to fit the budget by itself.
     const size_t used = want ? 0 : lut_bytes_of_family(srs);
     // below 8 bits the table no longer beats the bucket method — which, however, cannot index more than 2^15 bases, so
     // larger base sets accept any table that fits
     const unsigned c_min = want ? want : (srs->n_points > 32768 ? 4 : 8);
-    for (unsigned c = want ? want : 17; c >= c_min && (!have || c > have->bits); c--) {
-        if (msm_lookup_bytes(srs->n_points, c) + used > budget) continue;
-        if (msm_lookup_build(ctx, srs, c) == PLONK_OK) return true;
+    const unsigned c_max = kind == MSM_TABLE_COMB ? 22 : 17;
+    for (unsigned c = want ? want : c_max; c >= c_min && (!have || c > have->bits); c--) {
+        // a comb one tooth shorter with as many columns costs the same additions for half the memory
+        if (!want && kind == MSM_TABLE_COMB && c > c_min && msm_comb_columns(c - 1) == msm_comb_columns(c) && (!have || c - 1 > have->bits)) continue;
+        if (msm_table_bytes(srs->n_points, kind, c) + used > budget) continue;
+        if (msm_table_build(ctx, srs, kind, c) == PLONK_OK) return true;
     }
     if (have) {
         lut_attach(srs, have);
@@ -941,8 +1042,81 @@ static unsigned msm_round_aware_groups(int device, size_t M, unsigned g0, unsign
     return cost(2 * g0) < 0.97 * cost(g0) ? 2 * g0 : g0;
 }
 
+// digits kernel of the comb with h teeth (one instantiation per tooth count: the bit gather is unrolled at compile time)
+template <unsigned H> static void msm_comb_launch_digits(plonk_ctx* ctx, const Fr* d_scalars, size_t n, size_t stride, size_t inner, size_t outer_stride,
+                                                         size_t M, uint32_t* digits) {
+    PLONK_LAUNCH(msm_comb_digits_kernel<H>, dim3((unsigned)((M * n + 255) / 256)), dim3(256), 0, ctx->stream, d_scalars, n, stride, inner, outer_stride,
+                 M, digits);
+}
+typedef void (*msm_comb_digits_fn)(plonk_ctx*, const Fr*, size_t, size_t, size_t, size_t, size_t, uint32_t*);
+template <unsigned... H> static msm_comb_digits_fn msm_comb_digits_for(unsigned h, std::integer_sequence<unsigned, H...>) {
+    msm_comb_digits_fn fn = nullptr;
+    ((h == H + 2 ? (void)(fn = &msm_comb_launch_digits<H + 2>) : (void)0), ...);
+    return fn;
+}
+
+static int msm_run_comb(plonk_ctx* ctx, plonk_srs* srs, const Fr* d_scalars, size_t n, size_t M, size_t stride, Fq* d_out_xy, uint8_t* d_flags,
+                        size_t inner, size_t outer_stride) {
+    const unsigned h = srs->lookup_bits, a = srs->lookup_windows, hb = h - 1;
+    PLONK_REQUIRE((uint64_t)n * a < ((uint64_t)1 << 32), PLONK_ERR_ARG, "MSM size %zu too large for the lookup path", n);
+    unsigned G = ctx->msm_groups;
+    if (!G) {  // enough waves to occupy 1024 SIMDs three to four deep, in as few workgroups per MSM as that takes
+        G = 1;
+        while (G < 64 && M * G * (MSM_BLOCK / 64) < 3072) G *= 2;
+    }
+    if (!ctx->msm_groups) G = msm_round_aware_groups(ctx->device, M, G, 64, 0.035);
+    while (G > 1 && (size_t)G * MSM_BLOCK * 2 > n * a) G /= 2;  // at least two additions per lane
+    while (G > 1 && (size_t)G > n) G /= 2;
+    const size_t part_bytes = (M * G * a * sizeof(G1Xyzz) + 255) & ~(size_t)255;
+    const size_t col_bytes = G >= 4 ? (M * a * sizeof(G1Xyzz) + 255) & ~(size_t)255 : 0;
+    const size_t cnt_bytes = (M * 4 + 255) & ~(size_t)255;
+    const size_t dfr_bytes = M * MSM_DEFER_CAP * sizeof(MsmDeferred);
+    const size_t dig_bytes = (M * a * n * 4 + 255) & ~(size_t)255;
+    void* s;
+    PLONK_TRY(ctx_scratch(ctx, 1, part_bytes + col_bytes + cnt_bytes + dfr_bytes + dig_bytes, &s));
+    G1Xyzz* partial = (G1Xyzz*)s;
+    G1Xyzz* colsum = (G1Xyzz*)((uint8_t*)s + part_bytes);
+    uint32_t* n_deferred = (uint32_t*)((uint8_t*)s + part_bytes + col_bytes);
+    MsmDeferred* deferred = (MsmDeferred*)((uint8_t*)s + part_bytes + col_bytes + cnt_bytes);
+    uint32_t* digits = (uint32_t*)((uint8_t*)s + part_bytes + col_bytes + cnt_bytes + dfr_bytes);
+    const msm_comb_digits_fn digits_fn = msm_comb_digits_for(h, std::make_integer_sequence<unsigned, MSM_COMB_MAX_TEETH - 1>());
+    PLONK_REQUIRE(digits_fn, PLONK_ERR_ARG, "no comb of %u teeth", h);
+    PLONK_CHECK_HIP(hipMemsetAsync(n_deferred, 0, M * 4, ctx->stream));
+    PLONK_TRY(prof_begin(ctx, "msm_digits", (double)M * (double)n * (32.0 + 4.0 * a)));
+    digits_fn(ctx, d_scalars, n, stride, inner, outer_stride, M, digits);
+    PLONK_TRY(prof_end(ctx));
+    const size_t lds = (size_t)(MSM_BLOCK + a) * sizeof(G1Xyzz);
+    PLONK_TRY(prof_begin(ctx, "msm_comb", (double)M * (96.0 * (double)n + 64.0)));
+    PLONK_LAUNCH(msm_comb_kernel, dim3((unsigned)(M * G)), dim3(MSM_BLOCK), lds, ctx->stream, (const G1Affine*)srs->lookup, hb, a,
+                 (const uint32_t*)digits, n, G, partial, deferred, (size_t)MSM_DEFER_CAP, n_deferred);
+    PLONK_TRY(prof_end(ctx));
+    const G1Xyzz* sums = partial;
+    unsigned Gf = G;
+    if (G >= 4) {  // few MSMs in many pieces: a wave per (MSM, column) sums the pieces in parallel
+        PLONK_LAUNCH(msm_comb_colsum_kernel, dim3((unsigned)(M * a)), dim3(64), 0, ctx->stream, (const G1Xyzz*)partial, G, a, colsum);
+        sums = colsum;
+        Gf = 1;
+    }
+    // lanes per MSM in the Horner step: one for a batch (least work), sixteen when the MSMs are few (shortest chain)
+    static const unsigned forced_lpm = [] { const char* e = getenv("PLONK_MSM_COMB_LPM"); return e ? (unsigned)atoi(e) : 0u; }();
+    const unsigned lpm = forced_lpm ? forced_lpm : (M >= 1024 ? 1u : M >= 64 ? 4u : 16u);
+#define PLONK_COMB_FINALIZE(L)                                                                                                                  \
+    PLONK_LAUNCH(msm_comb_finalize_kernel<L>, dim3((unsigned)((M * L + 63) / 64)), dim3(64), 0, ctx->stream, sums, M, Gf, a,                      \
+                 (const G1Affine*)srs->lookup, hb, n, (const MsmDeferred*)deferred, (size_t)MSM_DEFER_CAP, (const uint32_t*)n_deferred, d_out_xy, \
+                 d_flags)
+    if (lpm >= 16) PLONK_COMB_FINALIZE(16);
+    else if (lpm >= 4) PLONK_COMB_FINALIZE(4);
+    else PLONK_COMB_FINALIZE(1);
+#undef PLONK_COMB_FINALIZE
+    PLONK_LAUNCH(msm_comb_slow_kernel, dim3((unsigned)M), dim3(256), 0, ctx->stream, (const G1Affine*)srs->lookup, hb, a, (const uint32_t*)digits, n,
+                 (const uint32_t*)n_deferred, d_out_xy, d_flags);
+    PLONK_CHECK_HIP(hipGetLastError());
+    return PLONK_OK;
+}
+
 static int msm_run_lookup(plonk_ctx* ctx, plonk_srs* srs, const Fr* d_scalars, size_t n, size_t M, size_t stride, Fq* d_out_xy,
                           uint8_t* d_flags, size_t inner, size_t outer_stride) {
+    if (srs->lookup_kind == MSM_TABLE_COMB) return msm_run_comb(ctx, srs, d_scalars, n, M, stride, d_out_xy, d_flags, inner, outer_stride);
     const unsigned c = srs->lookup_bits, W = srs->lookup_windows;
     const size_t items = n * W;
     PLONK_REQUIRE(items < ((size_t)1 << 32), PLONK_ERR_ARG, "MSM size %zu too large for the lookup path", n);

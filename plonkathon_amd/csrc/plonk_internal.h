@@ -81,12 +81,15 @@ struct NttTables {
     WaveTables wave;                 // the wave NTT kernels' tables for BN254 Fr (ntt_wave_host.h)
 };
 
+#define MSM_TABLE_COMB 1
+#define MSM_TABLE_WINDOWS 2
 // One lookup table per (process, device, base set), shared by every plonk_srs / context / stream that
 // loads the same bases (msm.hip keeps the registry; reference counted, freed with its last plonk_srs).
 struct MsmLookupTable {
     int device = 0;
     uint64_t key = 0;        // FNV-1a of the host bytes the bases were loaded from
     size_t n_points = 0;
+    unsigned kind = 0;       // MSM_TABLE_COMB (msm_comb.h: bits = teeth h, windows = columns a) or MSM_TABLE_WINDOWS (bits = c, windows = W)
     unsigned bits = 0, windows = 0;
     G1Affine* data = nullptr;
     size_t bytes = 0;
@@ -104,10 +107,11 @@ struct plonk_srs {
     G1Affine* table = nullptr;  // device: table[w * n_points + i] = 2^(c*w) * bases[i]
     // lookup MSM (msm.hip): every multiple d * 2^(c*w) * bases[i], d = 1 .. 2^(c-1), resident in HBM
     bool fixed = false;          // a reusable SRS (plonk_srs_load_ptau): worth a big table
-    unsigned lookup_bits = 0;    // c of the lookup table (0 = none)
-    unsigned lookup_windows = 0;
+    unsigned lookup_bits = 0;    // teeth h of the comb table / window bits c of the window table (0 = none)
+    unsigned lookup_windows = 0; // additions per base: columns a of the comb / windows W
+    unsigned lookup_kind = 0;    // MSM_TABLE_COMB / MSM_TABLE_WINDOWS (0 = none)
     bool lookup_failed = false;  // an automatic build did not fit: do not retry on every call
-    G1Affine* lookup = nullptr;  // lookup[((w * n_points + i) << (c - 1)) + d - 1]   (= shared->data)
+    G1Affine* lookup = nullptr;  // comb: lookup[(i << (h - 1)) + idx]; windows: lookup[((w * n_points + i) << (c - 1)) + d - 1]   (= shared->data)
     MsmLookupTable* shared = nullptr;
     // Lagrange-basis SRS (setup.py:66-72 without the ifft): lagrange[log_n] = [L_i(tau)]_1, i < 2^log_n, built on
     // demand by an EC inverse NTT of the first 2^log_n bases (msm.hip); each is a plonk_srs of its own.
@@ -129,7 +133,8 @@ struct plonk_ctx {
     Fr host_tmp[16];                 // small host-side staging that must outlive an asynchronous copy (every user synchronises before returning)
     unsigned msm_window_bits = 0, msm_groups = 0;
     int msm_lookup_mode = 0;         // 0 auto (fixed SRS only), 1 off, 2 force msm_lookup_bits for every base set
-    unsigned msm_lookup_bits = 0;    // 0 = largest window whose table fits the budget
+    unsigned msm_lookup_bits = 0;    // 0 = the table with the fewest additions per base that fits the budget
+    unsigned msm_lookup_kind = MSM_TABLE_COMB;  // layout of the tables this context builds (plonk_msm_lookup_configure: mode | 16 = window tables)
     size_t msm_lookup_budget = 0;    // bytes; 0 = default (PLONK_MSM_TABLE_GB if set, else 4 GiB)
     bool ntt_attr_set = false, msm_attr_set = false;  // hipFuncSetAttribute is per device: tracked per context
     // per-kernel HIP-event profiling (bench.py roofline): one record per instrumented launch
@@ -194,6 +199,7 @@ void g1_batch_to_affine(plonk_ctx*, const G1Xyzz* in, G1Affine* out, size_t n); 
 int g1_lagrange_by_ntt(plonk_ctx*, const plonk_srs*, unsigned log_n, G1Affine* d_bases_out);
 void msm_srs_release(plonk_srs*);  // drops the reference on the shared lookup table
 int msm_lookup_info(const plonk_srs*, unsigned* bits, size_t* bytes, double* build_s, int* sharers);
+int msm_lookup_layout(const plonk_srs*, unsigned* kind, unsigned* additions_per_base);
 uint64_t plonk_fnv1a64(const void* data, size_t n);
 // MSM m reads its scalars at d_scalars + (m % inner) * stride + (m / inner) * outer_stride (inner = 0: inner = M)
 int msm_run_device(plonk_ctx*, plonk_srs*, const Fr* d_scalars, size_t n, size_t M, size_t stride, Fq* d_out_xy,

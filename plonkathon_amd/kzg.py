@@ -91,18 +91,22 @@ class _DeviceBases:
 
     @property
     def lookup_bits(self):
-        """Window bits of the lookup table its MSMs run on (0: bucket method); built at the first MSM."""
+        """Bits of the table its MSMs run on — teeth of the comb, or window bits of a window table (0: bucket method); built at
+        the first MSM."""
         out = ctypes.c_uint(0)
         check(self.ctx.L.plonk_srs_lookup_bits(self.handle, ctypes.byref(out)))
         return out.value
 
     def lookup_info(self):
-        """{bits, bytes, build_s, sharers} of the lookup table attached to these bases (one table per device and
-        base set, shared by every context / stream / prover that loaded the same SRS)."""
+        """{bits, bytes, build_s, sharers, layout, additions_per_base} of the table attached to these bases (one table per device,
+        base set and layout, shared by every context / stream / prover that loaded the same SRS)."""
         bits, nbytes, secs, sharers = ctypes.c_uint(0), ctypes.c_size_t(0), ctypes.c_double(0), ctypes.c_int(0)
         check(self.ctx.L.plonk_srs_lookup_info(self.handle, ctypes.byref(bits), ctypes.byref(nbytes), ctypes.byref(secs),
                                                ctypes.byref(sharers)))
-        return {"bits": bits.value, "bytes": nbytes.value, "build_s": secs.value, "sharers": sharers.value}
+        kind, adds = ctypes.c_uint(0), ctypes.c_uint(0)
+        check(self.ctx.L.plonk_srs_lookup_layout(self.handle, ctypes.byref(kind), ctypes.byref(adds)))
+        return {"bits": bits.value, "bytes": nbytes.value, "build_s": secs.value, "sharers": sharers.value,
+                "layout": {0: None, 1: "comb", 2: "windows"}[kind.value], "additions_per_base": adds.value}
 
     def __del__(self):
         try:

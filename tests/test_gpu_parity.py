@@ -154,19 +154,22 @@ def test_msm_window_configs(setup):
 
 
 def test_msm_lookup_tables():
-    """Lookup MSM at several table sizes (forced), then the automatic choice (the library's default budget, 1/16 of the device's
-    memory: c = 13 for the 2^11 bases on an MI355X)."""
+    """Table MSM at several table sizes (forced; comb tables, then the window tables of rounds 2 - 5), then the automatic choice
+    (the library's default budget, 1/16 of the device's memory: the comb of 17 teeth for the 2^11 bases on an MI355X)."""
     from plonkathon_amd import Setup, get_context
 
     ctx = get_context()
     try:
-        for c, groups in ((6, 0), (11, 3), (14, 1)):
-            ctx.msm_lookup(2, c)
+        for c, groups, windows in ((6, 0, False), (11, 3, False), (14, 1, False), (17, 0, False), (17, 2, False), (6, 0, True), (11, 3, True), (14, 1, True)):
+            ctx.msm_lookup(2, c, 0, windows=windows)
             ctx.msm_configure(0, groups)
             s = Setup.from_file(pc.PTAU)
             pc.msm_vs_oracle(s, 300, seed=60 + c)
+            pc.msm_vs_oracle(s, 2048, seed=80 + c, batch=2)
             pc.msm_extreme_scalars(s)
             pc.lincomb_golden(s, full_size=(c == 11))
+            info = s.device_bases().lookup_info()
+            assert info["layout"] == ("windows" if windows else "comb") and info["bits"] == c, info
             del s
     finally:
         ctx.msm_lookup(0)
@@ -174,7 +177,8 @@ def test_msm_lookup_tables():
     s = Setup.from_file(pc.PTAU)
     pc.msm_vs_oracle(s, 2048, seed=99)
     pc.lincomb_golden(s, full_size=True)
-    assert s.device_bases().lookup_bits >= 12  # (13 on a 288 GB device; 11 was round 4's fixed 4 GiB)
+    info = s.device_bases().lookup_info()
+    assert info["layout"] == "comb" and info["additions_per_base"] <= 16, info  # (17 teeth, 15 additions, on a 288 GB device)
 
 
 def test_lookup_and_bucket_methods_agree():
@@ -608,23 +612,23 @@ def test_distributed_ntt_single_rank_rccl(log_n):
 
 @pytest.mark.gpu
 def test_full_size_lookup_table_on_an_explicit_budget():
-    """The c = 17 table (128.8 GB: what bench.py opts into with a 150 GB budget) — the default budget never builds it.
-    MSMs against the oracle, both methods byte-identical on 64 full-size commitments, the 2^11 chain proofs against the
-    fixtures, and the table really is the one attached (bits, bytes, shared by a second context)."""
+    """The comb of 20 teeth (68.7 GB, 13 additions per base: what bench.py opts into with its 100 GB budget) — the default budget
+    never builds it.  The 2^11 chain proofs against the fixtures, both methods byte-identical on 8 more proofs, and the table
+    really is the one attached (layout, bits, bytes, shared by a second context)."""
     import json
 
     import bench
     from plonkathon_amd import BatchProver, Context, Program, Setup
 
     a, b = Context(0), Context(0)
-    a.msm_lookup(0, 0, int(150e9))
-    b.msm_lookup(0, 0, int(150e9))
+    a.msm_lookup(0, 0, int(100e9))
+    b.msm_lookup(0, 0, int(100e9))
     sa = Setup.from_file(pc.PTAU)
     bench.GROUP_ORDER = 2048
     program = Program(pc.chain_lines(2048), 2048)
     proofs = BatchProver(sa, program, a).prove_batch([bench.witness_for(0), bench.witness_for(1)])
     info = sa.device_bases(a).lookup_info()
-    assert info["bits"] == 17 and info["bytes"] == 2048 * 15 * 65536 * 64, info
+    assert info["layout"] == "comb" and info["bits"] == 20 and info["additions_per_base"] == 13 and info["bytes"] == 2048 * (1 << 19) * 64, info
     fx = {c["name"]: c for c in json.load(open(os.path.join(pc.GOLDEN, "oracle_proofs.json")))["cases"]}
     for i, name in ((0, "chain_2048_x0_3"), (1, "chain_2048_x0_4")):
         got = pc.flat(proofs[i])
@@ -636,7 +640,7 @@ def test_full_size_lookup_table_on_an_explicit_budget():
     pb.upload(wits)
     pb.run()
     blob_lookup = pb.download_raw()[0]
-    assert sa.device_bases(b).lookup_info()["bits"] == 17 and sa.device_bases(b).lookup_info()["sharers"] == 2
+    assert sa.device_bases(b).lookup_info()["bits"] == 20 and sa.device_bases(b).lookup_info()["sharers"] == 2
     c = Context(0)
     c.msm_lookup(1)
     pcx = BatchProver(sa, program, c)

@@ -112,6 +112,25 @@ def lookup_table_bytes(n, c):
     return n * windows * (1 << (c - 1)) * 64 + n * (1 << (c - 1)) * 128  # table + one window of XYZZ staging
 
 
+def comb_columns(h):
+    return (254 + h - 1) // h
+
+
+def comb_table_bytes(n, h):
+    """csrc/msm.hip, msm_comb_bytes: the table and the XYZZ staging of its build (an eighth of the entries, at most 2^27)."""
+    half, bases = 1 << (h - 1), max(n // 8, 1)
+    while bases > 1 and bases * half > 1 << 27:
+        bases //= 2
+    return n * half * 64 + bases * half * 128
+
+
+def comb_fit(n, budget):
+    """The comb the library's automatic choice builds within `budget`: fewest columns, then fewest teeth."""
+    fits = [h for h in range(8, 23) if comb_table_bytes(n, h) <= budget]
+    best = min(comb_columns(h) for h in fits)
+    return min(h for h in fits if comb_columns(h) == best)
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 _NTT_SRC = {}
 
@@ -312,11 +331,14 @@ def fallbacks(run):
     B, n = run.B, run.group_order
     fb = {}
     hbm_total = run.ctx.mem_info()[1]
-    fit = lambda budget: max(c for c in range(8, 18) if lookup_table_bytes(n, c) <= budget)
+    fit = lambda budget: comb_fit(n, budget)
+    wfit = lambda budget: max(c for c in range(8, 18) if lookup_table_bytes(n, c) <= budget)
     wits = [run.witness_for(idx) for idx in run.mine[:B]]
-    # (explicit window sizes: with an automatic choice a context would simply attach to the big table the headline built)
+    # (explicit sizes: with an automatic choice a context would simply attach to the big table the headline built)
     for name, conf in (("library_default_budget", (0, fit(hbm_total // 16), hbm_total // 16)), ("table_budget_4GiB", (0, fit(4 << 30), 4 << 30)),
-                       ("table_budget_40GB", (0, fit(40e9), int(40e9))), ("table_budget_80GB", (0, fit(80e9), int(80e9))), ("bucket_method", (1, 0, 0))):
+                       ("table_budget_1GiB", (0, fit(1 << 30), 1 << 30)), ("table_budget_128MiB", (0, fit(128 << 20), 128 << 20)),
+                       ("window_table_150GB", (0, wfit(150e9), int(150e9), True)), ("window_table_default_budget", (0, wfit(hbm_total // 16), hbm_total // 16, True)),
+                       ("bucket_method", (1, 0, 0))):
         c2 = Context(run.local_rank)
         c2.msm_lookup(*conf)
         pr = BatchProver(run.setup, run.program, c2)
@@ -331,7 +353,8 @@ def fallbacks(run):
         dt = (time.perf_counter() - t) / 3
         assert not any(st)
         i2 = run.setup.device_bases(c2).lookup_info()
-        fb[name] = {"proofs_per_s": B / dt, "ms_per_batch_of_%d" % B: 1e3 * dt, "msm_table_bits": i2["bits"],
+        fb[name] = {"proofs_per_s": B / dt, "ms_per_batch_of_%d" % B: 1e3 * dt, "msm_table_layout": i2["layout"], "msm_table_bits": i2["bits"],
+                    "additions_per_base": i2["additions_per_base"],
                     "msm_table_bytes": i2["bytes"], "msm_table_build_s": i2["build_s"],
                     "msm_table_fraction_of_hbm": i2["bytes"] / hbm_total, "fraction_of_value": (B / dt) / run.value, "streams": 1}
         del pr

@@ -2,7 +2,8 @@
 """Batched MSM rate against the method and its window size: 1152 MSMs of 2^11 scalars per call — the mean
 launch of a lock-step batch of 512 proofs — over the SRS slice, for
   bucket   the bucket method (Pippenger; no lookup table: what arbitrary bases get) at c = 9 .. 13 signed-digit windows,
-  lookup   the lookup table at c = 8 .. 14 (0.4 .. 20 GB: what a caller who grants less than bench.py's 150 GB gets).
+  windows  the window tables at c = 8 .. 14 (0.4 .. 20 GB), and c = 16, 17 (68.7, 128.8 GB) with `big`,
+  comb     the comb tables at h = 10 .. 20 teeth (67 MB .. 68.7 GB; csrc/msm_comb.h).
 One JSON line per row: ms per call (best of 3, HIP events), MSMs/s, the proofs/s nine such MSMs per proof would allow, and the
 kernels' own times from the library's events."""
 import ctypes
@@ -17,6 +18,8 @@ from plonkathon_amd import Context, Setup, set_context  # noqa: E402
 from plonkathon_amd._lib import check  # noqa: E402
 
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 1152
+WHAT = sys.argv[2].split(",") if len(sys.argv) > 2 else ["bucket", "windows", "comb"]
+BIG = "big" in sys.argv[3:]
 n = 2048
 ctx = Context(0)
 set_context(ctx)
@@ -32,7 +35,7 @@ PTAU = os.path.join(REPO, "tests", "golden", "srs_2048.ptau")
 
 
 def run(tag, mode, c, groups=0):
-    ctx.msm_lookup(mode, c if mode == 2 else 0)
+    ctx.msm_lookup(mode, c if mode == 2 else 0, 0, windows=(tag == "windows"))
     check(L.plonk_msm_configure(H, c if mode == 1 else 0, groups))
     setup = Setup.from_file(PTAU)
     bases = setup.device_bases()
@@ -48,9 +51,10 @@ def run(tag, mode, c, groups=0):
         ms = ctx.timer_stop_ms()
         best = ms if best is None or ms < best else best
     ctx.profile(False)
-    row = {"method": tag, "c": c, "groups": groups, "msms": M, "ms": best, "msms_per_s": M / (best * 1e-3), "proofs_per_s_at_9_msms": M / 9.0 / (best * 1e-3),
-           "table_bytes": bases.lookup_info()["bytes"], "xy0": xy.raw[:8].hex()}
-    for k in ("msm_lookup", "msm_sort", "msm_accumulate", "msm_bucket_reduce"):
+    info = bases.lookup_info()
+    row = {"method": tag, "c": c, "additions_per_base": info["additions_per_base"], "groups": groups, "msms": M, "ms": best, "msms_per_s": M / (best * 1e-3), "proofs_per_s_at_9_msms": M / 9.0 / (best * 1e-3),
+           "table_bytes": info["bytes"], "table_build_s": info["build_s"], "xy0": xy.raw[:8].hex()}
+    for k in ("msm_digits", "msm_comb", "msm_lookup", "msm_sort", "msm_accumulate", "msm_bucket_reduce"):
         t, cnt, _ = ctx.profile_read(k)
         if cnt:
             row[k + "_ms"] = t / cnt
@@ -58,9 +62,14 @@ def run(tag, mode, c, groups=0):
     del bases, setup
 
 
-for c in (9, 10, 11, 12, 13):
-    for g in ((0,) if c != 10 else (0, 1, 2)):
-        run("bucket", 1, c, g)
-for c in (8, 10, 11, 12, 13, 14):
-    run("lookup", 2, c)
+if "bucket" in WHAT:
+    for c in (9, 10, 11, 12, 13):
+        for g in ((0,) if c != 10 else (0, 1, 2)):
+            run("bucket", 1, c, g)
+if "windows" in WHAT:
+    for c in (8, 10, 11, 12, 13, 14) + ((16, 17) if BIG else ()):
+        run("windows", 2, c)
+if "comb" in WHAT:
+    for h in (10, 12, 13, 14, 15, 16, 17) + ((19, 20) if BIG else ()):
+        run("comb", 2, h)
 ctx.msm_lookup(0)
