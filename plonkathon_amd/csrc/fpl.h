@@ -389,6 +389,29 @@ template <class P, int JLO, int JHI> PLONK_HD bool fpl_maybe_zero_mod(const FpL<
     return ((minus_j + (uint32_t)JHI) & FP29_MASK) <= (uint32_t)(JHI - JLO);
 }
 
+// exact, inline and call-free: "a == 0 (mod m)" for a within [JLO m, JHI m] (limbs: any int32 whose sweep does not overflow).
+// The filter above names the only candidate j; a - j m is then carry-swept and compared with zero (~45 instructions, reached
+// with probability 2^-26).  For the reductions that must not contain a call (g1l_add_fast in the MSM kernels' trees).
+template <class P, int JLO, int JHI> PLONK_HD bool fpl_is_zero_mod_in(const FpL<P>& a) {
+    const uint32_t minus_j = ((uint32_t)a.l[0] * (P::NINV & FP29_MASK)) & FP29_MASK;
+    const uint32_t t = (minus_j + (uint32_t)JHI) & FP29_MASK;
+    if (t > (uint32_t)(JHI - JLO)) return false;
+    const int64_t j = (int64_t)JHI - (int64_t)t;
+    int64_t carry = 0;
+    uint32_t nz = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        const int64_t v = (int64_t)a.l[i] - j * (int64_t)fp29_mod_limb<P>(i) + carry;
+        if (i < 8) {
+            nz |= (uint32_t)v & FP29_MASK;
+            carry = v >> 29;  // arithmetic: floor
+        } else {
+            nz |= (uint32_t)v | (uint32_t)((uint64_t)v >> 32);
+        }
+    }
+    return nz == 0;
+}
+
 // exact test, a within (-16 m, 16 m)
 template <class P> PLONK_HD bool fpl_is_zero_mod(const FpL<P>& a) {
     if (!fpl_maybe_zero_mod<P, -15, 15>(a)) return false;

@@ -223,6 +223,57 @@ PLONK_HD bool g1l_madd_fast(G1XyzzL& p, const Fq& x2p, const Fq& y2p, bool neg_y
     return true;
 }
 
+// acc += q, both on lazy limbs (add-2008-s: 14 products under 13 reductions, ~2 700 instructions against ~4 600 for the
+// packed g1_add) — the tree reductions and the Horner chains of the table MSMs (msm_comb.h), where a general addition is the
+// step every other lane or wave waits for.  Operands: normalised limbs, |x| <= 7 m, |y|, |zz|, |zzz| <= 4 m — the invariants
+// of g1l_madd_fast's accumulator as well as a "piece" in [0, 4m) unpacked as it is (g1l_from_piece).  Result within the
+// accumulator invariants: x in (-7m, 5m), y, zz, zzz in (-m, 2m).  Returns false WITHOUT touching p when the operands are
+// equal or opposite (an exact, call-free test: fpl_is_zero_mod_in): the caller takes the packed formulas (g1l_add below) or,
+// where a call would cost the kernel its registers, hands the whole MSM to the general-formula kernel.
+// Bounds (|value| / m): U1, U2 <= 7 * 4, S1, S2, ZZ1 ZZ2, ZZZ1 ZZZ2 <= 16; P, R in (-3, 3); P^2 <= 9, P PP <= 6, U1 PP <= 4,
+// (ZZ1 ZZ2) PP <= 4; X3 = R^2 - PPP - 2Q in (-7, 5); D = Q - X3 in (-6, 9); R D + S1 PPP <= 27 + 4 — all below 128.
+PLONK_HD bool g1l_add_fast(G1XyzzL& p, const G1XyzzL& q) {
+    if (q.inf) return true;
+    if (p.inf) {
+        p = q;
+        return true;
+    }
+    const FqL u1 = fpl_mul(p.x, q.zz), u2 = fpl_mul(q.x, p.zz);
+    const FqL pp_ = fpl_sub(u2, u1);
+    if (fpl_is_zero_mod_in<FqParams, -3, 3>(pp_)) return false;
+    const FqL s1 = fpl_mul(p.y, q.zzz), s2 = fpl_mul(q.y, p.zzz);
+    const FqL rr = fpl_sub(s2, s1);
+    const FqL pp = fpl_sqr(pp_);
+    const FqL qq = fpl_mul(u1, pp);
+    const FqL ppp = fpl_mul(pp_, pp);
+    p.zz = fpl_mul(fpl_mul(p.zz, q.zz), pp);
+    p.zzz = fpl_mul(fpl_mul(p.zzz, q.zzz), ppp);
+    const FqL r2 = fpl_sqr(rr);
+    p.x = fpl_norm(fpl_sub(fpl_sub(r2, ppp), fpl_add(qq, qq)));
+    const FqL d = fpl_sub(qq, p.x);
+    p.y = fpl_mul_add(rr, d, fpl_neg(s1), ppp);
+    return true;
+}
+
+// acc = 2 acc on lazy limbs (dbl-2008-s-1, a = 0: 9 products, three of them squarings, under 8 reductions).  Operand and
+// result ranges as g1l_add_fast.  Bounds: U = 2Y <= 8, U^2 <= 64, U V <= 16, X V <= 14, X^2 <= 49, M = 3 X^2 in (-3, 6),
+// M^2 <= 36, X3 = M^2 - 2S in (-5, 4), M (S - X3) + W Y <= 6 * 7 + 2 * 4.  (No exceptional case: G1 has no point of order two.)
+PLONK_HD void g1l_dbl(G1XyzzL& p) {
+    if (p.inf) return;
+    const FqL u = fpl_norm(fpl_add(p.y, p.y));
+    const FqL v = fpl_sqr(u);
+    const FqL w = fpl_mul(u, v);
+    const FqL s = fpl_mul(p.x, v);
+    const FqL xx = fpl_sqr(p.x);
+    const FqL m = fpl_norm(fpl_add(fpl_add(xx, xx), xx));
+    p.zz = fpl_mul(v, p.zz);
+    p.zzz = fpl_mul(w, p.zzz);
+    const FqL m2 = fpl_sqr(m);
+    p.x = fpl_norm(fpl_sub(m2, fpl_add(s, s)));
+    const FqL d = fpl_sub(s, p.x);
+    p.y = fpl_mul_add(m, d, fpl_neg(w), p.y);
+}
+
 // Piece form of a lazy accumulator for msm_accumulate_kernel: four 256-bit words in [0, 4m) (not canonical;
 // g1_piece_load canonicalises), identity = all zero.  Costs ~150 instructions, no multiplication, so flushing at a
 // bucket boundary stays cheap.
@@ -279,4 +330,30 @@ PLONK_HD G1Xyzz g1_piece_load(const G1Xyzz* src) {
         fp_reduce_once<FqParams>(r.zzz.v);
     }
     return r;
+}
+
+
+// lazy limbs of a stored piece as it is (no canonicalisation: a piece in [0, 4m) is a valid operand of g1l_add_fast / g1l_dbl);
+// the identity is the all-zero piece
+PLONK_HD G1XyzzL g1l_from_piece(const G1Xyzz* src) {
+    G1XyzzL r;
+    const Fq x = fp_load(&src->x), y = fp_load(&src->y), zz = fp_load(&src->zz), zzz = fp_load(&src->zzz);
+    r.inf = fp_is_zero(zz);
+    r.x = fpl_from_fp(x);
+    r.y = fpl_from_fp(y);
+    r.zz = fpl_from_fp(zz);
+    r.zzz = fpl_from_fp(zzz);
+    return r;
+}
+
+// the exceptional exit of g1l_add: both operands through the packed general formulas (identity, P == +-Q)
+PLONK_HD_NOINLINE G1XyzzL g1l_add_slow(const G1XyzzL p, const G1XyzzL q) {
+    G1Xyzz a = g1l_to_xyzz(p);
+    g1_add(a, g1l_to_xyzz(q));
+    return g1l_from_xyzz(a);
+}
+
+// acc += q on lazy limbs, every case
+PLONK_HD void g1l_add(G1XyzzL& p, const G1XyzzL& q) {
+    if (!g1l_add_fast(p, q)) p = g1l_add_slow(p, q);
 }

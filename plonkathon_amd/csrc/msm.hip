@@ -1093,17 +1093,18 @@ static int msm_run_comb(plonk_ctx* ctx, plonk_srs* srs, const Fr* d_scalars, siz
     const G1Xyzz* sums = partial;
     unsigned Gf = G;
     if (G >= 4) {  // few MSMs in many pieces: a wave per (MSM, column) sums the pieces in parallel
-        PLONK_LAUNCH(msm_comb_colsum_kernel, dim3((unsigned)(M * a)), dim3(64), 0, ctx->stream, (const G1Xyzz*)partial, G, a, colsum);
+        PLONK_LAUNCH(msm_comb_colsum_kernel, dim3((unsigned)(M * a)), dim3(64), 0, ctx->stream, (const G1Xyzz*)partial, G, a, colsum, n_deferred);
         sums = colsum;
         Gf = 1;
     }
-    // lanes per MSM in the Horner step: one for a batch (least work), sixteen when the MSMs are few (shortest chain)
+    // lanes per MSM in the Horner step (chain of a - 1 doublings and the additions between them, on lazy limbs): four for a batch
+    // (12 doublings + 6 additions per lane, 16 MSMs per wave), sixteen when the MSMs are few (12 + 4: the shortest chain);
+    // one lane per MSM would be the least work and the longest chain (12 + 12).  PLONK_MSM_COMB_LPM = 1 / 4 / 16 forces one (A/B).
     static const unsigned forced_lpm = [] { const char* e = getenv("PLONK_MSM_COMB_LPM"); return e ? (unsigned)atoi(e) : 0u; }();
-    const unsigned lpm = forced_lpm ? forced_lpm : (M >= 1024 ? 1u : M >= 64 ? 4u : 16u);
+    const unsigned lpm = forced_lpm ? forced_lpm : (M >= 64 ? 4u : 16u);
 #define PLONK_COMB_FINALIZE(L)                                                                                                                  \
     PLONK_LAUNCH(msm_comb_finalize_kernel<L>, dim3((unsigned)((M * L + 63) / 64)), dim3(64), 0, ctx->stream, sums, M, Gf, a,                      \
-                 (const G1Affine*)srs->lookup, hb, n, (const MsmDeferred*)deferred, (size_t)MSM_DEFER_CAP, (const uint32_t*)n_deferred, d_out_xy, \
-                 d_flags)
+                 (const G1Affine*)srs->lookup, hb, n, (const MsmDeferred*)deferred, (size_t)MSM_DEFER_CAP, n_deferred, d_out_xy, d_flags)
     if (lpm >= 16) PLONK_COMB_FINALIZE(16);
     else if (lpm >= 4) PLONK_COMB_FINALIZE(4);
     else PLONK_COMB_FINALIZE(1);

@@ -198,10 +198,7 @@ __global__ void __launch_bounds__(MSM_BLOCK, MSM_ACC_WAVES) msm_comb_kernel(cons
         slot = a * pl.q + u + j;
     }
     G1XyzzL run = g1l_identity();
-    auto flush = [&]() {
-        red[slot] = g1l_to_piece(run);
-        red[slot] = g1_piece_load(&red[slot]);
-    };
+    auto flush = [&]() { red[slot] = g1l_to_piece(run); };  // [0, 4m) words: what g1l_from_piece takes
     for (uint32_t k = 0; k < count; k++) {
         const uint32_t d = dg[(size_t)j * n + i];
         const G1Affine* src = tab + (((size_t)i << hb) + (d & 0x7fffffffu));
@@ -232,9 +229,9 @@ __global__ void __launch_bounds__(MSM_BLOCK, MSM_ACC_WAVES) msm_comb_kernel(cons
             msm_comb_left_pieces(pl, jj, ulo, x);
             if (r + half < pl.q + x) {
                 const uint32_t sa = msm_comb_slot(pl, a, jj, r, ulo), sb = msm_comb_slot(pl, a, jj, r + half, ulo);
-                G1Xyzz v = red[sa];
-                g1_add(v, red[sb]);
-                red[sa] = v;
+                G1XyzzL v = g1l_from_piece(&red[sa]);
+                if (!g1l_add_fast(v, g1l_from_piece(&red[sb]))) atomicAdd(n_deferred + m, MSM_DEFER_CAP + 1u);  // equal or opposite sums: msm_comb_slow_kernel
+                red[sa] = g1l_to_piece(v);
             }
         }
         __syncthreads();
@@ -244,16 +241,20 @@ __global__ void __launch_bounds__(MSM_BLOCK, MSM_ACC_WAVES) msm_comb_kernel(cons
 }
 
 // colsum[m * a + j] = sum_g partial[(m * G + g) * a + j]: a wave per (MSM, column), lane g (G <= 64)
-__global__ void __launch_bounds__(64) msm_comb_colsum_kernel(const G1Xyzz* partial, unsigned G, unsigned a, G1Xyzz* colsum) {
+__global__ void __launch_bounds__(64) msm_comb_colsum_kernel(const G1Xyzz* partial, unsigned G, unsigned a, G1Xyzz* colsum, uint32_t* n_deferred) {
     const size_t m = blockIdx.x / a, j = blockIdx.x % a;
     const unsigned lane = threadIdx.x;
-    G1Xyzz acc = g1_xyzz_identity();
-    for (unsigned g = lane; g < G; g += 64) {
-        if (g == lane) acc = partial[(m * G + g) * a + j];
-        else g1_add(acc, partial[(m * G + g) * a + j]);
-    }
-    g1_wave_reduce(acc, lane);
-    if (lane == 0) colsum[m * a + j] = acc;
+    G1XyzzL acc = g1l_identity();
+    bool ok = true;
+    for (unsigned g = lane; g < G; g += 64) ok &= g1l_add_fast(acc, g1l_from_piece(&partial[(m * G + g) * a + j]));
+    ok &= g1l_wave_reduce_step<32>(acc, lane);
+    ok &= g1l_wave_reduce_step<16>(acc, lane);
+    ok &= g1l_wave_reduce_step<8>(acc, lane);
+    ok &= g1l_wave_reduce_step<4>(acc, lane);
+    ok &= g1l_wave_reduce_step<2>(acc, lane);
+    ok &= g1l_wave_reduce_step<1>(acc, lane);
+    if (!ok) atomicAdd(n_deferred + m, MSM_DEFER_CAP + 1u);  // equal or opposite operands somewhere: msm_comb_slow_kernel
+    if (lane == 0) colsum[m * a + j] = g1l_to_piece(acc);
 }
 
 // sum_j 2^j S_j for MSM m, S_j = sum_g sums[(m G + g) a + j] + the deferred additions of column j.  LPM lanes per MSM: lane l
@@ -263,10 +264,11 @@ __global__ void __launch_bounds__(64) msm_comb_colsum_kernel(const G1Xyzz* parti
 template <unsigned LPM> __global__ void __launch_bounds__(64) msm_comb_finalize_kernel(const G1Xyzz* sums, size_t M, unsigned G, unsigned a,
                                                                                        const G1Affine* lookup, unsigned hb, size_t n,
                                                                                        const MsmDeferred* deferred, size_t deferred_stride,
-                                                                                       const uint32_t* n_deferred, Fq* out_xy, uint8_t* flags) {
+                                                                                       uint32_t* n_deferred, Fq* out_xy, uint8_t* flags) {
     const size_t gid = (size_t)blockIdx.x * 64 + threadIdx.x, m = gid / LPM;
     const unsigned l = (unsigned)(gid % LPM), lane = threadIdx.x;
-    G1Xyzz acc = g1_xyzz_identity();
+    G1XyzzL acc = g1l_identity();
+    bool ok = true;  // false: an addition met equal or opposite operands — the MSM goes to msm_comb_slow_kernel
     if (m < M && l < a) {
         const uint32_t nd = n_deferred[m] < MSM_DEFER_CAP ? n_deferred[m] : MSM_DEFER_CAP;  // past the cap: msm_comb_slow_kernel
         const unsigned jtop = l + ((a - 1 - l) / LPM) * LPM;
@@ -274,33 +276,32 @@ template <unsigned LPM> __global__ void __launch_bounds__(64) msm_comb_finalize_
         for (int j = (int)jtop; j >= 0; j -= (int)LPM) {
             if (j != (int)jtop)
 #pragma unroll 1
-                for (unsigned d = 0; d < LPM; d++) g1_dbl(acc);
+                for (unsigned d = 0; d < LPM; d++) g1l_dbl(acc);
 #pragma unroll 1
-            for (unsigned g = 0; g < G; g++) g1_add(acc, sums[(m * G + g) * a + j]);
+            for (unsigned g = 0; g < G; g++) ok &= g1l_add_fast(acc, g1l_from_piece(&sums[(m * G + g) * a + j]));
 #pragma unroll 1
             for (uint32_t k = 0; k < nd; k++) {
                 const MsmDeferred e = deferred[m * deferred_stride + k];  // `bucket` carries the item j * n + i here
                 if (e.bucket / n != (uint32_t)j) continue;
                 const size_t i = e.bucket - (size_t)j * n;
                 const G1Affine* src = lookup + ((i << hb) + (e.entry & 0x7fffffffu));
-                G1Affine pt;
-                pt.x = fp_load(&src->x);
-                pt.y = fp_load(&src->y);
-                if (e.entry >> 31) pt.y = fp_neg(pt.y);
-                g1_madd(acc, pt);
+                // deferred for being exceptional against its LANE's sum at the time; against the column's sum it normally is not
+                const Fq x = fp_load(&src->x), y = fp_load(&src->y);
+                if (!(fp_is_zero(x) && fp_is_zero(y))) ok &= g1l_madd_fast(acc, x, y, (e.entry >> 31) != 0);
             }
         }
 #pragma unroll 1
-        for (unsigned d = 0; d < l; d++) g1_dbl(acc);
+        for (unsigned d = 0; d < l; d++) g1l_dbl(acc);
     }
-    if constexpr (LPM >= 2) g1_wave_reduce_step<1>(acc, lane);
-    if constexpr (LPM >= 4) g1_wave_reduce_step<2>(acc, lane);
-    if constexpr (LPM >= 8) g1_wave_reduce_step<4>(acc, lane);
-    if constexpr (LPM >= 16) g1_wave_reduce_step<8>(acc, lane);
-    if constexpr (LPM >= 32) g1_wave_reduce_step<16>(acc, lane);
-    if constexpr (LPM >= 64) g1_wave_reduce_step<32>(acc, lane);
+    if constexpr (LPM >= 2) ok &= g1l_wave_reduce_step<1>(acc, lane);
+    if constexpr (LPM >= 4) ok &= g1l_wave_reduce_step<2>(acc, lane);
+    if constexpr (LPM >= 8) ok &= g1l_wave_reduce_step<4>(acc, lane);
+    if constexpr (LPM >= 16) ok &= g1l_wave_reduce_step<8>(acc, lane);
+    if constexpr (LPM >= 32) ok &= g1l_wave_reduce_step<16>(acc, lane);
+    if constexpr (LPM >= 64) ok &= g1l_wave_reduce_step<32>(acc, lane);
+    if (m < M && !ok) atomicAdd(n_deferred + m, MSM_DEFER_CAP + 1u);
     if (m < M && l == 0) {
-        G1Affine r = g1_to_affine(acc);
+        G1Affine r = g1_to_affine(g1l_to_xyzz(acc));
         flags[m] = g1_affine_is_identity(r) ? 1 : 0;
         fp_store(out_xy + 2 * m, fp_from_mont(r.x));
         fp_store(out_xy + 2 * m + 1, fp_from_mont(r.y));

@@ -69,6 +69,9 @@ if "bucket" in WHAT:
 if "windows" in WHAT:
     for c in (8, 10, 11, 12, 13, 14) + ((16, 17) if BIG else ()):
         run("windows", 2, c)
+if "comb20" in WHAT:
+    run("comb", 2, 20)
+    run("windows", 2, 17)
 if "comb" in WHAT:
     for h in (10, 12, 13, 14, 15, 16, 17) + ((19, 20) if BIG else ()):
         run("comb", 2, h)
