@@ -315,6 +315,19 @@ PLONK_HD G1Xyzz g1l_to_piece(const G1XyzzL& p) {
     return r;
 }
 
+// The same for a sum that may itself be a piece taken over unchanged (g1l_add_fast with an identity accumulator copies its
+// operand): x within (-8m, 5m), y, zz, zzz within (-3m, 5m) -> four words in [0, 4m).  Idempotent on pieces: unpacking and
+// packing a piece any number of times stays inside [0, 4m) (g1l_to_piece would add m to y, zz, zzz every time).
+PLONK_HD G1Xyzz g1l_to_piece_wide(const G1XyzzL& p) {
+    if (p.inf) return g1_xyzz_identity();
+    G1Xyzz r;
+    fpl_pack_lt4m<8>(p.x, r.x.v);
+    fpl_pack_lt4m<3>(p.y, r.y.v);           // (-3m, 5m) + 3m -> (0, 8m) -> [0, 4m)
+    fpl_pack_lt4m<3>(p.zz, r.zz.v);
+    fpl_pack_lt4m<3>(p.zzz, r.zzz.v);
+    return r;
+}
+
 // canonical XYZZ from a stored piece (either form: canonical pieces pass through unchanged)
 PLONK_HD G1Xyzz g1_piece_load(const G1Xyzz* src) {
     G1Xyzz r;

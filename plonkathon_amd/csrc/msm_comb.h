@@ -37,6 +37,10 @@
 #define MSM_COMB_MAX_TEETH 24
 #define MSM_COMB_SEG_BITS 8
 #define MSM_COMB_SCALAR_BITS 254   // r < 2^254
+// n_deferred[m]: the number of deferred additions of MSM m in the low bits (the list holds the first MSM_DEFER_CAP of them), and this
+// flag when a tree / Horner addition met equal or opposite operands.  Either way past the cap: msm_comb_slow_kernel redoes the MSM.
+#define MSM_COMB_REDO 0x80000000u
+PLONK_HD bool msm_comb_needs_redo(uint32_t v) { return (v & MSM_COMB_REDO) != 0 || v > MSM_DEFER_CAP; }
 
 PLONK_HD unsigned msm_comb_columns(unsigned h) { return (MSM_COMB_SCALAR_BITS + h - 1) / h; }
 
@@ -229,9 +233,12 @@ __global__ void __launch_bounds__(MSM_BLOCK, MSM_ACC_WAVES) msm_comb_kernel(cons
             msm_comb_left_pieces(pl, jj, ulo, x);
             if (r + half < pl.q + x) {
                 const uint32_t sa = msm_comb_slot(pl, a, jj, r, ulo), sb = msm_comb_slot(pl, a, jj, r + half, ulo);
-                G1XyzzL v = g1l_from_piece(&red[sa]);
-                if (!g1l_add_fast(v, g1l_from_piece(&red[sb]))) atomicAdd(n_deferred + m, MSM_DEFER_CAP + 1u);  // equal or opposite sums: msm_comb_slow_kernel
-                red[sa] = g1l_to_piece(v);
+                const G1XyzzL o = g1l_from_piece(&red[sb]);
+                if (!o.inf) {
+                    G1XyzzL v = g1l_from_piece(&red[sa]);
+                    if (!g1l_add_fast(v, o)) atomicOr(n_deferred + m, MSM_COMB_REDO);  // equal or opposite sums: msm_comb_slow_kernel
+                    red[sa] = g1l_to_piece_wide(v);
+                }
             }
         }
         __syncthreads();
@@ -253,8 +260,8 @@ __global__ void __launch_bounds__(64) msm_comb_colsum_kernel(const G1Xyzz* parti
     ok &= g1l_wave_reduce_step<4>(acc, lane);
     ok &= g1l_wave_reduce_step<2>(acc, lane);
     ok &= g1l_wave_reduce_step<1>(acc, lane);
-    if (!ok) atomicAdd(n_deferred + m, MSM_DEFER_CAP + 1u);  // equal or opposite operands somewhere: msm_comb_slow_kernel
-    if (lane == 0) colsum[m * a + j] = g1l_to_piece(acc);
+    if (!ok) atomicOr(n_deferred + m, MSM_COMB_REDO);  // equal or opposite operands somewhere: msm_comb_slow_kernel
+    if (lane == 0) colsum[m * a + j] = g1l_to_piece_wide(acc);
 }
 
 // sum_j 2^j S_j for MSM m, S_j = sum_g sums[(m G + g) a + j] + the deferred additions of column j.  LPM lanes per MSM: lane l
@@ -270,7 +277,7 @@ template <unsigned LPM> __global__ void __launch_bounds__(64) msm_comb_finalize_
     G1XyzzL acc = g1l_identity();
     bool ok = true;  // false: an addition met equal or opposite operands — the MSM goes to msm_comb_slow_kernel
     if (m < M && l < a) {
-        const uint32_t nd = n_deferred[m] < MSM_DEFER_CAP ? n_deferred[m] : MSM_DEFER_CAP;  // past the cap: msm_comb_slow_kernel
+        const uint32_t nd = msm_comb_needs_redo(n_deferred[m]) ? 0u : n_deferred[m];  // (an MSM to be redone: its list may have holes, its sum is overwritten)
         const unsigned jtop = l + ((a - 1 - l) / LPM) * LPM;
 #pragma unroll 1
         for (int j = (int)jtop; j >= 0; j -= (int)LPM) {
@@ -299,7 +306,7 @@ template <unsigned LPM> __global__ void __launch_bounds__(64) msm_comb_finalize_
     if constexpr (LPM >= 16) ok &= g1l_wave_reduce_step<8>(acc, lane);
     if constexpr (LPM >= 32) ok &= g1l_wave_reduce_step<16>(acc, lane);
     if constexpr (LPM >= 64) ok &= g1l_wave_reduce_step<32>(acc, lane);
-    if (m < M && !ok) atomicAdd(n_deferred + m, MSM_DEFER_CAP + 1u);
+    if (m < M && !ok) atomicOr(n_deferred + m, MSM_COMB_REDO);
     if (m < M && l == 0) {
         G1Affine r = g1_to_affine(g1l_to_xyzz(acc));
         flags[m] = g1_affine_is_identity(r) ? 1 : 0;
@@ -314,7 +321,7 @@ __global__ void __launch_bounds__(256) msm_comb_slow_kernel(const G1Affine* look
                                                             const uint32_t* n_deferred, Fq* out_xy, uint8_t* flags) {
     __shared__ G1Xyzz red[256];
     const unsigned m = blockIdx.x, tid = threadIdx.x;
-    if (n_deferred[m] <= MSM_DEFER_CAP) return;
+    if (!msm_comb_needs_redo(n_deferred[m])) return;
     const uint32_t* dg = digits + (size_t)m * a * n;
     G1Xyzz acc = g1_xyzz_identity();
 #pragma unroll 1

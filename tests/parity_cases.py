@@ -996,6 +996,39 @@ def msm_deferred_overflow(setup_unused=None):
         ctx.msm_configure(0, 0)
 
 
+def comb_table_shapes(shapes, seed=5150):
+    """The comb-table MSM (csrc/msm_comb.h) against the oracle over (teeth h, number of bases n, workgroups per MSM): the lane
+    partition of msm_comb_kernel — q = 256 / a lanes per column, left-over lanes crossing columns, pieces per column — depends
+    on a = ceil(254 / h) and n alone, so small tables over ARBITRARY bases (forced mode: a table per ec_lincomb call) walk every
+    branch of it: n below / at / above the lanes of a column, ragged tails, a > n, one scalar, scalar 0 / 1 / r - 1 / even / odd,
+    an identity base, a repeated base (equal pieces in one column's tree: the general-formula kernel takes the MSM)."""
+    import random
+
+    from plonkathon_amd import get_context
+
+    ctx = get_context()
+    rng = random.Random(seed)
+    g = (1, 2)
+    special = [0, 1, 2, R_MOD - 1, R_MOD - 2, (R_MOD - 1) // 2, 1 << 253, (1 << 127) + 1]
+    try:
+        for h, n, groups in shapes:
+            ctx.msm_lookup(2, h)
+            ctx.msm_configure(0, groups)
+            ks = [rng.randrange(1, R_MOD) for _ in range(n)]
+            pts = [og1.multiply(g, k) for k in ks[: min(n, 24)]]
+            pts = [pts[i % len(pts)] for i in range(n)]  # (24 distinct points, repeated: the oracle multiplies in pure Python)
+            if n > 3:
+                pts[3] = None
+            sc = [special[i % len(special)] if i % 3 == 0 else rng.randrange(R_MOD) for i in range(n)]
+            pairs = [(None if q is None else (Fq(q[0]), Fq(q[1])), k) for q, k in zip(pts, sc)]
+            got = pa.ec_lincomb(pairs)
+            want = og1.ec_lincomb(list(zip(pts, sc)))
+            assert (None if got is None else affine(got)) == want, (h, n, groups)
+    finally:
+        ctx.msm_lookup(0)
+        ctx.msm_configure(0, 0)
+
+
 def lagrange_srs_paths(setup):
     """Setup.commit goes through the Lagrange-basis SRS: it must equal ifft + coefficient-basis MSM (setup.py:66-72) at
     several sizes, and a BatchProver committing rounds 1-2 from Lagrange values must produce the same proofs."""

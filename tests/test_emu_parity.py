@@ -122,12 +122,22 @@ def test_msm_window_configs(emu):
         check(ctx.L.plonk_msm_configure(ctx.handle, 0, 0))
 
 
-def test_msm_lookup_tables(emu):
-    """The lookup MSM (every multiple of every window base precomputed) against the oracle and the goldens, at
-    window sizes small enough for the emulator; includes the identity / duplicate / cancelling base cases."""
+def test_msm_comb_table_shapes(emu):
+    """msm_comb_kernel's lane partition over tooth counts (a = 127 .. 29 columns), base counts and workgroups per MSM."""
+    pc.comb_table_shapes([(2, 5, 0), (3, 40, 1), (4, 1, 0), (4, 257, 1), (5, 300, 2), (6, 64, 0), (7, 19, 1), (7, 511, 1), (8, 256, 1),
+                          (9, 700, 1), (9, 33, 8), (13, 2, 0), (16, 1, 0), (17, 3, 1)])  # (the last three: one live piece in a column's list of 12 .. 17)
+
+
+@pytest.mark.parametrize("windows", [False, True])
+def test_msm_lookup_tables(emu, windows):
+    """The table MSM — comb tables (csrc/msm_comb.h), and the window tables of rounds 2 - 5 (every multiple of every window
+    base) — against the oracle and the goldens, at sizes small enough for the emulator; includes the identity / duplicate /
+    cancelling base cases."""
     from plonkathon_amd import Setup, get_context
 
     ctx = get_context()
+    real = ctx.msm_lookup
+    ctx.msm_lookup = lambda mode=0, bits=0, budget_bytes=0: real(mode, bits, budget_bytes, windows=windows)
     try:
         for c, groups in ((3, 0), (5, 2)):
             ctx.msm_lookup(2, c)
@@ -150,6 +160,7 @@ def test_msm_lookup_tables(emu):
         pc.prover_k6(Setup.from_file(pc.PTAU))
         pc.batch_prover_k6(Setup.from_file(pc.PTAU))
     finally:
+        del ctx.msm_lookup
         ctx.msm_lookup(0)
         ctx.msm_configure(0, 0)
 

@@ -181,6 +181,13 @@ def test_msm_lookup_tables():
     assert info["layout"] == "comb" and info["additions_per_base"] <= 16, info  # (17 teeth, 15 additions, on a 288 GB device)
 
 
+def test_msm_comb_table_shapes():
+    """msm_comb_kernel's lane partition over tooth counts, base counts and workgroups per MSM (the 13 columns of the 20-tooth
+    comb are covered at full size by test_full_size_lookup_table_on_an_explicit_budget and by bench.py's own verification)."""
+    pc.comb_table_shapes([(2, 5, 0), (3, 40, 1), (4, 257, 1), (5, 300, 2), (7, 511, 1), (8, 256, 1), (9, 700, 1), (9, 33, 8), (12, 1000, 0),
+                          (14, 2048, 1), (16, 700, 4), (19, 300, 1), (20, 120, 1), (20, 20, 0), (17, 1, 0), (17, 3, 1), (20, 2, 0)])
+
+
 def test_lookup_and_bucket_methods_agree():
     """512 commitments of 2^11 coefficients: byte-identical from the lookup table and from the bucket method."""
     import ctypes

@@ -92,7 +92,7 @@ for name, (nf, vf, nw, vw) in sorted(agg.items(), key=lambda kv: -(kv[1][1] + kv
     if name.startswith("__amd") or vf + vw < 1000:
         continue
     # the lookup MSM's reads are random 64-byte table entries; everything else streams
-    factor = res["factors"].get("random64", 1.0) if name == "msm_lookup_kernel" else res["factors"].get("streaming", 2.0)
+    factor = res["factors"].get("random64", 1.0) if name in ("msm_lookup_kernel", "msm_comb_kernel") else res["factors"].get("streaming", 2.0)
     fetch, write = (vf / nf if nf else 0.0), (vw / nw if nw else 0.0)
     traffic = factor * fetch * 1024 + write * 1024
     res["bench"][name] = traffic

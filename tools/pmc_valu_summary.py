@@ -73,10 +73,13 @@ res = {"units": __doc__.split("Units")[1].strip()[:1200]}
 # ---- msm_lookup_kernel: every launch of the pass (2 prover runs x 4 launches: 1536 / 512 / 1536 / 1024 MSMs), counters SUMMED over
 # the launches of a pass and set against the summed cycles / additions of the same launches (one run = 9 x 512 MSMs of 2^11
 # scalars x 15 windows of 17 bits = 4608 x 30720 mixed additions; 64 lanes per wave instruction)
-ADDS_PER_RUN = 4608.0 * 15 * 2048
+# (comb tables, csrc/msm_comb.h: msm_comb_kernel, 13 columns of 20 teeth = 4608 x 26624 mixed additions per run)
+MSM_KERNEL = "msm_comb_kernel" if any(name == "msm_comb_kernel" for (name, _, _) in launches("bench_issue")) else "msm_lookup_kernel"
+ADDS_PER_BASE = float(os.environ.get("MSM_ADDS_PER_BASE", "13" if MSM_KERNEL == "msm_comb_kernel" else "15"))
+ADDS_PER_RUN = 4608.0 * ADDS_PER_BASE * 2048
 b = {}
 for tag in ("bench_issue", "bench_mem", "bench_utcl"):
-    ls = [d for (name, grid, wg), ds in launches(tag).items() if name == "msm_lookup_kernel" for d in ds]
+    ls = [d for (name, grid, wg), ds in launches(tag).items() if name == MSM_KERNEL for d in ds]
     if not ls:
         continue
     tot = collections.defaultdict(float)
@@ -126,7 +129,8 @@ if b:
     for k in ("vmem_rd_insts_per_addition", "salu_insts_per_addition"):
         if k in b.get("bench_mem", {}):
             top[k] = b["bench_mem"][k]
-    res["msm_lookup_kernel"] = top
+    top["additions_per_base"] = ADDS_PER_BASE
+    res[MSM_KERNEL] = top
 
 # ---- the two passes of a lone 2^20 transform
 ntt = {}
