@@ -14,10 +14,10 @@ SRS slice, synthetic witness — a 2047-gate squaring chain + one public input, 
 the defaults a step is 20 x 512 = 10240 proofs per GPU (~0.24 s), so that the driver's 20 timed steps last ~5 s.
 Proofs are independent, so N GPUs shard by proof index with no data-path collective; every step ends with the one
 collective of the path, an all-gather of the finished proofs (768 B each) over RCCL ("scaling": "weak").  Inputs
-(circuit polynomials, the MSM lookup table of the SRS, witness columns) are resident in HBM before the timed region.
+(circuit polynomials, the MSM comb table of the SRS, witness columns) are resident in HBM before the timed region.
 
 OUTPUT.  stdout carries ONE JSON line of under 4 KB (asserted): the contract fields, `config` (workload + a dozen
-scalars), `roofline` (the dominant kernel, msm_lookup_kernel, against the HBM roofline — durations from HIP events on the
+scalars), `roofline` (the dominant kernel, msm_comb_kernel, against the HBM roofline — durations from HIP events on the
 library's own streams, traffic from this round's committed PMC passes, the ALU view from this round's tools/ubench run
 and SQ counter passes — with `secondary` = the standalone 2^20 transform north_star puts a number on) and `cpu_baseline`
 (the oracle on one host core; the GPU proof of the same witness compared byte for byte).  EVERYTHING ELSE the run
@@ -185,7 +185,7 @@ def main():
     ap.add_argument("--no-lookup", action="store_true", help="bucket-method MSM only")
     ap.add_argument("--host-gather", action="store_true", help="N > 1 with RCCL: gather through host buffers (plonk_gather_results) instead of straight from the provers' device buffers (plonk_gather_proofs_device)")
     ap.add_argument("--dump-proofs", default="", help="rank 0 writes the last step's gathered proofs (768 bytes each, global order) to this file")
-    ap.add_argument("--lagrange-commits", action="store_true", help="commit rounds 1-2 from Lagrange values over the Lagrange-basis SRS (a second lookup table)")
+    ap.add_argument("--lagrange-commits", action="store_true", help="commit rounds 1-2 from Lagrange values over the Lagrange-basis SRS (a second table)")
     ap.add_argument("--msm-groups", type=int, default=0, help="plonk_msm_configure groups: workgroups per MSM (0 = library default)")
     ap.add_argument("--ntt-kind", type=int, default=0, help="plonk_ntt_select_kernel: 0 auto, 1 / 4 the LDS kernel (radix-2 stages; A/B), 5 wave kernels wherever they apply, 6 / 7 wave kernels without / with the latency forms")
     ap.add_argument("--log-n", type=int, default=11, help="log2(group_order); 11 = the BASELINE workload, smaller values are for functional tests only")
@@ -523,7 +523,7 @@ def main():
             "traffic_GBps": traffic / k_avg / 1e9 if traffic else None,
             "note": "algorithmic bytes = 96*N+64 per MSM (SURVEY.md 8(d)); the kernel is integer-ALU bound (DESIGN.md 3/4.2): alu_frac = "
                     "mixed additions/s over the bare-loop rate of tools/ubench on this round's headers (a millisecond burst at the nominal "
-                    "clock; `_at_sustained_clock` scales the ceiling by the clock sampled in the timed region); with the lookup table every "
+                    "clock; `_at_sustained_clock` scales the ceiling by the clock sampled in the timed region); with the table every "
                     "addition also reads 64 table bytes: `traffic` (rocprofv3 --pmc FETCH_SIZE x calibrated factor + WRITE_SIZE) is the real "
                     "HBM demand; frac / avg_launch_us = the kernel with one stream active right after the timed region, frac_concurrent = "
                     "the same launches inside the %d-stream timed region (diluted by sharing the chip)" % NS})

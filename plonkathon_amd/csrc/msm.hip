@@ -4,12 +4,14 @@
 // (/root/reference/curve.py:38-111), i.e. everything Setup.commit does after its ifft
 // (setup.py:66-72).  The reference bit-slices the scalars into 255 subsets and adds affine points
 // with one Fq inversion per addition (~109k additions for N = 2^11); the result is a group element,
-// so any correct schedule yields the same affine point.  Two schedules:
+// so any correct schedule yields the same affine point.  The schedules:
 //
-// A. LOOKUP MSM — for a reusable SRS (plonk_srs_load_ptau), within the HBM budget the caller grants (4 GiB by
-//    default: c = 11; bench.py opts into 150 GB: c = 17).  Every multiple L[w][i][d] = d * 2^(c w) * P_i a signed
-//    c-bit digit can select is precomputed into HBM (128.8 GB at c = 17 for 2^11 points), ONE table per (device,
-//    base set, c) shared by every context; an MSM is N * ceil(255 / c) mixed additions of looked-up points:
+// A. TABLE MSM — for a reusable SRS (plonk_srs_load_ptau), within the HBM budget the caller grants (1/16 of the device's memory by
+//    default; bench.py opts into 100 GB).  ONE table per (device, base set, layout, bits), shared by every context.
+//    A1. comb tables (msm_comb.h, the default): 2^(h-1) entries per base, N * ceil(254 / h) mixed additions per MSM — 13 per base
+//        from 68.7 GB, 15 from 8.6 GB for 2^11 points — and ceil(254 / h) - 1 doublings per MSM.
+//    A2. window tables (rounds 2 - 5; plonk_msm_lookup_configure mode | 16): every multiple L[w][i][d] = d * 2^(c w) * P_i a signed
+//        c-bit digit can select (128.8 GB at c = 17 for 2^11 points), N * ceil(255 / c) mixed additions of looked-up points:
 //      msm_lookup_kernel           lanes walk flat ranges of (scalar, window) items, 64 random bytes per item
 //      msm_lookup_finalize_kernel  sum of the workgroup partials + deferred additions -> canonical affine
 //    See the section "Lookup MSM" below.
