@@ -700,6 +700,7 @@ __global__ void __launch_bounds__(64) lut_verify_windows_kernel(const G1Affine* 
 }
 static unsigned windows_for(unsigned c);
 static size_t msm_comb_stage_entries(size_t n, unsigned h);
+static MsmCombScale msm_comb_scale_constant();
 static MsmLookupTable* lut_verified(plonk_ctx* ctx, const plonk_srs* srs, MsmLookupTable* t) {  // g_lut_mu held
     if (!t) return nullptr;
     if (t->n_points != srs->n_points) return nullptr;
@@ -717,7 +718,7 @@ static MsmLookupTable* lut_verified(plonk_ctx* ctx, const plonk_srs* srs, MsmLoo
     if (t->kind == MSM_TABLE_COMB) {
         const size_t lanes = srs->n_points + 2 * LUT_VERIFY_SAMPLES;
         PLONK_LAUNCH(msm_comb_verify_kernel, dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0, ctx->stream, (const G1Affine*)srs->bases,
-                     (const G1Affine*)t->data, srs->n_points, t->windows, t->bits, (unsigned)LUT_VERIFY_SAMPLES, (unsigned*)flag);
+                     (const G1Affine*)t->data, srs->n_points, t->windows, t->bits, (unsigned)LUT_VERIFY_SAMPLES, msm_comb_scale_constant(), (unsigned*)flag);
     } else {
         PLONK_LAUNCH(lut_verify_kernel, dim3((unsigned)((srs->n_points + 255) / 256)), dim3(256), 0, ctx->stream, (const G1Affine*)srs->bases,
                      (const G1Affine*)t->data, srs->n_points, t->bits, (unsigned*)flag);
@@ -891,6 +892,16 @@ static size_t msm_comb_bytes(size_t n, unsigned h) {  // table + staging
     return (n << (h - 1)) * sizeof(G1Affine) + msm_comb_stage_entries(n, h) * sizeof(G1Xyzz);
 }
 
+// R^-1 mod r as a plain integer (R = 2^261, Fr's Montgomery radix): the comb tables hold multiples of R^-1 P_i (msm_comb.h)
+static MsmCombScale msm_comb_scale_constant() {
+    Fr one_plain = fp_zero<FrParams>();
+    one_plain.v[0] = 1;
+    const Fr c = fp_from_mont(one_plain);  // fp_from_mont multiplies the integer it is given by R^-1 mod r: here the integer 1
+    MsmCombScale k;
+    for (int i = 0; i < 8; i++) k.c[i] = c.v[i];
+    return k;
+}
+
 // Builds the comb table of h teeth.  PLONK_ERR_NOMEM (nothing allocated, nothing changed) if it does not fit.
 static int msm_comb_build(plonk_ctx* ctx, plonk_srs* srs, unsigned h) {  // g_lut_mu held
     const auto t0 = std::chrono::steady_clock::now();
@@ -910,10 +921,15 @@ static int msm_comb_build(plonk_ctx* ctx, plonk_srs* srs, unsigned h) {  // g_lu
     if (!plonk_dev_malloc(&gb, n * h * sizeof(G1Affine))) return fail();
     if (!plonk_dev_malloc(&dx, n * (sb ? sb : 1) * sizeof(G1Xyzz))) return fail();
     if (!plonk_dev_malloc(&db, n * (sb ? sb : 1) * sizeof(G1Affine))) return fail();
-    // tooth points G_k = 2^(a k) P_i (k < h) and the Gray-code steps 2 G_k (k < sb), affine
+    // P'_i = R^-1 P_i (the scalars arrive as Montgomery residues: msm_comb.h), through the staging buffers of the next step
     unsigned grid = (unsigned)((n + 63) / 64);
     if (grid > 2048) grid = 2048;
-    PLONK_LAUNCH(msm_table_kernel, dim3(grid), dim3(64), 0, ctx->stream, srs->bases, n, a, h, (G1Xyzz*)gx);
+    void* pb = nullptr;
+    if (!plonk_dev_malloc(&pb, n * sizeof(G1Affine))) return fail();
+    PLONK_LAUNCH(msm_comb_scale_kernel, dim3(grid), dim3(64), 0, ctx->stream, (const G1Affine*)srs->bases, n, msm_comb_scale_constant(), (G1Xyzz*)gx);
+    g1_batch_to_affine(ctx, (const G1Xyzz*)gx, (G1Affine*)pb, n);
+    // tooth points G_k = 2^(a k) P'_i (k < h) and the Gray-code steps 2 G_k (k < sb), affine
+    PLONK_LAUNCH(msm_table_kernel, dim3(grid), dim3(64), 0, ctx->stream, (const G1Affine*)pb, n, a, h, (G1Xyzz*)gx);
     g1_batch_to_affine(ctx, (const G1Xyzz*)gx, (G1Affine*)gb, n * h);
     if (sb) {
         unsigned gd = (unsigned)((n * sb + 255) / 256);
@@ -927,8 +943,11 @@ static int msm_comb_build(plonk_ctx* ctx, plonk_srs* srs, unsigned h) {  // g_lu
                      (G1Xyzz*)tmp);
         g1_batch_to_affine(ctx, (const G1Xyzz*)tmp, (G1Affine*)tab + i0 * half, nb * half);
     }
-    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) return fail();
-    for (void* q : {gx, gb, dx, db, tmp}) hipFree(q);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) {
+        hipFree(pb);
+        return fail();
+    }
+    for (void* q : {gx, gb, dx, db, tmp, pb}) hipFree(q);
     MsmLookupTable* t = new MsmLookupTable();
     t->device = srs->device;
     t->key = srs->content_key;
@@ -1047,8 +1066,8 @@ static unsigned msm_round_aware_groups(int device, size_t M, unsigned g0, unsign
 // digits kernel of the comb with h teeth (one instantiation per tooth count: the bit gather is unrolled at compile time)
 template <unsigned H> static void msm_comb_launch_digits(plonk_ctx* ctx, const Fr* d_scalars, size_t n, size_t stride, size_t inner, size_t outer_stride,
                                                          size_t M, uint32_t* digits) {
-    PLONK_LAUNCH(msm_comb_digits_kernel<H>, dim3((unsigned)((M * n + 255) / 256)), dim3(256), 0, ctx->stream, d_scalars, n, stride, inner, outer_stride,
-                 M, digits);
+    PLONK_LAUNCH(msm_comb_digits_kernel<H>, dim3((unsigned)((n + 255) / 256), (unsigned)M), dim3(256), 0, ctx->stream, d_scalars, n, stride, inner,
+                 outer_stride, M, digits);
 }
 typedef void (*msm_comb_digits_fn)(plonk_ctx*, const Fr*, size_t, size_t, size_t, size_t, size_t, uint32_t*);
 template <unsigned... H> static msm_comb_digits_fn msm_comb_digits_for(unsigned h, std::integer_sequence<unsigned, H...>) {

@@ -15,6 +15,8 @@
 // the negated entry of the complemented lower teeth, so the table has 2^(h-1) entries per base,
 //     E_P[idx] = 2^(a (h-1)) P + sum_{k < h-1} (idx_k ? + : -) 2^(a k) P,
 // and EVERY (scalar, column) item is exactly one mixed addition: no zero digits, no branches in the loop.
+// The table is built over P'_i = R^-1 P_i (R = 2^261, the Montgomery radix of Fr): the scalars reach the MSM as Montgomery residues
+// s R mod r, and (s R) (R^-1 P) = s P — the digit kernel takes the residue as it is, sparing a conversion (a fifth of its work).
 //
 // Kernels (one launch each per batch of MSMs):
 //   msm_comb_digits_kernel<H>   one lane per scalar: canonical value, parity fold, t, and the a column indices (sign in bit 31)
@@ -43,6 +45,26 @@
 PLONK_HD bool msm_comb_needs_redo(uint32_t v) { return (v & MSM_COMB_REDO) != 0 || v > MSM_DEFER_CAP; }
 
 PLONK_HD unsigned msm_comb_columns(unsigned h) { return (MSM_COMB_SCALAR_BITS + h - 1) / h; }
+
+// c P by double-and-add over the bits of a wave-uniform constant (c = R^-1 mod r, 254 bits): one-off, per base
+struct MsmCombScale { uint32_t c[8]; };
+PLONK_DEV G1Xyzz msm_comb_scaled_base(const G1Affine& P, const MsmCombScale& k) {
+    G1Xyzz acc = g1_xyzz_identity();
+#pragma unroll 1
+    for (int bit = 255; bit >= 0; bit--) {
+        g1_dbl(acc);
+        if ((k.c[bit >> 5] >> (bit & 31)) & 1u) g1_madd<true>(acc, P);
+    }
+    return acc;
+}
+__global__ void __launch_bounds__(64) msm_comb_scale_kernel(const G1Affine* bases, size_t n, MsmCombScale k, G1Xyzz* out) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        G1Affine b;
+        b.x = fp_load(&bases[i].x);
+        b.y = fp_load(&bases[i].y);
+        out[i] = msm_comb_scaled_base(b, k);
+    }
+}
 
 // E_P[idx] by the definition (signed Horner from the top tooth): used by the verification of a shared table only
 PLONK_DEV G1Xyzz msm_comb_entry_slow(const G1Affine& P, unsigned a, unsigned h, uint32_t idx) {
@@ -107,11 +129,10 @@ template <unsigned H> __global__ void __launch_bounds__(256) msm_comb_digits_ker
                                                                                     size_t outer_stride, size_t M, uint32_t* digits) {
     constexpr unsigned A = (MSM_COMB_SCALAR_BITS + H - 1) / H, L = A * H;
     static_assert(L <= 9 * 32 && H <= MSM_COMB_MAX_TEETH, "the recoded scalar is kept in nine words");
-    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= M * n) return;
-    const size_t m = gid / n, i = gid - m * n;
+    const size_t m = blockIdx.y, i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // (a grid row per MSM: no division per lane)
+    if (i >= n) return;
     const Fr* sc = scalars + (m % inner) * stride + (m / inner) * outer_stride;
-    const Fr s = fp_from_mont(fp_load(sc + i));
+    const Fr s = fp_load(sc + i);  // the Montgomery residue s R mod r, taken as the integer it is: the table holds multiples of R^-1 P
     // odd representative: s, or r - s with the sign of the base flipped (r is odd; s = 0 becomes r, and r P = O comes out of the sums)
     const bool even = !(s.v[0] & 1u);
     uint32_t sp[8], br = 0;
@@ -360,17 +381,18 @@ __global__ void __launch_bounds__(256) msm_comb_slow_kernel(const G1Affine* look
 }
 
 // Verification of a comb table found in the registry by its 64-bit key (msm.hip, lut_verified), against THIS SRS's bases:
-//   every base: the all-ones entry = (sum_k 2^(a k)) P_i, recomputed by doublings and additions from the base;
+//   every base: the all-ones entry = (sum_k 2^(a k)) R^-1 P_i, recomputed by doublings and additions from the base;
 //   LUT_VERIFY_SAMPLES bases: entry 0 (every lower tooth -1) and the entry of the alternating index 0101.. as well.
 // A table of another tooth count / spacing, or of other bases, filed under the same key fails here.
-PLONK_DEV bool msm_comb_entry_matches(const G1Affine& P, unsigned a, unsigned h, uint32_t idx, const G1Affine* e) {
+PLONK_DEV bool msm_comb_entry_matches(const G1Affine& P0, const MsmCombScale& k, unsigned a, unsigned h, uint32_t idx, const G1Affine* e) {
+    const G1Affine P = g1_to_affine(msm_comb_scaled_base(P0, k));
     const G1Xyzz v = msm_comb_entry_slow(P, a, h, idx);
     const Fq ex = fp_load(&e->x), ey = fp_load(&e->y);
     if (g1_is_identity(v)) return fp_is_zero(ex) && fp_is_zero(ey);
     return fp_eq(fp_mul(ex, v.zz), v.x) && fp_eq(fp_mul(ey, v.zzz), v.y);
 }
 __global__ void __launch_bounds__(64) msm_comb_verify_kernel(const G1Affine* bases, const G1Affine* lookup, size_t n, unsigned a, unsigned h,
-                                                             unsigned samples, unsigned* mismatches) {
+                                                             unsigned samples, MsmCombScale k, unsigned* mismatches) {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n + 2 * (size_t)samples) return;
     const uint32_t mask = (1u << (h - 1)) - 1u;
@@ -387,5 +409,5 @@ __global__ void __launch_bounds__(64) msm_comb_verify_kernel(const G1Affine* bas
     G1Affine b;
     b.x = fp_load(&bases[i].x);
     b.y = fp_load(&bases[i].y);
-    if (!msm_comb_entry_matches(b, a, h, idx, lookup + ((i << (h - 1)) + idx))) atomicAdd(mismatches, 1u);
+    if (!msm_comb_entry_matches(b, k, a, h, idx, lookup + ((i << (h - 1)) + idx))) atomicAdd(mismatches, 1u);
 }
