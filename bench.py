@@ -186,7 +186,7 @@ def main():
     ap.add_argument("--host-gather", action="store_true", help="N > 1 with RCCL: gather through host buffers (plonk_gather_results) instead of straight from the provers' device buffers (plonk_gather_proofs_device)")
     ap.add_argument("--dump-proofs", default="", help="rank 0 writes the last step's gathered proofs (768 bytes each, global order) to this file")
     ap.add_argument("--lagrange-commits", action="store_true", help="commit rounds 1-2 from Lagrange values over the Lagrange-basis SRS (a second table)")
-    ap.add_argument("--msm-groups", type=int, default=0, help="plonk_msm_configure groups: workgroups per MSM (0 = library default)")
+    ap.add_argument("--msm-groups", type=int, default=-1, help="plonk_msm_configure groups: workgroups per MSM (0 = library default; -1 = 1 with eight or more streams, else the library default)")
     ap.add_argument("--ntt-kind", type=int, default=0, help="plonk_ntt_select_kernel: 0 auto, 1 / 4 the LDS kernel (radix-2 stages; A/B), 5 wave kernels wherever they apply, 6 / 7 wave kernels without / with the latency forms")
     ap.add_argument("--log-n", type=int, default=11, help="log2(group_order); 11 = the BASELINE workload, smaller values are for functional tests only")
     ap.add_argument("--detail", default=os.path.join(REPO, "bench_detail.json"), help="where the full record goes (the stdout line stays under 4 KB)")
@@ -252,8 +252,12 @@ def main():
     ctxs = [ctx] + [Context(local_rank) for _ in range(NS - 1)]
     for c in ctxs:
         c.msm_lookup(1 if args.no_lookup else 0, 0, budget)
-        if args.msm_groups:
-            c.msm_configure(0, args.msm_groups)
+        # Workgroups per MSM: the library cuts an MSM into as many workgroups as fill the chip in whole rounds ON ITS OWN (1 536 MSMs
+        # into 3 072 workgroups); with eight or more streams the other streams' kernels fill a partial round, and one workgroup per
+        # MSM — half the per-column trees — is 0.5 - 1 % faster (profiles/r05_u_msm_groups_ab.txt).  --msm-groups overrides.
+        groups = args.msm_groups if args.msm_groups >= 0 else (1 if NS >= 8 else 0)
+        if groups:
+            c.msm_configure(0, groups)
         if args.ntt_kind:
             from plonkathon_amd._lib import check as _check
 
