@@ -250,6 +250,7 @@ def main():
     B, S = args.batch, args.batches_per_step
     NS = max(1, args.streams or S)
     ctxs = [ctx] + [Context(local_rank) for _ in range(NS - 1)]
+    groups = 0
     for c in ctxs:
         c.msm_lookup(1 if args.no_lookup else 0, 0, budget)
         # Workgroups per MSM: the library cuts an MSM into as many workgroups as fill the chip in whole rounds ON ITS OWN (1 536 MSMs
@@ -372,6 +373,9 @@ def main():
     # The same kernel with the chip to itself: with several streams a launch's event-to-event duration includes the time
     # it shares the CUs with the other streams' kernels, so the per-launch figures of the timed region understate the
     # kernel.  A short untimed phase runs the batches of stream 0 alone (the other streams idle) and reads its events.
+    if args.msm_groups < 0:  # the timed region's one-workgroup-per-MSM setting is for many streams: everything below runs one
+        for c in ctxs:
+            c.msm_configure(0, 0)
     iso = None
     if NS > 1 and msm_launches:
         barrier()
@@ -434,6 +438,7 @@ def main():
             "gather_path": ("device buffers -> ncclAllGather -> host (plonk_gather_proofs_device)" if device_gather else
                             ("host buffers (plonk_gather_results / sockets)" if comm is not None else "none")),
             "msm_table_bits": lookup_bits,
+            "msm_workgroups_per_msm_in_the_timed_region": groups or "library default",
             "msm_table_build_s": info["build_s"],
             "msm_table_budget_bytes": budget,
             "msm_table_shared_by": info["sharers"],
