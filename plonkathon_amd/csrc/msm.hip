@@ -1066,8 +1066,11 @@ static unsigned msm_round_aware_groups(int device, size_t M, unsigned g0, unsign
 // digits kernel of the comb with h teeth (one instantiation per tooth count: the bit gather is unrolled at compile time)
 template <unsigned H> static void msm_comb_launch_digits(plonk_ctx* ctx, const Fr* d_scalars, size_t n, size_t stride, size_t inner, size_t outer_stride,
                                                          size_t M, uint32_t* digits) {
-    PLONK_LAUNCH(msm_comb_digits_kernel<H>, dim3((unsigned)((n + 255) / 256), (unsigned)M), dim3(256), 0, ctx->stream, d_scalars, n, stride, inner,
-                 outer_stride, M, digits);
+    for (size_t m0 = 0; m0 < M; m0 += 32768) {  // (a grid's second dimension ends at 65 535)
+        const size_t rows = M - m0 < 32768 ? M - m0 : 32768;
+        PLONK_LAUNCH(msm_comb_digits_kernel<H>, dim3((unsigned)((n + 255) / 256), (unsigned)rows), dim3(256), 0, ctx->stream, d_scalars, n, stride, inner,
+                     outer_stride, m0, digits);
+    }
 }
 typedef void (*msm_comb_digits_fn)(plonk_ctx*, const Fr*, size_t, size_t, size_t, size_t, size_t, uint32_t*);
 template <unsigned... H> static msm_comb_digits_fn msm_comb_digits_for(unsigned h, std::integer_sequence<unsigned, H...>) {

@@ -126,10 +126,10 @@ __global__ void __launch_bounds__(64) msm_comb_fill_kernel(const G1Affine* cb, c
 // digits[(m * A + j) * n + i] = column j of scalar i of MSM m: the index of its table entry in bits 0 .. H-2, bit 31 set when the
 // entry is to be subtracted.  Scalar vector of MSM m as in msm_sort_kernel (stride / inner / outer_stride).
 template <unsigned H> __global__ void __launch_bounds__(256) msm_comb_digits_kernel(const Fr* scalars, size_t n, size_t stride, size_t inner,
-                                                                                    size_t outer_stride, size_t M, uint32_t* digits) {
+                                                                                    size_t outer_stride, size_t m0, uint32_t* digits) {
     constexpr unsigned A = (MSM_COMB_SCALAR_BITS + H - 1) / H, L = A * H;
     static_assert(L <= 9 * 32 && H <= MSM_COMB_MAX_TEETH, "the recoded scalar is kept in nine words");
-    const size_t m = blockIdx.y, i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // (a grid row per MSM: no division per lane)
+    const size_t m = m0 + blockIdx.y, i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // (a grid row per MSM: no division per lane)
     if (i >= n) return;
     const Fr* sc = scalars + (m % inner) * stride + (m / inner) * outer_stride;
     const Fr s = fp_load(sc + i);  // the Montgomery residue s R mod r, taken as the integer it is: the table holds multiples of R^-1 P
