@@ -16,10 +16,10 @@
 //     E_P[idx] = 2^(a (h-1)) P + sum_{k < h-1} (idx_k ? + : -) 2^(a k) P,
 // and EVERY (scalar, column) item is exactly one mixed addition: no zero digits, no branches in the loop.
 // The table is built over P'_i = R^-1 P_i (R = 2^261, the Montgomery radix of Fr): the scalars reach the MSM as Montgomery residues
-// s R mod r, and (s R) (R^-1 P) = s P — the digit kernel takes the residue as it is, sparing a conversion (a fifth of its work).
+// s R mod r, and (s R) (R^-1 P) = s P — the digit kernel takes the residue as it is, sparing a conversion (a quarter of its work).
 //
 // Kernels (one launch each per batch of MSMs):
-//   msm_comb_digits_kernel<H>   one lane per scalar: canonical value, parity fold, t, and the a column indices (sign in bit 31)
+//   msm_comb_digits_kernel<H>   one lane per scalar: the residue as stored, parity fold, t, and the a column indices (sign in bit 31)
 //                               written column-major (digits[m][j][i], 4 B per item) — read back coalesced by the next kernel
 //   msm_comb_kernel             one workgroup per (MSM, scalar sub-range).  Lanes are bound to COLUMNS (a lane's accumulator can
 //                               only hold one column's sum): q = 256 / a lanes per column walk scalars r, r + q, .. — the whole
@@ -32,7 +32,7 @@
 //   msm_comb_colsum_kernel      (only when an MSM is cut into >= 4 workgroups) a wave per (MSM, column) sums the workgroups' sums
 //   msm_comb_finalize_kernel    sum_j 2^j S_j by Horner over groups of LPM lanes per MSM, deferred additions, unique affine form
 //   msm_comb_slow_kernel        the recovery path of MSM_DEFER_CAP (general formulas throughout)
-// Table build: msm_table_kernel gives G_k = 2^(a k) P_i; msm_comb_fill_kernel walks each run of 2^8 consecutive indices in
+// Table build: msm_comb_scale_kernel gives P'_i; msm_table_kernel G_k = 2^(a k) P'_i; msm_comb_fill_kernel walks each run of 2^8 consecutive indices in
 // Gray-code order (one mixed addition of +-2 G_k per entry); g1_batch_to_affine_kernel converts a chunk of bases at a time.
 #pragma once
 
