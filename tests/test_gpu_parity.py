@@ -185,7 +185,7 @@ def test_msm_comb_table_shapes():
     """msm_comb_kernel's lane partition over tooth counts, base counts and workgroups per MSM (the 13 columns of the 20-tooth
     comb are covered at full size by test_full_size_lookup_table_on_an_explicit_budget and by bench.py's own verification)."""
     pc.comb_table_shapes([(2, 5, 0), (3, 40, 1), (4, 257, 1), (5, 300, 2), (7, 511, 1), (8, 256, 1), (9, 700, 1), (9, 33, 8), (12, 1000, 0),
-                          (14, 2048, 1), (16, 700, 4), (19, 300, 1), (20, 120, 1), (20, 20, 0), (17, 1, 0), (17, 3, 1), (20, 2, 0)])
+                          (14, 2048, 1), (16, 700, 4), (19, 300, 1), (20, 120, 1), (20, 20, 0), (17, 1, 0), (17, 3, 1), (20, 2, 0), (12, 8192, 0), (13, 4097, 1)])  # (the last two: beyond 2^11 bases)
 
 
 def test_lookup_and_bucket_methods_agree():
