@@ -360,36 +360,39 @@ def fallbacks(run):
         del pr
         c2.close()
     if run.NS > 1:
-        # the headline's own shape — one lock-step batch per stream, every stream busy — on the LIBRARY-DEFAULT table budget:
-        # what a caller who grants no memory gets from the same twenty streams
+        # the headline's own shape — one lock-step batch per stream, every stream busy — (a) on the LIBRARY-DEFAULT table budget: what a
+        # caller who grants no memory gets from the same twenty streams; (b) on the bucket method: the algorithm `north_star` names
+        # (Pippenger, no table at all) under the headline's conditions
         bits = fit(hbm_total // 16)
-        cs = [Context(run.local_rank) for _ in range(run.NS)]
-        for c2 in cs:
-            c2.msm_lookup(0, bits, hbm_total // 16)
-            c2.msm_configure(0, 1)  # (as the timed region: bench.py)
-        prs = [BatchProver(run.setup, run.program, c2) for c2 in cs]
-        for k, q in enumerate(prs):
-            q.upload(wits)  # (the same batch on every stream: the timing does not depend on the witnesses)
+        for name, conf, groups in (("library_default_budget_all_streams", (0, bits, hbm_total // 16), 1), ("bucket_method_all_streams", (1, 0, 0), 0)):
+            cs = [Context(run.local_rank) for _ in range(run.NS)]
+            for c2 in cs:
+                c2.msm_lookup(*conf)
+                if groups:
+                    c2.msm_configure(0, groups)  # (one workgroup per MSM, as the timed region: bench.py; the bucket method keeps its own choice)
+            prs = [BatchProver(run.setup, run.program, c2) for c2 in cs]
+            for k, q in enumerate(prs):
+                q.upload(wits)  # (the same batch on every stream: the timing does not depend on the witnesses)
 
-        def multi():
-            for q in prs:
-                q.run()
-            return [q.download_raw()[1] for q in prs]
+            def multi():
+                for q in prs:
+                    q.run()
+                return [q.download_raw()[1] for q in prs]
 
-        for _ in range(2):
-            multi()
-        t = time.perf_counter()
-        for _ in range(3):
-            sts = multi()
-        dt = (time.perf_counter() - t) / 3
-        assert not any(any(st) for st in sts)
-        i2 = run.setup.device_bases(cs[0]).lookup_info()
-        fb["library_default_budget_all_streams"] = {"proofs_per_s": run.NS * B / dt, "ms_per_step": 1e3 * dt, "streams": run.NS, "msm_table_layout": i2["layout"],
-                                                    "msm_table_bits": i2["bits"], "additions_per_base": i2["additions_per_base"], "msm_table_bytes": i2["bytes"],
-                                                    "msm_table_fraction_of_hbm": i2["bytes"] / hbm_total, "fraction_of_value": (run.NS * B / dt) / run.value}
-        del prs
-        for c2 in cs:
-            c2.close()
+            for _ in range(2):
+                multi()
+            t = time.perf_counter()
+            for _ in range(3):
+                sts = multi()
+            dt = (time.perf_counter() - t) / 3
+            assert not any(any(st) for st in sts)
+            i2 = run.setup.device_bases(cs[0]).lookup_info()
+            fb[name] = {"proofs_per_s": run.NS * B / dt, "ms_per_step": 1e3 * dt, "streams": run.NS, "msm_table_layout": i2["layout"],
+                        "msm_table_bits": i2["bits"], "additions_per_base": i2["additions_per_base"], "msm_table_bytes": i2["bytes"],
+                        "msm_table_fraction_of_hbm": i2["bytes"] / hbm_total, "fraction_of_value": (run.NS * B / dt) / run.value}
+            del prs
+            for c2 in cs:
+                c2.close()
     fb["ec_lincomb_arbitrary_bases"] = ec_lincomb_arbitrary(run)
     return fb
 

@@ -34,6 +34,7 @@ for step in "$@"; do
     pmc) bash tools/pmc_collect.sh "$out" $arg ;;
     pmcu) bash tools/pmc_ntt_util.sh "$out/pmcu" ;;
     valu) bash tools/pmc_valu.sh "$out/valu" ;;
+    stepvalu) bash tools/pmc_step.sh "$out/stepvalu" $arg ;;
     msm_sweep) timeout 600 python tools/msm_sweep.py $arg > "$out/msm_sweep.jsonl" 2> "$out/msm_sweep.err"; echo "rc=$?"; cat "$out/msm_sweep.jsonl" ;;
     env_sweep)   # "VAR=VALUE <ntt_sweep args>": the sweep under one environment setting, rows tagged VAR=VALUE
       kv=${arg%% *}; rest=${arg#* }
