@@ -98,10 +98,29 @@ def proof_matches_fixture(proof, name):
     return True
 
 
+EXIT_PEER_LOST = 76  # this rank is healthy but another one stopped answering (a collective's deadline, a closed socket)
+EXIT_INJECTED = 17   # --inject-fault (tests)
+
+
+def _tail(path, n=12):
+    try:
+        with open(path, "rb") as f:
+            f.seek(0, 2)
+            f.seek(max(0, f.tell() - 16384))
+            return [l for l in f.read().decode("utf-8", "replace").splitlines() if l.strip()][-n:]
+    except OSError:
+        return []
+
+
 def spawn_ranks(args):
-    """`--gpus N` without a launcher: one child process per GPU, rank 0's JSON line is ours."""
+    """`--gpus N` without a launcher: one child process per GPU, rank 0's JSON line is ours.  EVERY child is watched: the first one
+    that exits non-zero ends the job — the others are stopped, and the report names the rank that failed first (a rank that only
+    lost a peer exits with EXIT_PEER_LOST and is not blamed while another rank died of its own), its exit code or signal and the tail
+    of its stderr.  A rank that hangs is ended by the deadlines inside the ranks (--comm-timeout), not here."""
     import ctypes
+    import signal
     import socket
+    import tempfile
 
     from plonkathon_amd import _lib
 
@@ -113,19 +132,107 @@ def spawn_ranks(args):
     with socket.socket() as s:  # a free port pair for the rendezvous
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    procs = []
+    logdir = tempfile.mkdtemp(prefix="plonk_bench_ranks_")
+    procs, outs, errs = [], [], []
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), PLONK_RDZV_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0",
                    PLONK_JOB_ID=os.environ.get("PLONK_JOB_ID", "bench-%d-%d" % (os.getpid(), port)))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out.decode())
-    sys.stdout.flush()
-    if any(rcs):
-        sys.exit("bench.py: rank exit codes %s" % rcs)
+        outs.append(os.path.join(logdir, "rank%d.out" % r))
+        errs.append(os.path.join(logdir, "rank%d.err" % r))
+        with open(outs[r], "wb") as fo, open(errs[r], "wb") as fe:
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=fo, stderr=fe))
+    order = []  # ranks in the order their exit was seen
+    first_bad_at = None
+    while len(order) < len(procs):
+        for r, p in enumerate(procs):
+            if r not in order and p.poll() is not None:
+                order.append(r)
+                if p.returncode != 0 and first_bad_at is None:
+                    first_bad_at = time.monotonic()
+        # after the first failure the others get two seconds to notice by themselves (their own message is worth more than ours)
+        if first_bad_at is not None and time.monotonic() - first_bad_at > 2.0:
+            break
+        time.sleep(0.02)
+    stopped = [r for r in range(len(procs)) if procs[r].poll() is None]
+    for r in stopped:
+        procs[r].terminate()
+    t_kill = time.monotonic() + 5.0
+    for r in stopped:
+        try:
+            procs[r].wait(timeout=max(0.1, t_kill - time.monotonic()))
+        except subprocess.TimeoutExpired:
+            procs[r].kill()
+            procs[r].wait()
+    rcs = [p.returncode for p in procs]
+    with open(errs[0], "rb") as f:  # rank 0's stderr is ours (the detail record travels on it)
+        sys.stderr.write(f.read().decode("utf-8", "replace"))
+    with open(outs[0], "rb") as f:
+        out = f.read().decode("utf-8", "replace")
+    bad = [r for r in order if rcs[r] != 0]
+    if not bad:
+        sys.stdout.write(out)
+        sys.stdout.flush()
+        import shutil
+
+        shutil.rmtree(logdir, ignore_errors=True)
+        return
+
+    def how(rc):
+        if rc < 0:
+            try:
+                return "was killed by %s" % signal.Signals(-rc).name
+            except ValueError:
+                return "was killed by signal %d" % -rc
+        return "exited with code %d" % rc + (" (it lost a peer)" if rc == EXIT_PEER_LOST else "")
+
+    own = [r for r in bad if rcs[r] != EXIT_PEER_LOST]
+    culprit = (own or bad)[0]
+    if own or not stopped:
+        sys.stderr.write("bench.py: rank %d of %d %s first; the job was stopped.\n" % (culprit, args.gpus, how(rcs[culprit])))
+    else:  # nobody died of its own: the ranks that gave up were waiting for one that never answered and was still running
+        sys.stderr.write("bench.py: rank %s of %d did not exit and had to be stopped (stuck?); rank %d %s waiting for it; the job was stopped.\n"
+                         % (", ".join(map(str, stopped)), args.gpus, culprit, how(rcs[culprit])))
+    for r in range(args.gpus):
+        state = "stopped by the launcher while still running" if r in stopped else how(rcs[r])
+        last = _tail(errs[r], 1)
+        sys.stderr.write("bench.py:   rank %d %s%s\n" % (r, state, (" | last stderr line: " + last[0][:300]) if last and r != culprit else ""))
+    if culprit != 0:
+        sys.stderr.write("bench.py: stderr tail of rank %d:\n" % culprit)
+        for l in _tail(errs[culprit]):
+            sys.stderr.write("bench.py:     " + l[:400] + "\n")
+    sys.stderr.write("bench.py: per-rank logs kept in %s\n" % logdir)
+    sys.exit(1)
+
+
+class Watchdog:
+    """Host-side deadline for the multi-rank phases of this process: a daemon thread that ends the process — naming
+    the rank and what it was waiting in — when an armed phase outlives its deadline.  The transports have deadlines of their own
+    (RCCL: plonk_comm_set_timeout -> PLONK_ERR_TIMEOUT; sockets: PeerLost); this is the backstop for a wait neither of them sees
+    (a GPU that stops answering, a rank stuck before its first collective)."""
+
+    def __init__(self, rank, world):
+        import threading
+
+        self.rank, self.world, self.deadline, self.label = rank, world, None, ""
+        self._t = threading.Thread(target=self._run, daemon=True)
+        self._t.start()
+
+    def arm(self, label, seconds):
+        self.label, self.deadline = label, (time.monotonic() + seconds if seconds > 0 else None)
+
+    def disarm(self):
+        self.deadline = None
+
+    def _run(self):
+        while True:
+            time.sleep(0.25)
+            d = self.deadline
+            if d is not None and time.monotonic() > d:
+                sys.stderr.write("bench.py[rank %d of %d]: '%s' outlived its deadline: another rank is dead or stuck, or this rank's GPU "
+                                 "stopped answering - giving up\n" % (self.rank, self.world, self.label))
+                sys.stderr.flush()
+                os._exit(EXIT_PEER_LOST)
 
 
 def _round(x, digits=6):
@@ -163,6 +270,46 @@ def emit(line, detail, detail_path):
     print(text, flush=True)
 
 
+def preflight(args, ctx, comm, rank, world, local_rank, setup, comm_init_s, step_s, gather_ms, device_gather):
+    """`--preflight`: what every rank sees, gathered by rank 0 into ONE JSON line — the questions a failed or slow N-GPU run raises
+    first (is every rank on its own device, how much HBM is free, can the devices map each other's memory, which RCCL, how long did
+    the communicator and the MSM table take, what does one all-gather cost)."""
+    import ctypes
+
+    free, total = ctx.mem_info()
+    n_dev = ctypes.c_int(0)
+    ctx.L.plonk_device_count(ctypes.byref(n_dev))
+    row = (ctypes.c_int * max(n_dev.value, 1))()
+    peer = list(row) if ctx.L.plonk_device_peer_access(ctx.device, row, len(row)) == 0 else None
+    info = setup.device_bases(ctx).lookup_info()
+    rec = {"rank": rank, "local_rank": local_rank, "device": ctx.device, "devices_visible": n_dev.value, "name": ctx.name(), "pid": os.getpid(),
+           "hbm_free_gb": round(free / 1e9, 2), "hbm_total_gb": round(total / 1e9, 2), "peer_access": peer,
+           "comm_init_s": round(comm_init_s, 3), "first_step_s": round(step_s[0], 3), "next_step_ms": round(1e3 * step_s[-1], 2),
+           "msm_table": {"layout": info["layout"], "bits": info["bits"], "gb": round(info["bytes"] / 1e9, 2), "build_s": round(info["build_s"], 3)},
+           "transport": comm.kind if comm is not None else "none (single rank)"}
+    if comm is not None and comm.kind == "rccl":
+        ri = comm.info()
+        rec.update({"rccl_path": ri["path"], "rccl_version": ri["version"]})
+    if comm is not None and gather_ms[2]:
+        rec["allgather_us"] = round(1e3 * gather_ms[0] / gather_ms[2], 1)
+        rec["allgather_measured_by"] = "HIP events around ncclAllGather" if device_gather else "host clock around the exchange"
+    if comm is not None:
+        blob = json.dumps(rec).encode()
+        assert len(blob) <= 4096
+        rows = [json.loads(b.rstrip(b"\0").decode()) for b in comm.all_gather(blob + bytes(4096 - len(blob)))]
+    else:
+        rows = [rec]
+    if rank == 0:
+        devs = [r["device"] for r in rows]
+        report = {"preflight": True, "n_gpus": world, "ranks_in_communicator": comm.world if comm is not None else 1,
+                  "distinct_devices": len(set(devs)), "all_peers_reachable": all(all(r["peer_access"] or [0]) for r in rows), "ranks": rows}
+        sys.stderr.write("bench_preflight: " + json.dumps(report, indent=1) + "\n")
+        print(json.dumps(_round(report), separators=(",", ":")), flush=True)
+    if comm is not None:
+        comm.barrier()
+        comm.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -182,6 +329,16 @@ def main():
     ap.add_argument("--force-comm", action="store_true",
                     help="with --gpus 1: still create a ONE-rank RCCL communicator and run the gather (plonk_gather_proofs_device), the "
                          "max over ranks and the barrier inside the timed region — the code path of an N-GPU run, exercised on one GPU")
+    ap.add_argument("--comm-timeout", type=float, default=120.0,
+                    help="N > 1: seconds a collective of a step may wait for the other ranks before this rank gives up (RCCL: plonk_comm_set_timeout "
+                         "-> the communicator is aborted, PLONK_ERR_TIMEOUT; sockets: PeerLost); a host-side watchdog at 1.5 x + 30 s backs it up")
+    ap.add_argument("--init-timeout", type=float, default=300.0, help="N > 1: seconds for the rendezvous and ncclCommInitRank")
+    ap.add_argument("--preflight", action="store_true",
+                    help="set everything up (communicator, MSM table, one step with its gather), print ONE JSON line with a record per rank - device, "
+                         "free HBM, hipDeviceCanAccessPeer row, RCCL path / version, communicator and table build seconds, one all-gather in us - and exit")
+    ap.add_argument("--inject-fault", default="", metavar="RANK:STEP:MODE",
+                    help="tests: rank RANK fails in timed step STEP (0-based) between enqueueing its batches and the gather; MODE = exit (os._exit), "
+                         "kill (SIGKILL) or hang (sleeps for ever)")
     ap.add_argument("--no-lookup", action="store_true", help="bucket-method MSM only")
     ap.add_argument("--host-gather", action="store_true", help="N > 1 with RCCL: gather through host buffers (plonk_gather_results) instead of straight from the provers' device buffers (plonk_gather_proofs_device)")
     ap.add_argument("--dump-proofs", default="", help="rank 0 writes the last step's gathered proofs (768 bytes each, global order) to this file")
@@ -222,6 +379,24 @@ def main():
 
     ctx = Context(local_rank)
     set_context(ctx)
+    multi = world > 1 or args.force_comm
+    wd = Watchdog(rank, world) if multi else None
+    guard = 1.5 * args.comm_timeout + 30.0  # the host-side backstop fires after the transport's own deadline had its chance
+
+    def phase(msg):  # one stderr line per phase of a multi-rank run: what a rank was doing when the job stopped
+        if world > 1:
+            sys.stderr.write("bench.py[rank %d of %d, device %d, pid %d]: %s\n" % (rank, world, ctx.device, os.getpid(), msg))
+            sys.stderr.flush()
+
+    fault = None
+    if args.inject_fault:
+        fr, fk, fmode = args.inject_fault.split(":")
+        if int(fr) == rank:
+            fault = (int(fk), fmode)
+    phase("context up; creating the communicator (%s)" % args.dist_backend)
+    t_comm = time.perf_counter()
+    if wd:
+        wd.arm("communicator set-up (rendezvous + ncclCommInitRank)", args.init_timeout + 30.0)
     # librccl announces itself on C stdout ("RCCL version : ..", five lines, flushed whenever libc pleases — after this script's JSON
     # line when stdout is a pipe): while the communicator is created, file descriptor 1 points at stderr, and libc's buffer is flushed
     # before it is restored, so that stdout carries the one JSON line and nothing else
@@ -231,12 +406,14 @@ def main():
     saved_fd = os.dup(1)
     os.dup2(2, 1)
     try:
-        comm = D.init_from_env(ctx, args.dist_backend) if world > 1 else None
+        comm = D.init_from_env(ctx, args.dist_backend, timeout=args.init_timeout) if world > 1 else None
         if comm is None and args.force_comm:
-            comm = D.RcclComm(ctx, 0, 1) if args.dist_backend == "rccl" else D.SocketComm(0, 1)
+            comm = D.RcclComm(ctx, 0, 1, args.init_timeout) if args.dist_backend == "rccl" else D.SocketComm(0, 1, args.init_timeout)
         if comm is not None and comm.kind == "rccl":
             comm.barrier()  # (the first collective: whatever the library prints lazily, it prints now)
             ctx.sync()
+        if comm is not None:
+            comm.set_timeout(args.comm_timeout)  # from here on the ranks move in step: a collective that waits longer has lost a rank
     finally:
         try:
             ctypes.CDLL(None).fflush(None)
@@ -244,8 +421,12 @@ def main():
             pass
         os.dup2(saved_fd, 1)
         os.close(saved_fd)
+    comm_init_s = time.perf_counter() - t_comm
+    if wd:
+        wd.disarm()
     if comm is not None and comm.world != world:
         sys.exit("bench.py: communicator has %d ranks, expected %d" % (comm.world, world))
+    phase("communicator up in %.2f s; staging witnesses" % comm_init_s)
     budget = 0 if args.no_lookup else int(args.lookup_budget_gb * 1e9)
     B, S = args.batch, args.batches_per_step
     NS = max(1, args.streams or S)
@@ -305,9 +486,21 @@ def main():
     device_gather = comm is not None and comm.kind == "rccl" and not args.host_gather
     gather_ms = [0.0, 0.0, 0]  # this rank: collective ms, copy-to-host ms, gathers (reset before the timed region)
 
+    timed_step = [-1]  # index of the timed step being run (-1: warm-up)
+
     def step():
         for pr in provers:
             pr.run()                   # five rounds + transcript: one stream of kernel launches each
+        if fault is not None and fault[0] == timed_step[0]:  # --inject-fault (tests): this rank dies or stalls mid-step
+            phase("INJECTED FAULT '%s' in timed step %d" % (fault[1], timed_step[0]))
+            if fault[1] == "kill":
+                import signal
+
+                os.kill(os.getpid(), signal.SIGKILL)
+            if fault[1] == "hang":
+                while True:
+                    time.sleep(3600)
+            os._exit(EXIT_INJECTED)
         if device_gather:              # proofs go from the provers' device buffers into the all-gather, one host copy at the end
             gathered, status = D.gather_proofs_device(provers, B, total, comm)
             a_ms, h_ms = comm.last_gather_ms()   # HIP events around the ncclAllGather and the copy to the host
@@ -331,24 +524,51 @@ def main():
         if comm is not None:
             comm.barrier()
 
-    for _ in range(args.warmup):
+    if args.preflight:
+        args.warmup = max(2, args.warmup)
+    step_s = []
+    for i in range(args.warmup):
+        if wd:  # (the first step builds the MSM table: seconds that differ from rank to rank)
+            wd.arm("warm-up step %d (its gather waits for every rank; the first one also builds the MSM table)" % i, guard + (60.0 if i == 0 else 0.0))
+        t_s = time.perf_counter()
         proofs = step()
+        for c in ctxs:
+            c.sync()
+        step_s.append(time.perf_counter() - t_s)
+        if i == 0:
+            phase("first step done in %.2f s (MSM table: %s)" % (step_s[0], setup.device_bases(ctx).lookup_info()))
+    if args.preflight:
+        if wd:
+            wd.arm("preflight report", guard)
+        return preflight(args, ctx, comm, rank, world, local_rank, setup, comm_init_s, step_s, gather_ms, device_gather)
     for c in ctxs:
         c.profile_reset()
         c.profile(True)
+    if wd:
+        wd.arm("barrier before the timed region", guard)
     barrier()
+    phase("warm-up done; timed region: %d steps" % args.steps)
     sampler = ClockSampler(local_rank) if rank == 0 else None  # one sampler per job: rank 0's GPU
     if sampler:
         sampler.start()
     gather_ms[:] = [0.0, 0.0, 0]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for k in range(args.steps):
+        timed_step[0] = k
+        if wd:
+            wd.arm("timed step %d of %d" % (k, args.steps), guard)
         proofs = step()
+    timed_step[0] = -1
     for c in ctxs:
         c.sync()
     own_elapsed = time.perf_counter() - t0   # this rank's own clock, before it waits for the others
+    if wd:
+        wd.arm("barrier / max over ranks after the timed region", guard)
     barrier()
     elapsed = D.max_over_ranks(time.perf_counter() - t0, comm)
+    if wd:
+        wd.disarm()
+    phase("timed region done: %.3f s" % elapsed)
     clocks = sampler.summary() if sampler else None
     for c in ctxs:
         c.profile(False)
@@ -605,4 +825,15 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except (TimeoutError, ConnectionError) as exc:
+        # a collective's deadline passed or a peer closed its socket: this rank is healthy, another one is not.  One line, the
+        # launcher's exit code for "lost a peer", and no interpreter shutdown (destructors would wait for the device or the dead peer)
+        import traceback
+
+        traceback.print_exc()
+        sys.stderr.write("bench.py[rank %s of %s]: giving up: %s: %s\n" % (os.environ.get("RANK", "0"), os.environ.get("WORLD_SIZE", "1"), type(exc).__name__, exc))
+        sys.stderr.flush()
+        sys.stdout.flush()
+        os._exit(EXIT_PEER_LOST)

@@ -32,6 +32,7 @@ extern "C" {
 #define PLONK_ERR_HIP (-2)   /* a HIP runtime call failed */
 #define PLONK_ERR_NOMEM (-3) /* device allocation failed */
 #define PLONK_ERR_STATE (-4) /* object used in the wrong state */
+#define PLONK_ERR_TIMEOUT (-5) /* a collective (or ncclCommInitRank) did not complete within the communicator's deadline */
 
 #define PLONK_ABI_VERSION 2
 
@@ -314,6 +315,16 @@ int plonk_gather_proofs_device(plonk_comm* comm, plonk_prover* const* provers, s
                                uint8_t* h_recv);
 int plonk_comm_max_f64(plonk_comm* comm, double* inout);
 int plonk_comm_barrier(plonk_comm* comm);
+/* Deadlines.  A collective waits for every rank, so one dead or stuck rank would block the others for ever.  Every wait behind
+ * a collective (and ncclCommInitRank inside plonk_comm_create) therefore has a deadline, after which the communicator is aborted
+ * (ncclCommAbort) and the call returns PLONK_ERR_TIMEOUT, plonk_last_error naming the operation, the rank and the device; every
+ * later call on that communicator returns PLONK_ERR_STATE.  plonk_comm_set_default_timeout: the process default, taken by
+ * plonk_comm_create (initially $PLONK_COMM_TIMEOUT_S, else 600 s; 0 = wait for ever); plonk_comm_set_timeout: one communicator. */
+int plonk_comm_set_default_timeout(double seconds);
+int plonk_comm_set_timeout(plonk_comm* comm, double seconds);
+/* out_row[p] = 1 iff `device` can map the memory of device p (hipDeviceCanAccessPeer; 1 on the diagonal), p < min(cap, devices):
+ * what RCCL's peer-to-peer transport over xGMI needs between two ranks of a node (bench.py --preflight prints it per rank). */
+int plonk_device_peer_access(int device, int* out_row, size_t cap);
 /* device time of the last plonk_gather_proofs_device on this communicator: the ncclAllGather itself and the copy of every
  * rank's records to the host (HIP events on the communicator's stream).                                              */
 int plonk_comm_last_gather_ms(plonk_comm* comm, float* out_allgather_ms, float* out_to_host_ms);

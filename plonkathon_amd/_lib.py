@@ -91,6 +91,9 @@ SIGNATURES = {
     "plonk_gather_results": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "plonk_comm_max_f64": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double)]),
     "plonk_comm_barrier": (ctypes.c_int, [ctypes.c_void_p]),
+    "plonk_comm_set_default_timeout": (ctypes.c_int, [ctypes.c_double]),
+    "plonk_comm_set_timeout": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_double]),
+    "plonk_device_peer_access": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.c_size_t]),
     "plonk_comm_last_gather_ms": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]),
     "plonk_comm_info": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_uint64)]),
     "plonk_fr_ntt_dist_columns": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint, ctypes.c_uint, ctypes.c_uint, ctypes.c_int]),
@@ -111,7 +114,7 @@ SIGNATURES = {
     "plonk_timer_stop_ms": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]),
 }
 
-PLONK_OK, PLONK_ERR_ARG, PLONK_ERR_HIP, PLONK_ERR_NOMEM, PLONK_ERR_STATE = 0, -1, -2, -3, -4
+PLONK_OK, PLONK_ERR_ARG, PLONK_ERR_HIP, PLONK_ERR_NOMEM, PLONK_ERR_STATE, PLONK_ERR_TIMEOUT = 0, -1, -2, -3, -4, -5
 OP_ADD, OP_SUB, OP_MUL, OP_DIV = 0, 1, 2, 3
 
 
@@ -155,4 +158,6 @@ def check(rc):
         raise AssertionError(msg)  # the reference guards these conditions with `assert`
     if rc == PLONK_ERR_NOMEM:
         raise MemoryError(msg)
+    if rc == PLONK_ERR_TIMEOUT:
+        raise TimeoutError(msg)  # a collective's deadline passed: another rank is dead or stuck (plonk_comm_set_timeout)
     raise BackendError("libplonk_hip: %s (status %d)" % (msg, rc))

@@ -11,6 +11,14 @@
 #include <dlfcn.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
+
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <memory>
+#include <mutex>
+#include <thread>
 
 #include <rccl/rccl.h>  // types and enums only: every call goes through the dlsym table below
 
@@ -22,6 +30,8 @@ struct Rccl {
     ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;                          // optional (NCCL >= 2.4): the deadline's way out
+    ncclResult_t (*CommGetAsyncError)(ncclComm_t, ncclResult_t*) = nullptr;   // optional
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -74,8 +84,25 @@ int rccl_load() {
     PLONK_RCCL_SYM(GetVersion, "ncclGetVersion");
     PLONK_RCCL_SYM(GetErrorString, "ncclGetErrorString");
 #undef PLONK_RCCL_SYM
+    *(void**)(&g_rccl.CommAbort) = dlsym(h, "ncclCommAbort");
+    *(void**)(&g_rccl.CommGetAsyncError) = dlsym(h, "ncclCommGetAsyncError");
     g_rccl.handle = h;
     return PLONK_OK;
+}
+
+// Deadlines.  A collective waits for EVERY rank: with one rank dead or stuck, ncclCommInitRank and any
+// hipStreamSynchronize behind a collective wait for ever, and an 8-GPU job ends in its launcher's timeout with nothing learned.
+// Every wait of this file therefore has a deadline — process default: $PLONK_COMM_TIMEOUT_S, else 600 s; 0 = none — after which
+// the communicator is aborted (ncclCommAbort) and the call returns PLONK_ERR_TIMEOUT naming rank and operation.
+std::atomic<double> g_default_timeout_s{-1.0};
+double default_timeout_s() {
+    double t = g_default_timeout_s.load();
+    if (t >= 0) return t;
+    const char* e = getenv("PLONK_COMM_TIMEOUT_S");
+    t = (e && *e) ? atof(e) : 600.0;
+    if (t < 0) t = 0;
+    g_default_timeout_s.store(t);
+    return t;
 }
 }  // namespace
 
@@ -99,7 +126,53 @@ struct plonk_comm {
     hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr, ev_t2 = nullptr;  // timing: collective start / end, host copy end
     bool timed = false;
     uint64_t collectives = 0;  // RCCL calls issued through this communicator (tests: the one-rank legs really call RCCL)
+    double timeout_s = 0;      // deadline of every wait behind a collective (0 = none)
 };
+
+// ncclCommAbort, once: the communicator is unusable afterwards (every entry point checks c->comm)
+static void comm_abort(plonk_comm* c) {
+    if (!c->comm) return;
+    if (g_rccl.CommAbort) g_rccl.CommAbort(c->comm);  // (without the symbol the handle is dropped: the process is about to exit)
+    c->comm = nullptr;
+}
+
+// hipStreamSynchronize(the communicator's stream) with the deadline: polls the stream and RCCL's asynchronous error state.
+// The first polls spin (a step's all-gather is over in microseconds), later ones sleep 50 us.
+static int comm_wait(plonk_comm* c, const char* what) {
+    hipStream_t s = c->ctx->stream;
+    if (c->timeout_s <= 0) {
+        PLONK_CHECK_HIP(hipStreamSynchronize(s));
+        return PLONK_OK;
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned polls = 0;; polls++) {
+        hipError_t q = hipStreamQuery(s);
+        if (q == hipSuccess) return PLONK_OK;
+        if (q != hipErrorNotReady) {
+            plonk_set_error("%s on rank %d of %d: the stream reports %s", what, c->rank, c->world, hipGetErrorString(q));
+            return PLONK_ERR_HIP;
+        }
+        if (polls >= 256) {
+            if (c->comm && g_rccl.CommGetAsyncError && (polls & 63) == 0) {
+                ncclResult_t ar = ncclSuccess;
+                if (g_rccl.CommGetAsyncError(c->comm, &ar) == ncclSuccess && ar != ncclSuccess && ar != ncclInProgress) {
+                    plonk_set_error("%s on rank %d of %d: RCCL reports an asynchronous error: %s", what, c->rank, c->world, g_rccl.GetErrorString(ar));
+                    comm_abort(c);
+                    return PLONK_ERR_HIP;
+                }
+            }
+            const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            if (el > c->timeout_s) {
+                plonk_set_error("%s did not complete within %.0f s on rank %d of %d (device %d): another rank is dead or stuck — the "
+                                "communicator has been aborted", what, c->timeout_s, c->rank, c->world, c->ctx->device);
+                comm_abort(c);
+                return PLONK_ERR_TIMEOUT;
+            }
+            usleep(50);
+        }
+    }
+}
+#define PLONK_COMM_LIVE(c) PLONK_REQUIRE((c)->comm, PLONK_ERR_STATE, "the communicator was aborted after a failed or timed-out collective")
 
 static int comm_staging(plonk_comm* c, size_t bytes) {
     if (c->cap >= bytes) return PLONK_OK;
@@ -141,9 +214,44 @@ int plonk_comm_create(plonk_ctx* ctx, const uint8_t id_bytes[PLONK_COMM_ID_BYTES
     c->ctx = ctx;
     c->rank = rank;
     c->world = world;
-    ncclResult_t r = g_rccl.CommInitRank(&c->comm, world, id, rank);
+    c->timeout_s = default_timeout_s();
+    ncclResult_t r = ncclSuccess;
+    if (c->timeout_s <= 0) {
+        r = g_rccl.CommInitRank(&c->comm, world, id, rank);
+    } else {
+        // ncclCommInitRank blocks until all `world` ranks have called it.  It runs on a helper thread so that this one can give up:
+        // on a timeout the helper is left behind (it may still be inside RCCL) — the caller is expected to report and exit
+        struct Job {
+            std::mutex m;
+            std::condition_variable cv;
+            bool done = false;
+            ncclResult_t r = ncclSuccess;
+            ncclComm_t comm = nullptr;
+        };
+        auto job = std::make_shared<Job>();
+        const int device = ctx->device;
+        std::thread([job, id, world, rank, device]() {
+            ncclComm_t cm = nullptr;
+            ncclResult_t rr = hipSetDevice(device) == hipSuccess ? g_rccl.CommInitRank(&cm, world, id, rank) : ncclUnhandledCudaError;
+            std::lock_guard<std::mutex> lk(job->m);
+            job->comm = cm;
+            job->r = rr;
+            job->done = true;
+            job->cv.notify_all();
+        }).detach();
+        std::unique_lock<std::mutex> lk(job->m);
+        if (!job->cv.wait_for(lk, std::chrono::duration<double>(c->timeout_s), [&] { return job->done; })) {
+            plonk_set_error("ncclCommInitRank(rank %d of %d, device %d) did not return within %.0f s: not every rank reached the "
+                            "communicator (a rank died before it, or the ranks disagree on the unique id / world size)", rank, world, device, c->timeout_s);
+            delete c;
+            return PLONK_ERR_TIMEOUT;
+        }
+        r = job->r;
+        c->comm = job->comm;
+    }
     if (r != ncclSuccess) {
         plonk_set_error("ncclCommInitRank(rank %d of %d, device %d) failed: %s", rank, world, ctx->device, g_rccl.GetErrorString(r));
+        c->comm = nullptr;
         delete c;
         return PLONK_ERR_HIP;
     }
@@ -160,13 +268,39 @@ int plonk_comm_create(plonk_ctx* ctx, const uint8_t id_bytes[PLONK_COMM_ID_BYTES
 int plonk_comm_destroy(plonk_comm* c) {
     if (!c) return PLONK_OK;
     plonk_use_device(c->ctx->device);
-    hipStreamSynchronize(c->ctx->stream);
-    if (c->comm) g_rccl.CommDestroy(c->comm);
+    if (c->comm && comm_wait(c, "plonk_comm_destroy") == PLONK_OK && c->comm) g_rccl.CommDestroy(c->comm);  // (a timed-out wait has aborted it)
     if (c->d_buf) hipFree(c->d_buf);
     for (hipEvent_t e : c->events) hipEventDestroy(e);
     for (hipEvent_t e : {c->ev_free, c->ev_t0, c->ev_t1, c->ev_t2})
         if (e) hipEventDestroy(e);
     delete c;
+    return PLONK_OK;
+}
+
+int plonk_comm_set_default_timeout(double seconds) {
+    PLONK_REQUIRE(seconds >= 0, PLONK_ERR_ARG, "a timeout is >= 0 seconds (0 = wait for ever)");
+    g_default_timeout_s.store(seconds);
+    return PLONK_OK;
+}
+
+int plonk_comm_set_timeout(plonk_comm* c, double seconds) {
+    PLONK_REQUIRE(c && seconds >= 0, PLONK_ERR_ARG, "bad argument");
+    c->timeout_s = seconds;
+    return PLONK_OK;
+}
+
+// out_row[p] = 1 iff `device` can map device p's memory (hipDeviceCanAccessPeer; the diagonal is 1): what RCCL's P2P / xGMI
+// transport needs between two ranks of one node.  bench.py --preflight prints the row per rank.
+int plonk_device_peer_access(int device, int* out_row, size_t cap) {
+    PLONK_REQUIRE(out_row && cap, PLONK_ERR_ARG, "bad argument");
+    int n = 0;
+    PLONK_CHECK_HIP(hipGetDeviceCount(&n));
+    PLONK_REQUIRE(device >= 0 && device < n, PLONK_ERR_ARG, "device %d of %d", device, n);
+    for (int p = 0; p < n && (size_t)p < cap; p++) {
+        int ok = 1;
+        if (p != device) PLONK_CHECK_HIP(hipDeviceCanAccessPeer(&ok, device, p));
+        out_row[p] = ok;
+    }
     return PLONK_OK;
 }
 
@@ -180,6 +314,7 @@ int plonk_comm_size(const plonk_comm* c, int* out_rank, int* out_world) {
 // h_recv[r * bytes_per_rank ..] = rank r's h_send, for every r: one ncclAllGather of uint8 on the context's stream
 int plonk_gather_results(plonk_comm* c, const uint8_t* h_send, size_t bytes_per_rank, uint8_t* h_recv) {
     PLONK_REQUIRE(c && h_send && h_recv && bytes_per_rank, PLONK_ERR_ARG, "bad argument");
+    PLONK_COMM_LIVE(c);
     PLONK_ENTER(c->ctx);
     const size_t total = bytes_per_rank * (size_t)c->world;
     PLONK_TRY(comm_staging(c, bytes_per_rank + total));
@@ -189,8 +324,7 @@ int plonk_gather_results(plonk_comm* c, const uint8_t* h_send, size_t bytes_per_
     PLONK_CHECK_RCCL(g_rccl.AllGather(d_send, d_recv, bytes_per_rank, ncclUint8, c->comm, s));
     c->collectives++;
     PLONK_CHECK_HIP(hipMemcpyAsync(h_recv, d_recv, total, hipMemcpyDeviceToHost, s));
-    PLONK_CHECK_HIP(hipStreamSynchronize(s));
-    return PLONK_OK;
+    return comm_wait(c, "plonk_gather_results (ncclAllGather)");
 }
 
 // The gather of a step's proofs without the host round trip of plonk_gather_results (D -> H -> D -> all-gather -> D -> H):
@@ -200,6 +334,7 @@ int plonk_gather_results(plonk_comm* c, const uint8_t* h_send, size_t bytes_per_
 // h_recv[r] = [n_provers * batch records | n_provers * batch status bytes, padded to 16] of rank r.
 int plonk_gather_proofs_device(plonk_comm* c, plonk_prover* const* provers, size_t n_provers, size_t batch, int compressed, uint8_t* h_recv) {
     PLONK_REQUIRE(c && provers && n_provers && batch && h_recv, PLONK_ERR_ARG, "bad argument");
+    PLONK_COMM_LIVE(c);
     PLONK_ENTER(c->ctx);
     const size_t rec = compressed ? 480 : 768;
     const size_t n = n_provers * batch;
@@ -245,7 +380,7 @@ int plonk_gather_proofs_device(plonk_comm* c, plonk_prover* const* provers, size
     PLONK_CHECK_HIP(hipEventRecord(c->ev_t1, s));
     PLONK_CHECK_HIP(hipMemcpyAsync(h_recv, d_recv, total, hipMemcpyDeviceToHost, s));
     PLONK_CHECK_HIP(hipEventRecord(c->ev_t2, s));
-    PLONK_CHECK_HIP(hipStreamSynchronize(s));
+    PLONK_TRY(comm_wait(c, "plonk_gather_proofs_device (ncclAllGather of the step's proofs)"));
     c->timed = true;
     return PLONK_OK;
 }
@@ -279,6 +414,7 @@ int plonk_comm_info(const plonk_comm* c, char* out_path, size_t path_cap, int* o
 // *inout = max over ranks (bench.py: the step time is the slowest rank's); also serves as the barrier
 int plonk_comm_max_f64(plonk_comm* c, double* inout) {
     PLONK_REQUIRE(c && inout, PLONK_ERR_ARG, "bad argument");
+    PLONK_COMM_LIVE(c);
     PLONK_ENTER(c->ctx);
     PLONK_TRY(comm_staging(c, 64));
     hipStream_t s = c->ctx->stream;
@@ -287,14 +423,14 @@ int plonk_comm_max_f64(plonk_comm* c, double* inout) {
     PLONK_CHECK_RCCL(g_rccl.AllReduce(d, d, 1, ncclDouble, ncclMax, c->comm, s));
     c->collectives++;
     PLONK_CHECK_HIP(hipMemcpyAsync(inout, d, sizeof(double), hipMemcpyDeviceToHost, s));
-    PLONK_CHECK_HIP(hipStreamSynchronize(s));
-    return PLONK_OK;
+    return comm_wait(c, "plonk_comm_max_f64 / plonk_comm_barrier (ncclAllReduce)");
 }
 
 // d_recv[r * bytes_per_peer ..] = block `rank` of rank r's d_send, for every r: the transpose step of the distributed
 // NTT, as one group of point-to-point ncclSend / ncclRecv pairs over xGMI (device buffers, the context's stream)
 int plonk_comm_all_to_all(plonk_comm* c, const void* d_send, void* d_recv, size_t bytes_per_peer) {
     PLONK_REQUIRE(c && d_send && d_recv && bytes_per_peer, PLONK_ERR_ARG, "bad argument");
+    PLONK_COMM_LIVE(c);
     PLONK_ENTER(c->ctx);
     hipStream_t s = c->ctx->stream;
     // (one rank included: a send / receive pair to oneself inside a group is RCCL's own copy)

@@ -25,6 +25,20 @@ PROOF_BYTES = 768
 _ID_BYTES = 128
 
 
+class PeerLost(ConnectionError):
+    """A rank of the job stopped answering (closed its socket, or kept silent beyond the transport's deadline): `.rank` names it."""
+
+    def __init__(self, rank, what):
+        super().__init__("rank %d %s" % (rank, what))
+        self.rank = rank
+
+
+def default_timeout():
+    """Seconds a collective may wait for the other ranks before the transport gives up (PLONK_COMM_TIMEOUT_S, default 600; the
+    library applies the same variable to RCCL: include/plonk_hip.h, plonk_comm_set_default_timeout)."""
+    return float(os.environ.get("PLONK_COMM_TIMEOUT_S", "600") or 600)
+
+
 def shard_indices(total: int, rank: int, world: int):
     """Indices of the proofs rank `rank` of `world` is responsible for (round-robin)."""
     return list(range(rank, total, world))
@@ -84,12 +98,15 @@ def _job_token():
 class _Star:
     """Rank 0 listens, ranks 1..W-1 connect and introduce themselves; the sockets stay open.
     Hello = magic, rank, job token; rank 0 answers magic, world; the rank confirms ("K"); rank 0 stores it and acknowledges ("A").
-    A rank that does not hear the acknowledgement goes back to probing, so neither side ever believes in a registration the other
-    dropped.  A port that is taken (rank 0) or that answers anything else (the others) is skipped, so a foreign service on
-    MASTER_PORT + 1 delays the launch instead of breaking it."""
+    A rank that does not hear the acknowledgement closes its socket and goes back to probing; its next hello REPLACES the connection
+    rank 0 had registered for it (the old one is dead by then), so a lost acknowledgement costs a retry, not the launch.  A port that
+    is taken (rank 0) or that answers anything else (the others) is skipped, so a foreign service on MASTER_PORT + 1 delays the launch
+    instead of breaking it.  `timeout`: the rendezvous as a whole; `io_timeout`: every later receive — a peer that keeps silent for
+    longer, or closes its socket, raises PeerLost naming it (one dead rank must not hang the others)."""
 
-    def __init__(self, rank, world, timeout=120.0):
+    def __init__(self, rank, world, timeout=120.0, io_timeout=None):
         self.rank, self.world = rank, world
+        self.io_timeout = default_timeout() if io_timeout is None else io_timeout
         host, port = _rdzv_addr()
         self.peers = {}
         if world == 1:
@@ -129,7 +146,7 @@ class _Star:
                 except (OSError, ConnectionError, struct.error):
                     conn.close()
                     continue
-                if magic != _MAGIC or tok != token or not 0 < r < world or r in self.peers:
+                if magic != _MAGIC or tok != token or not 0 < r < world:
                     conn.close()
                     continue
                 try:  # answer, and hear the rank confirm it: one that gave up waiting and reconnected must not be registered twice.
@@ -143,7 +160,10 @@ class _Star:
                 except (OSError, ConnectionError):
                     conn.close()
                     continue
-                conn.settimeout(timeout)
+                conn.settimeout(self.io_timeout)
+                stale = self.peers.pop(r, None)
+                if stale is not None:  # the rank did not hear the earlier "A" and came back: that socket is closed on its side
+                    stale.close()
                 self.peers[r] = conn
             srv.close()
         else:
@@ -172,9 +192,28 @@ class _Star:
                         raise TimeoutError("rendezvous: rank %d found no rank 0 of this job on %s:%d .. %d within %.0f s"
                                            % (rank, host, port, port + _PORT_SPAN - 1, timeout))
                     time.sleep(0.05)
-            s.settimeout(timeout)
+            s.settimeout(self.io_timeout)
             s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
             self.peers[0] = s
+
+    def set_timeout(self, seconds):
+        self.io_timeout = seconds
+        for sock in self.peers.values():
+            sock.settimeout(seconds)
+
+    def _recv_from(self, r):
+        try:
+            return _recv_msg(self.peers[r])
+        except socket.timeout:
+            raise PeerLost(r, "sent nothing for %.0f s" % self.io_timeout) from None
+        except (ConnectionError, OSError) as exc:
+            raise PeerLost(r, "closed its connection (%s)" % (exc,)) from None
+
+    def _send_to(self, r, payload):
+        try:
+            _send_msg(self.peers[r], payload)
+        except (ConnectionError, OSError) as exc:  # (socket.timeout is an OSError: a send buffer nobody drains)
+            raise PeerLost(r, "does not take data any more (%s)" % (exc,)) from None
 
     def broadcast(self, payload):
         """rank 0's bytes -> every rank"""
@@ -182,21 +221,21 @@ class _Star:
             return payload
         if self.rank == 0:
             for r in range(1, self.world):
-                _send_msg(self.peers[r], payload)
+                self._send_to(r, payload)
             return payload
-        return _recv_msg(self.peers[0])
+        return self._recv_from(0)
 
     def all_gather(self, payload):
         if self.world == 1:
             return [payload]
         if self.rank == 0:
-            parts = [payload] + [_recv_msg(self.peers[r]) for r in range(1, self.world)]
+            parts = [payload] + [self._recv_from(r) for r in range(1, self.world)]
             blob = b"".join(struct.pack("<Q", len(p)) + p for p in parts)
             for r in range(1, self.world):
-                _send_msg(self.peers[r], blob)
+                self._send_to(r, blob)
             return parts
-        _send_msg(self.peers[0], payload)
-        blob, parts, o = _recv_msg(self.peers[0]), [], 0
+        self._send_to(0, payload)
+        blob, parts, o = self._recv_from(0), [], 0
         for _ in range(self.world):
             (n,) = struct.unpack_from("<Q", blob, o)
             parts.append(blob[o + 8 : o + 8 + n])
@@ -217,9 +256,13 @@ class SocketComm:
 
     kind = "sockets"
 
-    def __init__(self, rank, world):
+    def __init__(self, rank, world, timeout=None):
         self.rank, self.world = rank, world
-        self._star = _Star(rank, world)
+        self._star = _Star(rank, world, io_timeout=timeout)
+
+    def set_timeout(self, seconds):
+        """Deadline of every later exchange: a rank that keeps silent for longer raises PeerLost on the ranks waiting for it."""
+        self._star.set_timeout(seconds)
 
     def all_gather(self, payload: bytes):
         return self._star.all_gather(payload)
@@ -246,12 +289,16 @@ class RcclComm:
 
     kind = "rccl"
 
-    def __init__(self, ctx, rank, world):
+    def __init__(self, ctx, rank, world, timeout=None):
+        """`timeout` (seconds, default PLONK_COMM_TIMEOUT_S or 600): deadline of ncclCommInitRank and of every wait behind a
+        collective; past it the library aborts the communicator and the call raises TimeoutError (PLONK_ERR_TIMEOUT)."""
         from ._lib import check
 
         self.ctx, self.rank, self.world = ctx, rank, world
         self._check = check
-        star = _Star(rank, world)  # only to hand out the unique id
+        if timeout is not None:
+            check(ctx.L.plonk_comm_set_default_timeout(float(timeout)))
+        star = _Star(rank, world, io_timeout=timeout)  # only to hand out the unique id
         try:
             ident = ctypes.create_string_buffer(_ID_BYTES)
             if rank == 0:
@@ -261,6 +308,9 @@ class RcclComm:
             star.close()
         self._h = ctypes.c_void_p()
         check(ctx.L.plonk_comm_create(ctx.handle, ident, rank, world, ctypes.byref(self._h)))
+
+    def set_timeout(self, seconds):
+        self._check(self.ctx.L.plonk_comm_set_timeout(self._h, float(seconds)))
 
     def all_gather(self, payload: bytes):
         """Equal-sized payloads (the caller pads): one ncclAllGather."""
@@ -297,8 +347,9 @@ class RcclComm:
             self._h = None
 
 
-def init_from_env(ctx=None, backend="rccl"):
-    """The communicator for this process (None for a single rank).  `backend`: "rccl" (default) or "sockets"."""
+def init_from_env(ctx=None, backend="rccl", timeout=None):
+    """The communicator for this process (None for a single rank).  `backend`: "rccl" (default) or "sockets"; `timeout`: seconds a
+    collective may wait for the other ranks (default PLONK_COMM_TIMEOUT_S or 600)."""
     rank, world, _ = env_rank_world()
     if world == 1:
         return None
@@ -307,9 +358,9 @@ def init_from_env(ctx=None, backend="rccl"):
             from .backend import get_context
 
             ctx = get_context()
-        return RcclComm(ctx, rank, world)
+        return RcclComm(ctx, rank, world, timeout)
     if backend == "sockets":
-        return SocketComm(rank, world)
+        return SocketComm(rank, world, timeout)
     raise ValueError("unknown distributed backend %r (rccl | sockets)" % (backend,))
 
 

@@ -28,6 +28,13 @@ int plonk_gather_proofs_device(plonk_comm*, plonk_prover* const* provers, size_t
     }
     return PLONK_OK;
 }
+int plonk_comm_set_default_timeout(double s) { return s >= 0 ? PLONK_OK : PLONK_ERR_ARG; }
+int plonk_comm_set_timeout(plonk_comm*, double s) { return s >= 0 ? PLONK_OK : PLONK_ERR_ARG; }
+int plonk_device_peer_access(int device, int* row, size_t cap) {
+    if (device != 0 || !row || !cap) return PLONK_ERR_ARG;  // the emulation reports one device
+    row[0] = 1;
+    return PLONK_OK;
+}
 int plonk_comm_max_f64(plonk_comm*, double*) { return PLONK_OK; }
 int plonk_comm_barrier(plonk_comm*) { return PLONK_OK; }
 int plonk_comm_last_gather_ms(plonk_comm*, float* a, float* b) { *a = *b = 0; return PLONK_OK; }

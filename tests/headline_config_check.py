@@ -50,9 +50,6 @@ def main():
         blobs.append(_pack_witnesses(wits, pr.variables, R_MOD))
         pr.upload_values(blobs[-1], B)
     t_wit = time.perf_counter() - t0
-    info = setup.device_bases(ctxs[0]).lookup_info()
-    assert info["layout"] == "comb" and info["bits"] == 20 and info["additions_per_base"] == 13 and info["sharers"] >= NS, info
-
     passes = []
     for _ in range(2):
         t0 = time.perf_counter()
@@ -64,6 +61,8 @@ def main():
         passes.append(([r[0] for r in raw], dt))
     assert passes[0][0] == passes[1][0], "the second pass of the step differs from the first"
     got = passes[0][0]
+    info = setup.device_bases(ctxs[0]).lookup_info()  # (the table is built by the first MSM that asks for it)
+    assert info["layout"] == "comb" and info["bits"] == 20 and info["additions_per_base"] == 13 and info["sharers"] >= NS, info
 
     # the bucket method on the same witnesses, alone on the chip, one batch at a time
     cb = Context(0)

@@ -128,3 +128,46 @@ GPU[1]		: Current Socket Graphics Package Power (W): 234.0
     out = s.summary()
     assert out["sclk_mhz_median"] == 2077 and out["sclk_mhz_min"] == 2050 and out["socket_power_w_median"] == 1200.0
     assert bench.ClockSampler(0).summary() is None  # nothing sampled (no rocm-smi): the bench line carries null
+
+
+def test_a_rank_that_dies_mid_step_stops_the_job_and_is_named(emu_cdll):
+    """rank 1 exits between enqueueing its batches and the gather of timed step 1.  The launcher watches every rank:
+    the job ends non-zero within seconds (not in a 30-minute timeout), names rank 1, its exit code and the tail of its stderr, and
+    does not blame rank 0, which only lost its peer (PeerLost -> exit code 76)."""
+    import time
+
+    t0 = time.monotonic()
+    r = _run(["--gpus", "2", "--dist-backend", "sockets", "--no-end-to-end", "--steps", "3", "--inject-fault", "1:1:exit"], timeout=120)
+    took = time.monotonic() - t0
+    assert r.returncode != 0 and not r.stdout.strip(), (r.returncode, r.stdout[-500:])
+    assert "rank 1 of 2 exited with code 17 first" in r.stderr, r.stderr[-3000:]
+    assert "rank 0 exited with code 76 (it lost a peer)" in r.stderr and "PeerLost: rank 1 closed its connection" in r.stderr
+    assert "INJECTED FAULT 'exit' in timed step 1" in r.stderr  # the stderr tail of the rank that failed
+    assert took < 60, took  # (start-up and one emulated warm-up step: ~15 s here; the failure itself is seen at once)
+
+
+def test_a_rank_that_hangs_mid_step_is_timed_out_and_named(emu_cdll):
+    """The same with a rank that stops without exiting: the other rank's collective has a deadline (--comm-timeout), it gives up
+    naming the silent rank, and the launcher stops the stuck one."""
+    import time
+
+    t0 = time.monotonic()
+    r = _run(["--gpus", "2", "--dist-backend", "sockets", "--no-end-to-end", "--steps", "3", "--inject-fault", "1:1:hang", "--comm-timeout", "3"], timeout=120)
+    took = time.monotonic() - t0
+    assert r.returncode != 0 and not r.stdout.strip()
+    assert "PeerLost: rank 1 sent nothing for 3 s" in r.stderr, r.stderr[-3000:]
+    assert "rank 1 of 2 did not exit and had to be stopped (stuck?)" in r.stderr
+    assert "rank 1 stopped by the launcher while still running" in r.stderr
+    assert took < 60, took
+
+
+def test_preflight_reports_every_rank(emu_cdll):
+    r = _run(["--gpus", "2", "--dist-backend", "sockets", "--preflight"], timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = r.stdout.strip().splitlines()
+    assert len(lines) == 1
+    rep = json.loads(lines[0])
+    assert rep["preflight"] is True and rep["n_gpus"] == 2 and rep["ranks_in_communicator"] == 2 and len(rep["ranks"]) == 2
+    for k, row in enumerate(rep["ranks"]):
+        assert row["rank"] == k and row["transport"] == "sockets" and row["peer_access"] == [1] and row["hbm_total_gb"] > 0
+        assert row["comm_init_s"] >= 0 and row["first_step_s"] > 0 and row["allgather_us"] > 0 and "msm_table" in row

@@ -146,3 +146,70 @@ def test_headline_configuration_is_bit_identical_to_the_bucket_method():
     assert out["contexts"] == 8 and out["hw_queues"] == 8 and out["comb_teeth"] == 20 and out["table_bytes"] == 2048 * (1 << 19) * 64
     assert out["proofs"] == 8192 and out["identical_to_bucket_method"] == 8192 and out["fixtures"] == 2 and len(out["pairing_checked"]) == 4
     print("headline configuration:", out)
+
+
+@pytest.mark.gpu
+def test_a_killed_rank_of_eight_stops_the_job_within_seconds():
+    """VERDICT r05 #1 on real kernels: eight processes on the one GPU (sockets transport), rank 5 is SIGKILLed between enqueueing its
+    batches and the gather of timed step 1.  The launcher names it; the other ranks give up on their own (PeerLost, exit code 76) or
+    are stopped; nothing waits for a timeout."""
+    import time
+
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    t0 = time.monotonic()
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "8", "--dist-backend", "sockets", "--steps", "3", "--warmup", "1",
+                        "--batch", "64", "--batches-per-step", "2", "--streams", "2", "--hw-queues", "4", "--lookup-budget-gb", "4", "--comm-timeout", "20",
+                        "--inject-fault", "5:1:kill"] + SHORT, env=env, capture_output=True, text=True, timeout=900)
+    took = time.monotonic() - t0
+    assert r.returncode != 0 and not r.stdout.strip(), (r.returncode, r.stdout[-500:])
+    assert "rank 5 of 8 was killed by SIGKILL first" in r.stderr, r.stderr[-4000:]
+    assert "PeerLost" in r.stderr  # rank 0 lost rank 5 and said so
+    print("killed rank named after %.1f s" % took)
+    assert took < 240, took  # (eight start-ups and table builds on one GPU; the failure itself is seen within a second)
+
+
+@pytest.mark.gpu
+def test_comm_init_has_a_deadline_on_real_rccl(tmp_path):
+    """ncclCommInitRank for rank 0 of TWO with nobody playing rank 1: plonk_comm_create gives up after the process-wide deadline with
+    PLONK_ERR_TIMEOUT and a message naming rank, world and device (before: it blocked for ever).  A subprocess, ended with os._exit:
+    the helper thread is still inside RCCL."""
+    script = tmp_path / "init_deadline.py"
+    script.write_text(
+        "import ctypes, os, sys, time\n"
+        "sys.path.insert(0, %r)\n"
+        "from plonkathon_amd import Context, _lib\n"
+        "ctx = Context(0)\n"
+        "L = ctx.L\n"
+        "assert L.plonk_comm_set_default_timeout(3.0) == 0\n"
+        "ident = ctypes.create_string_buffer(128)\n"
+        "assert L.plonk_comm_unique_id(ident) == 0\n"
+        "h = ctypes.c_void_p()\n"
+        "t0 = time.monotonic()\n"
+        "rc = L.plonk_comm_create(ctx.handle, ident, 0, 2, ctypes.byref(h))\n"
+        "print(rc, '%%.1f' %% (time.monotonic() - t0), L.plonk_last_error().decode(), flush=True)\n"
+        "os._exit(0)\n" % REPO)
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rc, took, msg = r.stdout.strip().splitlines()[-1].split(" ", 2)
+    assert int(rc) == -5 and 2.5 <= float(took) <= 30, r.stdout
+    assert "ncclCommInitRank(rank 0 of 2, device 0) did not return within 3 s" in msg, msg
+
+
+@pytest.mark.gpu
+def test_preflight_on_a_one_rank_rccl_communicator():
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--force-comm", "--preflight", "--batch", "64",
+                        "--batches-per-step", "2", "--streams", "2", "--lookup-budget-gb", "4"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    rep = json.loads(lines[0])
+    row = rep["ranks"][0]
+    assert rep["preflight"] is True and rep["ranks_in_communicator"] == 1 and rep["all_peers_reachable"] is True
+    assert row["transport"] == "rccl" and os.path.basename(row["rccl_path"]).startswith("librccl.so") and row["rccl_version"] != "0.0.0"
+    assert row["peer_access"][row["device"]] == 1 and row["hbm_total_gb"] > 200 and 0 < row["hbm_free_gb"] <= row["hbm_total_gb"]
+    assert row["msm_table"]["layout"] == "comb" and row["msm_table"]["bits"] == 15 and row["msm_table"]["build_s"] > 0
+    assert row["allgather_us"] > 0 and row["allgather_measured_by"].startswith("HIP events")
+    print("preflight:", row)
