@@ -250,7 +250,8 @@ def emit(line, detail, detail_path):
     """ONE line on stdout, under LINE_LIMIT bytes; the detail beside it and on stderr."""
     line = _round(line)
     text = json.dumps(line, separators=(",", ":"))
-    for optional in (("per_rank", "proofs_per_s"), ("roofline", "secondary", "valu"), ("roofline", "valu"), ("per_rank",), ("roofline", "secondary")):
+    for optional in (("per_rank", "proofs_per_s"), ("roofline", "secondary", "valu"), ("roofline", "valu"), ("roofline", "step_valu_source"), ("roofline", "valu_source"),
+                     ("roofline", "traffic_source"), ("per_rank",), ("roofline", "secondary")):
         if len(text) < LINE_LIMIT:
             break
         d = line  # shed optional blocks (they stay in the detail file) rather than print a line the driver cannot keep
@@ -431,19 +432,25 @@ def main():
     B, S = args.batch, args.batches_per_step
     NS = max(1, args.streams or S)
     ctxs = [ctx] + [Context(local_rank) for _ in range(NS - 1)]
-    groups = 0
+    # Workgroups per MSM: the library cuts an MSM into as many workgroups as fill the chip in whole rounds ON ITS OWN (1 536 MSMs
+    # into 3 072 workgroups); with eight or more streams the other streams' kernels fill a partial round, and one workgroup per
+    # MSM — half the per-column trees — is 0.5 - 1 % faster (profiles/r05_u_msm_groups_ab.txt).  --msm-groups overrides.
+    # The knobs are per-context state: they are set through Context.tuning() and leave with `knobs.close()` right after the timed
+    # region (everything measured below it runs on the library defaults unless --msm-groups / --ntt-kind pinned them explicitly)
+    import contextlib
+
+    groups = args.msm_groups if args.msm_groups >= 0 else (1 if NS >= 8 else 0)
+    knobs = contextlib.ExitStack()
     for c in ctxs:
         c.msm_lookup(1 if args.no_lookup else 0, 0, budget)
-        # Workgroups per MSM: the library cuts an MSM into as many workgroups as fill the chip in whole rounds ON ITS OWN (1 536 MSMs
-        # into 3 072 workgroups); with eight or more streams the other streams' kernels fill a partial round, and one workgroup per
-        # MSM — half the per-column trees — is 0.5 - 1 % faster (profiles/r05_u_msm_groups_ab.txt).  --msm-groups overrides.
-        groups = args.msm_groups if args.msm_groups >= 0 else (1 if NS >= 8 else 0)
-        if groups:
-            c.msm_configure(0, groups)
-        if args.ntt_kind:
+        if args.ntt_kind:  # explicit: for the whole run
             from plonkathon_amd._lib import check as _check
 
             _check(c.L.plonk_ntt_select_kernel(c.handle, args.ntt_kind))
+        if args.msm_groups >= 0:  # explicit: for the whole run
+            c.msm_configure(0, args.msm_groups)
+        elif groups:
+            knobs.enter_context(c.tuning(msm_groups=groups))
     setup = Setup.from_file(PTAU)
     program = Program(chain_program_lines(GROUP_ORDER), GROUP_ORDER)
     per_gpu = B * S
@@ -593,9 +600,7 @@ def main():
     # The same kernel with the chip to itself: with several streams a launch's event-to-event duration includes the time
     # it shares the CUs with the other streams' kernels, so the per-launch figures of the timed region understate the
     # kernel.  A short untimed phase runs the batches of stream 0 alone (the other streams idle) and reads its events.
-    if args.msm_groups < 0:  # the timed region's one-workgroup-per-MSM setting is for many streams: everything below runs one
-        for c in ctxs:
-            c.msm_configure(0, 0)
+    knobs.close()  # the timed region's one-workgroup-per-MSM setting is for many streams: everything below runs one
     iso = None
     if NS > 1 and msm_launches:
         barrier()
@@ -742,6 +747,14 @@ def main():
         if valu and valu.get(msm_kernel + "_kernel"):
             v = valu[msm_kernel + "_kernel"]
             roof["valu"] = {k: v.get(k) for k in ("valu_busy", "valu_insts_per_addition", "cycles_per_valu_inst")}
+        # where the replayed figures come from (rocprofv3 cannot run inside this process: they are this round's committed counter
+        # passes, not measurements of this run), and the WHOLE step's issue-slot account (tools/pmc_step.sh: every kernel of a
+        # 20-stream step, VALU-active cycles over the step's cycles)
+        roof["traffic_source"], roof["valu_source"] = pmc_src, (valu["source"] if valu else None)
+        stepv, stepv_src = legs.latest_profile("step_valu.json")
+        if stepv and B == 512 and info["layout"] == "comb":
+            roof["step_valu_busy"] = stepv.get("step_valu_busy")
+            roof["step_valu_source"] = stepv_src
         line["roofline"] = roof
         detail["roofline"] = dict(roof, **{
             "algorithmic_bytes_per_launch": bytes_per_launch, "msms_per_launch": msms_per_launch, "mixed_additions_per_msm": windows * GROUP_ORDER,

@@ -81,25 +81,6 @@ int plonk_fr_coset_extend(plonk_ctx* ctx, const void* d_in, void* d_out, unsigne
                           const uint8_t offset_le32[32], size_t batch);
 int plonk_fr_coset_to_coeffs(plonk_ctx* ctx, const void* d_in, void* d_out, unsigned log_m,
                              const uint8_t offset_le32[32], size_t batch);
-/* tuning / test knob (0 = default): LDS tile = 2^tile_log elements (<= 12), sizes <= 2^single_pass_log
- * (<= 11) run as one pass, larger sizes split into passes of radix <= 2^radix_log (<= 10). */
-int plonk_ntt_configure(plonk_ctx* ctx, unsigned tile_log, unsigned single_pass_log, unsigned radix_log);
-/* kernel family: 0 = auto (what measures fastest on MI355X: the in-register "wave" kernels — 2, 4 or 8 elements per
- * thread as signed 29-bit limbs, digits exchanged inside a wave by DPP / v_permlane16_swap / v_permlane32_swap, LDS only
- * across waves — for 2^7 .. 2^13 in one launch and 2^14 .. 2^26 as two passes of those; the LDS kernel, radix-2 stages,
- * below 2^7 and above 2^26), 1 = the LDS kernel at every size, 4 = the same (A/B runs; it used to choose among two LDS
- * kernels), 5 = the wave kernels wherever they apply, whatever plonk_ntt_configure says; 6 / 7 = as 5, but never / always
- * on the two-element "latency" forms (2^9, and the splits of 2^14 .. 2^18 built on 2^7 and 2^9) that 0 and 5 pick for
- * calls of at most 2^18 elements; 8 = as 5, with 2^12 on its 1024-thread, 4-element form instead of 512 threads x 8
- * elements (which 0 and 5 use wherever 2^12 is not a column pass on the one-table inter-pass twiddles).
- * (2, the Stockham LDS kernel, and 3 are retired.) */
-int plonk_ntt_select_kernel(plonk_ctx* ctx, unsigned kind);
-/* two-pass wave transforms N = R1 R2 (R1-point column transforms, then R2-point row transforms): log2 R1 for one
- * log2 N in [16, 26]; 0 = the default (as square as possible).  Both factors must lie in 2^8 .. 2^13.  A/B runs, tests. */
-int plonk_ntt_set_split(plonk_ctx* ctx, unsigned log_n, unsigned log_r1);
-/* log2 R1 of the split in force for 2^log_n (ctx NULL: the library default, which is what the distributed transform
- * uses on every rank — its column / frequency-strided layouts are [R1][R2 / W] and [R2][R1 / W]) */
-int plonk_ntt_get_split(plonk_ctx* ctx, unsigned log_n, unsigned* out_log_r1);
 /* Two-pass transforms multiply every output of the column pass by w_N^(column * frequency).  Within this budget (bytes per
  * context, default 4 GiB; 0 = never) the library keeps those N factors per (size, direction) as one table in the order
  * the kernel reads them — 80 bytes per point: 84 MB at 2^20, 1.3 GB at 2^24 — and spends one multiplication per element
@@ -202,8 +183,6 @@ int plonk_srs_lagrange(plonk_ctx* ctx, plonk_srs* srs, unsigned log_n, plonk_srs
 int plonk_srs_size(const plonk_srs* srs, size_t* out_n);
 int plonk_g1_msm(plonk_ctx* ctx, plonk_srs* srs, const void* d_scalars, size_t n, size_t batch,
                  size_t scalar_stride, uint8_t* h_out_xy_le, uint8_t* h_out_is_identity);
-/* tuning knobs (0 = library default): window bits c and window-groups per MSM (bucket method) */
-int plonk_msm_configure(plonk_ctx* ctx, unsigned window_bits, unsigned groups);
 /* Table MSM: for a reusable SRS (plonk_srs_load_ptau) a table per base is precomputed once into HBM, after which an MSM is
  * N * a mixed additions of looked-up points: no sorting, no buckets.  Two layouts, same results as the bucket method
  * (curve.py:38-111), bit for bit:
@@ -374,6 +353,34 @@ int plonk_transcript_challenge_bytes(plonk_transcript* t, const uint8_t* label, 
                                      size_t n);
 int plonk_transcript_challenge_scalar(plonk_transcript* t, const uint8_t* label, size_t label_len,
                                       uint8_t out_le32[32]);
+
+/* ---- DIAGNOSTICS: tuning knobs (tests, A/B runs, bench.py) --------------------------------------------------------
+ * Not part of the drop-in surface: nothing in the reference corresponds to them and no caller needs them — the defaults are
+ * what measured fastest on MI355X.  They are PER-CONTEXT MUTABLE STATE (a setting stays until it is set back to 0), so a
+ * caller that uses one should scope it: plonkathon_amd.Context.tuning() is a `with` block that restores the defaults, and it
+ * is how bench.py sets them.  (Resource POLICIES — how much HBM the library may take — are with their subsystems:
+ * plonk_ntt_set_table_budget, plonk_msm_lookup_configure.) */
+/* tuning / test knob (0 = default): LDS tile = 2^tile_log elements (<= 12), sizes <= 2^single_pass_log
+ * (<= 11) run as one pass, larger sizes split into passes of radix <= 2^radix_log (<= 10). */
+int plonk_ntt_configure(plonk_ctx* ctx, unsigned tile_log, unsigned single_pass_log, unsigned radix_log);
+/* kernel family: 0 = auto (what measures fastest on MI355X: the in-register "wave" kernels — 2, 4 or 8 elements per
+ * thread as signed 29-bit limbs, digits exchanged inside a wave by DPP / v_permlane16_swap / v_permlane32_swap, LDS only
+ * across waves — for 2^7 .. 2^13 in one launch and 2^14 .. 2^26 as two passes of those; the LDS kernel, radix-2 stages,
+ * below 2^7 and above 2^26), 1 = the LDS kernel at every size, 4 = the same (A/B runs; it used to choose among two LDS
+ * kernels), 5 = the wave kernels wherever they apply, whatever plonk_ntt_configure says; 6 / 7 = as 5, but never / always
+ * on the two-element "latency" forms (2^9, and the splits of 2^14 .. 2^18 built on 2^7 and 2^9) that 0 and 5 pick for
+ * calls of at most 2^18 elements; 8 = as 5, with 2^12 on its 1024-thread, 4-element form instead of 512 threads x 8
+ * elements (which 0 and 5 use wherever 2^12 is not a column pass on the one-table inter-pass twiddles).
+ * (2, the Stockham LDS kernel, and 3 are retired.) */
+int plonk_ntt_select_kernel(plonk_ctx* ctx, unsigned kind);
+/* two-pass wave transforms N = R1 R2 (R1-point column transforms, then R2-point row transforms): log2 R1 for one
+ * log2 N in [16, 26]; 0 = the default (as square as possible).  Both factors must lie in 2^8 .. 2^13.  A/B runs, tests. */
+int plonk_ntt_set_split(plonk_ctx* ctx, unsigned log_n, unsigned log_r1);
+/* log2 R1 of the split in force for 2^log_n (ctx NULL: the library default, which is what the distributed transform
+ * uses on every rank — its column / frequency-strided layouts are [R1][R2 / W] and [R2][R1 / W]) */
+int plonk_ntt_get_split(plonk_ctx* ctx, unsigned log_n, unsigned* out_log_r1);
+/* tuning knobs (0 = library default): window bits c and window-groups per MSM (bucket method) */
+int plonk_msm_configure(plonk_ctx* ctx, unsigned window_bits, unsigned groups);
 
 /* ---- timing support for bench.py (HIP events on the context's stream) ------------------------ */
 int plonk_timer_start(plonk_ctx* ctx);

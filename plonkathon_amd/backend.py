@@ -3,6 +3,7 @@
 One `Context` per (process, device) wraps a `plonk_ctx*`; `DeviceBuffer` owns one `plonk_mem_alloc`
 allocation and frees it when garbage collected (SURVEY.md §8(b) "Ownership").
 """
+import contextlib
 import ctypes
 import os
 
@@ -98,6 +99,22 @@ class Context:
     def msm_configure(self, window_bits=0, groups=0):
         """Bucket-method tuning knobs (0 = library default)."""
         check(self.L.plonk_msm_configure(self.handle, window_bits, groups))
+
+    @contextlib.contextmanager
+    def tuning(self, msm_window_bits=0, msm_groups=0, ntt_kind=0):
+        """The diagnostics knobs of include/plonk_hip.h (plonk_msm_configure, plonk_ntt_select_kernel) for the length of a
+        `with` block: they are per-context mutable state, and a caller that forgets to reset them measures the wrong thing
+        afterwards — on exit the library defaults are back, whatever happened inside."""
+        check(self.L.plonk_msm_configure(self.handle, msm_window_bits, msm_groups))
+        if ntt_kind:
+            check(self.L.plonk_ntt_select_kernel(self.handle, ntt_kind))
+        try:
+            yield self
+        finally:
+            if self.handle:
+                self.L.plonk_msm_configure(self.handle, 0, 0)
+                if ntt_kind:
+                    self.L.plonk_ntt_select_kernel(self.handle, 0)
 
     def msm_lookup(self, mode=0, bits=0, budget_bytes=0, windows=False):
         """Table-MSM policy (include/plonk_hip.h): mode 0 auto, 1 off, 2 force `bits` for every base set; comb tables (bits =

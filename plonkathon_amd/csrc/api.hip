@@ -572,10 +572,15 @@ static int srs_alloc(plonk_ctx* ctx, size_t n_points, plonk_srs** out) {
 }
 
 // Registry key of a base set: FNV-1a of the loaded bytes (a 64-bit hash is NOT an identity: the lookup-table registry compares
-// the bases themselves before it shares a table, msm.hip: lut_verified).  PLONK_TEST_SRS_KEY forces a constant key so that the
-// tests can file two different base sets under ONE key and watch the registry tell them apart.
+// the bases themselves before it shares a table, msm.hip: lut_verified).
+// TEST HOOK, unsupported: with PLONK_ENABLE_TEST_HOOKS=1, PLONK_TEST_SRS_KEY replaces the hash by a constant so that the tests can
+// file two different base sets under ONE key and watch the registry tell them apart.  The salt (which keeps .ptau and affine
+// loads in separate key spaces) stays in force, and without the first variable the second is ignored: a stray setting in a
+// production environment cannot collapse the registry.
 static uint64_t srs_content_key(const void* bytes, size_t n, uint64_t salt) {
-    if (const char* e = getenv("PLONK_TEST_SRS_KEY")) return strtoull(e, nullptr, 0);
+    const char* hooks = getenv("PLONK_ENABLE_TEST_HOOKS");  // (an SRS load is rare: two getenv calls cost nothing here)
+    if (hooks && !strcmp(hooks, "1"))
+        if (const char* e = getenv("PLONK_TEST_SRS_KEY")) return strtoull(e, nullptr, 0) ^ salt;
     return plonk_fnv1a64(bytes, n) ^ salt;
 }
 

@@ -232,7 +232,11 @@ PLONK_HD bool g1l_madd_fast(G1XyzzL& p, const Fq& x2p, const Fq& y2p, bool neg_y
 // where a call would cost the kernel its registers, hands the whole MSM to the general-formula kernel.
 // Bounds (|value| / m): U1, U2 <= 7 * 4, S1, S2, ZZ1 ZZ2, ZZZ1 ZZZ2 <= 16; P, R in (-3, 3); P^2 <= 9, P PP <= 6, U1 PP <= 4,
 // (ZZ1 ZZ2) PP <= 4; X3 = R^2 - PPP - 2Q in (-7, 5); D = Q - X3 in (-6, 9); R D + S1 PPP <= 27 + 4 — all below 128.
-PLONK_HD bool g1l_add_fast(G1XyzzL& p, const G1XyzzL& q) {
+// OPPOSITE_OK: p == -q is resolved here (the sum is the identity: one more exact test, reached only on equal x) and only p == q
+// still returns false.  For the last steps of an MSM whose true result is the identity — every scalar zero (a zero selector
+// polynomial), or cancelling terms: the comb recoding turns a zero scalar into r, so the cancellation happens in the final
+// Horner / butterfly addition and would otherwise send the whole MSM to the general-formula kernel.
+template <bool OPPOSITE_OK = false> PLONK_HD bool g1l_add_fast(G1XyzzL& p, const G1XyzzL& q) {
     if (q.inf) return true;
     if (p.inf) {
         p = q;
@@ -240,7 +244,15 @@ PLONK_HD bool g1l_add_fast(G1XyzzL& p, const G1XyzzL& q) {
     }
     const FqL u1 = fpl_mul(p.x, q.zz), u2 = fpl_mul(q.x, p.zz);
     const FqL pp_ = fpl_sub(u2, u1);
-    if (fpl_is_zero_mod_in<FqParams, -3, 3>(pp_)) return false;
+    if (fpl_is_zero_mod_in<FqParams, -3, 3>(pp_)) {
+        if constexpr (OPPOSITE_OK) {
+            const FqL t1 = fpl_mul(p.y, q.zzz), t2 = fpl_mul(q.y, p.zzz);
+            if (fpl_is_zero_mod_in<FqParams, -3, 3>(fpl_sub(t2, t1))) return false;  // equal points: a doubling, the caller's business
+            p = g1l_identity();  // equal x, different y: opposite points
+            return true;
+        }
+        return false;
+    }
     const FqL s1 = fpl_mul(p.y, q.zzz), s2 = fpl_mul(q.y, p.zzz);
     const FqL rr = fpl_sub(s2, s1);
     const FqL pp = fpl_sqr(pp_);

@@ -972,8 +972,11 @@ static int msm_table_build(plonk_ctx* ctx, plonk_srs* srs, unsigned kind, unsign
 
 static size_t msm_default_lookup_budget() {
     // The table is a memory-for-time trade the CALLER opts into beyond a modest default: 1/16 of the device's memory (18 GB of an
-    // MI355X's 288: the comb of 17 teeth for 2^11 bases, 8.6 GB + 1.1 GB while it is built, 15 additions per base), more only
-    // through plonk_msm_lookup_configure(budget) or PLONK_MSM_TABLE_GB (bench.py asks for the 68.7 GB comb of 20 teeth: 13 additions).
+    // MI355X's 288: the comb of 17 teeth for 2^11 bases, 8.6 GB + 1.1 GB while it is built, 15 additions per base) and never more
+    // than a quarter of what is FREE at the moment — the default is per process and per SRS family, so several processes or
+    // several SRS on one device each take theirs (eight ranks sharing a GPU: 8 x 9.7 GB), and a device that is already
+    // nearly full must not be pushed over by a table nobody asked for.  More only through plonk_msm_lookup_configure(budget)
+    // or PLONK_MSM_TABLE_GB (bench.py asks for the 68.7 GB comb of 20 teeth: 13 additions).
     // Window tables, measured (profiles/r05_d_msm_sweep.jsonl, 1152 MSMs of 2^11 per call): c = 11 4.50 ms, 12 4.11, 13 3.86, 14 3.65.
     const char* e = getenv("PLONK_MSM_TABLE_GB");
     if (e && atof(e) > 0) return (size_t)(atof(e) * 1e9);
@@ -982,7 +985,7 @@ static size_t msm_default_lookup_budget() {
         (void)hipGetLastError();
         return (size_t)4 << 30;
     }
-    return total_b / 16;
+    return total_b / 16 < free_b / 4 ? total_b / 16 : free_b / 4;
 }
 
 // Decides whether this call runs on a lookup table: attaches the table another context of this device already

@@ -30,7 +30,9 @@
 //                               scalars in 13 columns.  The pieces are tree-reduced per column through LDS; the workgroup
 //                               stores a column sums.
 //   msm_comb_colsum_kernel      (only when an MSM is cut into >= 4 workgroups) a wave per (MSM, column) sums the workgroups' sums
-//   msm_comb_finalize_kernel    sum_j 2^j S_j by Horner over groups of LPM lanes per MSM, deferred additions, unique affine form
+//   msm_comb_finalize_kernel    sum_j 2^j S_j by Horner over groups of LPM lanes per MSM, deferred additions, unique affine form; an
+//                               addition of OPPOSITE operands gives the identity here (an MSM whose result is the identity — all
+//                               scalars zero — cancels in these last additions, not before)
 //   msm_comb_slow_kernel        the recovery path of MSM_DEFER_CAP (general formulas throughout)
 // Table build: msm_comb_scale_kernel gives P'_i; msm_table_kernel G_k = 2^(a k) P'_i; msm_comb_fill_kernel walks each run of 2^8 consecutive indices in
 // Gray-code order (one mixed addition of +-2 G_k per entry); g1_batch_to_affine_kernel converts a chunk of bases at a time.
@@ -306,7 +308,7 @@ template <unsigned LPM> __global__ void __launch_bounds__(64) msm_comb_finalize_
 #pragma unroll 1
                 for (unsigned d = 0; d < LPM; d++) g1l_dbl(acc);
 #pragma unroll 1
-            for (unsigned g = 0; g < G; g++) ok &= g1l_add_fast(acc, g1l_from_piece(&sums[(m * G + g) * a + j]));
+            for (unsigned g = 0; g < G; g++) ok &= g1l_add_fast<true>(acc, g1l_from_piece(&sums[(m * G + g) * a + j]));  // (<true>: opposite operands give the identity)
 #pragma unroll 1
             for (uint32_t k = 0; k < nd; k++) {
                 const MsmDeferred e = deferred[m * deferred_stride + k];  // `bucket` carries the item j * n + i here
@@ -321,12 +323,12 @@ template <unsigned LPM> __global__ void __launch_bounds__(64) msm_comb_finalize_
 #pragma unroll 1
         for (unsigned d = 0; d < l; d++) g1l_dbl(acc);
     }
-    if constexpr (LPM >= 2) ok &= g1l_wave_reduce_step<1>(acc, lane);
-    if constexpr (LPM >= 4) ok &= g1l_wave_reduce_step<2>(acc, lane);
-    if constexpr (LPM >= 8) ok &= g1l_wave_reduce_step<4>(acc, lane);
-    if constexpr (LPM >= 16) ok &= g1l_wave_reduce_step<8>(acc, lane);
-    if constexpr (LPM >= 32) ok &= g1l_wave_reduce_step<16>(acc, lane);
-    if constexpr (LPM >= 64) ok &= g1l_wave_reduce_step<32>(acc, lane);
+    if constexpr (LPM >= 2) ok &= g1l_wave_reduce_step<1, true>(acc, lane);
+    if constexpr (LPM >= 4) ok &= g1l_wave_reduce_step<2, true>(acc, lane);
+    if constexpr (LPM >= 8) ok &= g1l_wave_reduce_step<4, true>(acc, lane);
+    if constexpr (LPM >= 16) ok &= g1l_wave_reduce_step<8, true>(acc, lane);
+    if constexpr (LPM >= 32) ok &= g1l_wave_reduce_step<16, true>(acc, lane);
+    if constexpr (LPM >= 64) ok &= g1l_wave_reduce_step<32, true>(acc, lane);
     if (m < M && !ok) atomicOr(n_deferred + m, MSM_COMB_REDO);
     if (m < M && l == 0) {
         G1Affine r = g1_to_affine(g1l_to_xyzz(acc));

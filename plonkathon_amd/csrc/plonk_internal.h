@@ -135,7 +135,7 @@ struct plonk_ctx {
     int msm_lookup_mode = 0;         // 0 auto (fixed SRS only), 1 off, 2 force msm_lookup_bits for every base set
     unsigned msm_lookup_bits = 0;    // 0 = the table with the fewest additions per base that fits the budget
     unsigned msm_lookup_kind = MSM_TABLE_COMB;  // layout of the tables this context builds (plonk_msm_lookup_configure: mode | 16 = window tables)
-    size_t msm_lookup_budget = 0;    // bytes; 0 = default (PLONK_MSM_TABLE_GB if set, else 4 GiB)
+    size_t msm_lookup_budget = 0;    // bytes; 0 = default (PLONK_MSM_TABLE_GB if set, else min(device memory / 16, free memory / 4): msm.hip)
     bool ntt_attr_set = false, msm_attr_set = false;  // hipFuncSetAttribute is per device: tracked per context
     // per-kernel HIP-event profiling (bench.py roofline): one record per instrumented launch
     struct ProfRec { const char* name; hipEvent_t a, b; double algo_bytes; };

@@ -81,7 +81,7 @@ template <unsigned MASK> PLONK_DEV void g1_wave_reduce_step(G1Xyzz& p, unsigned 
 
 // the same on lazy limbs (g1l_add: ~2 700 instructions against ~4 600): the Horner step of the comb MSM (msm_comb.h)
 // returns false (p untouched in that lane) where the two operands were equal or opposite: g1l_add_fast
-template <unsigned MASK> PLONK_DEV bool g1l_wave_reduce_step(G1XyzzL& p, unsigned lane) {
+template <unsigned MASK, bool OPPOSITE_OK = false> PLONK_DEV bool g1l_wave_reduce_step(G1XyzzL& p, unsigned lane) {
     G1XyzzL o;
 #pragma unroll
     for (int i = 0; i < 9; i++) {
@@ -91,7 +91,7 @@ template <unsigned MASK> PLONK_DEV bool g1l_wave_reduce_step(G1XyzzL& p, unsigne
         o.zzz.l[i] = (int32_t)wave_lane_xor<MASK>((uint32_t)p.zzz.l[i], lane);
     }
     o.inf = wave_lane_xor<MASK>(p.inf ? 1u : 0u, lane) != 0;
-    return g1l_add_fast(p, o);
+    return g1l_add_fast<OPPOSITE_OK>(p, o);
 }
 
 // Suffix sums over the lanes of a wave: afterwards lane l holds p_l + p_(l+1) + .. + p_63 (Hillis-Steele; the value of

@@ -226,10 +226,14 @@ def _g1_neg(pt):
 G2 = (Fq2(_G2_COORDS[0]), Fq2(_G2_COORDS[1]))
 
 
-# Largest 2^k for which Setup.commit builds the Lagrange-basis SRS on first use.  Up to 2^12 the view is n MSMs of size n (a few
-# milliseconds at the prover's sizes); above, an inverse DFT over the group (csrc/g1_ntt.hip: n log n group operations, tens of
-# milliseconds at 2^16) — round 4 stopped at 2^12 because only the quadratic route existed.
-LAGRANGE_SRS_MAX_LOG = 28
+# Setup.commit and the Lagrange-basis SRS.  Up to 2^LAGRANGE_SRS_EAGER_LOG the view is built by the FIRST commit of a size (n MSMs
+# of size n: a few milliseconds at the prover's sizes).  Above it the view is an inverse DFT over the group (csrc/g1_ntt.hip: log n
+# stages of n / 2 scalar multiplications, tens of milliseconds at 2^16, about a second at 2^20) plus 2 n 128 B of staging, and a fixed
+# SRS then gets a comb table of its own charged to the budget: that pays only when a size is committed repeatedly, so the first
+# commit of such a size takes the reference's route (ifft + one MSM, setup.py:66-72) and the SECOND builds the view.  Beyond
+# 2^LAGRANGE_SRS_MAX_LOG no view is built at all (the largest size the GPU tests cover the group transform at is 2^16).
+LAGRANGE_SRS_EAGER_LOG = 12
+LAGRANGE_SRS_MAX_LOG = 20
 
 
 class Setup:
@@ -244,6 +248,7 @@ class Setup:
         self._raw = _g1_mont_bytes
         self._n = len(_g1_mont_bytes) // 64
         self._dev = {}  # per-context device copies (bases + window table)
+        self._commits = {}  # log2(size) -> Lagrange-value commits seen (a large size builds its view on the second)
 
     # setup.py:23-63
     @classmethod
@@ -293,9 +298,9 @@ class Setup:
         n = len(values)
         assert n <= self._n  # setup.py:70
         bases, log_n = self.device_bases(), _log2_exact(n)
-        # Building the view is a one-off per size (n MSMs of size n up to 2^12, an EC inverse NTT above); beyond
-        # LAGRANGE_SRS_MAX_LOG polynomials take the reference's route, ifft then one MSM.
-        if log_n > LAGRANGE_SRS_MAX_LOG and log_n not in bases._views:
+        seen = self._commits.get(log_n, 0)
+        self._commits[log_n] = seen + 1
+        if log_n not in bases._views and (log_n > LAGRANGE_SRS_MAX_LOG or (log_n > LAGRANGE_SRS_EAGER_LOG and seen == 0)):
             return self.commit_coeffs(values.ifft())
         lag = bases.lagrange(log_n)
         return _msm(lag, values.device().ptr, n, 1, n)[0]

@@ -1024,6 +1024,13 @@ def comb_table_shapes(shapes, seed=5150):
             got = pa.ec_lincomb(pairs)
             want = og1.ec_lincomb(list(zip(pts, sc)))
             assert (None if got is None else affine(got)) == want, (h, n, groups)
+            # a result that IS the identity: every scalar zero (the recoding turns 0 into r: the sum cancels in the last Horner /
+            # butterfly addition, which the finalize kernel resolves itself), and a pair s P + (r - s) P among zeros
+            assert pa.ec_lincomb([(q, 0) for q, _ in pairs]) is None, (h, n, groups, "all scalars zero")
+            if n >= 2 and pairs[0][0] is not None:
+                k = rng.randrange(1, R_MOD)
+                canc = [(pairs[0][0], k), (pairs[0][0], R_MOD - k)] + [(q, 0) for q, _ in pairs[2:]]
+                assert pa.ec_lincomb(canc) is None, (h, n, groups, "cancelling pair")
     finally:
         ctx.msm_lookup(0)
         ctx.msm_configure(0, 0)
@@ -1078,6 +1085,9 @@ def lagrange_srs_by_ntt(log_ns):
             assert got["ntt"][0] == og1.ec_lincomb(list(zip(osetup.powers_of_x[:n], coeffs))), log_n
 
 
+import plonkathon_amd.kzg as pk  # noqa: E402
+
+
 def lagrange_srs_beyond_2e12(log_n=13):
     """Above 2^12 only the group NTT builds the view (round 4 fell back to ifft + MSM there).  The .ptau slice holds 2^11 points, so
     the base set is synthetic — s_j G for random s_j, made by one batched MSM of size 1 — which is all the transform needs: it is
@@ -1101,9 +1111,12 @@ def lagrange_srs_beyond_2e12(log_n=13):
     pts = _msm(gen, buf.ptr, 1, n, 1)
     s = Setup(pts)
     vals = [rng.randrange(R_MOD) for _ in range(n)]
-    a = s.commit(P(vals))
-    assert log_n in s.device_bases()._views  # the view was built (by the group NTT: log_n > 12)
     b = s.commit_coeffs(P(vals).ifft())
+    if log_n > pk.LAGRANGE_SRS_EAGER_LOG:
+        # a one-off commit of a large size takes the reference's route (ifft + one MSM): no view, no staging, no second table
+        assert affine(s.commit(P(vals))) == affine(b) and log_n not in s.device_bases()._views
+    a = s.commit(P(vals))
+    assert log_n in s.device_bases()._views  # a size committed again gets its view (by the group NTT: log_n > 12)
     assert affine(a) == affine(b)
     first = affine(s.commit(P([1] + [0] * (n - 1))))
     assert first == og1.multiply((1, 2), sum(sc) * pow(n, -1, R_MOD) % R_MOD)
@@ -1157,6 +1170,7 @@ def lookup_table_colliding_key():
     same = Setup(list(pts))
     first = Setup(list(pts))
     coeffs = list(range(3, 3 + 64))
+    os.environ["PLONK_ENABLE_TEST_HOOKS"] = "1"  # (without it the library ignores PLONK_TEST_SRS_KEY)
     os.environ["PLONK_TEST_SRS_KEY"] = "0x1234"
     try:
         for ctx in (a, b, c):
@@ -1174,6 +1188,7 @@ def lookup_table_colliding_key():
         assert i1["sharers"] == 2 and i3["sharers"] == 2 and i2["sharers"] == 1, (i1, i2, i3)
     finally:
         del os.environ["PLONK_TEST_SRS_KEY"]
+        del os.environ["PLONK_ENABLE_TEST_HOOKS"]
         for ctx in (a, b, c):
             ctx.msm_lookup(0)
 

@@ -460,6 +460,7 @@ def test_msm_deferred_overflow_is_recomputed():
 def test_lagrange_srs_by_group_ntt_equals_the_msm_route():
     pc.lagrange_srs_by_ntt((0, 3, 8, 11))
     pc.lagrange_srs_beyond_2e12(13)
+    pc.lagrange_srs_beyond_2e12(16)  # the largest size the group transform is covered at (kzg.LAGRANGE_SRS_MAX_LOG caps the view at 2^20)
 
 
 @pytest.mark.gpu
