@@ -427,14 +427,27 @@ template <class P> PLONK_HD bool fpl_is_zero_mod(const FpL<P>& a) {
 #define FPL_RS_J 24
 // BIAS = 1 subtracts (j - 1) m instead: the result lies within (0.49 m, 1.51 m) — what the last store wants, one
 // conditional subtraction away from canonical (fpl_pack_positive).
-template <class P, int BIAS = 0> PLONK_HD FpL<P> fpl_reduce_small(const FpL<P>& x, const int32_t* jm) {
+// (in two halves, so that a caller with several values to reduce can request all the table entries before it needs the first:
+// fpl_reduce_small_lookup issues the loads, fpl_reduce_small_apply subtracts)
+struct FplJmEntry {
+    u32x4 t0, t1;
+    int32_t t8;
+};
+template <class P, int BIAS = 0> PLONK_HD FplJmEntry fpl_reduce_small_lookup(const FpL<P>& x, const int32_t* jm) {
     constexpr float inv_top = 1.0f / (float)(P::mod(7) >> 8);  // m >> 232
     int j = (int)rintf((float)x.l[8] * inv_top);
     FPL_CHECK(j > -FPL_RS_J && j < FPL_RS_J, "fpl_reduce_small: |value| beyond the table");
     j = j < -FPL_RS_J + BIAS ? -FPL_RS_J + BIAS : (j > FPL_RS_J ? FPL_RS_J : j);  // (memory safety only: the bound above keeps |j| <= FPL_RS_J - 1)
     const int32_t* t = jm + (j + FPL_RS_J - BIAS) * 12;
-    const u32x4 t0 = *reinterpret_cast<const u32x4*>(t), t1 = *reinterpret_cast<const u32x4*>(t + 4);
-    const int32_t t8 = t[8];
+    FplJmEntry e;
+    e.t0 = *reinterpret_cast<const u32x4*>(t);
+    e.t1 = *reinterpret_cast<const u32x4*>(t + 4);
+    e.t8 = t[8];
+    return e;
+}
+template <class P, int BIAS = 0> PLONK_HD FpL<P> fpl_reduce_small_apply(const FpL<P>& x, const FplJmEntry& e) {
+    const u32x4 t0 = e.t0, t1 = e.t1;
+    const int32_t t8 = e.t8;
     FpL<P> r;
     r.l[0] = x.l[0] - (int32_t)t0.x; r.l[1] = x.l[1] - (int32_t)t0.y; r.l[2] = x.l[2] - (int32_t)t0.z; r.l[3] = x.l[3] - (int32_t)t0.w;
     r.l[4] = x.l[4] - (int32_t)t1.x; r.l[5] = x.l[5] - (int32_t)t1.y; r.l[6] = x.l[6] - (int32_t)t1.z; r.l[7] = x.l[7] - (int32_t)t1.w;
@@ -449,6 +462,9 @@ template <class P, int BIAS = 0> PLONK_HD FpL<P> fpl_reduce_small(const FpL<P>& 
     }
 #endif
     return fpl_norm(r);
+}
+template <class P, int BIAS = 0> PLONK_HD FpL<P> fpl_reduce_small(const FpL<P>& x, const int32_t* jm) {
+    return fpl_reduce_small_apply<P, BIAS>(x, fpl_reduce_small_lookup<P, BIAS>(x, jm));
 }
 
 // host side: entry j of that table

@@ -162,6 +162,9 @@ PLONK_HD constexpr unsigned wavel_tw_offset(unsigned log_e, unsigned nlds, unsig
     return o;
 }
 #define NTT_PLANE_WORDS 4  // a plane holds 16 bytes of every entry of its block; five planes per block
+#ifndef NTT_TW_PREFETCH
+#define NTT_TW_PREFETCH 1  // 0: twiddle factors loaded where they are used (rounds 2 - 5; A/B builds)
+#endif
 
 // entry `low` of a block of nb entries
 template <class P> PLONK_DEV FpLS<P> wavel_ld_root_planar(const int32_t* block, unsigned nb, unsigned low) {
@@ -190,12 +193,34 @@ PLONK_DEV void wavel_twiddle(FpL<P> (&x)[E], unsigned low, const int32_t* roots,
     static_assert(COUNT - 1 == wavel_tw_count(LOG_E, NLDS, STAGE), "twiddle layout");
     const int32_t* blocks = roots + (size_t)wavel_tw_offset(LOG_E, NLDS, STAGE) * NTT_SHOUP_STRIDE;
     constexpr bool TIGHT_MUL = LOG_E == 3 && WAVEL_TIGHT_LOG_N(LOG_N);
-    x[BASE] = fpl_reduce_small(x[BASE], jm);
-    wave_for<COUNT - 1>([&](auto F) {
-        constexpr unsigned f = decltype(F)::value + 1;
-        x[BASE + f] = fpl_mul_shoup<P, TIGHT_MUL>(x[BASE + f], wavel_ld_root_planar<P>(blocks + (f - 1) * NB * NTT_SHOUP_STRIDE, NB, low));
-        if constexpr (TIGHT_MUL) PLONK_SCHED_FENCE();  // 128 VGPRs: keeps the scheduler from holding several twiddles in flight
-    });
+    if constexpr (TIGHT_MUL || LOG_E == 3 || !NTT_TW_PREFETCH) {  // (every 8-element kernel sits at 128 registers)
+        x[BASE] = fpl_reduce_small(x[BASE], jm);
+        wave_for<COUNT - 1>([&](auto F) {
+            constexpr unsigned f = decltype(F)::value + 1;
+            x[BASE + f] = fpl_mul_shoup<P, TIGHT_MUL>(x[BASE + f], wavel_ld_root_planar<P>(blocks + (f - 1) * NB * NTT_SHOUP_STRIDE, NB, low));
+            if constexpr (TIGHT_MUL) PLONK_SCHED_FENCE();  // 128 VGPRs: keeps the scheduler from holding several twiddles in flight
+        });
+    } else {
+        // Round 6: the compiler placed each factor's five loads a dozen instructions before the multiplication that needs them — an
+        // L2 round trip in front of every one of the ~14 twiddle multiplications of a transform, which a batch hides behind other
+        // workgroups and a lone transform (one round of workgroups, all in the same phase) does not.  Here the factor of
+        // multiplication f + 1 is requested BEFORE multiplication f starts (the fences pin the order: the scheduler would sink
+        // the loads again to save registers), the first one before the range reduction of the factor-free output: one factor
+        // (18 registers) in flight beside the one in use.  Not in the 128-register kernels (TIGHT_MUL).
+        FpLS<P> tw = wavel_ld_root_planar<P>(blocks, NB, low);
+        PLONK_SCHED_FENCE();
+        x[BASE] = fpl_reduce_small(x[BASE], jm);
+        wave_for<COUNT - 1>([&](auto F) {
+            constexpr unsigned f = decltype(F)::value + 1;
+            FpLS<P> nxt = tw;
+            if constexpr (f + 1 < COUNT) {
+                nxt = wavel_ld_root_planar<P>(blocks + f * NB * NTT_SHOUP_STRIDE, NB, low);
+                PLONK_SCHED_FENCE();
+            }
+            x[BASE + f] = fpl_mul_shoup<P, false>(x[BASE + f], tw);
+            tw = nxt;
+        });
+    }
 }
 // inputs N-form, |value| < 2.8.  Outputs: x0 in [0, 2^31) (for fpl_reduce_small), x1..x3 multiplicands; |value| < 11.2
 template <class P> PLONK_DEV void dft4l(FpL<P>& x0, FpL<P>& x1, FpL<P>& x2, FpL<P>& x3, const FpLS<P>& w2) {
@@ -323,18 +348,43 @@ PLONK_DEV void wavel_transform(const NttWaveT<P>& p, unsigned char* smem) {
     const FpLS<P> &w8_1 = p.w8[0], &w8_2 = p.w8[1], &w8_3 = p.w8[2];  // kernel arguments: scalar registers
 
     FpL<P> x[E];
-    wave_for<E>([&](auto J) {  // position j * NT + tid: consecutive lanes read consecutive positions
-        constexpr unsigned j = decltype(J)::value;
-        const unsigned pos = j * NT + tid0;
-        const unsigned g = p.chunk_stride ? (pos >> p.chunk_log) * p.chunk_stride + (pos & chunk_mask) + in_off : (pos << in_shift) + in_off;
-        x[j] = g < p.in_len ? fpl_from_fp(fp_load(wavel_at(in, g))) : fpl_zero<P>();  // [0, 2m): canonical input, or the column pass's redundant residues
-    });
-    if (p.in_scale) {
+    {
+        // The loads of a group of LB elements are issued before the first of them is waited for (round 6): with a bounds check
+        // around each load the compiler emitted load - wait - unpack per element, E memory round trips in a row at the start of
+        // every workgroup — hidden in a batch, exposed in a lone transform, whose workgroups all start together.  Out-of-range
+        // positions (zero padding n -> 4n) read element 0 instead and are masked to zero afterwards.  LB = E up to four elements
+        // per thread; the 8-element kernels sit at 128 registers and take two groups of four.
+        constexpr unsigned LB = E < 4 ? E : 4;
+        wave_for<E / LB>([&](auto GRP) {
+            constexpr unsigned j0 = decltype(GRP)::value * LB;
+            Fp<P> raw[LB];
+            bool inside[LB];
+            wave_for<LB>([&](auto J) {  // position j * NT + tid: consecutive lanes read consecutive positions
+                constexpr unsigned j = j0 + decltype(J)::value;
+                const unsigned pos = j * NT + tid0;
+                const unsigned g = p.chunk_stride ? (pos >> p.chunk_log) * p.chunk_stride + (pos & chunk_mask) + in_off : (pos << in_shift) + in_off;
+                inside[j - j0] = g < p.in_len;
+                raw[j - j0] = fp_load(wavel_at(in, inside[j - j0] ? g : 0u));  // [0, 2m): canonical input, or the column pass's redundant residues
+            });
+            wave_for<LB>([&](auto J) {
+                constexpr unsigned j = j0 + decltype(J)::value;
+                wave_for<8>([&](auto W) { raw[j - j0].v[decltype(W)::value] = inside[j - j0] ? raw[j - j0].v[decltype(W)::value] : 0u; });
+                x[j] = fpl_from_fp(raw[j - j0]);
+            });
+        });
+    }
+    if (p.in_scale) {  // the factor of element j + 1 is requested before element j is multiplied (one load in flight: registers)
         const Fp<P>* in_scale = p.in_scale + ((p.fan & NTT_FAN_SCALE) ? fan : 0u);
+        const auto scale_at = [&](unsigned j) PLONK_LAMBDA_INLINE {
+            const unsigned g = ((j * NT + tid0) << in_shift) + in_off;
+            return fp_load(wavel_at(in_scale, g < p.in_len ? g : 0u));  // (a padded position is zero: any factor will do)
+        };
+        Fp<P> sc = scale_at(0);
         wave_for<E>([&](auto J) {
             constexpr unsigned j = decltype(J)::value;
-            const unsigned g = ((j * NT + tid0) << in_shift) + in_off;
-            if (g < p.in_len) x[j] = fpl_mul(x[j], fpl_from_fp(fp_load(wavel_at(in_scale, g))));
+            const Fp<P> cur = sc;
+            if constexpr (j + 1 < E) sc = scale_at(j + 1);
+            x[j] = fpl_mul(x[j], fpl_from_fp(cur));
         });
     }
     if constexpr (E == 2) {
@@ -521,10 +571,22 @@ PLONK_DEV void wavel_transform(const NttWaveT<P>& p, unsigned char* smem) {
         const FpL<P> sc = fpl_from_fp_uniform(p.out_scalar);
         wave_for<E>([&](auto J) { x[decltype(J)::value] = fpl_mul(x[decltype(J)::value], sc); });
     }
-    wave_for<E>([&](auto J) {  // |value| <= 22.4 m whatever happened above -> (0.49 m, 1.51 m) -> canonical (the column pass skips that last step)
-        constexpr unsigned j = decltype(J)::value;
-        fp_store(wavel_at(out, ((k | (j << shift)) << out_shift) + out_off), fpl_pack_positive(fpl_reduce_small<P, 1>(x[j], jm), p.mode != 1));
-    });
+    // |value| <= 22.4 m whatever happened above -> (0.49 m, 1.51 m) -> canonical (the column pass skips that last step).  The table
+    // entries of all E values are requested first (round 6: the entry is a dependent load in front of every store otherwise); the
+    // 8-element kernels have no registers for that and reduce one value at a time
+    if constexpr (E <= 4) {
+        FplJmEntry je[E];
+        wave_for<E>([&](auto J) { je[decltype(J)::value] = fpl_reduce_small_lookup<P, 1>(x[decltype(J)::value], jm); });
+        wave_for<E>([&](auto J) {
+            constexpr unsigned j = decltype(J)::value;
+            fp_store(wavel_at(out, ((k | (j << shift)) << out_shift) + out_off), fpl_pack_positive(fpl_reduce_small_apply<P, 1>(x[j], je[j]), p.mode != 1));
+        });
+    } else {
+        wave_for<E>([&](auto J) {
+            constexpr unsigned j = decltype(J)::value;
+            fp_store(wavel_at(out, ((k | (j << shift)) << out_shift) + out_off), fpl_pack_positive(fpl_reduce_small<P, 1>(x[j], jm), p.mode != 1));
+        });
+    }
 }
 
 template <class P, unsigned LOG_E, unsigned NLDS>
