@@ -44,6 +44,12 @@ from bench_legs import HBM_PEAK_GBS, NOMINAL_SCLK_MHZ, R_MOD, ClockSampler  # no
 MSM_WINDOW_BITS = 10      # bucket-method default (csrc/msm.hip); 26 windows of signed 10-bit digits
 GROUP_ORDER = 2048
 PTAU = os.path.join(REPO, "tests", "golden", "srs_2048.ptau")
+def table_adds(info, n):
+    """mixed additions of one MSM of n scalars on the table `info` describes (a comb with top tables: its virtual scalars too)"""
+    a, g = info["additions_per_base"], info.get("top_group", 0)
+    return a * (n + (-(-(-(-n // g)) // a) if g else 0))
+
+
 DEFAULT_TABLE_GB = 100.0  # opt-in budget for the MSM table: the comb of 20 teeth over 2^11 bases is 68.7 GB + 17.2 GB of build staging
 LINE_LIMIT = 4096         # bytes of the stdout line (the driver's record keeps the last 8 KB of stdout)
 
@@ -327,6 +333,8 @@ def main():
                     help="transport of the final gather for N > 1: rccl = RCCL over xGMI through the C-ABI (default); sockets = TCP, lets ranks share one GPU")
     ap.add_argument("--lookup-budget-gb", type=float, default=DEFAULT_TABLE_GB,
                     help="HBM budget for the MSM table (the library's own default is 1/16 of the device's memory; the 20-tooth comb of 2^11 bases is 68.7 GB)")
+    ap.add_argument("--lookup-bits", type=int, default=0,
+                    help="teeth of the comb table (0 = the largest the budget affords: 20 for 2^11 bases under the default budget); A/B runs")
     ap.add_argument("--force-comm", action="store_true",
                     help="with --gpus 1: still create a ONE-rank RCCL communicator and run the gather (plonk_gather_proofs_device), the "
                          "max over ranks and the barrier inside the timed region — the code path of an N-GPU run, exercised on one GPU")
@@ -442,7 +450,7 @@ def main():
     groups = args.msm_groups if args.msm_groups >= 0 else (1 if NS >= 8 else 0)
     knobs = contextlib.ExitStack()
     for c in ctxs:
-        c.msm_lookup(1 if args.no_lookup else 0, 0, budget)
+        c.msm_lookup(1 if args.no_lookup else 0, args.lookup_bits, budget)
         if args.ntt_kind:  # explicit: for the whole run
             from plonkathon_amd._lib import check as _check
 
@@ -632,7 +640,10 @@ def main():
         "parallelism": "proof-sharded x%d" % world,
         "ranks_in_communicator": comm.world if comm is not None else 1,
         "gather_transport": comm.kind if comm is not None else "none (single rank)",
-        "msm_method": ("comb table, %d teeth: %d additions per base" % (lookup_bits, info["additions_per_base"]) if info["layout"] == "comb" else
+        "msm_method": ("comb table, %d teeth, %d columns + a joint table per %d bases for the top %d bits: %.2f additions per base"
+                       % (lookup_bits, info["additions_per_base"], info["top_group"], info["top_bits"], table_adds(info, GROUP_ORDER) / GROUP_ORDER)
+                       if info["layout"] == "comb" and info.get("top_group") else
+                       "comb table, %d teeth: %d additions per base" % (lookup_bits, info["additions_per_base"]) if info["layout"] == "comb" else
                        "window table, %d-bit windows: %d additions per base" % (lookup_bits, info["additions_per_base"]) if lookup_bits else
                        "bucket method, %d-bit windows" % MSM_WINDOW_BITS),
         "msm_table_bytes": info["bytes"],
@@ -721,7 +732,7 @@ def main():
         traffic = pmc["bench"].get(msm_kernel + "_kernel") if B == 512 else None
         windows = info["additions_per_base"] or (255 + MSM_WINDOW_BITS - 1) // MSM_WINDOW_BITS
         msms_per_launch = bytes_per_launch / (96.0 * GROUP_ORDER + 64.0)
-        adds_per_launch = msms_per_launch * windows * GROUP_ORDER
+        adds_per_launch = msms_per_launch * (table_adds(info, GROUP_ORDER) if info["additions_per_base"] else windows * GROUP_ORDER)
         sclk = clocks["sclk_mhz_median"] if clocks else None
         ceiling = ub["g1_lazy_madd_G"] if ub else None  # bare mixed-addition loop, millisecond burst at the nominal clock
         k_avg, k_n = (iso[0], iso[2]) if iso else (avg_s, msm_launches)  # the kernel alone on the chip when several streams ran

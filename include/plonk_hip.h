@@ -189,13 +189,18 @@ int plonk_g1_msm(plonk_ctx* ctx, plonk_srs* srs, const void* d_scalars, size_t n
  *   comb tables (default; csrc/msm_comb.h)   h teeth spaced a = ceil(254 / h) bits apart: 2^(h-1) entries per base, a additions
  *       per base and a - 1 doublings per MSM (shared by its bases).  2^11 points: 68.7 GB at h = 20 (13 additions per base),
  *       8.6 GB at h = 17 (15), 67 MB at h = 10 (26).
+ *   ... with TOP TABLES (round 6; where 254 mod h is 1 or 2)   floor(254 / h) columns cover all but the top one or two bits of a
+ *       scalar; those select an entry of a joint table shared by g consecutive bases ((2^(R+1) - 1)^g <= 2^(h-1) entries, R the
+ *       bits left over): 1 / g of an addition per base instead of a whole column.  2^11 points: h = 21, 12 columns, g = 7 —
+ *       12.15 additions per base from 157.6 GB (137.4 + 20.1), between the 13 of h = 20 and the 12 of h = 22 (275 GB).
  *   window tables (mode | 16; rounds 2 - 5)  every multiple d * 2^(c w) * P_i, d <= 2^(c-1): ceil(255 / c) windows of 2^(c-1)
  *       entries per base and as many additions, no doublings.  128.8 GB at c = 17 (15 additions), 10.7 GB at c = 13 (20).
  * mode 0 (default): automatic — the table with the fewest additions per base that, with its build staging, fits `budget_bytes`;
  * budget 0 = the library default of 1/16 of the device's memory (18 GB on an MI355X: h = 17 for 2^11 points), or
  * PLONK_MSM_TABLE_GB gigabytes if that variable is set: the big tables are a memory-for-time trade the caller opts into
  * explicitly.  Bucket method when nothing fits or for plonk_srs_load_affine bases; mode 1: never; mode 2: use `bits`
- * (h, or c with | 16) for every base set (tests).                                                                      */
+ * (h, or c with | 16) for every base set (tests).  The automatic choice weighs combs with and without top tables alike; an
+ * explicit `bits` means the plain comb of h teeth, and mode | 32 the one with top tables (PLONK_ERR_ARG if h takes none). */
 int plonk_msm_lookup_configure(plonk_ctx* ctx, int mode, unsigned bits, size_t budget_bytes);
 /* bits (teeth h / window bits c) of the table currently attached to `srs` (0 = none: its MSMs use the bucket method) */
 int plonk_srs_lookup_bits(const plonk_srs* srs, unsigned* out_bits);
@@ -204,8 +209,12 @@ int plonk_srs_lookup_bits(const plonk_srs* srs, unsigned* out_bits);
  * streams / provers using that SRS on the device; it is freed with the last plonk_srs that references it.      */
 int plonk_srs_lookup_info(const plonk_srs* srs, unsigned* out_bits, size_t* out_bytes, double* out_build_s,
                           int* out_sharers);
-/* its layout: kind 1 = comb, 2 = windows (0 = no table), and the mixed additions an MSM performs per base on it */
+/* its layout: kind 1 = comb, 2 = windows (0 = no table), and the mixed additions an MSM performs per base on it (a comb: its
+ * columns) */
 int plonk_srs_lookup_layout(const plonk_srs* srs, unsigned* out_kind, unsigned* out_additions_per_base);
+/* the top tables of the attached comb: the bits R they take and the bases g sharing one (0, 0 = none).  An MSM of n scalars
+ * then performs  columns * (n + ceil(ceil(n / g) / columns))  mixed additions.                                           */
+int plonk_srs_lookup_top(const plonk_srs* srs, unsigned* out_top_bits, unsigned* out_bases_per_group);
 
 /* ---- batched GPU-resident prover ---------------------------------------------------------------------
  * Replaces Prover.__init__ / Prover.prove / round_1..round_5 (prover.py:45-306) for `batch`

@@ -72,6 +72,7 @@ SIGNATURES = {
     "plonk_srs_lookup_bits": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint)]),
     "plonk_srs_lookup_info": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint), ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]),
     "plonk_srs_lookup_layout": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint), ctypes.POINTER(ctypes.c_uint)]),
+    "plonk_srs_lookup_top": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint), ctypes.POINTER(ctypes.c_uint)]),
     "plonk_msm_lookup_configure": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint, ctypes.c_size_t]),
     "plonk_g1_msm": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]),
     "plonk_msm_configure": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint, ctypes.c_uint]),

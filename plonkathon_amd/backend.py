@@ -116,10 +116,11 @@ class Context:
                 if ntt_kind:
                     self.L.plonk_ntt_select_kernel(self.handle, 0)
 
-    def msm_lookup(self, mode=0, bits=0, budget_bytes=0, windows=False):
+    def msm_lookup(self, mode=0, bits=0, budget_bytes=0, windows=False, top=False):
         """Table-MSM policy (include/plonk_hip.h): mode 0 auto, 1 off, 2 force `bits` for every base set; comb tables (bits =
-        teeth) unless `windows` (bits = window bits: the layout of rounds 2 - 5, kept for comparison)."""
-        check(self.L.plonk_msm_lookup_configure(self.handle, mode | (16 if windows else 0), bits, budget_bytes))
+        teeth; `top`: the comb of that many teeth with top tables) unless `windows` (bits = window bits: the layout of rounds
+        2 - 5, kept for comparison)."""
+        check(self.L.plonk_msm_lookup_configure(self.handle, mode | (16 if windows else 0) | (32 if top else 0), bits, budget_bytes))
 
     def profile(self, on):
         check(self.L.plonk_profile_enable(self.handle, 1 if on else 0))

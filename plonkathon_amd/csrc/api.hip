@@ -678,18 +678,27 @@ int plonk_srs_lookup_layout(const plonk_srs* srs, unsigned* out_kind, unsigned* 
     return msm_lookup_layout(srs, out_kind, out_additions_per_base);
 }
 
+int plonk_srs_lookup_top(const plonk_srs* srs, unsigned* out_top_bits, unsigned* out_bases_per_group) {
+    PLONK_REQUIRE(srs && out_top_bits && out_bases_per_group, PLONK_ERR_ARG, "bad argument");
+    return msm_lookup_top(srs, out_top_bits, out_bases_per_group);
+}
+
 int plonk_msm_lookup_configure(plonk_ctx* ctx, int mode, unsigned bits, size_t budget_bytes) {
     PLONK_REQUIRE(ctx, PLONK_ERR_ARG, "ctx is NULL");
     PLONK_ENTER(ctx);
-    const bool windows = (mode & 16) != 0;
-    mode &= ~16;
-    PLONK_REQUIRE(mode >= 0 && mode <= 2, PLONK_ERR_ARG, "mode must be 0 (auto), 1 (off) or 2 (force), optionally + 16 (window tables)");
+    const bool windows = (mode & 16) != 0, top = (mode & 32) != 0;
+    mode &= ~(16 | 32);
+    PLONK_REQUIRE(mode >= 0 && mode <= 2, PLONK_ERR_ARG,
+                  "mode must be 0 (auto), 1 (off) or 2 (force), optionally + 16 (window tables) or + 32 (the comb of `bits` teeth with top tables)");
+    PLONK_REQUIRE(!top || (!windows && bits && msm_comb_takes_top(bits)), PLONK_ERR_ARG,
+                  "mode + 32 needs a comb (not + 16) of an explicit number of teeth with 254 mod teeth = 1 or 2 (7, 9, 11, 12, 14, 18, 21, 23 ..)");
     const unsigned max_bits = windows ? 17u : 24u;
     PLONK_REQUIRE(bits == 0 || (bits >= 2 && bits <= max_bits), PLONK_ERR_ARG, "bits must be 0 (auto) or in [2, %u]", max_bits);
     PLONK_REQUIRE(mode != 2 || bits, PLONK_ERR_ARG, "mode 2 needs an explicit number of bits");
     ctx->msm_lookup_mode = mode;
     ctx->msm_lookup_kind = windows ? MSM_TABLE_WINDOWS : MSM_TABLE_COMB;
     ctx->msm_lookup_bits = bits;
+    ctx->msm_lookup_top = top;
     ctx->msm_lookup_budget = budget_bytes;
     return PLONK_OK;
 }

@@ -655,6 +655,8 @@ static void lut_attach(plonk_srs* srs, MsmLookupTable* t) {  // g_lut_mu held
     srs->lookup_bits = t ? t->bits : 0;
     srs->lookup_windows = t ? t->windows : 0;
     srs->lookup_kind = t ? t->kind : 0;
+    srs->lookup_top_bits = t ? t->top_bits : 0;
+    srs->lookup_top_g = t ? t->top_g : 0;
     if (t) t->refs++;
 }
 
@@ -705,8 +707,12 @@ static MsmLookupTable* lut_verified(plonk_ctx* ctx, const plonk_srs* srs, MsmLoo
     if (!t) return nullptr;
     if (t->n_points != srs->n_points) return nullptr;
     if (t->kind == MSM_TABLE_COMB) {
-        if (t->bits < 2 || t->bits > MSM_COMB_MAX_TEETH || t->windows != msm_comb_columns(t->bits) ||
-            t->bytes != (t->n_points << (t->bits - 1)) * sizeof(G1Affine))
+        if (t->bits < 2 || t->bits > MSM_COMB_MAX_TEETH) return nullptr;
+        const bool top = t->top_g != 0;
+        if (top && !msm_comb_top_ok(t->bits)) return nullptr;
+        const MsmCombShape sh = msm_comb_shape(t->bits, top);
+        if (t->windows != sh.a || t->top_bits != sh.top_bits || t->top_g != sh.top_g ||
+            t->bytes != (msm_comb_blocks(t->n_points, sh) << (t->bits - 1)) * sizeof(G1Affine))
             return nullptr;
     } else if (t->windows != windows_for(t->bits) || t->bytes != t->n_points * t->windows * ((size_t)1 << (t->bits - 1)) * sizeof(G1Affine)) {
         return nullptr;
@@ -719,6 +725,12 @@ static MsmLookupTable* lut_verified(plonk_ctx* ctx, const plonk_srs* srs, MsmLoo
         const size_t lanes = srs->n_points + 2 * LUT_VERIFY_SAMPLES;
         PLONK_LAUNCH(msm_comb_verify_kernel, dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0, ctx->stream, (const G1Affine*)srs->bases,
                      (const G1Affine*)t->data, srs->n_points, t->windows, t->bits, (unsigned)LUT_VERIFY_SAMPLES, msm_comb_scale_constant(), (unsigned*)flag);
+        if (t->top_g) {
+            const size_t groups = msm_comb_top_groups(srs->n_points, t->top_g);
+            PLONK_LAUNCH(msm_comb_verify_top_kernel, dim3((unsigned)((groups + 63) / 64)), dim3(64), 0, ctx->stream, (const G1Affine*)srs->bases,
+                         (const G1Affine*)t->data, srs->n_points, t->windows, t->bits, t->top_g, (2u << t->top_bits) - 1u, msm_comb_scale_constant(),
+                         (unsigned*)flag);
+        }
     } else {
         PLONK_LAUNCH(lut_verify_kernel, dim3((unsigned)((srs->n_points + 255) / 256)), dim3(256), 0, ctx->stream, (const G1Affine*)srs->bases,
                      (const G1Affine*)t->data, srs->n_points, t->bits, (unsigned*)flag);
@@ -730,10 +742,12 @@ static MsmLookupTable* lut_verified(plonk_ctx* ctx, const plonk_srs* srs, MsmLoo
 }
 // the registered table of this base set with `bits` window bits (0: the one with the most) that passes the comparison above;
 // several tables may sit under one key (a collision, or several window sizes): every candidate is tried, widest first
-static MsmLookupTable* lut_find_verified(plonk_ctx* ctx, const plonk_srs* srs, unsigned kind, unsigned bits) {  // g_lut_mu held
+// (top: 0 = without top tables, 1 = with, -1 = either)
+static MsmLookupTable* lut_find_verified(plonk_ctx* ctx, const plonk_srs* srs, unsigned kind, unsigned bits, int top = -1) {  // g_lut_mu held
     std::vector<MsmLookupTable*> cand;
     for (MsmLookupTable* t : g_luts)
-        if (t->device == srs->device && t->key == srs->content_key && t->n_points == srs->n_points && t->kind == kind && (!bits || t->bits == bits))
+        if (t->device == srs->device && t->key == srs->content_key && t->n_points == srs->n_points && t->kind == kind && (!bits || t->bits == bits) &&
+            (top < 0 || (t->top_g != 0) == (top != 0)))
             cand.push_back(t);
     std::sort(cand.begin(), cand.end(), [](const MsmLookupTable* a, const MsmLookupTable* b) { return a->bits > b->bits; });
     for (MsmLookupTable* t : cand)
@@ -771,6 +785,16 @@ int msm_lookup_layout(const plonk_srs* srs, unsigned* kind, unsigned* additions_
     const MsmLookupTable* t = srs->shared;
     *kind = t ? t->kind : 0;
     *additions_per_base = t ? t->windows : 0;
+    return PLONK_OK;
+}
+
+bool msm_comb_takes_top(unsigned teeth) { return teeth >= 2 && teeth <= MSM_COMB_MAX_TEETH && msm_comb_top_ok(teeth); }
+
+int msm_lookup_top(const plonk_srs* srs, unsigned* top_bits, unsigned* bases_per_group) {
+    std::lock_guard<std::mutex> lk(g_lut_mu);
+    const MsmLookupTable* t = srs->shared;
+    *top_bits = t ? t->top_bits : 0;
+    *bases_per_group = t ? t->top_g : 0;
     return PLONK_OK;
 }
 
@@ -888,8 +912,8 @@ static size_t msm_comb_stage_entries(size_t n, unsigned h) {
     while (bases > 1 && bases * half > ((size_t)1 << 27)) bases /= 2;
     return bases * half;
 }
-static size_t msm_comb_bytes(size_t n, unsigned h) {  // table + staging
-    return (n << (h - 1)) * sizeof(G1Affine) + msm_comb_stage_entries(n, h) * sizeof(G1Xyzz);
+static size_t msm_comb_bytes(size_t n, unsigned h, bool top = false) {  // table + staging
+    return (msm_comb_blocks(n, msm_comb_shape(h, top)) << (h - 1)) * sizeof(G1Affine) + msm_comb_stage_entries(n, h) * sizeof(G1Xyzz);
 }
 
 // R^-1 mod r as a plain integer (R = 2^261, Fr's Montgomery radix): the comb tables hold multiples of R^-1 P_i (msm_comb.h)
@@ -903,19 +927,26 @@ static MsmCombScale msm_comb_scale_constant() {
 }
 
 // Builds the comb table of h teeth.  PLONK_ERR_NOMEM (nothing allocated, nothing changed) if it does not fit.
-static int msm_comb_build(plonk_ctx* ctx, plonk_srs* srs, unsigned h) {  // g_lut_mu held
+// top: with top tables (msm_comb.h: floor(254 / h) columns, a joint table per group of bases for the bits left over)
+static int msm_comb_build(plonk_ctx* ctx, plonk_srs* srs, unsigned h, bool top = false) {  // g_lut_mu held
     const auto t0 = std::chrono::steady_clock::now();
-    const unsigned a = msm_comb_columns(h), sb = h - 1 < MSM_COMB_SEG_BITS ? h - 1 : MSM_COMB_SEG_BITS;
+    if (top && !msm_comb_top_ok(h)) {
+        plonk_set_error("a comb of %u teeth takes no top tables (254 mod teeth must be 1 or 2)", h);
+        return PLONK_ERR_ARG;
+    }
+    const MsmCombShape sh = msm_comb_shape(h, top);
+    const unsigned a = sh.a, sb = h - 1 < MSM_COMB_SEG_BITS ? h - 1 : MSM_COMB_SEG_BITS;
     const size_t n = srs->n_points, half = (size_t)1 << (h - 1), stage = msm_comb_stage_entries(n, h), chunk_bases = stage / half;
+    const size_t blocks = msm_comb_blocks(n, sh);
     void *gx = nullptr, *gb = nullptr, *dx = nullptr, *db = nullptr, *tmp = nullptr, *tab = nullptr;
     auto fail = [&]() {
         for (void* q : {gx, gb, dx, db, tmp, tab})
             if (q) hipFree(q);
         (void)hipGetLastError();
-        plonk_set_error("the %u-tooth comb table (%zu MiB) does not fit in device memory", h, msm_comb_bytes(n, h) >> 20);
+        plonk_set_error("the %u-tooth comb table (%zu MiB) does not fit in device memory", h, msm_comb_bytes(n, h, top) >> 20);
         return PLONK_ERR_NOMEM;
     };
-    if (!plonk_dev_malloc(&tab, n * half * sizeof(G1Affine))) return fail();
+    if (!plonk_dev_malloc(&tab, blocks * half * sizeof(G1Affine))) return fail();
     if (!plonk_dev_malloc(&tmp, stage * sizeof(G1Xyzz))) return fail();
     if (!plonk_dev_malloc(&gx, n * h * sizeof(G1Xyzz))) return fail();
     if (!plonk_dev_malloc(&gb, n * h * sizeof(G1Affine))) return fail();
@@ -943,6 +974,25 @@ static int msm_comb_build(plonk_ctx* ctx, plonk_srs* srs, unsigned h) {  // g_lu
                      (G1Xyzz*)tmp);
         g1_batch_to_affine(ctx, (const G1Xyzz*)tmp, (G1Affine*)tab + i0 * half, nb * half);
     }
+    if (top) {
+        // tooth points of the top tables 2^(L - j) P'_i (through gx / gb, free by now), then the joint tables a chunk of groups at a
+        // time; a block past the last group (the columns are padded to equal lengths) stays all identity
+        PLONK_LAUNCH(msm_comb_top_base_kernel, dim3(grid), dim3(64), 0, ctx->stream, (const G1Affine*)pb, n, a * h, a, sh.top_g, (G1Xyzz*)gx);
+        g1_batch_to_affine(ctx, (const G1Xyzz*)gx, (G1Affine*)gb, n);
+        const size_t groups = msm_comb_top_groups(n, sh.top_g), vblocks = blocks - n, run = sh.top_g >= 2 ? (size_t)sh.top_b * sh.top_b : sh.top_b;
+        for (size_t g0 = 0; g0 < vblocks; g0 += chunk_bases) {
+            const size_t nb = vblocks - g0 < chunk_bases ? vblocks - g0 : chunk_bases;
+            const size_t ng = g0 >= groups ? 0 : (groups - g0 < nb ? groups - g0 : nb);
+            if (hipMemsetAsync(tmp, 0, nb * half * sizeof(G1Xyzz), ctx->stream) != hipSuccess) break;
+            if (ng) {
+                const size_t lanes = ng * (sh.top_entries / run);
+                unsigned gf = (unsigned)((lanes + 63) / 64 > 65536 ? 65536 : (lanes + 63) / 64);
+                PLONK_LAUNCH(msm_comb_top_fill_kernel, dim3(gf), dim3(64), 0, ctx->stream, (const G1Affine*)gb, n, g0, ng, h - 1, sh.top_g, sh.top_b,
+                             sh.top_entries, (G1Xyzz*)tmp);
+            }
+            g1_batch_to_affine(ctx, (const G1Xyzz*)tmp, (G1Affine*)tab + (n + g0) * half, nb * half);
+        }
+    }
     if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) {
         hipFree(pb);
         return fail();
@@ -955,19 +1005,21 @@ static int msm_comb_build(plonk_ctx* ctx, plonk_srs* srs, unsigned h) {  // g_lu
     t->kind = MSM_TABLE_COMB;
     t->bits = h;
     t->windows = a;
+    t->top_bits = sh.top_bits;
+    t->top_g = sh.top_g;
     t->data = (G1Affine*)tab;
-    t->bytes = n * half * sizeof(G1Affine);
+    t->bytes = blocks * half * sizeof(G1Affine);
     t->build_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     g_luts.push_back(t);
     lut_attach(srs, t);
     return PLONK_OK;
 }
 
-static size_t msm_table_bytes(size_t n, unsigned kind, unsigned bits) {
-    return kind == MSM_TABLE_COMB ? msm_comb_bytes(n, bits) : msm_lookup_bytes(n, bits);
+static size_t msm_table_bytes(size_t n, unsigned kind, unsigned bits, bool top = false) {
+    return kind == MSM_TABLE_COMB ? msm_comb_bytes(n, bits, top) : msm_lookup_bytes(n, bits);
 }
-static int msm_table_build(plonk_ctx* ctx, plonk_srs* srs, unsigned kind, unsigned bits) {
-    return kind == MSM_TABLE_COMB ? msm_comb_build(ctx, srs, bits) : msm_lookup_build(ctx, srs, bits);
+static int msm_table_build(plonk_ctx* ctx, plonk_srs* srs, unsigned kind, unsigned bits, bool top = false) {
+    return kind == MSM_TABLE_COMB ? msm_comb_build(ctx, srs, bits, top) : msm_lookup_build(ctx, srs, bits);
 }
 
 static size_t msm_default_lookup_budget() {
@@ -993,19 +1045,21 @@ static size_t msm_default_lookup_budget() {
 static bool msm_lookup_prepare(plonk_ctx* ctx, plonk_srs* srs) {
     if (ctx->msm_lookup_mode == 1) return false;
     const unsigned want = ctx->msm_lookup_bits, kind = ctx->msm_lookup_kind;
+    const bool wtop = want && kind == MSM_TABLE_COMB && ctx->msm_lookup_top;  // an explicit size names its variant
     std::lock_guard<std::mutex> lk(g_lut_mu);
+    const auto attached_is = [&](unsigned bits) { return srs->shared && srs->lookup_kind == kind && srs->lookup_bits == bits && (srs->lookup_top_g != 0) == wtop; };
     if (ctx->msm_lookup_mode == 2) {  // forced size, any base set
-        if (srs->shared && srs->lookup_kind == kind && srs->lookup_bits == want) return true;
-        if (MsmLookupTable* t = lut_find_verified(ctx, srs, kind, want)) {
+        if (attached_is(want)) return true;
+        if (MsmLookupTable* t = lut_find_verified(ctx, srs, kind, want, wtop)) {
             lut_attach(srs, t);
             return true;
         }
-        return msm_table_build(ctx, srs, kind, want) == PLONK_OK;
+        return msm_table_build(ctx, srs, kind, want, wtop) == PLONK_OK;
     }
     if (!srs->fixed) return false;
-    if (srs->shared && srs->lookup_kind == kind && (!want || want == srs->lookup_bits)) return true;
+    if (srs->shared && srs->lookup_kind == kind && (!want || attached_is(want))) return true;
     if (want) {
-        if (MsmLookupTable* t = lut_find_verified(ctx, srs, kind, want)) {
+        if (MsmLookupTable* t = lut_find_verified(ctx, srs, kind, want, wtop)) {
             lut_attach(srs, t);
             return true;
         }
@@ -1013,7 +1067,7 @@ static bool msm_lookup_prepare(plonk_ctx* ctx, plonk_srs* srs) {
     if (srs->lookup_failed) return false;
     const size_t budget = ctx->msm_lookup_budget ? ctx->msm_lookup_budget : msm_default_lookup_budget();
     // A table another context of this device already built for these bases is taken as it is — unless this context's
-    // budget affords a bigger one (more bits = fewer additions), which is then built and shared in its turn.
+    // budget affords a better one (fewer additions per base), which is then built and shared in its turn.
     MsmLookupTable* have = want ? nullptr : lut_find_verified(ctx, srs, kind, 0);
     // The automatic choice charges the tables of the same SRS family (an SRS and its Lagrange-basis views) against one
     // budget.  An explicit size (`want`) is an explicit request and only has to fit the budget by itself.
@@ -1021,12 +1075,30 @@ static bool msm_lookup_prepare(plonk_ctx* ctx, plonk_srs* srs) {
     // below 8 bits the table no longer beats the bucket method — which, however, cannot index more than 2^15 bases, so
     // larger base sets accept any table that fits
     const unsigned c_min = want ? want : (srs->n_points > 32768 ? 4 : 8);
-    const unsigned c_max = kind == MSM_TABLE_COMB ? 22 : 17;
-    for (unsigned c = want ? want : c_max; c >= c_min && (!have || c > have->bits); c--) {
-        // a comb one tooth shorter with as many columns costs the same additions for half the memory
-        if (!want && kind == MSM_TABLE_COMB && c > c_min && msm_comb_columns(c - 1) == msm_comb_columns(c) && (!have || c - 1 > have->bits)) continue;
-        if (msm_table_bytes(srs->n_points, kind, c) + used > budget) continue;
-        if (msm_table_build(ctx, srs, kind, c) == PLONK_OK) return true;
+    const unsigned c_max = want ? want : (kind == MSM_TABLE_COMB ? 22 : 17);
+    // Candidates in the order of their additions per base, the smaller table first among equals (a comb one tooth shorter with
+    // as many columns costs the same additions for half the memory).  Combs come without and — where 254 mod teeth allows — with
+    // top tables (msm_comb.h): 21 teeth + top tables = 12.15 additions per base of 2^11 from 157.5 GB, between the 13 of 20 teeth
+    // (68.7 GB) and the 12 of 22 (275 GB).
+    struct Cand { unsigned c; bool top; double adds; size_t bytes; };
+    std::vector<Cand> cands;
+    const auto adds_of = [&](unsigned c, bool top) {
+        if (kind != MSM_TABLE_COMB) return (double)windows_for(c);
+        const MsmCombShape sh = msm_comb_shape(c, top);
+        return (double)sh.a + (top ? 1.0 / sh.top_g : 0.0);
+    };
+    for (unsigned c = c_max; c >= c_min; c--)
+        for (int top = 0; top < 2; top++) {
+            if (top && (kind != MSM_TABLE_COMB || !msm_comb_top_ok(c))) continue;
+            if (want && (top != 0) != wtop) continue;
+            cands.push_back(Cand{c, top != 0, adds_of(c, top != 0), msm_table_bytes(srs->n_points, kind, c, top != 0)});
+        }
+    std::sort(cands.begin(), cands.end(), [](const Cand& x, const Cand& y) { return x.adds != y.adds ? x.adds < y.adds : x.bytes < y.bytes; });
+    const double have_adds = have ? adds_of(have->bits, have->top_g != 0) : 1e9;
+    for (const Cand& k : cands) {
+        if (k.adds >= have_adds) break;
+        if (k.bytes + used > budget) continue;
+        if (msm_table_build(ctx, srs, kind, k.c, k.top) == PLONK_OK) return true;
     }
     if (have) {
         lut_attach(srs, have);
@@ -1066,26 +1138,44 @@ static unsigned msm_round_aware_groups(int device, size_t M, unsigned g0, unsign
     return cost(2 * g0) < 0.97 * cost(g0) ? 2 * g0 : g0;
 }
 
-// digits kernel of the comb with h teeth (one instantiation per tooth count: the bit gather is unrolled at compile time)
-template <unsigned H> static void msm_comb_launch_digits(plonk_ctx* ctx, const Fr* d_scalars, size_t n, size_t stride, size_t inner, size_t outer_stride,
-                                                         size_t M, uint32_t* digits) {
-    for (size_t m0 = 0; m0 < M; m0 += 32768) {  // (a grid's second dimension ends at 65 535)
-        const size_t rows = M - m0 < 32768 ? M - m0 : 32768;
-        PLONK_LAUNCH(msm_comb_digits_kernel<H>, dim3((unsigned)((n + 255) / 256), (unsigned)rows), dim3(256), 0, ctx->stream, d_scalars, n, stride, inner,
-                     outer_stride, m0, digits);
+// digits kernel of the comb with h teeth (one instantiation per tooth count: the bit gather is unrolled at compile time); TOP: the
+// comb with top tables, whose workgroups take whole groups of scalars and add the virtual scalars' digits (nd = n + their number)
+template <unsigned H, bool TOP> static void msm_comb_launch_digits(plonk_ctx* ctx, const Fr* d_scalars, size_t n, size_t stride, size_t inner,
+                                                                   size_t outer_stride, size_t M, uint32_t* digits, size_t nd) {
+    if constexpr (!TOP || msm_comb_top_ok(H)) {
+        constexpr MsmCombShape SH = msm_comb_shape(H, TOP);
+        constexpr unsigned G = TOP ? SH.top_g : 1, PER = (256 / G) * G;
+        size_t gx = (n + PER - 1) / PER;
+        if (TOP) {  // every virtual scalar's digit is written, also those of the groups past the last scalar
+            const size_t gv = ((nd - n) * SH.a + PER / G - 1) / (PER / G);
+            gx = gx > gv ? gx : gv;
+        }
+        void (*kern)(const Fr*, size_t, size_t, size_t, size_t, size_t, uint32_t*, size_t) = msm_comb_digits_kernel<H, TOP>;  // (a template-id's comma would split the macro's arguments)
+        for (size_t m0 = 0; m0 < M; m0 += 32768) {  // (a grid's second dimension ends at 65 535)
+            const size_t rows = M - m0 < 32768 ? M - m0 : 32768;
+            PLONK_LAUNCH(kern, dim3((unsigned)gx, (unsigned)rows), dim3(256), 0, ctx->stream, d_scalars, n, stride, inner,
+                         outer_stride, m0, digits, nd);
+        }
     }
 }
-typedef void (*msm_comb_digits_fn)(plonk_ctx*, const Fr*, size_t, size_t, size_t, size_t, size_t, uint32_t*);
-template <unsigned... H> static msm_comb_digits_fn msm_comb_digits_for(unsigned h, std::integer_sequence<unsigned, H...>) {
+typedef void (*msm_comb_digits_fn)(plonk_ctx*, const Fr*, size_t, size_t, size_t, size_t, size_t, uint32_t*, size_t);
+template <bool TOP, unsigned... H> static msm_comb_digits_fn msm_comb_digits_for(unsigned h, std::integer_sequence<unsigned, H...>) {
     msm_comb_digits_fn fn = nullptr;
-    ((h == H + 2 ? (void)(fn = &msm_comb_launch_digits<H + 2>) : (void)0), ...);
+    ((h == H + 2 && (!TOP || msm_comb_top_ok(H + 2)) ? (void)(fn = &msm_comb_launch_digits<H + 2, TOP>) : (void)0), ...);
     return fn;
 }
 
-static int msm_run_comb(plonk_ctx* ctx, plonk_srs* srs, const Fr* d_scalars, size_t n, size_t M, size_t stride, Fq* d_out_xy, uint8_t* d_flags,
+static int msm_run_comb(plonk_ctx* ctx, plonk_srs* srs, const Fr* d_scalars, size_t n_real, size_t M, size_t stride, Fq* d_out_xy, uint8_t* d_flags,
                         size_t inner, size_t outer_stride) {
     const unsigned h = srs->lookup_bits, a = srs->lookup_windows, hb = h - 1;
-    PLONK_REQUIRE((uint64_t)n * a < ((uint64_t)1 << 32), PLONK_ERR_ARG, "MSM size %zu too large for the lookup path", n);
+    // top tables (msm_comb.h): the kernels see n = n_real + nv scalars, the last nv of each column being its share of the groups
+    const bool top = srs->lookup_top_g != 0;
+    const MsmCombShape sh = msm_comb_shape(h, top);
+    const size_t nv = msm_comb_virtual(n_real, sh), n = n_real + nv;
+    const unsigned top_delta = (unsigned)(srs->n_points - n_real);  // block of virtual scalar n_real + v = n_points + v (+ the digit's offset)
+    PLONK_REQUIRE((uint64_t)n * a < ((uint64_t)1 << 32), PLONK_ERR_ARG, "MSM size %zu too large for the lookup path", n_real);
+    PLONK_REQUIRE(!top || ((uint64_t)(nv * (a - 1) + a) << hb) < ((uint64_t)1 << 31), PLONK_ERR_ARG, "MSM size %zu too large for the top tables of %u teeth",
+                  n_real, h);
     unsigned G = ctx->msm_groups;
     if (!G) {  // enough waves to occupy 1024 SIMDs three to four deep, in as few workgroups per MSM as that takes
         G = 1;
@@ -1106,16 +1196,17 @@ static int msm_run_comb(plonk_ctx* ctx, plonk_srs* srs, const Fr* d_scalars, siz
     uint32_t* n_deferred = (uint32_t*)((uint8_t*)s + part_bytes + col_bytes);
     MsmDeferred* deferred = (MsmDeferred*)((uint8_t*)s + part_bytes + col_bytes + cnt_bytes);
     uint32_t* digits = (uint32_t*)((uint8_t*)s + part_bytes + col_bytes + cnt_bytes + dfr_bytes);
-    const msm_comb_digits_fn digits_fn = msm_comb_digits_for(h, std::make_integer_sequence<unsigned, MSM_COMB_MAX_TEETH - 1>());
+    const auto teeth = std::make_integer_sequence<unsigned, MSM_COMB_MAX_TEETH - 1>();
+    const msm_comb_digits_fn digits_fn = top ? msm_comb_digits_for<true>(h, teeth) : msm_comb_digits_for<false>(h, teeth);
     PLONK_REQUIRE(digits_fn, PLONK_ERR_ARG, "no comb of %u teeth", h);
     PLONK_CHECK_HIP(hipMemsetAsync(n_deferred, 0, M * 4, ctx->stream));
     PLONK_TRY(prof_begin(ctx, "msm_digits", (double)M * (double)n * (32.0 + 4.0 * a)));
-    digits_fn(ctx, d_scalars, n, stride, inner, outer_stride, M, digits);
+    digits_fn(ctx, d_scalars, n_real, stride, inner, outer_stride, M, digits, n);
     PLONK_TRY(prof_end(ctx));
     const size_t lds = (size_t)(MSM_BLOCK + a) * sizeof(G1Xyzz);
-    PLONK_TRY(prof_begin(ctx, "msm_comb", (double)M * (96.0 * (double)n + 64.0)));
+    PLONK_TRY(prof_begin(ctx, "msm_comb", (double)M * (96.0 * (double)n_real + 64.0)));
     PLONK_LAUNCH(msm_comb_kernel, dim3((unsigned)(M * G)), dim3(MSM_BLOCK), lds, ctx->stream, (const G1Affine*)srs->lookup, hb, a,
-                 (const uint32_t*)digits, n, G, partial, deferred, (size_t)MSM_DEFER_CAP, n_deferred);
+                 (const uint32_t*)digits, n, G, partial, deferred, (size_t)MSM_DEFER_CAP, n_deferred, (unsigned)n_real, top_delta);
     PLONK_TRY(prof_end(ctx));
     const G1Xyzz* sums = partial;
     unsigned Gf = G;
@@ -1131,13 +1222,14 @@ static int msm_run_comb(plonk_ctx* ctx, plonk_srs* srs, const Fr* d_scalars, siz
     const unsigned lpm = forced_lpm ? forced_lpm : (M >= 64 ? 4u : 16u);
 #define PLONK_COMB_FINALIZE(L)                                                                                                                  \
     PLONK_LAUNCH(msm_comb_finalize_kernel<L>, dim3((unsigned)((M * L + 63) / 64)), dim3(64), 0, ctx->stream, sums, M, Gf, a,                      \
-                 (const G1Affine*)srs->lookup, hb, n, (const MsmDeferred*)deferred, (size_t)MSM_DEFER_CAP, n_deferred, d_out_xy, d_flags)
+                 (const G1Affine*)srs->lookup, hb, n, (const MsmDeferred*)deferred, (size_t)MSM_DEFER_CAP, n_deferred, d_out_xy, d_flags,         \
+                 (unsigned)n_real, top_delta)
     if (lpm >= 16) PLONK_COMB_FINALIZE(16);
     else if (lpm >= 4) PLONK_COMB_FINALIZE(4);
     else PLONK_COMB_FINALIZE(1);
 #undef PLONK_COMB_FINALIZE
     PLONK_LAUNCH(msm_comb_slow_kernel, dim3((unsigned)M), dim3(256), 0, ctx->stream, (const G1Affine*)srs->lookup, hb, a, (const uint32_t*)digits, n,
-                 (const uint32_t*)n_deferred, d_out_xy, d_flags);
+                 (const uint32_t*)n_deferred, d_out_xy, d_flags, (unsigned)n_real, top_delta);
     PLONK_CHECK_HIP(hipGetLastError());
     return PLONK_OK;
 }

@@ -48,6 +48,51 @@ PLONK_HD bool msm_comb_needs_redo(uint32_t v) { return (v & MSM_COMB_REDO) != 0 
 
 PLONK_HD unsigned msm_comb_columns(unsigned h) { return (MSM_COMB_SCALAR_BITS + h - 1) / h; }
 
+// ---- combs with TOP TABLES (round 6) -----------------------------------------------------------
+// ceil(254 / h) rounds up: 20 teeth need 13 columns (260 positions for 254 bits), and the next count of columns, 12, needs 22
+// teeth — 275 GB for 2^11 bases.  21 teeth x 12 columns cover 252 bits; the two bits left over are worth one addition per base
+// if they get a column of their own, but only 1 / g of one when g bases share a joint table for them:
+//     s' = v + 2^L u,  L = a h,  v = s' mod 2^L (odd: all digits +-1 as before),  u = s' >> L in [0, 2^R),  R = 254 - L  (1 or 2)
+//     sum_i s'_i P_i = (the comb over the v_i)  +  sum_groups  T_grp[ codes of its g bases ],
+//     T_grp[idx] = sum_pos code_pos 2^(L - j) P'_(g grp + pos),   code = +-u in [-(2^R - 1), 2^R - 1]  (B = 2^(R+1) - 1 values),
+//     idx = sum_pos (code_pos + (B - 1) / 2) B^pos  <  B^g <= 2^(h-1).
+// Group grp is dealt to column j = grp mod a (hence the 2^(L - j): the Horner step multiplies column j's sum by 2^j), as the
+// "virtual scalar" n + grp / a of that column: msm_comb_kernel sees an MSM of n + ceil(ceil(n / g) / a) scalars and runs
+// unchanged — its table simply has one more 2^(h-1)-entry block per group behind the blocks of the N bases (block N + grp), and
+// a virtual scalar's digit carries the block offset (v (a - 1) + j) beside idx.  2^11 bases, h = 21: 12 columns of 2 073
+// (virtual) scalars = 12.15 additions per base from 137.4 + 20.1 GB, against 13 from 68.7 GB.
+struct MsmCombShape {
+    unsigned h, a;                // teeth, columns
+    unsigned top_bits, top_g;     // R and g (0, 0: no top tables — a = ceil(254 / h))
+    unsigned top_b;               // B = 2^(R+1) - 1
+    uint32_t top_entries;         // B^g
+};
+PLONK_HD constexpr MsmCombShape msm_comb_shape(unsigned h, bool top) {
+    MsmCombShape s{h, (MSM_COMB_SCALAR_BITS + h - 1) / h, 0, 0, 0, 0};
+    if (!top) return s;
+    s.a = MSM_COMB_SCALAR_BITS / h;
+    s.top_bits = MSM_COMB_SCALAR_BITS - s.a * h;
+    s.top_b = (2u << s.top_bits) - 1;
+    s.top_entries = 1;
+    while (s.top_bits && (uint64_t)s.top_entries * s.top_b <= ((uint64_t)1 << (h - 1))) {
+        s.top_entries *= s.top_b;
+        s.top_g++;
+    }
+    return s;
+}
+// a comb of h teeth can take top tables: one or two bits left over, and a block holds the joint table of at least one base
+PLONK_HD constexpr bool msm_comb_top_ok(unsigned h) {
+    const MsmCombShape s = msm_comb_shape(h, true);
+    return h >= 2 && s.a >= 1 && s.top_bits >= 1 && s.top_bits <= 2 && s.top_g >= 1;
+}
+PLONK_HD size_t msm_comb_top_groups(size_t n, unsigned g) { return g ? (n + g - 1) / g : 0; }
+// virtual scalars per column of an MSM of n scalars (= virtual blocks per column of a table of n bases)
+PLONK_HD size_t msm_comb_virtual(size_t n, const MsmCombShape& s) { return s.top_g ? (msm_comb_top_groups(n, s.top_g) + s.a - 1) / s.a : 0; }
+// blocks of 2^(h-1) entries in the table of n bases
+PLONK_HD size_t msm_comb_blocks(size_t n, const MsmCombShape& s) { return n + msm_comb_virtual(n, s) * s.a; }
+// block of the table an item of scalar i (real: i < n_real; virtual: the others) starts from
+PLONK_HD size_t msm_comb_block_of(size_t i, size_t n_real, size_t top_delta) { return i + (i >= n_real ? top_delta : 0); }
+
 // c P by double-and-add over the bits of a wave-uniform constant (c = R^-1 mod r, 254 bits): one-off, per base
 struct MsmCombScale { uint32_t c[8]; };
 PLONK_DEV G1Xyzz msm_comb_scaled_base(const G1Affine& P, const MsmCombScale& k) {
@@ -125,43 +170,145 @@ __global__ void __launch_bounds__(64) msm_comb_fill_kernel(const G1Affine* cb, c
     }
 }
 
-// digits[(m * A + j) * n + i] = column j of scalar i of MSM m: the index of its table entry in bits 0 .. H-2, bit 31 set when the
-// entry is to be subtracted.  Scalar vector of MSM m as in msm_sort_kernel (stride / inner / outer_stride).
-template <unsigned H> __global__ void __launch_bounds__(256) msm_comb_digits_kernel(const Fr* scalars, size_t n, size_t stride, size_t inner,
-                                                                                    size_t outer_stride, size_t m0, uint32_t* digits) {
-    constexpr unsigned A = (MSM_COMB_SCALAR_BITS + H - 1) / H, L = A * H;
-    static_assert(L <= 9 * 32 && H <= MSM_COMB_MAX_TEETH, "the recoded scalar is kept in nine words");
-    const size_t m = m0 + blockIdx.y, i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // (a grid row per MSM: no division per lane)
-    if (i >= n) return;
-    const Fr* sc = scalars + (m % inner) * stride + (m / inner) * outer_stride;
-    const Fr s = fp_load(sc + i);  // the Montgomery residue s R mod r, taken as the integer it is: the table holds multiples of R^-1 P
-    // odd representative: s, or r - s with the sign of the base flipped (r is odd; s = 0 becomes r, and r P = O comes out of the sums)
-    const bool even = !(s.v[0] & 1u);
-    uint32_t sp[8], br = 0;
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-        const uint32_t d = fp_sbb(FrParams::mod(k), s.v[k], br);
-        sp[k] = even ? d : s.v[k];
+// ---- top tables: build ----
+// out[i] = 2^(L - j) P'_i, j = (i / g) mod a: the tooth point of base i in the joint table of its group (XYZZ)
+__global__ void __launch_bounds__(64) msm_comb_top_base_kernel(const G1Affine* pb, size_t n, unsigned L, unsigned a, unsigned g, G1Xyzz* out) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        G1Affine b;
+        b.x = fp_load(&pb[i].x);
+        b.y = fp_load(&pb[i].y);
+        G1Xyzz p = g1_xyzz_from_affine(b);
+        const unsigned j = (unsigned)((i / g) % a);
+#pragma unroll 1
+        for (unsigned k = 0; k < L - j; k++) g1_dbl(p);
+        out[i] = p;
     }
-    // t = (s' + 2^L - 1) / 2 = (s' >> 1) + 2^(L-1): bit p of t is 1 where the digit of 2^p is +1
-    uint32_t w[9];
-#pragma unroll
-    for (int k = 0; k < 8; k++) w[k] = (sp[k] >> 1) | (k < 7 ? sp[k + 1] << 31 : 0u);
-    w[8] = 0;
-    w[(L - 1) >> 5] |= 1u << ((L - 1) & 31);
-    uint32_t* out = digits + (m * A) * n + i;
-#pragma unroll
-    for (unsigned j = 0; j < A; j++) {
-        uint32_t idx = 0;
-#pragma unroll
-        for (unsigned k = 0; k < H; k++) {
-            const unsigned p = j + A * k;
-            idx |= ((w[p >> 5] >> (p & 31)) & 1u) << k;
+}
+PLONK_DEV G1Affine msm_comb_top_point(const G1Affine* tq, size_t n, size_t i, bool neg) {
+    G1Affine q = g1_affine_identity();
+    if (i < n) {
+        q.x = fp_load(&tq[i].x);
+        q.y = fp_load(&tq[i].y);
+        if (neg && !g1_affine_is_identity(q)) q.y = fp_neg(q.y);
+    }
+    return q;
+}
+// tmp[(grp - g0) << hb | idx] = T_grp[idx], idx < B^g, for the groups g0 .. g0 + ng - 1 (XYZZ; the caller zeroes tmp: the entries
+// from B^g up stay the identity).  tq: the n tooth points, affine.  A lane fills a run of B^2 consecutive indices (B when a
+// group is one base): the higher digits' share first, then the two low digits from (-c, -c) upwards in boustrophedon order, so that
+// every entry is one mixed addition of +-Q away from the one before.
+__global__ void __launch_bounds__(64) msm_comb_top_fill_kernel(const G1Affine* tq, size_t n, size_t g0, size_t ng, unsigned hb, unsigned g, unsigned B,
+                                                               uint32_t entries, G1Xyzz* tmp) {
+    const unsigned low = g >= 2 ? 2u : 1u, run = low == 2 ? B * B : B, c = (B - 1) / 2;
+    const size_t runs = entries / run;
+    for (size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x; id < ng * runs; id += (size_t)gridDim.x * blockDim.x) {
+        const size_t bi = id / runs, grp = g0 + bi, i0 = grp * g;
+        uint32_t t = (uint32_t)(id - bi * runs);
+        G1Xyzz* out = tmp + (bi << hb) + (size_t)t * run;
+        G1Xyzz acc = g1_xyzz_identity();
+#pragma unroll 1
+        for (unsigned pos = low; pos < g; pos++) {
+            const int code = (int)(t % B) - (int)c;
+            t /= B;
+            const G1Affine q = msm_comb_top_point(tq, n, i0 + pos, code < 0);
+#pragma unroll 1
+            for (int k = 0; k < (code < 0 ? -code : code); k++) g1_madd<true>(acc, q);
         }
-        const uint32_t top = idx >> (H - 1), mask = (1u << (H - 1)) - 1u;
-        const uint32_t low = top ? (idx & mask) : (~idx & mask);  // top tooth -1: minus the entry of the complemented teeth
-        const uint32_t neg = (top ? 0u : 1u) ^ (even ? 1u : 0u);
-        out[(size_t)j * n] = low | (neg << 31);
+        const G1Affine q0 = msm_comb_top_point(tq, n, i0, false), m0 = msm_comb_top_point(tq, n, i0, true);
+        const G1Affine q1 = msm_comb_top_point(tq, n, low == 2 ? i0 + 1 : n, false), m1 = msm_comb_top_point(tq, n, low == 2 ? i0 + 1 : n, true);
+#pragma unroll 1
+        for (unsigned k = 0; k < c; k++) {
+            g1_madd<true>(acc, m0);
+            g1_madd<true>(acc, m1);
+        }
+#pragma unroll 1
+        for (unsigned d1 = 0; d1 < (low == 2 ? B : 1u); d1++) {
+            const bool down = (d1 & 1u) != 0;
+#pragma unroll 1
+            for (unsigned st = 0; st < B; st++) {
+                out[d1 * B + (down ? B - 1 - st : st)] = acc;
+                if (st + 1 < B) g1_madd<true>(acc, down ? m0 : q0);
+            }
+            if (d1 + 1 < B) g1_madd<true>(acc, q1);
+        }
+    }
+}
+
+// digits[(m * A + j) * nd + i] = column j of scalar i of MSM m: the index of its table entry in bits 0 .. H-2, bit 31 set when the
+// entry is to be subtracted.  Scalar vector of MSM m as in msm_sort_kernel (stride / inner / outer_stride).  nd = n without top
+// tables.  TOP (see msm_comb_shape): a workgroup takes PER = g floor(256 / g) scalars — whole groups — and, after the columns,
+// lane t < PER / g folds the top codes of its group into the digit of virtual scalar n + grp / A of column grp % A
+// (nd = n + ceil(ceil(n / g) / A); a group past the last scalar gets the all-zero code: the identity entry of its block).
+template <unsigned H, bool TOP> __global__ void __launch_bounds__(256) msm_comb_digits_kernel(const Fr* scalars, size_t n, size_t stride, size_t inner,
+                                                                                              size_t outer_stride, size_t m0, uint32_t* digits, size_t nd) {
+    constexpr MsmCombShape SH = msm_comb_shape(H, TOP);
+    constexpr unsigned A = SH.a, L = A * H;
+    static_assert(L <= 9 * 32 && H <= MSM_COMB_MAX_TEETH, "the recoded scalar is kept in nine words");
+    constexpr unsigned PER = TOP ? (256 / (SH.top_g ? SH.top_g : 1)) * (SH.top_g ? SH.top_g : 1) : 256;
+    const size_t m = m0 + blockIdx.y, i = (size_t)blockIdx.x * PER + threadIdx.x;  // (a grid row per MSM: no division per lane)
+    const bool live = threadIdx.x < PER && i < n;
+    int code = 0;
+    if (live) {
+        const Fr* sc = scalars + (m % inner) * stride + (m / inner) * outer_stride;
+        const Fr s = fp_load(sc + i);  // the Montgomery residue s R mod r, taken as the integer it is: the table holds multiples of R^-1 P
+        // odd representative: s, or r - s with the sign of the base flipped (r is odd; s = 0 becomes r, and r P = O comes out of the sums)
+        const bool even = !(s.v[0] & 1u);
+        uint32_t sp[8], br = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const uint32_t d = fp_sbb(FrParams::mod(k), s.v[k], br);
+            sp[k] = even ? d : s.v[k];
+        }
+        // t = (v + 2^L - 1) / 2 = (v >> 1) + 2^(L-1), v = s' (mod 2^L when the top tables take the rest): bit p of t is 1 where the
+        // digit of 2^p is +1
+        uint32_t w[9];
+#pragma unroll
+        for (int k = 0; k < 8; k++) w[k] = (sp[k] >> 1) | (k < 7 ? sp[k + 1] << 31 : 0u);
+        w[8] = 0;
+        if constexpr (TOP) {
+            constexpr unsigned hi = L >> 5, sh = L & 31;  // u = bits L .. 253 of s'
+            uint32_t u = sp[hi] >> sh;
+            if constexpr (sh + SH.top_bits > 32 && hi + 1 < 8) u |= sp[hi + 1] << (32 - sh);
+            code = (int)(u & ((1u << SH.top_bits) - 1u));
+            if (even) code = -code;
+#pragma unroll
+            for (unsigned k = 0; k < 9; k++) {  // v >> 1 keeps bits 0 .. L-2
+                if (k > ((L - 1) >> 5)) w[k] = 0;
+                else if (k == ((L - 1) >> 5)) w[k] &= (1u << ((L - 1) & 31)) - 1u;
+            }
+        }
+        w[(L - 1) >> 5] |= 1u << ((L - 1) & 31);
+        uint32_t* out = digits + (m * A) * nd + i;
+#pragma unroll
+        for (unsigned j = 0; j < A; j++) {
+            uint32_t idx = 0;
+#pragma unroll
+            for (unsigned k = 0; k < H; k++) {
+                const unsigned p = j + A * k;
+                idx |= ((w[p >> 5] >> (p & 31)) & 1u) << k;
+            }
+            const uint32_t top = idx >> (H - 1), mask = (1u << (H - 1)) - 1u;
+            const uint32_t low = top ? (idx & mask) : (~idx & mask);  // top tooth -1: minus the entry of the complemented teeth
+            const uint32_t neg = (top ? 0u : 1u) ^ (even ? 1u : 0u);
+            out[(size_t)j * nd] = low | (neg << 31);
+        }
+    }
+    if constexpr (TOP) {
+        constexpr unsigned G = SH.top_g, B = SH.top_b;
+        __shared__ int codes[256];
+        codes[threadIdx.x] = code;
+        __syncthreads();
+        const size_t grp = (size_t)blockIdx.x * (PER / G) + threadIdx.x, nv = msm_comb_virtual(n, SH);
+        if (threadIdx.x < PER / G && grp < nv * A) {
+            uint32_t idx = 0, pw = 1;
+#pragma unroll
+            for (unsigned pos = 0; pos < G; pos++) {
+                idx += (uint32_t)(codes[threadIdx.x * G + pos] + (int)((B - 1) / 2)) * pw;
+                pw *= B;
+            }
+            const size_t v = grp / A, j = grp - v * A;
+            digits[(m * A + j) * nd + n + v] = (uint32_t)((v * (A - 1) + j) << (H - 1)) + idx;
+        }
     }
 }
 
@@ -198,7 +345,8 @@ PLONK_HD uint32_t msm_comb_slot(const MsmCombPlan& pl, uint32_t a, uint32_t j, u
 __global__ void __launch_bounds__(MSM_BLOCK, MSM_ACC_WAVES) msm_comb_kernel(const G1Affine* lookup, unsigned hb, unsigned a,
                                                                              const uint32_t* digits, size_t n, unsigned G,
                                                                              G1Xyzz* partial, MsmDeferred* deferred, size_t deferred_stride,
-                                                                             uint32_t* n_deferred) {
+                                                                             uint32_t* n_deferred, unsigned n_real, unsigned top_delta) {
+    // (n counts the virtual scalars of a comb with top tables, n_real the real ones: block of scalar i = msm_comb_block_of)
     PLONK_DYN_SMEM(smem);  // (MSM_BLOCK + a) pieces of 128 B
     G1Xyzz* red = reinterpret_cast<G1Xyzz*>(smem);
     const unsigned m = blockIdx.x / G, g = blockIdx.x % G, tid = threadIdx.x;
@@ -207,6 +355,7 @@ __global__ void __launch_bounds__(MSM_BLOCK, MSM_ACC_WAVES) msm_comb_kernel(cons
     const MsmCombPlan pl = msm_comb_plan(nsub, a);
     const uint32_t* dg = digits + (size_t)m * a * n + s0;  // dg[j * n + i], i relative to s0
     const G1Affine* tab = lookup + ((size_t)s0 << hb);
+    const uint32_t nr_rel = n_real > s0 ? n_real - s0 : 0u;  // first virtual scalar, relative to s0
     uint32_t j, i, step, count, slot;
     const bool column_lane = tid < a * pl.q;
     if (column_lane) {
@@ -228,7 +377,7 @@ __global__ void __launch_bounds__(MSM_BLOCK, MSM_ACC_WAVES) msm_comb_kernel(cons
     auto flush = [&]() { red[slot] = g1l_to_piece(run); };  // [0, 4m) words: what g1l_from_piece takes
     for (uint32_t k = 0; k < count; k++) {
         const uint32_t d = dg[(size_t)j * n + i];
-        const G1Affine* src = tab + (((size_t)i << hb) + (d & 0x7fffffffu));
+        const G1Affine* src = tab + (((size_t)(i + (i >= nr_rel ? top_delta : 0u)) << hb) + (d & 0x7fffffffu));
         const Fq x = fp_load(&src->x), y = fp_load(&src->y);
         if (!g1l_madd_fast(run, x, y, (d >> 31) != 0) && !(fp_is_zero(x) && fp_is_zero(y))) {  // see msm_accumulate_kernel
             const uint32_t sl = atomicAdd(n_deferred + m, 1u);
@@ -294,7 +443,8 @@ __global__ void __launch_bounds__(64) msm_comb_colsum_kernel(const G1Xyzz* parti
 template <unsigned LPM> __global__ void __launch_bounds__(64) msm_comb_finalize_kernel(const G1Xyzz* sums, size_t M, unsigned G, unsigned a,
                                                                                        const G1Affine* lookup, unsigned hb, size_t n,
                                                                                        const MsmDeferred* deferred, size_t deferred_stride,
-                                                                                       uint32_t* n_deferred, Fq* out_xy, uint8_t* flags) {
+                                                                                       uint32_t* n_deferred, Fq* out_xy, uint8_t* flags, unsigned n_real,
+                                                                                       unsigned top_delta) {
     const size_t gid = (size_t)blockIdx.x * 64 + threadIdx.x, m = gid / LPM;
     const unsigned l = (unsigned)(gid % LPM), lane = threadIdx.x;
     G1XyzzL acc = g1l_identity();
@@ -314,7 +464,7 @@ template <unsigned LPM> __global__ void __launch_bounds__(64) msm_comb_finalize_
                 const MsmDeferred e = deferred[m * deferred_stride + k];  // `bucket` carries the item j * n + i here
                 if (e.bucket / n != (uint32_t)j) continue;
                 const size_t i = e.bucket - (size_t)j * n;
-                const G1Affine* src = lookup + ((i << hb) + (e.entry & 0x7fffffffu));
+                const G1Affine* src = lookup + ((msm_comb_block_of(i, n_real, top_delta) << hb) + (e.entry & 0x7fffffffu));
                 // deferred for being exceptional against its LANE's sum at the time; against the column's sum it normally is not
                 const Fq x = fp_load(&src->x), y = fp_load(&src->y);
                 if (!(fp_is_zero(x) && fp_is_zero(y))) ok &= g1l_madd_fast(acc, x, y, (e.entry >> 31) != 0);
@@ -341,7 +491,7 @@ template <unsigned LPM> __global__ void __launch_bounds__(64) msm_comb_finalize_
 // Recovery path (MSM_DEFER_CAP): MSM m recomputed from its digits with the general formulas; one workgroup per MSM, which exits
 // at once unless the MSM overflowed its deferred list.  Lane t: Horner over the columns of the scalars t, t + 256, ..
 __global__ void __launch_bounds__(256) msm_comb_slow_kernel(const G1Affine* lookup, unsigned hb, unsigned a, const uint32_t* digits, size_t n,
-                                                            const uint32_t* n_deferred, Fq* out_xy, uint8_t* flags) {
+                                                            const uint32_t* n_deferred, Fq* out_xy, uint8_t* flags, unsigned n_real, unsigned top_delta) {
     __shared__ G1Xyzz red[256];
     const unsigned m = blockIdx.x, tid = threadIdx.x;
     if (!msm_comb_needs_redo(n_deferred[m])) return;
@@ -353,7 +503,7 @@ __global__ void __launch_bounds__(256) msm_comb_slow_kernel(const G1Affine* look
 #pragma unroll 1
         for (size_t i = tid; i < n; i += 256) {
             const uint32_t d = dg[(size_t)j * n + i];
-            const G1Affine* src = lookup + ((i << hb) + (d & 0x7fffffffu));
+            const G1Affine* src = lookup + ((msm_comb_block_of(i, n_real, top_delta) << hb) + (d & 0x7fffffffu));
             G1Affine pt;
             pt.x = fp_load(&src->x);
             pt.y = fp_load(&src->y);
@@ -412,4 +562,32 @@ __global__ void __launch_bounds__(64) msm_comb_verify_kernel(const G1Affine* bas
     b.x = fp_load(&bases[i].x);
     b.y = fp_load(&bases[i].y);
     if (!msm_comb_entry_matches(b, k, a, h, idx, lookup + ((i << (h - 1)) + idx))) atomicAdd(mismatches, 1u);
+}
+
+// ... and of its top tables: for every group the entry whose codes are all +1 = sum_pos 2^(L - j) R^-1 P_(g grp + pos), recomputed
+// from this SRS's bases (a table of another tooth count, group size or base set fails here)
+__global__ void __launch_bounds__(64) msm_comb_verify_top_kernel(const G1Affine* bases, const G1Affine* lookup, size_t n, unsigned a, unsigned h, unsigned g,
+                                                                 unsigned B, MsmCombScale k, unsigned* mismatches) {
+    const size_t grp = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (grp >= msm_comb_top_groups(n, g)) return;
+    const unsigned L = a * h, j = (unsigned)(grp % a);
+    G1Xyzz sum = g1_xyzz_identity();
+    uint32_t idx = 0, pw = 1;
+#pragma unroll 1
+    for (unsigned pos = 0; pos < g; pos++, pw *= B) {
+        const size_t i = grp * g + pos;
+        idx += ((B - 1) / 2 + (i < n ? 1u : 0u)) * pw;
+        if (i >= n) continue;
+        G1Affine b;
+        b.x = fp_load(&bases[i].x);
+        b.y = fp_load(&bases[i].y);
+        G1Xyzz p = msm_comb_scaled_base(b, k);
+#pragma unroll 1
+        for (unsigned d = 0; d < L - j; d++) g1_dbl(p);
+        g1_add(sum, p);
+    }
+    const G1Affine* e = lookup + (((n + grp) << (h - 1)) + idx);
+    const Fq ex = fp_load(&e->x), ey = fp_load(&e->y);
+    const bool ok = g1_is_identity(sum) ? (fp_is_zero(ex) && fp_is_zero(ey)) : (fp_eq(fp_mul(ex, sum.zz), sum.x) && fp_eq(fp_mul(ey, sum.zzz), sum.y));
+    if (!ok) atomicAdd(mismatches, 1u);
 }

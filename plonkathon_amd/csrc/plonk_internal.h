@@ -91,6 +91,7 @@ struct MsmLookupTable {
     size_t n_points = 0;
     unsigned kind = 0;       // MSM_TABLE_COMB (msm_comb.h: bits = teeth h, windows = columns a) or MSM_TABLE_WINDOWS (bits = c, windows = W)
     unsigned bits = 0, windows = 0;
+    unsigned top_bits = 0, top_g = 0;  // comb with top tables (msm_comb.h: windows = floor(254 / bits)): R and the bases per group; 0, 0 = none
     G1Affine* data = nullptr;
     size_t bytes = 0;
     double build_s = 0;      // wall time of the build (reported by bench.py)
@@ -110,6 +111,7 @@ struct plonk_srs {
     unsigned lookup_bits = 0;    // teeth h of the comb table / window bits c of the window table (0 = none)
     unsigned lookup_windows = 0; // additions per base: columns a of the comb / windows W
     unsigned lookup_kind = 0;    // MSM_TABLE_COMB / MSM_TABLE_WINDOWS (0 = none)
+    unsigned lookup_top_bits = 0, lookup_top_g = 0;  // the attached comb's top tables (0, 0 = none)
     bool lookup_failed = false;  // an automatic build did not fit: do not retry on every call
     G1Affine* lookup = nullptr;  // comb: lookup[(i << (h - 1)) + idx]; windows: lookup[((w * n_points + i) << (c - 1)) + d - 1]   (= shared->data)
     MsmLookupTable* shared = nullptr;
@@ -134,6 +136,7 @@ struct plonk_ctx {
     unsigned msm_window_bits = 0, msm_groups = 0;
     int msm_lookup_mode = 0;         // 0 auto (fixed SRS only), 1 off, 2 force msm_lookup_bits for every base set
     unsigned msm_lookup_bits = 0;    // 0 = the table with the fewest additions per base that fits the budget
+    bool msm_lookup_top = false;     // with explicit msm_lookup_bits: the comb WITH top tables (plonk_msm_lookup_configure mode | 32)
     unsigned msm_lookup_kind = MSM_TABLE_COMB;  // layout of the tables this context builds (plonk_msm_lookup_configure: mode | 16 = window tables)
     size_t msm_lookup_budget = 0;    // bytes; 0 = default (PLONK_MSM_TABLE_GB if set, else min(device memory / 16, free memory / 4): msm.hip)
     bool ntt_attr_set = false, msm_attr_set = false;  // hipFuncSetAttribute is per device: tracked per context
@@ -200,6 +203,8 @@ int g1_lagrange_by_ntt(plonk_ctx*, const plonk_srs*, unsigned log_n, G1Affine* d
 void msm_srs_release(plonk_srs*);  // drops the reference on the shared lookup table
 int msm_lookup_info(const plonk_srs*, unsigned* bits, size_t* bytes, double* build_s, int* sharers);
 int msm_lookup_layout(const plonk_srs*, unsigned* kind, unsigned* additions_per_base);
+int msm_lookup_top(const plonk_srs*, unsigned* top_bits, unsigned* bases_per_group);
+bool msm_comb_takes_top(unsigned teeth);  // msm.hip: a comb of this many teeth can take top tables
 uint64_t plonk_fnv1a64(const void* data, size_t n);
 // MSM m reads its scalars at d_scalars + (m % inner) * stride + (m / inner) * outer_stride (inner = 0: inner = M)
 int msm_run_device(plonk_ctx*, plonk_srs*, const Fr* d_scalars, size_t n, size_t M, size_t stride, Fq* d_out_xy,

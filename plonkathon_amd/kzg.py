@@ -98,15 +98,26 @@ class _DeviceBases:
         return out.value
 
     def lookup_info(self):
-        """{bits, bytes, build_s, sharers, layout, additions_per_base} of the table attached to these bases (one table per device,
-        base set and layout, shared by every context / stream / prover that loaded the same SRS)."""
+        """{bits, bytes, build_s, sharers, layout, additions_per_base, top_bits, top_group} of the table attached to these bases (one
+        table per device, base set and layout, shared by every context / stream / prover that loaded the same SRS).  A comb with top
+        tables (top_group = g > 0 bases per joint table) performs additions_per_base * (n + ceil(ceil(n / g) / additions_per_base))
+        mixed additions per MSM of n scalars: `additions(n)` below."""
         bits, nbytes, secs, sharers = ctypes.c_uint(0), ctypes.c_size_t(0), ctypes.c_double(0), ctypes.c_int(0)
         check(self.ctx.L.plonk_srs_lookup_info(self.handle, ctypes.byref(bits), ctypes.byref(nbytes), ctypes.byref(secs),
                                                ctypes.byref(sharers)))
         kind, adds = ctypes.c_uint(0), ctypes.c_uint(0)
         check(self.ctx.L.plonk_srs_lookup_layout(self.handle, ctypes.byref(kind), ctypes.byref(adds)))
+        tb, tg = ctypes.c_uint(0), ctypes.c_uint(0)
+        check(self.ctx.L.plonk_srs_lookup_top(self.handle, ctypes.byref(tb), ctypes.byref(tg)))
         return {"bits": bits.value, "bytes": nbytes.value, "build_s": secs.value, "sharers": sharers.value,
-                "layout": {0: None, 1: "comb", 2: "windows"}[kind.value], "additions_per_base": adds.value}
+                "layout": {0: None, 1: "comb", 2: "windows"}[kind.value], "additions_per_base": adds.value,
+                "top_bits": tb.value, "top_group": tg.value}
+
+    @staticmethod
+    def table_additions(info, n):
+        """Mixed additions of one MSM of n scalars on the table `info` (lookup_info) describes."""
+        a, g = info["additions_per_base"], info.get("top_group", 0)
+        return a * (n + (-(-(-(-n // g)) // a) if g else 0))
 
     def __del__(self):
         try:

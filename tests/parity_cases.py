@@ -997,7 +997,7 @@ def msm_deferred_overflow(setup_unused=None):
 
 
 def comb_table_shapes(shapes, seed=5150):
-    """The comb-table MSM (csrc/msm_comb.h) against the oracle over (teeth h, number of bases n, workgroups per MSM): the lane
+    """The comb-table MSM (csrc/msm_comb.h) against the oracle over (teeth h, number of bases n, workgroups per MSM[, top tables]): the lane
     partition of msm_comb_kernel — q = 256 / a lanes per column, left-over lanes crossing columns, pieces per column — depends
     on a = ceil(254 / h) and n alone, so small tables over ARBITRARY bases (forced mode: a table per ec_lincomb call) walk every
     branch of it: n below / at / above the lanes of a column, ragged tails, a > n, one scalar, scalar 0 / 1 / r - 1 / even / odd,
@@ -1011,8 +1011,10 @@ def comb_table_shapes(shapes, seed=5150):
     g = (1, 2)
     special = [0, 1, 2, R_MOD - 1, R_MOD - 2, (R_MOD - 1) // 2, 1 << 253, (1 << 127) + 1]
     try:
-        for h, n, groups in shapes:
-            ctx.msm_lookup(2, h)
+        for shape in shapes:
+            h, n, groups = shape[:3]
+            top = len(shape) > 3 and bool(shape[3])  # the comb of h teeth with top tables (floor(254 / h) columns + joint tables)
+            ctx.msm_lookup(2, h, 0, top=top)
             ctx.msm_configure(0, groups)
             ks = [rng.randrange(1, R_MOD) for _ in range(n)]
             pts = [og1.multiply(g, k) for k in ks[: min(n, 24)]]
@@ -1023,7 +1025,7 @@ def comb_table_shapes(shapes, seed=5150):
             pairs = [(None if q is None else (Fq(q[0]), Fq(q[1])), k) for q, k in zip(pts, sc)]
             got = pa.ec_lincomb(pairs)
             want = og1.ec_lincomb(list(zip(pts, sc)))
-            assert (None if got is None else affine(got)) == want, (h, n, groups)
+            assert (None if got is None else affine(got)) == want, (h, n, groups, top)
             # a result that IS the identity: every scalar zero (the recoding turns 0 into r: the sum cancels in the last Horner /
             # butterfly addition, which the finalize kernel resolves itself), and a pair s P + (r - s) P among zeros
             assert pa.ec_lincomb([(q, 0) for q, _ in pairs]) is None, (h, n, groups, "all scalars zero")

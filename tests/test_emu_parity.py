@@ -128,6 +128,14 @@ def test_msm_comb_table_shapes(emu):
                           (9, 700, 1), (9, 33, 8), (13, 2, 0), (16, 1, 0), (17, 3, 1)])  # (the last three: one live piece in a column's list of 12 .. 17)
 
 
+def test_msm_comb_top_tables(emu):
+    """Combs with top tables (msm_comb.h: floor(254 / h) columns, the one or two bits left over through a joint table per group of
+    g bases, dealt to the columns as virtual scalars): R = 2 with g = 2 (h = 7, 9) and g = 3 (h = 12), R = 1 with g = 6 (h = 11);
+    fewer bases than a group, ragged last groups, several workgroups per MSM (virtual scalars in the last one), and — inside
+    comb_table_shapes — scalars 0 / 1 / r - 1 / 2^253 (top bits set), an identity base, all-zero and cancelling MSMs."""
+    pc.comb_table_shapes([(7, 1, 0, 1), (7, 19, 1, 1), (7, 300, 2, 1), (9, 33, 4, 1), (11, 64, 0, 1), (11, 7, 1, 1), (12, 50, 1, 1)])
+
+
 @pytest.mark.parametrize("windows", [False, True])
 def test_msm_lookup_tables(emu, windows):
     """The table MSM — comb tables (csrc/msm_comb.h), and the window tables of rounds 2 - 5 (every multiple of every window

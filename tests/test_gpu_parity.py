@@ -188,6 +188,14 @@ def test_msm_comb_table_shapes():
                           (14, 2048, 1), (16, 700, 4), (19, 300, 1), (20, 120, 1), (20, 20, 0), (17, 1, 0), (17, 3, 1), (20, 2, 0), (12, 8192, 0), (13, 4097, 1)])  # (the last two: beyond 2^11 bases)
 
 
+def test_msm_comb_top_tables():
+    """Combs with top tables (msm_comb.h): floor(254 / h) columns plus a joint table per group of g bases for the one or two bits
+    left over, dealt to the columns as virtual scalars — R = 2 with g = 1 .. 6 (h = 4 .. 18), R = 1 with g = 6 (h = 11); ragged last
+    groups, fewer bases than a group, virtual scalars alone in an MSM's last workgroup, more than 2^11 bases."""
+    pc.comb_table_shapes([(4, 40, 0, 1), (7, 1, 0, 1), (7, 511, 1, 1), (9, 700, 1, 1), (9, 33, 8, 1), (11, 300, 2, 1), (11, 7, 1, 1), (12, 1000, 0, 1),
+                          (14, 2048, 1, 1), (14, 257, 4, 1), (18, 64, 1, 1), (12, 4097, 1, 1)])
+
+
 def test_lookup_and_bucket_methods_agree():
     """512 commitments of 2^11 coefficients: byte-identical from the lookup table and from the bucket method."""
     import ctypes
@@ -656,6 +664,66 @@ def test_full_size_lookup_table_on_an_explicit_budget():
     pcx.run()
     assert pcx.download_raw()[0] == blob_lookup
     del pb, pcx, proofs
+
+
+@pytest.mark.gpu
+def test_full_size_comb_with_top_tables():
+    """What a 180 GB budget buys (bench.py's opt-in): the comb of 21 teeth with top tables over the 2^11 SRS bases — 12 columns and a
+    joint table per 7 bases for the two bits left over: 12 x 2 073 additions per MSM of 2^11 (12.15 per base; 13 on the 20-tooth
+    comb), 2 348 blocks of 2^20 entries = 157.6 GB.  The 2^11 chain proofs against the fixtures; 8 more proofs byte-identical on
+    the table, on the plain 17-tooth comb and on the bucket method; commitments of fewer coefficients than the SRS has bases (the
+    virtual scalars then sit further from their blocks) and of the last top bits (scalars from 2^253 up) against the oracle."""
+    import json
+
+    import bench
+    from oracle import c_oracle
+    from plonkathon_amd import BatchProver, Context, Program, Setup
+    from plonkathon_amd.polynomial import Basis
+
+    a = Context(0)
+    a.msm_lookup(0, 0, int(180e9))
+    sa = Setup.from_file(pc.PTAU)
+    bench.GROUP_ORDER = 2048
+    program = Program(pc.chain_lines(2048), 2048)
+    proofs = BatchProver(sa, program, a).prove_batch([bench.witness_for(0), bench.witness_for(1)])
+    info = sa.device_bases(a).lookup_info()
+    assert info["layout"] == "comb" and info["bits"] == 21 and info["additions_per_base"] == 12 and info["top_bits"] == 2 and info["top_group"] == 7, info
+    assert info["bytes"] == (2048 + 25 * 12) * (1 << 20) * 64 and sa.device_bases(a).table_additions(info, 2048) == 12 * 2073, info
+    fx = {c["name"]: c for c in json.load(open(os.path.join(pc.GOLDEN, "oracle_proofs.json")))["cases"]}
+    for i, name in ((0, "chain_2048_x0_3"), (1, "chain_2048_x0_4")):
+        got = pc.flat(proofs[i])
+        for k, v in fx[name]["proof"].items():
+            assert got[k] == (pc.pt(v) if isinstance(v, list) else int(v)), (name, k)
+    wits = [bench.witness_for(10 + i) for i in range(8)]
+    pa_ = BatchProver(sa, program, a)
+    pa_.upload(wits)
+    pa_.run()
+    blob = pa_.download_raw()[0]
+    for conf in ((1,), (0, 17, int(20e9))):  # bucket method; the plain comb of 17 teeth
+        c = Context(0)
+        c.msm_lookup(*conf)
+        pcx = BatchProver(sa, program, c)
+        pcx.upload(wits)
+        pcx.run()
+        assert pcx.download_raw()[0] == blob, conf
+        del pcx
+    # short MSMs on the same table, top bits set
+    import random
+
+    from plonkathon_amd import backend
+
+    rng = random.Random(606)
+    prev = backend.get_context()
+    backend.set_context(a)
+    try:
+        pts = [pc.affine(p) for p in sa.powers_of_x[:300]]
+        for n in (1, 6, 7, 8, 85, 300):
+            sc = [rng.choice([pc.R_MOD - 1 - rng.randrange(1 << 200), (1 << 253) + rng.randrange(1 << 250), rng.randrange(pc.R_MOD)]) for _ in range(n)]
+            got = sa.commit_coeffs(pc.P(sc, Basis.MONOMIAL))
+            assert pc.affine(got) == c_oracle.g1_lincomb(pts[:n], sc), n
+    finally:
+        backend.set_context(prev)
+    del pa_, proofs
 
 
 @pytest.mark.gpu
