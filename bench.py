@@ -50,7 +50,10 @@ def table_adds(info, n):
     return a * (n + (-(-(-(-n // g)) // a) if g else 0))
 
 
-DEFAULT_TABLE_GB = 100.0  # opt-in budget for the MSM table: the comb of 20 teeth over 2^11 bases is 68.7 GB + 17.2 GB of build staging
+# opt-in budget for the MSM table: the comb of 21 teeth with top tables over 2^11 bases is 157.6 GB + 17.2 GB of build staging (12.15
+# additions per base); 100 buys the plain comb of 20 teeth (68.7 GB, 13 additions: rounds 5's headline), the library's own default
+# (1/16 of the device's memory) the one of 17 teeth (8.6 GB, 15)
+DEFAULT_TABLE_GB = 180.0
 LINE_LIMIT = 4096         # bytes of the stdout line (the driver's record keeps the last 8 KB of stdout)
 
 
@@ -332,7 +335,7 @@ def main():
     ap.add_argument("--dist-backend", default="rccl", choices=["rccl", "sockets"],
                     help="transport of the final gather for N > 1: rccl = RCCL over xGMI through the C-ABI (default); sockets = TCP, lets ranks share one GPU")
     ap.add_argument("--lookup-budget-gb", type=float, default=DEFAULT_TABLE_GB,
-                    help="HBM budget for the MSM table (the library's own default is 1/16 of the device's memory; the 20-tooth comb of 2^11 bases is 68.7 GB)")
+                    help="HBM budget for the MSM table (the library's own default is 1/16 of the device's memory; 100 = the 20-tooth comb of 2^11 bases, 68.7 GB)")
     ap.add_argument("--lookup-bits", type=int, default=0,
                     help="teeth of the comb table (0 = the largest the budget affords: 20 for 2^11 bases under the default budget); A/B runs")
     ap.add_argument("--force-comm", action="store_true",

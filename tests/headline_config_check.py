@@ -2,8 +2,8 @@
 """The headline configuration of bench.py as a parity check (run as a subprocess by tests/test_gpu_multiprocess.py: the number of
 hardware queues is fixed when the HIP runtime starts, so pytest's own process cannot host it).
 
-BASELINE configs[1] the way the bench line runs it: several contexts (HIP streams) on as many hardware queues, the 100 GB table
-budget (the comb of 20 teeth over the 2^11 SRS bases: 13 additions per base), ONE workgroup per MSM (`msm_configure(0, 1)`), two
+BASELINE configs[1] the way the bench line runs it: several contexts (HIP streams) on as many hardware queues, bench.py's table
+budget (180 GB: the comb of 21 teeth with top tables over the 2^11 SRS bases, 12.15 additions per base), ONE workgroup per MSM (`msm_configure(0, 1)`), two
 lock-step batches of 512 proofs per context, every batch of the step in flight before the first download — twice over, so that a
 batch also runs behind its stream's previous one.  Checks, bit for bit:
   * every proof of the step against the SAME witnesses proved on the bucket method (the path of `ec_lincomb`, curve.py:38-111,
@@ -62,7 +62,7 @@ def main():
     assert passes[0][0] == passes[1][0], "the second pass of the step differs from the first"
     got = passes[0][0]
     info = setup.device_bases(ctxs[0]).lookup_info()  # (the table is built by the first MSM that asks for it)
-    assert info["layout"] == "comb" and info["bits"] == 20 and info["additions_per_base"] == 13 and info["sharers"] >= NS, info
+    assert info["layout"] == "comb" and info["bits"] == 21 and info["additions_per_base"] == 12 and info["top_group"] == 7 and info["sharers"] >= NS, info
 
     # the bucket method on the same witnesses, alone on the chip, one batch at a time
     cb = Context(0)
@@ -96,7 +96,7 @@ def main():
         bad = BatchProver.decode(bytes(rec))
     assert not vk.verify_proof(2048, bad, [wit[v] for v in program.get_public_assignments()]), "a corrupted proof was accepted"
     print(json.dumps({"contexts": NS, "hw_queues": int(os.environ["GPU_MAX_HW_QUEUES"]), "batches": S, "batch": B, "proofs": S * B,
-                      "comb_teeth": info["bits"], "table_bytes": info["bytes"], "workgroups_per_msm": 1,
+                      "comb_teeth": info["bits"], "comb_columns": info["additions_per_base"], "top_group": info["top_group"], "table_bytes": info["bytes"], "workgroups_per_msm": 1,
                       "identical_to_bucket_method": S * B, "fixtures": 2, "pairing_checked": idx,
                       "proofs_per_s_pass": [S * B / p[1] for p in passes], "witness_s": t_wit, "bucket_method_s": t_bucket}), flush=True)
 

@@ -133,8 +133,8 @@ def test_dress_rehearsal_eight_ranks_at_the_default_batch():
 
 @pytest.mark.gpu
 def test_headline_configuration_is_bit_identical_to_the_bucket_method():
-    """what bench.py's line is measured on — eight contexts on eight hardware queues, the 100 GB budget (the comb
-    of 20 teeth), one workgroup per MSM, sixteen lock-step batches of 512 distinct witnesses in flight together — with EVERY one of
+    """what bench.py's line is measured on — eight contexts on eight hardware queues, bench.py's table budget (180 GB: the comb
+    of 21 teeth with top tables), one workgroup per MSM, sixteen lock-step batches of 512 distinct witnesses in flight together — with EVERY one of
     the 8 192 proofs compared byte for byte with the bucket method's, the step run twice, proofs 0 / 1 against the fixtures and four
     under the pairing check (tests/headline_config_check.py; a subprocess because GPU_MAX_HW_QUEUES is read when the runtime starts)."""
     env = dict(os.environ)
@@ -143,7 +143,7 @@ def test_headline_configuration_is_bit_identical_to_the_bucket_method():
                        capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-    assert out["contexts"] == 8 and out["hw_queues"] == 8 and out["comb_teeth"] == 20 and out["table_bytes"] == 2048 * (1 << 19) * 64
+    assert out["contexts"] == 8 and out["hw_queues"] == 8 and out["comb_teeth"] == 21 and out["comb_columns"] == 12 and out["top_group"] == 7 and out["table_bytes"] == (2048 + 300) * (1 << 20) * 64
     assert out["proofs"] == 8192 and out["identical_to_bucket_method"] == 8192 and out["fixtures"] == 2 and len(out["pairing_checked"]) == 4
     print("headline configuration:", out)
 

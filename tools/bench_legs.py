@@ -334,10 +334,12 @@ def fallbacks(run):
     fit = lambda budget: comb_fit(n, budget)
     wfit = lambda budget: max(c for c in range(8, 18) if lookup_table_bytes(n, c) <= budget)
     wits = [run.witness_for(idx) for idx in run.mine[:B]]
-    # (explicit sizes: with an automatic choice a context would simply attach to the big table the headline built)
+    # (explicit sizes: with an automatic choice a context would simply attach to the big table the headline built; the headline's
+    # 157.6 GB table stays resident meanwhile, so the legs here stay small — the 20-tooth comb of round 5 (68.7 GB + 17.2 GB of
+    # staging, 13 additions per base) against the one with top tables is an A/B of its own: profiles/r06_m_comb_top_ab.json)
     for name, conf in (("library_default_budget", (0, fit(hbm_total // 16), hbm_total // 16)), ("table_budget_4GiB", (0, fit(4 << 30), 4 << 30)),
                        ("table_budget_1GiB", (0, fit(1 << 30), 1 << 30)), ("table_budget_128MiB", (0, fit(128 << 20), 128 << 20)),
-                       ("window_table_150GB", (0, wfit(150e9), int(150e9), True)), ("window_table_default_budget", (0, wfit(hbm_total // 16), hbm_total // 16, True)),
+                       ("window_table_40GB", (0, wfit(40e9), int(40e9), True)), ("window_table_default_budget", (0, wfit(hbm_total // 16), hbm_total // 16, True)),
                        ("bucket_method", (1, 0, 0))):
         c2 = Context(run.local_rank)
         c2.msm_lookup(*conf)

@@ -37,7 +37,7 @@ runs = by.get("quotient_kernel", {}).get("launches", 0.0)
 if not runs:
     sys.exit("pmc_step_summary: no quotient_kernel dispatch in %s/step_issue" % src)
 
-ONE_OFF = ("msm_comb_fill", "msm_comb_scale", "msm_table_kernel", "g1_batch_to_affine", "msm_comb_delta", "fq_rescale", "msm_comb_verify",
+ONE_OFF = ("msm_comb_fill", "msm_comb_top_fill", "msm_comb_top_base", "msm_comb_scale", "msm_table_kernel", "g1_batch_to_affine", "msm_comb_delta", "fq_rescale", "msm_comb_verify",
            "li_coset", "witness_scatter", "public_gather", "fr_to_mont", "fr_powers", "ntt_program_block", "__amd_rocclr")
 plain = {}
 try:

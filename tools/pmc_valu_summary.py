@@ -11,7 +11,8 @@ it.  Derived per kernel (per launch, mean over the launches of the pass):
   cycles_per_valu_inst   = 4 * SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU
   waves_per_simd         = 4 * SQ_WAVE_CYCLES / (SIMDS * cycles)                [average resident waves]
   wave_time_split        = VALU-active / waiting (s_waitcnt, barrier) / issue-stalled fractions of a wave's resident time
-  valu_insts_per_addition (MSM: launch = 1152 MSMs x 30720 additions / 64 lanes) and valu_insts_per_element (NTT)."""
+  valu_insts_per_addition (MSM: launch = 1152 MSMs x ADDS_PER_BASE x 2048 additions / 64 lanes: 24 876 per MSM on the comb of 21 teeth
+  with top tables, 26 624 on the 20-tooth comb) and valu_insts_per_element (NTT)."""
 import collections
 import csv
 import glob
@@ -75,7 +76,9 @@ res = {"units": __doc__.split("Units")[1].strip()[:1200]}
 # scalars x 15 windows of 17 bits = 4608 x 30720 mixed additions; 64 lanes per wave instruction)
 # (comb tables, csrc/msm_comb.h: msm_comb_kernel, 13 columns of 20 teeth = 4608 x 26624 mixed additions per run)
 MSM_KERNEL = "msm_comb_kernel" if any(name == "msm_comb_kernel" for (name, _, _) in launches("bench_issue")) else "msm_lookup_kernel"
-ADDS_PER_BASE = float(os.environ.get("MSM_ADDS_PER_BASE", "13" if MSM_KERNEL == "msm_comb_kernel" else "15"))
+# (round 6, bench.py's default budget: 21 teeth + top tables = 12 columns of 2 073 real and virtual scalars = 24 876 additions per MSM
+# of 2^11, 12.146 per base; MSM_ADDS_PER_BASE=13 for a pass on the 20-tooth comb, 15 for the 17-tooth one)
+ADDS_PER_BASE = float(os.environ.get("MSM_ADDS_PER_BASE", str(24876 / 2048) if MSM_KERNEL == "msm_comb_kernel" else "15"))
 ADDS_PER_RUN = 4608.0 * ADDS_PER_BASE * 2048
 b = {}
 for tag in ("bench_issue", "bench_mem", "bench_utcl"):
