@@ -380,8 +380,6 @@ int plonk_ntt_configure(plonk_ctx* ctx, unsigned tile_log, unsigned single_pass_
  * on the two-element "latency" forms (2^9, and the splits of 2^14 .. 2^18 built on 2^7 and 2^9) that 0 and 5 pick for
  * calls of at most 2^18 elements; 8 = as 5, with 2^12 on its 1024-thread, 4-element form instead of 512 threads x 8
  * elements (which 0 and 5 use wherever 2^12 is not a column pass on the one-table inter-pass twiddles).
- * 9 / 10 = as 5, with the passes of a two-pass transform on the two-columns-per-workgroup form of the 2^8 / 2^10 kernels wherever
- * it exists / never (0 and 5 take it for a pass that is a single round of workgroups: a lone 2^20).
  * (2, the Stockham LDS kernel, and 3 are retired.) */
 int plonk_ntt_select_kernel(plonk_ctx* ctx, unsigned kind);
 /* two-pass wave transforms N = R1 R2 (R1-point column transforms, then R2-point row transforms): log2 R1 for one

@@ -299,10 +299,9 @@ int plonk_ntt_configure(plonk_ctx* ctx, unsigned tile_log, unsigned single_pass_
 int plonk_ntt_select_kernel(plonk_ctx* ctx, unsigned kind) {
     PLONK_REQUIRE(ctx, PLONK_ERR_ARG, "ctx is NULL");
     PLONK_ENTER(ctx);
-    PLONK_REQUIRE(kind <= 10 && kind != 2 && kind != 3, PLONK_ERR_ARG,
+    PLONK_REQUIRE(kind <= 8 && kind != 2 && kind != 3, PLONK_ERR_ARG,
                   "kernel kind must be 0 (auto), 1 or 4 (the LDS kernel: radix-2 stages), 5 (in-register wave kernels wherever they apply), 6 (wave kernels, "
-                  "never the two-element latency forms), 7 (wave kernels, the latency forms wherever they exist), 8 (wave kernels, 2^12 on its 1024-thread form), "
-                  "9 / 10 (wave kernels, the passes of a two-pass transform two columns per workgroup wherever that form exists / never)");
+                  "never the two-element latency forms), 7 (wave kernels, the latency forms wherever they exist) or 8 (wave kernels, 2^12 on its 1024-thread form)");
     ctx->ntt_kind = kind;
     ctx->ntt_cfg_epoch++;
     return PLONK_OK;

@@ -318,10 +318,8 @@ template <unsigned LOG_E, unsigned NLDS> struct WavelCfg {
 // One transform (or one column / row of a two-pass transform) by one workgroup: the body of both kernels below.
 // FULL: the column pass of a two-pass transform with its inter-pass twiddles in ONE table (p.tw_lo; see the end of this file)
 // — a kernel of its own, for E = 4 only: the E = 8 kernels sit at 128 registers and any change to this epilogue spills
-// PRE (round 6, ntt_wavel_pair_kernel below): the E input elements were requested by the caller (wavel_request: `pre` / `pre_in`
-// hold them), b / nb stand for blockIdx.x / gridDim.x of a launch with one workgroup per column
-template <class P, unsigned LOG_E, unsigned NLDS, bool FULL = false, bool PRE = false>
-PLONK_DEV void wavel_transform(const NttWaveT<P>& p, unsigned char* smem, const unsigned b, const unsigned nb, const Fp<P>* pre, const bool* pre_in) {
+template <class P, unsigned LOG_E, unsigned NLDS, bool FULL = false>
+PLONK_DEV void wavel_transform(const NttWaveT<P>& p, unsigned char* smem) {
     constexpr unsigned E = 1u << LOG_E, LOG_T = wavel_log_t(NLDS), LOG_N = LOG_E + LOG_T, NT = 1u << LOG_T;
     constexpr unsigned LSLOTS = E >= 4 ? 4 : 1;    // elements per thread and exchange round
     u32x4* l_lo = reinterpret_cast<u32x4*>(smem);  // LSLOTS * NT elements as two 16-byte planes and one 4-byte plane
@@ -333,7 +331,8 @@ PLONK_DEV void wavel_transform(const NttWaveT<P>& p, unsigned char* smem, const 
     Fp<P>* out = p.out + (size_t)bidx * p.out_bstride + ((p.fan & NTT_FAN_OUT) ? fan : 0u);
     // column / row of a two-pass transform.  Workgroup b runs on XCD b % 8 (each XCD has its own L2): the remap gives
     // every XCD four ADJACENT columns (rows) per group of 32, so the 32-byte elements it touches share 128-byte lines.
-    const unsigned sub = !p.mode ? 0 : ((nb & 31u) ? b : ((b & ~31u) | ((b & 7u) << 2) | ((b >> 3) & 3u)));
+    const unsigned b = blockIdx.x;
+    const unsigned sub = !p.mode ? 0 : ((gridDim.x & 31u) ? b : ((b & ~31u) | ((b & 7u) << 2) | ((b >> 3) & 3u)));
     // global index of sub-transform position pos on the input side, of frequency o on the output side
     // The intermediate buffer of a two-pass transform is kept TRANSPOSED (NTT_TMP_TRANSPOSED in `fan`, which modes 1 and 2 do not
     // otherwise use): the column pass stores column c as one contiguous run tmp[c R1 + k1], the row pass gathers row k1 with stride
@@ -349,14 +348,7 @@ PLONK_DEV void wavel_transform(const NttWaveT<P>& p, unsigned char* smem, const 
     const FpLS<P> &w8_1 = p.w8[0], &w8_2 = p.w8[1], &w8_3 = p.w8[2];  // kernel arguments: scalar registers
 
     FpL<P> x[E];
-    if constexpr (PRE) {
-        wave_for<E>([&](auto J) {
-            constexpr unsigned j = decltype(J)::value;
-            Fp<P> raw = pre[j];
-            wave_for<8>([&](auto W) { raw.v[decltype(W)::value] = pre_in[j] ? raw.v[decltype(W)::value] : 0u; });
-            x[j] = fpl_from_fp(raw);
-        });
-    } else {
+    {
         // The loads of a group of LB elements are issued before the first of them is waited for (round 6): with a bounds check
         // around each load the compiler emitted load - wait - unpack per element, E memory round trips in a row at the start of
         // every workgroup — hidden in a batch, exposed in a lone transform, whose workgroups all start together.  Out-of-range
@@ -600,7 +592,7 @@ PLONK_DEV void wavel_transform(const NttWaveT<P>& p, unsigned char* smem, const 
 template <class P, unsigned LOG_E, unsigned NLDS>
 __global__ void __launch_bounds__(1u << wavel_log_t(NLDS), (WavelCfg<LOG_E, NLDS>::WAVES)) ntt_wavel_kernel(NttWaveT<P> p) {
     PLONK_DYN_SMEM(smem);
-    wavel_transform<P, LOG_E, NLDS>(p, smem, blockIdx.x, gridDim.x, nullptr, nullptr);
+    wavel_transform<P, LOG_E, NLDS>(p, smem);
 }
 // (E = 4 only.  The E = 8 forms spill at 128 registers with every variant of the table epilogue; compiled for three waves per
 // SIMD — 132-135 registers, no scratch — they were measured: batches gain 4-5 %, but a lone 2^21 loses 8 % and a lone 2^24
@@ -608,48 +600,7 @@ __global__ void __launch_bounds__(1u << wavel_log_t(NLDS), (WavelCfg<LOG_E, NLDS
 template <class P, unsigned LOG_E, unsigned NLDS>
 __global__ void __launch_bounds__(1u << wavel_log_t(NLDS), (WavelCfg<LOG_E, NLDS>::WAVES)) ntt_wavel_column_kernel(NttWaveT<P> p) {
     PLONK_DYN_SMEM(smem);
-    wavel_transform<P, LOG_E, NLDS, true>(p, smem, blockIdx.x, gridDim.x, nullptr, nullptr);
-}
-
-// ---- two columns (rows) per workgroup: the passes of a LONE two-pass transform (round 6) --------------------------------------
-// A lone 2^20 transform is one round of workgroups per pass — 1 024 columns on 1 024 workgroup slots — that all load, compute
-// and store at the same moments: memory and ALUs take turns (VALU busy 0.60 against 0.90 for the same kernels in a batch).  Here
-// a workgroup takes columns b and b + gridDim.x (half the grid): the elements of both are requested first — the second
-// column's 4 x 8 words stay in flight in registers while the first is transformed — and the first column's stores drain while
-// the second is computed, so only half of the loads and half of the stores stand outside the arithmetic.  E = 4 only (73 - 75
-// registers + 32: still four waves per SIMD); modes 1 and 2.
-template <class P, unsigned LOG_E, unsigned NLDS>
-PLONK_DEV void wavel_request(const NttWaveT<P>& p, const unsigned b, const unsigned nb, Fp<P> (&raw)[1u << LOG_E], bool (&inside)[1u << LOG_E]) {
-    constexpr unsigned E = 1u << LOG_E, LOG_T = wavel_log_t(NLDS), LOG_N = LOG_E + LOG_T, NT = 1u << LOG_T;
-    const unsigned sub = (nb & 31u) ? b : ((b & ~31u) | ((b & 7u) << 2) | ((b >> 3) & 3u));
-    const Fp<P>* in = p.in + (size_t)blockIdx.y * p.in_bstride;
-    const unsigned in_shift = p.mode == 1 ? p.log_other : 0;
-    const unsigned in_off = p.mode == 1 ? sub : (p.chunk_stride ? sub << p.chunk_log : sub << LOG_N);
-    const unsigned chunk_mask = (1u << p.chunk_log) - 1;
-    wave_for<E>([&](auto J) {
-        constexpr unsigned j = decltype(J)::value;
-        const unsigned pos = j * NT + threadIdx.x;
-        const unsigned g = p.chunk_stride ? (pos >> p.chunk_log) * p.chunk_stride + (pos & chunk_mask) + in_off : (pos << in_shift) + in_off;
-        inside[j] = g < p.in_len;
-        raw[j] = fp_load(wavel_at(in, inside[j] ? g : 0u));
-    });
-}
-// (compiled for two waves per SIMD — what half a grid of one round leaves resident anyway: the second column's words fit beside the
-// first column's 106 registers without scratch)
-template <class P, unsigned LOG_E, unsigned NLDS, bool FULL>
-__global__ void __launch_bounds__(1u << wavel_log_t(NLDS), 2) ntt_wavel_pair_kernel(NttWaveT<P> p) {
-    PLONK_DYN_SMEM(smem);
-    constexpr unsigned E = 1u << LOG_E;
-    static_assert(LOG_E == 2, "two columns per workgroup: the 4-element kernels");
-    const unsigned nb = 2 * gridDim.x, b0 = blockIdx.x, b1 = blockIdx.x + gridDim.x;
-    Fp<P> r0[E], r1[E];
-    bool i0[E], i1[E];
-    wavel_request<P, LOG_E, NLDS>(p, b0, nb, r0, i0);
-    wavel_request<P, LOG_E, NLDS>(p, b1, nb, r1, i1);
-    PLONK_SCHED_FENCE();  // (both requests before the first unpack: the scheduler would sink the second column's loads behind the first transform)
-    wavel_transform<P, LOG_E, NLDS, FULL, true>(p, smem, b0, nb, r0, i0);
-    if (NLDS) __syncthreads();  // the first column's last LDS round is read before the second column writes its first
-    wavel_transform<P, LOG_E, NLDS, FULL, true>(p, smem, b1, nb, r1, i1);
+    wavel_transform<P, LOG_E, NLDS, true>(p, smem);
 }
 
 

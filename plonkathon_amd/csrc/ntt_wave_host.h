@@ -164,17 +164,9 @@ template <class F> static void wave_params_init(NttWaveT<typename F::P>* p, unsi
     p->w8[2] = fpl_shoup_from_mont(fp_mul(w4, w8), ninv);
 }
 
-template <class F, unsigned LOG_E, unsigned NLDS> static int wave_launch_as(plonk_ctx* ctx, const NttWaveT<typename F::P>& q, unsigned grid_x, unsigned grid_y,
-                                                                            bool pair) {
+template <class F, unsigned LOG_E, unsigned NLDS> static int wave_launch_as(plonk_ctx* ctx, const NttWaveT<typename F::P>& q, unsigned grid_x, unsigned grid_y) {
     typedef typename F::P P;
     constexpr unsigned nt = 1u << wavel_log_t(NLDS);
-    if constexpr (LOG_E == 2 && NLDS <= 1) {
-        if (pair && q.mode && !(grid_x & 1u)) {  // two columns (rows) per workgroup: ntt_wave.h, ntt_wavel_pair_kernel
-            void (*k2)(NttWaveT<P>) = q.tw_always == 2u ? ntt_wavel_pair_kernel<P, LOG_E, NLDS, true> : ntt_wavel_pair_kernel<P, LOG_E, NLDS, false>;
-            PLONK_LAUNCH(k2, dim3(grid_x / 2, grid_y), dim3(nt), NLDS ? (size_t)4 * nt * 36 : 0, ctx->stream, q);
-            return PLONK_OK;
-        }
-    }
     const size_t shmem = NLDS ? (size_t)(LOG_E >= 2 ? 4 : 1) * nt * 36 : 0;  // one round of the wave-bit exchange: 4 elements (E = 2: one) of 9 words per thread
     WaveTables& T = F::tables(ctx);
     if (NLDS == 2 && LOG_E >= 2 && !T.attr_set[LOG_E >= 2 ? LOG_E - 2 : 0]) {  // 144 KiB: above the default limit; a per-device attribute, tracked per context
@@ -203,20 +195,19 @@ template <class F, unsigned LOG_E, unsigned NLDS> static int wave_launch_as(plon
 }
 
 // log_r = 8, 10, 12: 4 elements per thread; 9, 11, 13 (and 12 in its 512-thread form): 8; 7, and 9 in its latency form: 2
-template <class F> static int wave_launch(plonk_ctx* ctx, const NttWaveT<typename F::P>& p, unsigned log_r, unsigned log_e, unsigned grid_x, unsigned grid_y,
-                                          bool pair = false) {
+template <class F> static int wave_launch(plonk_ctx* ctx, const NttWaveT<typename F::P>& p, unsigned log_r, unsigned log_e, unsigned grid_x, unsigned grid_y) {
     NttWaveT<typename F::P> q = p;
     if (!q.jm) PLONK_TRY(wave_jm<F>(ctx, &q.jm));  // (wave_run's cached plans carry it)
     switch (log_r | (log_e << 8)) {
-        case 8 | (2 << 8): return wave_launch_as<F, 2, 0>(ctx, q, grid_x, grid_y, pair);
-        case 10 | (2 << 8): return wave_launch_as<F, 2, 1>(ctx, q, grid_x, grid_y, pair);
-        case 12 | (2 << 8): return wave_launch_as<F, 2, 2>(ctx, q, grid_x, grid_y, pair);
-        case 9 | (3 << 8): return wave_launch_as<F, 3, 0>(ctx, q, grid_x, grid_y, pair);
-        case 11 | (3 << 8): return wave_launch_as<F, 3, 1>(ctx, q, grid_x, grid_y, pair);
-        case 13 | (3 << 8): return wave_launch_as<F, 3, 2>(ctx, q, grid_x, grid_y, pair);
-        case 12 | (3 << 8): return wave_launch_as<F, 3, 3>(ctx, q, grid_x, grid_y, pair);  // 512 threads x 8 elements
-        case 7 | (1 << 8): return wave_launch_as<F, 1, 0>(ctx, q, grid_x, grid_y, pair);
-        case 9 | (1 << 8): return wave_launch_as<F, 1, 1>(ctx, q, grid_x, grid_y, pair);
+        case 8 | (2 << 8): return wave_launch_as<F, 2, 0>(ctx, q, grid_x, grid_y);
+        case 10 | (2 << 8): return wave_launch_as<F, 2, 1>(ctx, q, grid_x, grid_y);
+        case 12 | (2 << 8): return wave_launch_as<F, 2, 2>(ctx, q, grid_x, grid_y);
+        case 9 | (3 << 8): return wave_launch_as<F, 3, 0>(ctx, q, grid_x, grid_y);
+        case 11 | (3 << 8): return wave_launch_as<F, 3, 1>(ctx, q, grid_x, grid_y);
+        case 13 | (3 << 8): return wave_launch_as<F, 3, 2>(ctx, q, grid_x, grid_y);
+        case 12 | (3 << 8): return wave_launch_as<F, 3, 3>(ctx, q, grid_x, grid_y);  // 512 threads x 8 elements
+        case 7 | (1 << 8): return wave_launch_as<F, 1, 0>(ctx, q, grid_x, grid_y);
+        case 9 | (1 << 8): return wave_launch_as<F, 1, 1>(ctx, q, grid_x, grid_y);
     }
     plonk_set_error("no wave kernel for a 2^%u-point transform with 2^%u elements per thread", log_r, log_e);
     return PLONK_ERR_ARG;
@@ -394,18 +385,11 @@ static int wave_run(plonk_ctx* ctx, const Fp<typename F::P>* in, Fp<typename F::
     a.in_bstride = in_bstride;
     a.in_len = in_len32;
     a.in_scale = in_scale;
-    // A pass that is ONE round of workgroups (more than half of the chip's 1 024 slots of 256 threads, not more than all of them: a
-    // lone 2^20) runs two columns per workgroup where its kernel has that form (ntt_wave.h: ntt_wavel_pair_kernel — loads and stores of
-    // one column behind the other's arithmetic); plonk_ntt_select_kernel 9 / 10: wherever the form exists / never (tests, A/B)
-    const auto pair = [&](unsigned cols) {
-        const size_t wgs = (size_t)cols * batch;
-        return ctx->ntt_kind == 9 || (ctx->ntt_kind != 10 && wgs > 512 && wgs <= 1024);
-    };
     PLONK_TRY(prof_begin(ctx, "ntt_pass_columns", 32.0 * (double)N * (double)batch));
-    PLONK_TRY(wave_launch<F>(ctx, a, log_r1, plan->log_e1, 1u << log_r2, (unsigned)batch, pair(1u << log_r2)));
+    PLONK_TRY(wave_launch<F>(ctx, a, log_r1, plan->log_e1, 1u << log_r2, (unsigned)batch));
     PLONK_TRY(prof_end(ctx));
     PLONK_TRY(prof_begin(ctx, "ntt_pass_rows", 32.0 * (double)N * (double)batch));
-    PLONK_TRY(wave_launch<F>(ctx, c, log_r2, plan->log_e2, 1u << log_r1, (unsigned)batch, pair(1u << log_r1)));
+    PLONK_TRY(wave_launch<F>(ctx, c, log_r2, plan->log_e2, 1u << log_r1, (unsigned)batch));
     PLONK_TRY(prof_end(ctx));
     PLONK_CHECK_HIP(hipGetLastError());
     return PLONK_OK;

@@ -151,7 +151,7 @@ struct plonk_ctx {
     size_t ntt_table_budget = (size_t)4 << 30, ntt_tables_bytes = 0;  // full inter-pass twiddle tables (80 B per point and direction): plonk_ntt_set_table_budget
     unsigned char ntt_split[32] = {0};  // plonk_ntt_set_split: log2 R1 of the two-pass wave plan per log2 N (0 = default)
     unsigned ntt_cfg_epoch = 0;  // bumped by every plonk_ntt_* setter: cached launch plans are rebuilt
-    unsigned ntt_kind = 0;  // 0 = auto (wave kernels where they apply, else the LDS kernel), 1 / 4 = the LDS kernel, 5 = force wave, 6 / 7 = force wave without / with the two-element latency forms, 8 = force wave with 2^12 on 1024 threads, 9 / 10 = force wave, two columns per workgroup in two-pass transforms wherever / never
+    unsigned ntt_kind = 0;  // 0 = auto (wave kernels where they apply, else the LDS kernel), 1 / 4 = the LDS kernel, 5 = force wave, 6 / 7 = force wave without / with the two-element latency forms, 8 = force wave with 2^12 on 1024 threads
 };
 
 // scratch slot use: 0 = NTT inter-pass buffer, 1 = MSM digits/partials, 2-3 = API-level temporaries

@@ -300,24 +300,6 @@ def test_ntt_two_pass_wave_kernel(emu):
         check(ctx.L.plonk_ntt_select_kernel(ctx.handle, 0))
 
 
-def test_ntt_two_columns_per_workgroup(emu):
-    """The passes of a two-pass transform on ntt_wavel_pair_kernel (kernel kind 9: wherever the form exists — the 4-element 2^8 and
-    2^10 kernels): 2^16 = 2^8 x 2^8 with the column pass on the one-table inter-pass twiddles and on the two small tables, 2^18 =
-    2^10 x 2^8 (the LDS exchange of the first column is over before the second begins); forward out of place, inverse in place."""
-    from plonkathon_amd import get_context
-    from plonkathon_amd._lib import check
-
-    ctx = get_context()
-    with pc.ntt_kind(9):
-        pc.ntt_two_pass_exact((16,), batch=5)  # (more than 2^18 elements per call: the throughput forms)
-        try:
-            check(ctx.L.plonk_ntt_set_table_budget(ctx.handle, 0))
-            pc.ntt_two_pass_exact((16,), seed0=4500, batch=5)
-        finally:
-            check(ctx.L.plonk_ntt_set_table_budget(ctx.handle, 4 << 30))
-        pc.ntt_two_pass_exact((18,), batch=2)
-
-
 def test_ntt_2_14_and_2_15(emu):
     pc.ntt_quad_sizes()
 

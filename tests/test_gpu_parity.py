@@ -667,32 +667,6 @@ def test_full_size_lookup_table_on_an_explicit_budget():
 
 
 @pytest.mark.gpu
-def test_ntt_two_columns_per_workgroup():
-    """The passes of a two-pass transform on ntt_wavel_pair_kernel — two columns (rows) per workgroup, both columns' loads in flight
-    before the first transform: what a lone 2^20 takes by default (a pass of 1 024 workgroups = one round).  Forced on (kernel kind
-    9) at 2^16 = 2^8 x 2^8, 2^18 = 2^10 x 2^8 and batches of 2^20; the default rule on a lone 2^20 (pair) and on two (not); forced
-    off (kind 10): all exact against the C oracle, forward out of place and inverse in place; with and without the one-table
-    inter-pass twiddles."""
-    from plonkathon_amd import get_context
-    from plonkathon_amd._lib import check
-
-    ctx = get_context()
-    with pc.ntt_kind(9):
-        pc.ntt_two_pass_exact((16,), batch=8)
-        pc.ntt_two_pass_exact((18,), batch=4)
-        pc.ntt_two_pass_exact((20,), batch=3)
-        try:
-            check(ctx.L.plonk_ntt_set_table_budget(ctx.handle, 0))
-            pc.ntt_two_pass_exact((16, 20), seed0=4500, batch=8)
-        finally:
-            check(ctx.L.plonk_ntt_set_table_budget(ctx.handle, 4 << 30))
-    pc.ntt_two_pass_exact((20,), seed0=4600)
-    pc.ntt_two_pass_exact((20,), seed0=4700, batch=2)
-    with pc.ntt_kind(10):
-        pc.ntt_two_pass_exact((20,), seed0=4800)
-
-
-@pytest.mark.gpu
 def test_full_size_comb_with_top_tables():
     """What a 180 GB budget buys (bench.py's opt-in): the comb of 21 teeth with top tables over the 2^11 SRS bases — 12 columns and a
     joint table per 7 bases for the two bits left over: 12 x 2 073 additions per MSM of 2^11 (12.15 per base; 13 on the 20-tooth
