@@ -771,9 +771,9 @@ def main():
             roof["step_valu_source"] = stepv_src
         line["roofline"] = roof
         detail["roofline"] = dict(roof, **{
-            "algorithmic_bytes_per_launch": bytes_per_launch, "msms_per_launch": msms_per_launch, "mixed_additions_per_msm": windows * GROUP_ORDER,
+            "algorithmic_bytes_per_launch": bytes_per_launch, "msms_per_launch": msms_per_launch, "mixed_additions_per_msm": adds_per_launch / msms_per_launch,
             "concurrent_streams": NS, "avg_launch_us_concurrent": avg_s * 1e6, "launches_concurrent": msm_launches,
-            "whole_step_g1_gmadd_per_s": (msm_bytes / (96.0 * GROUP_ORDER + 64.0)) * windows * GROUP_ORDER / elapsed / 1e9,
+            "whole_step_g1_gmadd_per_s": (msm_bytes / (96.0 * GROUP_ORDER + 64.0)) * (adds_per_launch / msms_per_launch) / elapsed / 1e9,
             "traffic_source": pmc_src, "traffic_factors": pmc.get("factors"), "alu_source": ub["source"] if ub else None,
             "valu_counters": valu.get(msm_kernel + "_kernel") if valu else None, "valu_source": valu["source"] if valu else None,
             "traffic_GBps": traffic / k_avg / 1e9 if traffic else None,
