@@ -134,6 +134,14 @@ def test_msm_comb_top_tables(emu):
     fewer bases than a group, ragged last groups, several workgroups per MSM (virtual scalars in the last one), and — inside
     comb_table_shapes — scalars 0 / 1 / r - 1 / 2^253 (top bits set), an identity base, all-zero and cancelling MSMs."""
     pc.comb_table_shapes([(7, 1, 0, 1), (7, 19, 1, 1), (7, 300, 2, 1), (9, 33, 4, 1), (11, 64, 0, 1), (11, 7, 1, 1), (12, 50, 1, 1)])
+    # the request is refused where a comb takes no top tables (254 mod teeth not 1 or 2), without an explicit tooth count, or on window tables
+    from plonkathon_amd import get_context
+
+    ctx = get_context()
+    for args, kw in (((2, 20, 0), {"top": True}), ((2, 8, 0), {"top": True}), ((0, 0, 0), {"top": True}), ((2, 12, 0), {"top": True, "windows": True})):
+        with pytest.raises(AssertionError):
+            ctx.msm_lookup(*args, **kw)
+    ctx.msm_lookup(0)
 
 
 @pytest.mark.parametrize("windows", [False, True])

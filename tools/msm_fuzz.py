@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised cross-check of the MSM schedules on the GPU: for random (number of scalars n <= 2^11, MSMs per call M, scalar stride,
-workgroups per MSM, table layout and size) the table MSM must return the bytes the bucket method returns — scalars include 0, 1,
+workgroups per MSM, table layout — combs with and without top tables, window tables — and size) the table MSM must return the bytes the bucket method returns — scalars include 0, 1,
 r - 1, repeated values and runs of equal scalars (equal pieces in a column's tree).  One JSON line per round; exit status 1 on a
 mismatch.        python tools/msm_fuzz.py [rounds] [seed]"""
 import ctypes
@@ -26,8 +26,9 @@ for rd in range(rounds):
     n = rng.choice([1, 2, 3, 17, 19, 20, 63, 64, 65, 255, 256, 257, 300, 1000, 2047, 2048, rng.randrange(1, 2049)])
     M = rng.choice([1, 2, 3, 9, 64, 65, 300])
     stride = n + rng.choice([0, 1, 7])
-    kind = rng.choice(["comb", "comb", "comb", "windows"])
-    bits = rng.choice([2, 3, 5, 8, 11, 13, 16, 17, 18]) if kind == "comb" else rng.choice([3, 6, 10, 13])
+    kind = rng.choice(["comb", "comb", "comb_top", "comb_top", "windows"])  # comb_top: the comb with top tables (csrc/msm_comb.h)
+    bits = (rng.choice([2, 3, 5, 8, 11, 13, 16, 17, 18]) if kind == "comb" else
+            rng.choice([4, 6, 7, 9, 11, 12, 14, 14, 18]) if kind == "comb_top" else rng.choice([3, 6, 10, 13]))
     groups = rng.choice([0, 0, 1, 2, 3, 8, 64])
     special = [0, 1, 2, R_MOD - 1, R_MOD - 2, (R_MOD - 1) // 2, 1 << 253]
     vals = []
@@ -44,7 +45,8 @@ for rd in range(rounds):
     sc = ctx.upload_ints(vals)
     out = []
     for method in ("table", "bucket"):
-        ctx.msm_lookup(2 if method == "table" else 1, bits if method == "table" else 0, 0, windows=(kind == "windows"))
+        ctx.msm_lookup(2 if method == "table" else 1, bits if method == "table" else 0, 0, windows=(kind == "windows"),
+                       top=(kind == "comb_top" and method == "table"))
         ctx.msm_configure(0, groups)
         setup = Setup.from_file(PTAU)
         bases = setup.device_bases()
