@@ -935,6 +935,10 @@ static int msm_comb_build(plonk_ctx* ctx, plonk_srs* srs, unsigned h, bool top =
         return PLONK_ERR_ARG;
     }
     const MsmCombShape sh = msm_comb_shape(h, top);
+    if (!msm_comb_top_reach_ok(srs->n_points, sh)) {
+        plonk_set_error("%zu bases are too many for the top tables of a %u-tooth comb (a virtual scalar's block offset must fit 31 bits)", srs->n_points, h);
+        return PLONK_ERR_ARG;
+    }
     const unsigned a = sh.a, sb = h - 1 < MSM_COMB_SEG_BITS ? h - 1 : MSM_COMB_SEG_BITS;
     const size_t n = srs->n_points, half = (size_t)1 << (h - 1), stage = msm_comb_stage_entries(n, h), chunk_bases = stage / half;
     const size_t blocks = msm_comb_blocks(n, sh);
@@ -1089,7 +1093,7 @@ static bool msm_lookup_prepare(plonk_ctx* ctx, plonk_srs* srs) {
     };
     for (unsigned c = c_max; c >= c_min; c--)
         for (int top = 0; top < 2; top++) {
-            if (top && (kind != MSM_TABLE_COMB || !msm_comb_top_ok(c))) continue;
+            if (top && (kind != MSM_TABLE_COMB || !msm_comb_top_ok(c) || !msm_comb_top_reach_ok(srs->n_points, msm_comb_shape(c, true)))) continue;
             if (want && (top != 0) != wtop) continue;
             cands.push_back(Cand{c, top != 0, adds_of(c, top != 0), msm_table_bytes(srs->n_points, kind, c, top != 0)});
         }
@@ -1174,8 +1178,7 @@ static int msm_run_comb(plonk_ctx* ctx, plonk_srs* srs, const Fr* d_scalars, siz
     const size_t nv = msm_comb_virtual(n_real, sh), n = n_real + nv;
     const unsigned top_delta = (unsigned)(srs->n_points - n_real);  // block of virtual scalar n_real + v = n_points + v (+ the digit's offset)
     PLONK_REQUIRE((uint64_t)n * a < ((uint64_t)1 << 32), PLONK_ERR_ARG, "MSM size %zu too large for the lookup path", n_real);
-    PLONK_REQUIRE(!top || ((uint64_t)(nv * (a - 1) + a) << hb) < ((uint64_t)1 << 31), PLONK_ERR_ARG, "MSM size %zu too large for the top tables of %u teeth",
-                  n_real, h);
+    PLONK_REQUIRE(msm_comb_top_reach_ok(n_real, sh), PLONK_ERR_ARG, "MSM size %zu too large for the top tables of %u teeth", n_real, h);
     unsigned G = ctx->msm_groups;
     if (!G) {  // enough waves to occupy 1024 SIMDs three to four deep, in as few workgroups per MSM as that takes
         G = 1;

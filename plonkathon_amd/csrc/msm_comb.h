@@ -90,6 +90,10 @@ PLONK_HD size_t msm_comb_top_groups(size_t n, unsigned g) { return g ? (n + g - 
 PLONK_HD size_t msm_comb_virtual(size_t n, const MsmCombShape& s) { return s.top_g ? (msm_comb_top_groups(n, s.top_g) + s.a - 1) / s.a : 0; }
 // blocks of 2^(h-1) entries in the table of n bases
 PLONK_HD size_t msm_comb_blocks(size_t n, const MsmCombShape& s) { return n + msm_comb_virtual(n, s) * s.a; }
+// a virtual scalar's digit carries its block offset (v (a - 1) + j) beside the index: 31 bits in all
+PLONK_HD bool msm_comb_top_reach_ok(size_t n, const MsmCombShape& s) {
+    return !s.top_g || ((uint64_t)(msm_comb_virtual(n, s) * (s.a - 1) + s.a) << (s.h - 1)) < ((uint64_t)1 << 31);
+}
 // block of the table an item of scalar i (real: i < n_real; virtual: the others) starts from
 PLONK_HD size_t msm_comb_block_of(size_t i, size_t n_real, size_t top_delta) { return i + (i >= n_real ? top_delta : 0); }
 
