@@ -7,9 +7,10 @@
 // so any correct schedule yields the same affine point.  The schedules:
 //
 // A. TABLE MSM — for a reusable SRS (plonk_srs_load_ptau), within the HBM budget the caller grants (1/16 of the device's memory by
-//    default; bench.py opts into 100 GB).  ONE table per (device, base set, layout, bits), shared by every context.
+//    default; bench.py opts into 180 GB).  ONE table per (device, base set, layout, bits), shared by every context.
 //    A1. comb tables (msm_comb.h, the default): 2^(h-1) entries per base, N * ceil(254 / h) mixed additions per MSM — 13 per base
-//        from 68.7 GB, 15 from 8.6 GB for 2^11 points — and ceil(254 / h) - 1 doublings per MSM.
+//        from 68.7 GB, 15 from 8.6 GB for 2^11 points — and ceil(254 / h) - 1 doublings per MSM; with TOP TABLES (round 6: floor(254 / h)
+//        columns + a joint table per g bases for the bits left over) 12.15 per base from 157.6 GB (h = 21, g = 7).
 //    A2. window tables (rounds 2 - 5; plonk_msm_lookup_configure mode | 16): every multiple L[w][i][d] = d * 2^(c w) * P_i a signed
 //        c-bit digit can select (128.8 GB at c = 17 for 2^11 points), N * ceil(255 / c) mixed additions of looked-up points:
 //      msm_lookup_kernel           lanes walk flat ranges of (scalar, window) items, 64 random bytes per item
@@ -1032,7 +1033,8 @@ static size_t msm_default_lookup_budget() {
     // than a quarter of what is FREE at the moment — the default is per process and per SRS family, so several processes or
     // several SRS on one device each take theirs (eight ranks sharing a GPU: 8 x 9.7 GB), and a device that is already
     // nearly full must not be pushed over by a table nobody asked for.  More only through plonk_msm_lookup_configure(budget)
-    // or PLONK_MSM_TABLE_GB (bench.py asks for the 68.7 GB comb of 20 teeth: 13 additions).
+    // or PLONK_MSM_TABLE_GB (bench.py asks for 180 GB: the 157.6 GB comb of 21 teeth with top tables, 12.15 additions; 100 GB buys
+    // the 68.7 GB comb of 20 teeth, 13 additions).
     // Window tables, measured (profiles/r05_d_msm_sweep.jsonl, 1152 MSMs of 2^11 per call): c = 11 4.50 ms, 12 4.11, 13 3.86, 14 3.65.
     const char* e = getenv("PLONK_MSM_TABLE_GB");
     if (e && atof(e) > 0) return (size_t)(atof(e) * 1e9);

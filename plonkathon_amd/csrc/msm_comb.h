@@ -18,9 +18,13 @@
 // The table is built over P'_i = R^-1 P_i (R = 2^261, the Montgomery radix of Fr): the scalars reach the MSM as Montgomery residues
 // s R mod r, and (s R) (R^-1 P) = s P — the digit kernel takes the residue as it is, sparing a conversion (a quarter of its work).
 //
+// With TOP TABLES (round 6, below: "combs with top tables") the comb has floor(254 / h) columns and the one or two bits they leave over
+// go through joint tables of g bases each: 21 teeth, 12 columns, g = 7 — 12.15 additions per base of 2^11 from 157.6 GB.
+//
 // Kernels (one launch each per batch of MSMs):
-//   msm_comb_digits_kernel<H>   one lane per scalar: the residue as stored, parity fold, t, and the a column indices (sign in bit 31)
-//                               written column-major (digits[m][j][i], 4 B per item) — read back coalesced by the next kernel
+//   msm_comb_digits_kernel<H, TOP>  one lane per scalar: the residue as stored, parity fold, t, and the a column indices (sign in bit 31)
+//                               written column-major (digits[m][j][i], 4 B per item) — read back coalesced by the next kernel;
+//                               TOP: a workgroup takes whole groups of g scalars and adds the digits of the virtual scalars
 //   msm_comb_kernel             one workgroup per (MSM, scalar sub-range).  Lanes are bound to COLUMNS (a lane's accumulator can
 //                               only hold one column's sum): q = 256 / a lanes per column walk scalars r, r + q, .. — the whole
 //                               chip reads the tables of q consecutive bases at a time (address translation: msm.hip,
@@ -35,7 +39,8 @@
 //                               scalars zero — cancels in these last additions, not before)
 //   msm_comb_slow_kernel        the recovery path of MSM_DEFER_CAP (general formulas throughout)
 // Table build: msm_comb_scale_kernel gives P'_i; msm_table_kernel G_k = 2^(a k) P'_i; msm_comb_fill_kernel walks each run of 2^8 consecutive indices in
-// Gray-code order (one mixed addition of +-2 G_k per entry); g1_batch_to_affine_kernel converts a chunk of bases at a time.
+// Gray-code order (one mixed addition of +-2 G_k per entry); g1_batch_to_affine_kernel converts a chunk of bases at a time;
+// msm_comb_top_base_kernel / msm_comb_top_fill_kernel: the joint tables, one block of 2^(h-1) entries per group behind the bases' blocks.
 #pragma once
 
 #define MSM_COMB_MAX_TEETH 24
