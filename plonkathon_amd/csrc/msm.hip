@@ -979,6 +979,7 @@ static int msm_comb_build(plonk_ctx* ctx, plonk_srs* srs, unsigned h, bool top =
                      (G1Xyzz*)tmp);
         g1_batch_to_affine(ctx, (const G1Xyzz*)tmp, (G1Affine*)tab + i0 * half, nb * half);
     }
+    bool build_failed = false;
     if (top) {
         // tooth points of the top tables 2^(L - j) P'_i (through gx / gb, free by now), then the joint tables a chunk of groups at a
         // time; a block past the last group (the columns are padded to equal lengths) stays all identity
@@ -988,7 +989,10 @@ static int msm_comb_build(plonk_ctx* ctx, plonk_srs* srs, unsigned h, bool top =
         for (size_t g0 = 0; g0 < vblocks; g0 += chunk_bases) {
             const size_t nb = vblocks - g0 < chunk_bases ? vblocks - g0 : chunk_bases;
             const size_t ng = g0 >= groups ? 0 : (groups - g0 < nb ? groups - g0 : nb);
-            if (hipMemsetAsync(tmp, 0, nb * half * sizeof(G1Xyzz), ctx->stream) != hipSuccess) break;
+            if (hipMemsetAsync(tmp, 0, nb * half * sizeof(G1Xyzz), ctx->stream) != hipSuccess) {
+                build_failed = true;
+                break;
+            }
             if (ng) {
                 const size_t lanes = ng * (sh.top_entries / run);
                 unsigned gf = (unsigned)((lanes + 63) / 64 > 65536 ? 65536 : (lanes + 63) / 64);
@@ -998,7 +1002,7 @@ static int msm_comb_build(plonk_ctx* ctx, plonk_srs* srs, unsigned h, bool top =
             g1_batch_to_affine(ctx, (const G1Xyzz*)tmp, (G1Affine*)tab + (n + g0) * half, nb * half);
         }
     }
-    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) {
+    if (build_failed || hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) {
         hipFree(pb);
         return fail();
     }
