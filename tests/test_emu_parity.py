@@ -134,10 +134,28 @@ def test_msm_comb_top_tables(emu):
     fewer bases than a group, ragged last groups, several workgroups per MSM (virtual scalars in the last one), and — inside
     comb_table_shapes — scalars 0 / 1 / r - 1 / 2^253 (top bits set), an identity base, all-zero and cancelling MSMs."""
     pc.comb_table_shapes([(7, 1, 0, 1), (7, 19, 1, 1), (7, 300, 2, 1), (9, 33, 4, 1), (11, 64, 0, 1), (11, 7, 1, 1), (12, 50, 1, 1)])
-    # the request is refused where a comb takes no top tables (254 mod teeth not 1 or 2), without an explicit tooth count, or on window tables
-    from plonkathon_amd import get_context
+    # the shape the library reports for an SRS table with top tables, and a commitment shorter than the SRS on it (the virtual scalars'
+    # blocks then lie N - n blocks further from their scalars: top_delta)
+    import random
+
+    from plonkathon_amd import Basis, Setup, get_context
 
     ctx = get_context()
+    setup = Setup.from_file(pc.PTAU)
+    rng = random.Random(9)
+    for h, cols, top_bits, group in ((7, 36, 2, 2), (9, 28, 2, 2)):
+        ctx.msm_lookup(2, h, 0, top=True)
+        n = 100
+        vals = [rng.randrange(pc.R_MOD) for _ in range(n - 2)] + [pc.R_MOD - 1, 1 << 253]
+        got = setup.commit_coeffs(pc.P(vals, Basis.MONOMIAL))
+        assert pc.affine(got) == pc.og1.ec_lincomb(list(zip([pc.affine(p) for p in setup.powers_of_x[:n]], vals))), h
+        info = setup.device_bases().lookup_info()
+        assert (info["layout"], info["bits"], info["additions_per_base"], info["top_bits"], info["top_group"]) == ("comb", h, cols, top_bits, group), info
+        groups = -(-2048 // group)
+        assert info["bytes"] == (2048 + -(-groups // cols) * cols) * (1 << (h - 1)) * 64, info
+        assert setup.device_bases().table_additions(info, n) == cols * (n + -(-(-(-n // group)) // cols)), info
+    ctx.msm_lookup(0)
+    # the request is refused where a comb takes no top tables (254 mod teeth not 1 or 2), without an explicit tooth count, or on window tables
     for args, kw in (((2, 20, 0), {"top": True}), ((2, 8, 0), {"top": True}), ((0, 0, 0), {"top": True}), ((2, 12, 0), {"top": True, "windows": True})):
         with pytest.raises(AssertionError):
             ctx.msm_lookup(*args, **kw)
