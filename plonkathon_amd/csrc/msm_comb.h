@@ -64,7 +64,8 @@ PLONK_HD unsigned msm_comb_columns(unsigned h) { return (MSM_COMB_SCALAR_BITS + 
 // Group grp is dealt to column j = grp mod a (hence the 2^(L - j): the Horner step multiplies column j's sum by 2^j), as the
 // "virtual scalar" n + grp / a of that column: msm_comb_kernel sees an MSM of n + ceil(ceil(n / g) / a) scalars and runs
 // unchanged — its table simply has one more 2^(h-1)-entry block per group behind the blocks of the N bases (block N + grp), and
-// a virtual scalar's digit carries the block offset (v (a - 1) + j) beside idx.  2^11 bases, h = 21: 12 columns of 2 073
+// a virtual scalar's digit carries the block offset (v (a - 1) + j) beside idx: scalar n + v starts from block N + v (the kernels add
+// top_delta = N - n to the index of a virtual scalar, msm_comb_block_of), and N + v + v (a - 1) + j = N + grp.  2^11 bases, h = 21: 12 columns of 2 073
 // (virtual) scalars = 12.15 additions per base from 137.4 + 20.1 GB, against 13 from 68.7 GB.
 struct MsmCombShape {
     unsigned h, a;                // teeth, columns
